@@ -1,0 +1,279 @@
+"""ctypes wrapper over oracle/libklat_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package never does.  See klat_oracle.c for the reference citations.
+"""
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libklat_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.kor_log_add.restype = C.c_double
+        _LIB.kor_log_add.argtypes = [C.c_double, C.c_double]
+        _LIB.kor_log_sub.restype = C.c_double
+        _LIB.kor_log_sub.argtypes = [C.c_double, C.c_double]
+        _LIB.kor_alphas_betas.restype = C.c_double
+        _LIB.kor_betas.restype = C.c_double
+        _LIB.kor_segment_index.restype = C.c_int64
+        _LIB.kor_position_index.restype = C.c_int64
+        _LIB.kor_frame_post.restype = C.c_int64
+        _LIB.kor_disambiguate_length.restype = C.c_int32
+        _LIB.kor_free.argtypes = [C.c_void_p]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+@dataclass
+class Lat:
+    """One lattice in stored (CSR-by-source) order; float32 costs, int32 ids."""
+
+    arc_begin: np.ndarray  # int64 [S+1]
+    dst: np.ndarray  # int32 [A]
+    ilabel: np.ndarray
+    olabel: np.ndarray
+    graph: np.ndarray  # float32 [A]
+    acoustic: np.ndarray
+    dur: np.ndarray  # int32 [A]  length of the transition-id string
+    final_graph: np.ndarray  # float32 [S]; +inf = non-final
+    final_acoustic: np.ndarray
+    final_dur: np.ndarray  # int32 [S]
+    key: str = ""
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def S(self):
+        return len(self.arc_begin) - 1
+
+    @property
+    def A(self):
+        return len(self.dst)
+
+    def src(self):
+        return np.repeat(np.arange(self.S, dtype=np.int32), np.diff(self.arc_begin)).astype(np.int32)
+
+    def copy(self):
+        return Lat(*[x.copy() if isinstance(x, np.ndarray) else x for x in
+                     (self.arc_begin, self.dst, self.ilabel, self.olabel, self.graph, self.acoustic,
+                      self.dur, self.final_graph, self.final_acoustic, self.final_dur)], key=self.key)
+
+
+def lat_from_arcs(S, arcs, finals, key="", start=0):
+    """arcs: list of (src,dst,ilabel,olabel,graph,acoustic,dur) in file order; finals:
+    dict state -> (graph, acoustic, dur).  Arcs are grouped by source keeping file order."""
+    by_src = [[] for _ in range(S)]
+    for a in arcs:
+        by_src[a[0]].append(a)
+    flat = [a for s in range(S) for a in by_src[s]]
+    ab = np.zeros(S + 1, np.int64)
+    for s in range(S):
+        ab[s + 1] = ab[s] + len(by_src[s])
+    fg = np.full(S, np.inf, np.float32)
+    fa = np.full(S, np.inf, np.float32)
+    fd = np.zeros(S, np.int32)
+    for s, (g, a, d) in finals.items():
+        fg[s], fa[s], fd[s] = g, a, d
+    col = lambda i, dt: np.array([a[i] for a in flat], dtype=dt)
+    lat = Lat(ab, col(1, np.int32), col(2, np.int32), col(3, np.int32), col(4, np.float32),
+              col(5, np.float32), col(6, np.int32), fg, fa, fd, key=key)
+    lat.extra["start"] = start
+    return lat
+
+
+def log_add(x, y):
+    return lib().kor_log_add(x, y)
+
+
+def scale_and_penalize(lat, graph_scale=1.0, acoustic_scale=1.0, insertion_penalty=0.0):
+    """Returns a scaled copy (a2/a3)."""
+    out = lat.copy()
+    lib().kor_scale_and_penalize(
+        C.c_int64(out.A), C.c_int64(out.S), _p(out.ilabel), _p(out.graph), _p(out.acoustic),
+        _p(out.final_graph), _p(out.final_acoustic), C.c_float(graph_scale),
+        C.c_float(acoustic_scale), C.c_float(insertion_penalty))
+    return out
+
+
+def is_top_sorted(lat):
+    return bool(lib().kor_is_top_sorted(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst)))
+
+
+def top_sort(lat, start=0):
+    """Returns (renumbered lattice, order[old]=new); raises on cycles."""
+    order = np.zeros(lat.S, np.int32)
+    rc = lib().kor_top_sort(C.c_int32(lat.S), C.c_int32(start), _p(lat.arc_begin), _p(lat.dst), _p(order))
+    if rc != 0:
+        raise RuntimeError("lattice is cyclic (kor_top_sort rc=%d)" % rc)
+    return renumber(lat, order), order
+
+
+def renumber(lat, order):
+    S = lat.S
+    inv = np.zeros(S, np.int64)
+    inv[order] = np.arange(S)
+    counts = np.diff(lat.arc_begin)[inv]
+    ab = np.zeros(S + 1, np.int64)
+    ab[1:] = np.cumsum(counts)
+    idx = np.concatenate([np.arange(lat.arc_begin[o], lat.arc_begin[o + 1]) for o in inv]) if lat.A else np.zeros(0, np.int64)
+    idx = idx.astype(np.int64)
+    out = Lat(ab, order[lat.dst[idx]].astype(np.int32), lat.ilabel[idx], lat.olabel[idx], lat.graph[idx],
+              lat.acoustic[idx], lat.dur[idx], lat.final_graph[inv], lat.final_acoustic[inv],
+              lat.final_dur[inv], key=lat.key)
+    out.extra["arc_old"] = idx
+    return out
+
+
+def state_times(lat):
+    times = np.zeros(lat.S, np.int32)
+    utt = C.c_int32(0)
+    warn = C.c_int32(0)
+    rc = lib().kor_state_times(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.dur),
+                               _p(lat.final_graph), _p(lat.final_acoustic), _p(lat.final_dur),
+                               _p(times), C.byref(utt), C.byref(warn))
+    if rc != 0:
+        raise RuntimeError("kor_state_times rc=%d" % rc)
+    return times, utt.value, warn.value
+
+
+def alphas_betas(lat):
+    alpha = np.zeros(lat.S, np.float64)
+    beta = np.zeros(lat.S, np.float64)
+    tf = C.c_double(0)
+    tb = C.c_double(0)
+    tot = lib().kor_alphas_betas(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.graph),
+                                 _p(lat.acoustic), _p(lat.final_graph), _p(lat.final_acoustic),
+                                 _p(alpha), _p(beta), C.byref(tf), C.byref(tb))
+    return alpha, beta, tot, tf.value, tb.value
+
+
+def betas(lat):
+    beta = np.zeros(lat.S, np.float64)
+    tot = lib().kor_betas(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.graph),
+                          _p(lat.acoustic), _p(lat.final_graph), _p(lat.final_acoustic), _p(beta))
+    return beta, tot
+
+
+def arc_through(lat, alpha, beta):
+    out = np.zeros(lat.A, np.float64)
+    lib().kor_arc_through(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.graph),
+                          _p(lat.acoustic), _p(alpha), _p(beta), _p(out))
+    return out
+
+
+def _sets(include, exclude):
+    inc = np.array(sorted(set(include or [])), np.int32)
+    exc = np.array(sorted(set(exclude or [])), np.int32)
+    return inc, exc
+
+
+def segment_index(lat, times, alpha, beta, total, include=None, exclude=None):
+    inc, exc = _sets(include, exclude)
+    n = max(lat.A, 1)
+    ol, t0, t1 = (np.zeros(n, np.int32) for _ in range(3))
+    lp = np.zeros(n, np.float64)
+    m = lib().kor_segment_index(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.olabel),
+                                _p(lat.graph), _p(lat.acoustic), _p(times), _p(alpha), _p(beta),
+                                C.c_double(total), _p(inc), C.c_int32(len(inc)), _p(exc),
+                                C.c_int32(len(exc)), _p(ol), _p(t0), _p(t1), _p(lp))
+    return [(int(ol[i]), int(t0[i]), int(t1[i]), float(lp[i])) for i in range(m)]
+
+
+def position_index(lat, times, state_len, alpha, beta, total, include=None, exclude=None):
+    inc, exc = _sets(include, exclude)
+    n = max(lat.A, 1)
+    ol, pos, t0, t1 = (np.zeros(n, np.int32) for _ in range(4))
+    lp = np.zeros(n, np.float64)
+    m = lib().kor_position_index(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.olabel),
+                                 _p(lat.graph), _p(lat.acoustic), _p(times), _p(state_len),
+                                 _p(alpha), _p(beta), C.c_double(total), _p(inc),
+                                 C.c_int32(len(inc)), _p(exc), C.c_int32(len(exc)), _p(ol), _p(pos),
+                                 _p(t0), _p(t1), _p(lp))
+    return [(int(ol[i]), int(pos[i]), int(t0[i]), int(t1[i]), float(lp[i])) for i in range(m)]
+
+
+def frame_post(lat, times, total_frames, alpha, beta, total):
+    """Returns (list per frame of [(label, float32 logp)], misaligned flag)."""
+    src = lat.src()
+    word = lat.ilabel != 0
+    span = np.maximum(times[lat.dst] - times[src], 0)
+    cap = int(span[word].sum()) + 1
+    fb = np.zeros(total_frames + 1, np.int64)
+    ol = np.zeros(cap, np.int32)
+    lp = np.zeros(cap, np.float32)
+    mis = C.c_int32(0)
+    m = lib().kor_frame_post(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.ilabel),
+                             _p(lat.graph), _p(lat.acoustic), _p(times), C.c_int32(total_frames),
+                             _p(alpha), _p(beta), C.c_double(total), C.c_int64(cap), _p(fb), _p(ol),
+                             _p(lp), C.byref(mis))
+    assert m >= 0
+    out = [[(int(ol[i]), np.float32(lp[i])) for i in range(fb[f], fb[f + 1])] for f in range(total_frames)]
+    return out, bool(mis.value)
+
+
+def disambiguate_length(lat, start=0, use_input=False):
+    """a14.  Returns (new lattice, state_len[int32], max_len)."""
+    L = lib()
+    ns = C.c_int32(0)
+    nab = C.POINTER(C.c_int64)()
+    nd = C.POINTER(C.c_int32)()
+    nao = C.POINTER(C.c_int64)()
+    nso = C.POINTER(C.c_int32)()
+    sl = C.POINTER(C.c_int32)()
+    max_len = L.kor_disambiguate_length(C.c_int32(lat.S), C.c_int32(start), _p(lat.arc_begin),
+                                        _p(lat.dst), _p(lat.ilabel), _p(lat.olabel),
+                                        C.c_int(1 if use_input else 0), C.byref(ns), C.byref(nab),
+                                        C.byref(nd), C.byref(nao), C.byref(nso), C.byref(sl))
+    NS = ns.value
+    if NS == 0:
+        z = lambda dt: np.zeros(0, dt)
+        return Lat(np.zeros(1, np.int64), z(np.int32), z(np.int32), z(np.int32), z(np.float32),
+                   z(np.float32), z(np.int32), z(np.float32), z(np.float32), z(np.int32), key=lat.key), z(np.int32), 0
+    ab = np.ctypeslib.as_array(nab, (NS + 1,)).copy()
+    NA = int(ab[-1])
+    dst = np.ctypeslib.as_array(nd, (max(NA, 1),))[:NA].copy()
+    arc_old = np.ctypeslib.as_array(nao, (max(NA, 1),))[:NA].copy()
+    st_old = np.ctypeslib.as_array(nso, (NS,)).copy()
+    state_len = np.ctypeslib.as_array(sl, (NS,)).copy()
+    for ptr in (nab, nd, nao, nso, sl):
+        L.kor_free(C.cast(ptr, C.c_void_p))
+    out = Lat(ab, dst, lat.ilabel[arc_old], lat.olabel[arc_old], lat.graph[arc_old],
+              lat.acoustic[arc_old], lat.dur[arc_old], lat.final_graph[st_old],
+              lat.final_acoustic[st_old], lat.final_dur[st_old], key=lat.key)
+    out.extra["arc_old"] = arc_old
+    out.extra["state_old"] = st_old
+    return out, state_len, max_len
+
+
+def batch_fb_post(state_off, arc_off, arc_begin_global, dst, ilabel, graph, acoustic, final_graph,
+                  final_acoustic, graph_scale, acoustic_scale, insertion_penalty):
+    """Timed CPU baseline body (bench.py cpu_baseline) and batch parity checker."""
+    U = len(state_off) - 1
+    S, A = int(state_off[-1]), int(arc_off[-1])
+    alpha = np.zeros(S, np.float64)
+    beta = np.zeros(S, np.float64)
+    total = np.zeros(U, np.float64)
+    through = np.zeros(A, np.float64)
+    lib().kor_batch_fb_post(C.c_int32(U), _p(state_off), _p(arc_off), _p(arc_begin_global), _p(dst),
+                            _p(ilabel), _p(graph), _p(acoustic), _p(final_graph), _p(final_acoustic),
+                            C.c_float(graph_scale), C.c_float(acoustic_scale),
+                            C.c_float(insertion_penalty), _p(alpha), _p(beta), _p(total), _p(through))
+    return alpha, beta, total, through

@@ -1,0 +1,164 @@
+"""Test-side readers for the Kaldi text formats on either side of the hot path (SURVEY.md
+Appendix B.2/B.3/B.5/B.6).  Independent of the product's C++ reader so that the two check
+each other.  Test infrastructure only."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import oracle as orc  # noqa: E402
+
+
+def _parse_weight(tok):
+    """'g,a,t1_t2_..' -> (graph, acoustic, dur).  Missing pieces default to One."""
+    parts = tok.split(",")
+    g = float(parts[0]) if len(parts) > 0 and parts[0] != "" else 0.0
+    a = float(parts[1]) if len(parts) > 1 and parts[1] != "" else 0.0
+    dur = 0
+    if len(parts) > 2 and parts[2] != "":
+        dur = len(parts[2].split("_"))
+    return g, a, dur
+
+
+def read_text_archive(path):
+    """Yields orc.Lat per entry.  Accepts CompactLattice text (B.2: 'src dst label
+    g,a,tids') and Lattice text (B.3: 'src dst ilabel olabel [g,a]'); the latter is turned
+    into a compact lattice one arc per arc (string = [ilabel] if ilabel != 0), which is
+    what ConvertLattice gives when no chain can be merged (every arc carries an olabel)."""
+    with open(path) as f:
+        lines = f.read().split("\n")
+    i = 0
+    out = []
+    while i < len(lines):
+        if lines[i].strip() == "":
+            i += 1
+            continue
+        key = lines[i].strip()
+        i += 1
+        arcs, finals, ids = [], {}, {}
+        start = None
+
+        def sid(x):
+            x = int(x)
+            if x not in ids:
+                ids[x] = x
+            return x
+
+        while i < len(lines) and lines[i].strip() != "":
+            t = lines[i].split()
+            i += 1
+            if len(t) <= 2 and (len(t) == 1 or "," in t[1] or _isnum(t[1])):
+                # final state line: "<state> [weight]"
+                s = sid(t[0])
+                if start is None:
+                    start = s
+                if len(t) == 1:
+                    finals[s] = (0.0, 0.0, 0)
+                else:
+                    finals[s] = _parse_weight(t[1])
+                continue
+            s, d = sid(t[0]), sid(t[1])
+            if start is None:
+                start = s
+            rest = t[2:]
+            if len(rest) >= 2 and "," not in rest[1] and _isint(rest[1]):
+                # Lattice format: ilabel olabel [weight]
+                il, ol = int(rest[0]), int(rest[1])
+                g, a, _ = _parse_weight(rest[2]) if len(rest) > 2 else (0.0, 0.0, 0)
+                arcs.append((s, d, ol, ol, g, a, 1 if il != 0 else 0))
+            else:
+                lab = int(rest[0])
+                g, a, dur = _parse_weight(rest[1]) if len(rest) > 1 else (0.0, 0.0, 0)
+                arcs.append((s, d, lab, lab, g, a, dur))
+        S = (max(ids) + 1) if ids else 0
+        lat = orc.lat_from_arcs(S, arcs, finals, key=key, start=start if start is not None else -1)
+        out.append(lat)
+    return out
+
+
+def _isint(s):
+    try:
+        int(s)
+        return True
+    except ValueError:
+        return False
+
+
+def _isnum(s):
+    try:
+        float(s)
+        return True
+    except ValueError:
+        return False
+
+
+def prepare(lat):
+    """Start state -> 0 and topological order, as TopSortCompactLatticeIfNeeded does
+    (only when needed).  Returns the lattice the sweep runs on."""
+    start = lat.extra.get("start", 0)
+    if lat.S == 0:
+        return lat
+    if start == 0 and orc.is_top_sorted(lat):
+        return lat
+    out, _ = orc.top_sort(lat, start)
+    return out
+
+
+def parse_tuple_line(line, ints):
+    """'key a b c x ; a b c x ...' -> (key, [(ints..., float)])."""
+    toks = line.strip().split(None, 1)
+    key = toks[0]
+    recs = []
+    if len(toks) > 1:
+        for chunk in toks[1].split(";"):
+            f = chunk.split()
+            if not f:
+                continue
+            assert len(f) == ints + 1, f
+            recs.append(tuple(int(v) for v in f[:ints]) + (float(f[ints]),))
+    return key, recs
+
+
+def parse_posterior_line(line):
+    """'key [ l p l p ] [ ] ...' -> (key, [[(label, logp)]])."""
+    toks = line.strip().split()
+    key = toks[0]
+    frames, cur = [], None
+    for t in toks[1:]:
+        if t == "[":
+            cur = []
+        elif t == "]":
+            frames.append([(int(cur[i]), float(cur[i + 1])) for i in range(0, len(cur), 2)])
+            cur = None
+        else:
+            cur.append(t)
+    return key, frames
+
+
+def logsumexp(xs):
+    xs = list(xs)
+    if not xs:
+        return -math.inf
+    m = max(xs)
+    if m == -math.inf:
+        return m
+    return m + math.log(sum(math.exp(x - m) for x in xs))
+
+
+def brute_force_paths(lat):
+    """Enumerate every start->final path of a tiny lattice (the reference's own test idiom,
+    fstext/expand-subpaths-test-utils.h:10-52).  Returns list of (arc index list, loglik)."""
+    paths = []
+
+    def rec(s, arcs, ll):
+        fg, fa = float(lat.final_graph[s]), float(lat.final_acoustic[s])
+        if not (math.isinf(fg) and math.isinf(fa)):
+            paths.append((list(arcs), ll - (fg + fa)))
+        for i in range(int(lat.arc_begin[s]), int(lat.arc_begin[s + 1])):
+            arcs.append(i)
+            rec(int(lat.dst[i]), arcs, ll - (float(lat.graph[i]) + float(lat.acoustic[i])))
+            arcs.pop()
+
+    if lat.S:
+        rec(0, [], 0.0)
+    return paths

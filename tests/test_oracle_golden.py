@@ -1,0 +1,133 @@
+"""Pins the CPU oracle to the reference's own known-answer vectors
+before anything else is allowed to trust it."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import latfmt
+from oracle import oracle as orc
+
+
+def _expected(golden_dir):
+    exp = {}
+    with open(os.path.join(golden_dir, "readme_expected.txt")) as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            kind, rest = line.split(None, 1)
+            exp[kind] = rest.strip()
+    return exp
+
+
+def _fmt7(x):
+    """Kaldi text output: os.precision(7) default float formatting (%g-like)."""
+    s = "%.7g" % x
+    return "0" if float(s) == 0 else s
+
+
+def _word_lattice(golden_dir):
+    (lat,) = latfmt.read_text_archive(os.path.join(golden_dir, "egs_word_lattice.ark.txt"))
+    return latfmt.prepare(lat)
+
+
+def test_state_times_match_readme(golden_dir):
+    lat = _word_lattice(golden_dir)
+    times, utt_len, warn = orc.state_times(lat)
+    want = [int(v) for v in _expected(golden_dir)["state_times"].split()]
+    assert times.tolist() == want
+    assert utt_len == 33 and warn == 0
+
+
+def test_segment_index_matches_readme(golden_dir):
+    lat = _word_lattice(golden_dir)
+    times, _, _ = orc.state_times(lat)
+    alpha, beta, total, tf, tb = orc.alphas_betas(lat)
+    assert abs(tf - tb) < 1e-12
+    got = orc.segment_index(lat, times, alpha, beta, total)
+    key, want = latfmt.parse_tuple_line(_expected(golden_dir)["segment"], 3)
+    assert key == lat.key == "lat1"
+    assert len(got) == len(want) == 10
+    # exact order and 7-significant-digit text identity with the README
+    for g, w in zip(got, want):
+        assert g[:3] == w[:3]
+        assert _fmt7(g[3]) == _fmt7(w[3]), (g, w)
+
+
+def test_position_index_matches_readme(golden_dir):
+    lat = _word_lattice(golden_dir)
+    dlat, state_len, max_len = orc.disambiguate_length(lat)
+    assert max_len == 7
+    alpha, beta, total, _, _ = orc.alphas_betas(dlat)
+    times, _, _ = orc.state_times(dlat)
+    got = orc.position_index(dlat, times, state_len, alpha, beta, total)
+    _, want = latfmt.parse_tuple_line(_expected(golden_dir)["position"], 4)
+    assert len(got) == len(want) == 9
+    for g, w in zip(got, want):
+        assert g[:4] == w[:4]
+        assert _fmt7(g[4]) == _fmt7(w[4]), (g, w)
+
+
+def test_utterance_total_matches_readme(golden_dir):
+    """kwsbin2/README.md:25 pins the betas-only total: words on every path have logp 0."""
+    lat = _word_lattice(golden_dir)
+    beta, total = orc.betas(lat)
+    _, want = latfmt.parse_tuple_line(_expected(golden_dir)["utterance"], 1)
+    # word 3 lies only on the P=0.8 branch: logp = log(0.8) - total
+    alpha, beta2, tot2, _, _ = orc.alphas_betas(lat)
+    assert np.allclose(beta, beta2, atol=0, rtol=0)
+    assert abs(total) < 1e-7
+    w3 = [w for w in want if w[0] == 3][0][1]
+    assert _fmt7(math.log(0.8) - total) == _fmt7(w3) or abs(math.log(0.8) - total - w3) < 5e-8
+
+
+def test_frame_post_appendix_c2(golden_dir):
+    """lattice-to-word-frame-post has no reference known-answer ("parity unpinned" for this
+    accumulator); SURVEY.md Appendix C.2 gives the analytically derived table."""
+    lat = _word_lattice(golden_dir)
+    times, T, _ = orc.state_times(lat)
+    alpha, beta, total, _, _ = orc.alphas_betas(lat)
+    post, mis = orc.frame_post(lat, times, T, alpha, beta, total)
+    assert T == 33 and not mis and len(post) == 33
+    l8, l2 = math.log(0.8), math.log(0.2)
+    table = {(0, 1): [(2, l8), (1, l2)], (2, 3): [(2, l8), (4, l2)], (4, 7): [(3, l8), (4, l2)],
+             (8, 8): [(5, l8), (4, l2)], (9, 11): [(5, 0.0)], (12, 15): [(2, 0.0)],
+             (16, 21): [(6, 0.0)], (22, 26): [(7, 0.0)], (27, 32): [(8, 0.0)]}
+    for (a, b), want in table.items():
+        for f in range(a, b + 1):
+            assert [p[0] for p in post[f]] == [w[0] for w in want], f
+            for (gl, gp), (wl, wp) in zip(post[f], want):
+                assert abs(float(gp) - wp) < 1e-6
+
+
+def test_logadd_semantics():
+    inf = math.inf
+    assert orc.log_add(-inf, -inf) == -inf
+    assert orc.log_add(-inf, 1.5) == 1.5
+    assert orc.log_add(2.0, -inf) == 2.0
+    assert orc.log_add(0.0, -40.0) == 0.0  # below log(DBL_EPSILON): larger one returned exactly
+    assert abs(orc.log_add(0.0, 0.0) - math.log(2.0)) < 1e-15
+    assert abs(orc.log_add(-3.0, -1.0) - math.log(math.exp(-3) + math.exp(-1))) < 1e-15
+
+
+@pytest.mark.parametrize("name", ["egs_expand_lattice.char.txt", "egs_expand_lattice2.char.txt",
+                                  "egs_char_lattice.lattice-format.ark.txt",
+                                  "egs_ctc_input.lattice-format.txt", "egs_word_lattice.ark.txt"])
+def test_sweep_equals_path_enumeration(golden_dir, name):
+    """The reference's test idiom (brute-force path oracle) applied to the five
+    shipped lattices: arc posteriors from the sweep == logsumexp over enumerated paths."""
+    (lat,) = latfmt.read_text_archive(os.path.join(golden_dir, name))
+    lat = latfmt.prepare(lat)
+    assert orc.is_top_sorted(lat)
+    alpha, beta, total, tf, tb = orc.alphas_betas(lat)
+    paths = latfmt.brute_force_paths(lat)
+    assert len(paths) > 0
+    assert abs(latfmt.logsumexp(p[1] for p in paths) - total) < 1e-9
+    through = orc.arc_through(lat, alpha, beta)
+    for i in range(lat.A):
+        want = latfmt.logsumexp(ll for arcs, ll in paths if i in arcs)
+        if want == -math.inf:
+            assert through[i] == -math.inf
+        else:
+            assert abs(through[i] - want) < 1e-9
