@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- lattice-arcs/second of the forward-backward + arc-posterior path on MI355X.
+
+One "step" = one pass of the hot path (klat_forward_backward: forward+backward lockstep
+sweep, per-lattice totals, arc log-posteriors, alpha/beta in natural log) over one batch of
+synthetic lattices already resident in HBM.  Workload at every N: BASELINE.json configs[1]
+per GPU (10k lattices x 2k states x fanout 3, SURVEY.md Appendix D generator, scales
+--acoustic-scale=0.1 --graph-scale=1), i.e. weak scaling with utterances sharded across
+ranks and no data-path collective.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(ns, fo, seed, scales, target_seconds=12.0):
+    """The oracle (CPU restatement of the reference algorithm, kind "port") timed on this
+    box's host cores on a bounded sample of the same workload, one lattice per task over
+    `cores` threads (TaskSequencer's model, kwsbin2/lattice-word-index-segment.cc:260-275)."""
+    import klat_amd
+    from oracle import oracle as orc
+
+    cores = max(1, min(os.cpu_count() or 1, 16))
+
+    def prep(n, first):
+        a = klat_amd.synth(seed, ns[:n], fo[:n], first_utt=first)
+        S = int(a["state_off"][-1])
+        gsrc = a["src"] + np.repeat(a["state_off"][:-1], np.diff(a["arc_off"]))
+        a["arc_begin"] = np.concatenate([[0], np.cumsum(np.bincount(gsrc, minlength=S))]).astype(np.int64)
+        return a
+
+    def run(a):
+        orc.batch_fb_post(a["state_off"], a["arc_off"], a["arc_begin"], a["dst"], a["ilabel"], a["graph"],
+                          a["acoustic"], a["final_graph"], a["final_acoustic"], *scales)
+
+    probe = prep(min(8, len(ns)), 0)
+    t0 = time.perf_counter()
+    run(probe)
+    per_lat = (time.perf_counter() - t0) / (len(probe["state_off"]) - 1)
+    per_thread = int(max(4, min(len(ns) // cores, target_seconds / max(per_lat, 1e-9))))
+    shards = [prep(per_thread, i * per_thread) for i in range(cores)]
+    arcs = sum(int(s["arc_off"][-1]) for s in shards)
+    threads = [threading.Thread(target=run, args=(s,)) for s in shards]  # ctypes drops the GIL
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": arcs / dt, "unit": "lattice-arcs/s", "cores": cores, "kind": "port",
+            "sample": "%d lattices x %d states x fanout %d (%d arcs), fb+arc posteriors, %d threads, %.1f s"
+                      % (per_thread * cores, int(ns[0]), int(fo[0]), arcs, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lattices", type=int, default=10000, help="lattices per GPU")
+    ap.add_argument("--states", type=int, default=2000)
+    ap.add_argument("--fanout", type=int, default=3)
+    ap.add_argument("--seed", type=int, default=20260001)
+    ap.add_argument("--lanes-per-lattice", type=int, default=0)
+    ap.add_argument("--ring-slots", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+
+    import klat_amd
+
+    if not torch.cuda.is_available() or klat_amd.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    U = args.lattices
+    ns = np.full(U, args.states, np.int32)
+    fo = np.full(U, args.fanout, np.int32)
+    scales = (1.0, 0.1, 0.0)
+    arrays = klat_amd.synth(args.seed, ns, fo, first_utt=rank * U)
+    ctx = klat_amd.Ctx(local_rank)
+    t0 = time.perf_counter()
+    batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=args.lanes_per_lattice, ring_slots=args.ring_slots)
+    pack_s = time.perf_counter() - t0
+    info = batch.info()
+    A, S = info["num_arcs"], info["num_states"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.forward_backward(*scales)
+    barrier()
+    sweep_ms, post_ms, conv_ms, tot_ms = [], [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.forward_backward(*scales)
+        # per-kernel durations from HIP events recorded on the ctx stream inside the library
+        # (klat_get_timings waits for the step's last event; steps are serial on one stream)
+        t = batch.timings()
+        sweep_ms.append(t["sweep_ms"]), post_ms.append(t["posterior_ms"])
+        conv_ms.append(t["convert_ms"]), tot_ms.append(t["total_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # light end-of-run sanity: forward and backward totals agree
+    total, tf, tb = batch.totals()
+    assert np.all(np.isfinite(total)) and float(np.max(np.abs(tf - tb))) < 1e-6
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * A * args.steps / elapsed
+        sweep_avg = float(np.mean(sweep_ms))
+        # algorithmic bytes of the sweep launch (SURVEY.md 8d "fb-only"): 32 B/arc + 32 B/state
+        sweep_bytes = 32.0 * A + 32.0 * S
+        achieved = sweep_bytes / (sweep_avg * 1e-3) / 1e9
+        step_bytes = 56.0 * A + 48.0 * S  # fb + arc posterior: 72 B/arc at fanout 3
+        out = {
+            "metric": "lattice-arcs/sec (whole node) on forward-backward + arc posteriors",
+            "value": value, "unit": "lattice-arcs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d lattices/GPU x %d states x fanout %d, "
+                                   "acoustic-scale 0.1 (SURVEY.md App. D seed %d)" % (U, args.states, args.fanout, args.seed),
+                       "lattices_per_gpu": U, "states": args.states, "fanout": args.fanout,
+                       "arcs_per_gpu": A, "lanes_per_lattice": info["lanes_per_lattice"],
+                       "ring_slots": info["ring_slots"], "sweep_waves": info["num_jobs"],
+                       "topological_depth": args.states, "sharding": "utterances across ranks, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "klat::sweep_kernel (forward+backward lockstep sweep)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_avg},
+            "roofline_step": {"bound": "hbm", "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_step": step_bytes},
+            "kernel_ms": {"sweep": sweep_avg, "posterior": float(np.mean(post_ms)),
+                          "convert": float(np.mean(conv_ms)), "device_total": float(np.mean(tot_ms))},
+            "pack_seconds_host": pack_s,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ns, fo, args.seed, scales)
+        print(json.dumps(out))
+    batch.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+/*
+ * klat.h -- C ABI of the MI355X-native lattice forward-backward / posterior path.
+ *
+ * The reference (jpuigcerver/kaldi-lattice-utils) has no FFI layer; the hot path sits behind
+ * two de-facto interfaces:
+ *   B2  double ComputeLatticeAlphasAndBetas(const CompactLattice&, bool viterbi,
+ *                                           vector<double>* alpha, vector<double>* beta)
+ *       int32 CompactLatticeStateTimes(const CompactLattice&, vector<int32>* times)
+ *       as called at latbin/lattice-to-word-frame-post.cc:84-90,
+ *       kwsbin2/lattice-word-index-segment.cc:62-63, kwsbin2/lattice-word-index-position.cc:66-67
+ *   B1  the command lines of lattice-to-word-frame-post / lattice-word-index-{segment,position}.
+ * This header is what a maintainer binds in place of B2; the C++ mirror
+ * with the reference's own names lives in kaldi-lattice-utils_amd/host/lattice-functions.h.
+ *
+ * Conventions: plain pointers and sizes, caller owns every host buffer, device memory is
+ * owned by opaque handles, no C++ exceptions cross the boundary.  Every function returns
+ * KLAT_OK (0) or an error code; klat_last_error() gives the thread-local message.
+ * One klat_ctx per host thread (it owns a HIP stream): calls on different contexts are
+ * re-entrant, which is what TaskSequencer-style callers need
+ * (kwsbin2/lattice-word-index-segment.cc:260-275).
+ */
+#ifndef KLAT_H_
+#define KLAT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KLAT_OK 0
+#define KLAT_ERR_INVALID_ARG 1   /* null pointer, negative size, bad option */
+#define KLAT_ERR_BAD_TOPOLOGY 2  /* arc with dst <= src or out of range: not top-sorted (KALDI_ERR in the reference) */
+#define KLAT_ERR_HIP 3           /* HIP runtime error; message has the hipError string */
+#define KLAT_ERR_NO_DEVICE 4     /* HIP extension present but no usable GPU */
+#define KLAT_ERR_OOM 5
+#define KLAT_ERR_STATE 6         /* call order violated (e.g. results requested before a sweep) */
+#define KLAT_ERR_TIMES 7         /* inconsistent state times (KALDI_ASSERT in CompactLatticeStateTimes) */
+
+typedef struct klat_ctx klat_ctx;
+typedef struct klat_batch klat_batch;
+
+/* A batch of top-sorted lattices, flattened CSR + SoA (float32 costs, int32 ids).
+ * Replaces the per-utterance `CompactLattice` argument of B2 (a1 in SURVEY.md 8a).
+ * Lattice u owns states [state_off[u], state_off[u+1]) and arcs [arc_off[u], arc_off[u+1]);
+ * src/dst are lattice-local state ids, the start state is local id 0 and every arc has
+ * dst > src (what TopSortCompactLatticeIfNeeded establishes, latbin/lattice-to-word-frame-post.cc:80).
+ * Arcs of one lattice must be grouped by src in stored order (the order the reference's
+ * ArcIterator visits them, needed by the first-maximum rule of
+ * kwsbin2/lattice-word-index-position.cc:178).
+ * final_graph/final_acoustic: +inf,+inf marks a non-final state (Weight::Zero()). */
+typedef struct {
+  int32_t num_lattices;
+  const int64_t* state_off;     /* [num_lattices+1] */
+  const int64_t* arc_off;       /* [num_lattices+1] */
+  const int32_t* src;           /* [A] */
+  const int32_t* dst;           /* [A] */
+  const int32_t* ilabel;        /* [A] */
+  const int32_t* olabel;        /* [A] */
+  const float* graph;           /* [A]  Value1 */
+  const float* acoustic;        /* [A]  Value2 */
+  const float* final_graph;     /* [S] */
+  const float* final_acoustic;  /* [S] */
+  const int32_t* state_time;    /* [S]  CompactLatticeStateTimes; may be NULL if no accumulator is used */
+} klat_batch_desc;
+
+/* Options of the three tools that reach the sweep. */
+typedef struct {
+  float graph_scale;        /* --graph-scale       default 1.0 */
+  float acoustic_scale;     /* --acoustic-scale    default 1.0 */
+  float insertion_penalty;  /* --insertion-penalty default 0.0 */
+} klat_scales;
+
+/* Packing options (device layout of the lockstep arc streams, DESIGN.md "Data layout"). */
+typedef struct {
+  int32_t lanes_per_lattice; /* G in {1,2,4,8,16,32,64}; 0 = choose from the batch shape */
+  int32_t ring_slots;        /* W, power of two in [8,1024]; 0 = choose from the batch */
+  int32_t host_threads;      /* threads used by the host packer; 0 = hardware concurrency */
+} klat_pack_options;
+
+typedef struct {
+  int64_t num_states, num_arcs;       /* totals over the batch */
+  int64_t fwd_slots, bwd_slots;       /* arc-stream slots incl. padding (12 B each) */
+  int64_t far_terms;                  /* stream terms whose source fell outside the LDS ring */
+  int32_t lanes_per_lattice, ring_slots;
+  int32_t num_jobs;                   /* waves launched by the sweep kernel */
+  int32_t max_rounds;                 /* longest lockstep stream, in rounds */
+} klat_batch_info;
+
+/* Per-kernel device times of the last klat_forward_backward (HIP events on the ctx stream). */
+typedef struct {
+  float sweep_ms;      /* forward+backward lockstep sweep kernel */
+  float totals_ms;     /* per-lattice total kernel */
+  float posterior_ms;  /* arc posterior kernel */
+  float convert_ms;    /* alpha/beta natural-log conversion kernel */
+  float total_ms;      /* first event to last event */
+} klat_timings;
+
+const char* klat_last_error(void);
+const char* klat_version(void);
+int klat_device_count(int* count);
+
+int klat_ctx_create(int device, klat_ctx** out);
+void klat_ctx_destroy(klat_ctx* ctx);
+int klat_ctx_sync(klat_ctx* ctx);
+/* the ctx's hipStream_t, for callers that enqueue their own work or events behind it */
+void* klat_ctx_stream(klat_ctx* ctx);
+
+/* Validates (KLAT_ERR_BAD_TOPOLOGY on a non-top-sorted lattice), builds the forward and
+ * backward lockstep arc streams on the host and uploads everything the sweeps need.
+ * The timed region of the reference starts after this point, too ("Timer does not include
+ * preprocessing time", kwsbin2/lattice-word-index-segment.cc:140-141). */
+int klat_batch_create(klat_ctx* ctx, const klat_batch_desc* desc, const klat_pack_options* opt,
+                      klat_batch** out);
+void klat_batch_destroy(klat_batch* batch);
+int klat_batch_get_info(const klat_batch* batch, klat_batch_info* info);
+
+/* a2+a3+a7+a8: ScaleLattice / AddWordInsPen fused into the cost load, forward and backward
+ * sweeps, per-lattice total = 0.5*(tot_fwd+tot_bwd), per-arc log posterior
+ * alpha[src] - cost + beta[dst] - total, alpha/beta in natural log.  Asynchronous on the
+ * ctx stream; results stay on the device until fetched. */
+int klat_forward_backward(klat_batch* batch, const klat_scales* scales);
+int klat_get_timings(const klat_batch* batch, klat_timings* t);
+
+/* Synchronising fetches (device -> caller's host buffers); any pointer may be NULL.
+ * alpha/beta: [S] doubles, -inf for unreachable / non-coaccessible states.
+ * total: [num_lattices]; tot_fwd/tot_bwd as the reference's warning compares them. */
+int klat_get_alpha_beta(klat_batch* batch, double* alpha, double* beta);
+int klat_get_totals(klat_batch* batch, double* total, double* tot_fwd, double* tot_bwd);
+int klat_get_arc_logpost(klat_batch* batch, double* logpost /* [A] */);
+
+/* ---- second stage: the reference's accumulators over the same batch (a10/a11/a12) ----
+ * Label filter of kwsbin2/lattice-word-index-segment.cc:148-154: label != 0 and
+ * (include non-empty ? label in include : label not in exclude). */
+typedef struct {
+  const int32_t* include; int32_t num_include;
+  const int32_t* exclude; int32_t num_exclude;
+} klat_label_filter;
+
+typedef struct { int32_t label, t0, t1, pad; double logp; } klat_segment_record;            /* 24 B */
+typedef struct { int32_t label, pos, t0, t1; double logp; } klat_position_record;           /* 24 B */
+
+/* Segment index (kwsbin2/lattice-word-index-segment.cc:143-174,98-126): one record per
+ * distinct (olabel,t0,t1) per lattice, logp = LogAdd over its arcs - total, records of a
+ * lattice sorted by (logp desc, label, t0, t1).  record_off[num_lattices+1] receives the
+ * per-lattice ranges; returns the record count through *num_records.  Call once with
+ * records == NULL to size the output. */
+int klat_segment_index(klat_batch* batch, const klat_label_filter* filter,
+                       int64_t* record_off, klat_segment_record* records, int64_t capacity,
+                       int64_t* num_records);
+
+/* Position index (kwsbin2/lattice-word-index-position.cc:144-187,100-127): state_len[S] is
+ * the per-state input length from DisambiguateStateInputSequenceLength
+ * (fstext/fstext-utils2.h:170-175); key (olabel, state_len[src]); value LogAdd sum plus the
+ * (t0,t1) of the first arc attaining the maximum; pos emitted 1-based; sort (logp desc,
+ * label, pos). */
+int klat_position_index(klat_batch* batch, const int32_t* state_len,
+                        const klat_label_filter* filter, int64_t* record_off,
+                        klat_position_record* records, int64_t capacity, int64_t* num_records);
+
+/* Frame posteriors (latbin/lattice-to-word-frame-post.cc:93-135): for each lattice and frame
+ * k < num_frames[u] the (label, float32 logp) entries sorted by (logp desc, label asc).
+ * frame_off[sum(num_frames)+1] indexes entries; lattice u's frames start at
+ * frame_base[u] = sum_{v<u} num_frames[v]. */
+int klat_frame_post(klat_batch* batch, const int32_t* num_frames, int64_t* frame_off,
+                    int32_t* labels, float* logps, int64_t capacity, int64_t* num_entries);
+
+/* Host-only view of the packed lockstep streams (no device needed): what klat_batch_create
+ * uploads.  jobs: 24-byte records {int64 chunk_off; int32 nchunks, dir, lane_tab, pad};
+ * lanes: 16-byte records {int64 state_base; int32 num_states, lattice};
+ * items: 16-byte records {int64 arc_begin; int32 count, lattice}.  Stream slot of
+ * (chunk c, lane l, round r) is ((chunk_off + c) * 64 + l) * 4 + r. */
+typedef struct klat_packed klat_packed;
+int klat_pack_host(const klat_batch_desc* desc, const klat_pack_options* opt, klat_packed** out);
+void klat_packed_destroy(klat_packed* p);
+int klat_packed_info(const klat_packed* p, klat_batch_info* info, int64_t* num_slots,
+                     int64_t* num_lane_infos, int64_t* num_items);
+int klat_packed_copy(const klat_packed* p, int32_t* sw, float* sg, float* sa, void* jobs,
+                     void* lanes, void* items);
+
+/* Synthetic lattice generator of SURVEY.md Appendix D (bench/test plumbing, host only).
+ * Fills caller-allocated arrays sized by klat_synth_sizes. */
+int klat_synth_sizes(int32_t num_lattices, const int32_t* num_states, const int32_t* fanout,
+                     int64_t* total_states, int64_t* total_arcs);
+int klat_synth_generate(uint64_t seed, int64_t first_utt_index, int32_t num_lattices,
+                        const int32_t* num_states, const int32_t* fanout, int64_t* state_off,
+                        int64_t* arc_off, int32_t* src, int32_t* dst, int32_t* ilabel,
+                        int32_t* olabel, float* graph, float* acoustic, float* final_graph,
+                        float* final_acoustic, int32_t* state_time, int32_t host_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KLAT_H_ */

@@ -1,0 +1,390 @@
+// klat_capi.cc -- the C ABI declared in include/klat.h (context, batch, sweep, fetches).
+//
+// There is no CPU fallback: every entry point that computes needs the HIP runtime and a GPU,
+// and fails loudly (KLAT_ERR_NO_DEVICE / KLAT_ERR_HIP) otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/klat.h"
+#include "klat_internal.h"
+
+namespace klat {
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return set_error(e == hipErrorOutOfMemory ? KLAT_ERR_OOM : KLAT_ERR_HIP,
+                   std::string(what) + ": " + hipGetErrorString(e));
+}
+
+}  // namespace klat
+
+using namespace klat;
+
+extern "C" {
+
+const char* klat_last_error(void) { return g_last_error.c_str(); }
+const char* klat_version(void) { return "klat 0.1 (gfx950)"; }
+
+int klat_device_count(int* count) {
+  if (!count) return set_error(KLAT_ERR_INVALID_ARG, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return set_error(KLAT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return KLAT_OK;
+}
+
+int klat_ctx_create(int device, klat_ctx** out) {
+  if (!out) return set_error(KLAT_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(KLAT_ERR_NO_DEVICE,
+                     "no HIP device available: the lattice forward-backward path has no CPU fallback");
+  if (device < 0 || device >= n) return set_error(KLAT_ERR_INVALID_ARG, "device index out of range");
+  KLAT_HIP(hipSetDevice(device));
+  klat_ctx* c = new (std::nothrow) klat_ctx();
+  if (!c) return set_error(KLAT_ERR_OOM, "host allocation failed");
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return hip_fail(e, "hipStreamCreate");
+  }
+  for (int i = 0; i < 5; ++i) {
+    e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+      delete c;
+      return hip_fail(e, "hipEventCreate");
+    }
+  }
+  *out = c;
+  return KLAT_OK;
+}
+
+void klat_ctx_destroy(klat_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < 5; ++i)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int klat_ctx_sync(klat_ctx* c) {
+  if (!c) return set_error(KLAT_ERR_INVALID_ARG, "ctx is null");
+  KLAT_HIP(hipSetDevice(c->device));
+  KLAT_HIP(hipStreamSynchronize(c->stream));
+  return KLAT_OK;
+}
+
+void* klat_ctx_stream(klat_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_options* opt,
+                      klat_batch** out) {
+  if (!c || !d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  klat_pack_options o = {0, 0, 0};
+  if (opt) o = *opt;
+  PackedBatch P;
+  std::string err;
+  int rc = pack_batch(*d, o, &P, &err);
+  if (rc != KLAT_OK) return set_error(rc, err);
+
+  KLAT_HIP(hipSetDevice(c->device));
+  klat_batch* b = new (std::nothrow) klat_batch();
+  if (!b) return set_error(KLAT_ERR_OOM, "host allocation failed");
+  b->ctx = c;
+  b->U = d->num_lattices;
+  b->S = b->U ? d->state_off[b->U] : 0;
+  b->A = b->U ? d->arc_off[b->U] : 0;
+  b->G = P.G;
+  b->W = P.W;
+  b->num_jobs = (int)P.jobs.size();
+  b->num_items = (int)P.items.size();
+  b->info.num_states = b->S;
+  b->info.num_arcs = b->A;
+  b->info.fwd_slots = P.fwd_slots;
+  b->info.bwd_slots = P.bwd_slots;
+  b->info.far_terms = P.far_terms;
+  b->info.lanes_per_lattice = P.G;
+  b->info.ring_slots = P.W;
+  b->info.num_jobs = b->num_jobs;
+  b->info.max_rounds = P.max_rounds;
+  b->h_state_off.assign(d->state_off, d->state_off + b->U + 1);
+  b->h_arc_off.assign(d->arc_off, d->arc_off + b->U + 1);
+
+#define UP(buf, ptr, n)                                              \
+  do {                                                               \
+    rc = b->buf.upload(ptr, (size_t)(n), c->stream);                 \
+    if (rc != KLAT_OK) {                                             \
+      klat_batch_destroy(b);                                         \
+      return rc;                                                     \
+    }                                                                \
+  } while (0)
+#define AL(buf, n)                                                   \
+  do {                                                               \
+    rc = b->buf.alloc((size_t)(n));                                  \
+    if (rc != KLAT_OK) {                                             \
+      klat_batch_destroy(b);                                         \
+      return rc;                                                     \
+    }                                                                \
+  } while (0)
+  UP(state_off, d->state_off, b->U + 1);
+  UP(arc_off, d->arc_off, b->U + 1);
+  UP(src, d->src, b->A);
+  UP(dst, d->dst, b->A);
+  UP(ilabel, d->ilabel, b->A);
+  if (d->olabel) UP(olabel, d->olabel, b->A);
+  UP(graph, d->graph, b->A);
+  UP(acoustic, d->acoustic, b->A);
+  if (d->state_time) UP(state_time, d->state_time, b->S);
+  UP(sw, P.sw.data(), P.sw.size());
+  UP(sg, P.sg.data(), P.sg.size());
+  UP(sa, P.sa.data(), P.sa.size());
+  UP(jobs, P.jobs.data(), P.jobs.size());
+  UP(lanes, P.lanes.data(), P.lanes.size());
+  UP(items, P.items.data(), P.items.size());
+  AL(fm, b->S);
+  AL(fe, b->S);
+  AL(bm, b->S);
+  AL(be, b->S);
+  AL(totf_m, b->U);
+  AL(totf_e, b->U);
+  AL(total, b->U);
+  AL(tot_fwd, b->U);
+  AL(tot_bwd, b->U);
+  AL(alpha, b->S);
+  AL(beta, b->S);
+  AL(logpost, b->A);
+#undef UP
+#undef AL
+  hipError_t e = hipStreamSynchronize(c->stream);  // uploads read pageable host memory of P
+  if (e != hipSuccess) {
+    klat_batch_destroy(b);
+    return hip_fail(e, "upload");
+  }
+  *out = b;
+  return KLAT_OK;
+}
+
+void klat_batch_destroy(klat_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  delete b;
+}
+
+int klat_batch_get_info(const klat_batch* b, klat_batch_info* info) {
+  if (!b || !info) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  *info = b->info;
+  return KLAT_OK;
+}
+
+int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  klat_scales s = {1.0f, 1.0f, 0.0f};
+  if (sc) s = *sc;
+  klat_ctx* c = b->ctx;
+  KLAT_HIP(hipSetDevice(c->device));
+  ScaleParams sp;
+  sp.gs = (double)s.graph_scale;
+  sp.as = (double)s.acoustic_scale;
+  sp.pen = s.insertion_penalty;
+  sp.scaled = (s.acoustic_scale != 1.0f || s.graph_scale != 1.0f) ? 1 : 0;
+  sp.penalized = (s.insertion_penalty != 0.0f) ? 1 : 0;
+  b->scales = s;
+
+  SweepArgs sa;
+  sa.jobs = b->jobs.p;
+  sa.lanes = b->lanes.p;
+  sa.sw = b->sw.p;
+  sa.sg = b->sg.p;
+  sa.sa = b->sa.p;
+  sa.fm = b->fm.p;
+  sa.fe = b->fe.p;
+  sa.bm = b->bm.p;
+  sa.be = b->be.p;
+  sa.totf_m = b->totf_m.p;
+  sa.totf_e = b->totf_e.p;
+  sa.sp = sp;
+  sa.ring_slots = b->W;
+
+  TotalsArgs ta;
+  ta.num_lattices = (int32_t)b->U;
+  ta.state_off = b->state_off.p;
+  ta.totf_m = b->totf_m.p;
+  ta.totf_e = b->totf_e.p;
+  ta.bm = b->bm.p;
+  ta.be = b->be.p;
+  ta.total = b->total.p;
+  ta.tot_fwd = b->tot_fwd.p;
+  ta.tot_bwd = b->tot_bwd.p;
+
+  PosteriorArgs pa;
+  pa.items = b->items.p;
+  pa.state_off = b->state_off.p;
+  pa.src = b->src.p;
+  pa.dst = b->dst.p;
+  pa.ilabel = b->ilabel.p;
+  pa.graph = b->graph.p;
+  pa.acoustic = b->acoustic.p;
+  pa.fm = b->fm.p;
+  pa.fe = b->fe.p;
+  pa.bm = b->bm.p;
+  pa.be = b->be.p;
+  pa.total = b->total.p;
+  pa.logpost = b->logpost.p;
+  pa.sp = sp;
+
+  ConvertArgs ca;
+  ca.num_states = b->S;
+  ca.fm = b->fm.p;
+  ca.fe = b->fe.p;
+  ca.bm = b->bm.p;
+  ca.be = b->be.p;
+  ca.alpha = b->alpha.p;
+  ca.beta = b->beta.p;
+
+  KLAT_HIP(hipEventRecord(c->ev[0], c->stream));
+  KLAT_HIP(launch_sweep(sa, b->num_jobs, b->G, c->stream));
+  KLAT_HIP(hipEventRecord(c->ev[1], c->stream));
+  KLAT_HIP(launch_totals(ta, c->stream));
+  KLAT_HIP(hipEventRecord(c->ev[2], c->stream));
+  KLAT_HIP(launch_posterior(pa, b->num_items, c->stream));
+  KLAT_HIP(hipEventRecord(c->ev[3], c->stream));
+  KLAT_HIP(launch_convert(ca, c->stream));
+  KLAT_HIP(hipEventRecord(c->ev[4], c->stream));
+  b->swept = true;
+  return KLAT_OK;
+}
+
+int klat_get_timings(const klat_batch* b, klat_timings* t) {
+  if (!b || !t) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  klat_ctx* c = b->ctx;
+  KLAT_HIP(hipSetDevice(c->device));
+  KLAT_HIP(hipEventSynchronize(c->ev[4]));
+  KLAT_HIP(hipEventElapsedTime(&t->sweep_ms, c->ev[0], c->ev[1]));
+  KLAT_HIP(hipEventElapsedTime(&t->totals_ms, c->ev[1], c->ev[2]));
+  KLAT_HIP(hipEventElapsedTime(&t->posterior_ms, c->ev[2], c->ev[3]));
+  KLAT_HIP(hipEventElapsedTime(&t->convert_ms, c->ev[3], c->ev[4]));
+  KLAT_HIP(hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[4]));
+  return KLAT_OK;
+}
+
+static int fetch(klat_batch* b, void* host, const void* dev, size_t bytes) {
+  if (!host || bytes == 0) return KLAT_OK;
+  KLAT_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+  return KLAT_OK;
+}
+
+int klat_get_alpha_beta(klat_batch* b, double* alpha, double* beta) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  int rc;
+  if ((rc = fetch(b, alpha, b->alpha.p, sizeof(double) * (size_t)b->S))) return rc;
+  if ((rc = fetch(b, beta, b->beta.p, sizeof(double) * (size_t)b->S))) return rc;
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
+  return KLAT_OK;
+}
+
+int klat_get_totals(klat_batch* b, double* total, double* tot_fwd, double* tot_bwd) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  int rc;
+  if ((rc = fetch(b, total, b->total.p, sizeof(double) * (size_t)b->U))) return rc;
+  if ((rc = fetch(b, tot_fwd, b->tot_fwd.p, sizeof(double) * (size_t)b->U))) return rc;
+  if ((rc = fetch(b, tot_bwd, b->tot_bwd.p, sizeof(double) * (size_t)b->U))) return rc;
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
+  return KLAT_OK;
+}
+
+int klat_get_arc_logpost(klat_batch* b, double* logpost) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  int rc;
+  if ((rc = fetch(b, logpost, b->logpost.p, sizeof(double) * (size_t)b->A))) return rc;
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
+  return KLAT_OK;
+}
+
+/* ---- host-only view of the packed streams (no device needed; used by the CPU-side tests
+ * that check the stream format against the oracle before any GPU time is spent) ---- */
+struct klat_packed {
+  klat::PackedBatch P;
+  klat_batch_info info;
+};
+
+int klat_pack_host(const klat_batch_desc* d, const klat_pack_options* opt, klat_packed** out) {
+  if (!d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  klat_pack_options o = {0, 0, 0};
+  if (opt) o = *opt;
+  klat_packed* p = new (std::nothrow) klat_packed();
+  if (!p) return set_error(KLAT_ERR_OOM, "host allocation failed");
+  std::string err;
+  int rc = pack_batch(*d, o, &p->P, &err);
+  if (rc != KLAT_OK) {
+    delete p;
+    return set_error(rc, err);
+  }
+  std::memset(&p->info, 0, sizeof(p->info));
+  p->info.num_states = d->num_lattices ? d->state_off[d->num_lattices] : 0;
+  p->info.num_arcs = d->num_lattices ? d->arc_off[d->num_lattices] : 0;
+  p->info.fwd_slots = p->P.fwd_slots;
+  p->info.bwd_slots = p->P.bwd_slots;
+  p->info.far_terms = p->P.far_terms;
+  p->info.lanes_per_lattice = p->P.G;
+  p->info.ring_slots = p->P.W;
+  p->info.num_jobs = (int32_t)p->P.jobs.size();
+  p->info.max_rounds = p->P.max_rounds;
+  *out = p;
+  return KLAT_OK;
+}
+
+void klat_packed_destroy(klat_packed* p) { delete p; }
+
+int klat_packed_info(const klat_packed* p, klat_batch_info* info, int64_t* num_slots,
+                     int64_t* num_lane_infos, int64_t* num_items) {
+  if (!p) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (info) *info = p->info;
+  if (num_slots) *num_slots = (int64_t)p->P.sw.size();
+  if (num_lane_infos) *num_lane_infos = (int64_t)p->P.lanes.size();
+  if (num_items) *num_items = (int64_t)p->P.items.size();
+  return KLAT_OK;
+}
+
+int klat_packed_copy(const klat_packed* p, int32_t* sw, float* sg, float* sa, void* jobs,
+                     void* lanes, void* items) {
+  if (!p) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (sw) std::memcpy(sw, p->P.sw.data(), p->P.sw.size() * sizeof(int32_t));
+  if (sg) std::memcpy(sg, p->P.sg.data(), p->P.sg.size() * sizeof(float));
+  if (sa) std::memcpy(sa, p->P.sa.data(), p->P.sa.size() * sizeof(float));
+  if (jobs) std::memcpy(jobs, p->P.jobs.data(), p->P.jobs.size() * sizeof(klat::SweepJob));
+  if (lanes) std::memcpy(lanes, p->P.lanes.data(), p->P.lanes.size() * sizeof(klat::LaneInfo));
+  if (items) std::memcpy(items, p->P.items.data(), p->P.items.size() * sizeof(klat::PostItem));
+  return KLAT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// klat_device.h -- structures shared by the host packer and the HIP kernels.
+//
+// Device data layout (DESIGN.md "Data layout in HBM"):
+//   * caller-order SoA arc arrays (src,dst,ilabel,olabel,graph,acoustic) -- the CSR-flattened
+//     batch exactly as klat_batch_desc hands it over;
+//   * two lockstep arc streams (forward: terms grouped by destination state in ascending
+//     order; backward: terms grouped by source state in descending order), sliced 64 lanes
+//     wide: a wave owns 64/G lattices, G lanes each; one *round* is one term per lane; four
+//     rounds of one lane are contiguous (16 B) so that every stream load is a 1 KiB
+//     dwordx4 wave access;
+//   * per-state scaled-linear values (mantissa double + int32 binary exponent) for both
+//     directions, natural-log alpha/beta, per-arc log posterior.
+#ifndef KLAT_DEVICE_H_
+#define KLAT_DEVICE_H_
+#include <stdint.h>
+
+namespace klat {
+
+// ---- stream term word -------------------------------------------------------------------
+// bits 0..26  rel   = target position - source position (>=1); 0 = constant-one source
+// bit  27     FAR   source is outside the LDS ring -> fetched from HBM/L2
+// bit  28     LAST  last round of this target state (uniform over the lattice's G lanes)
+// bit  29     WORD  ilabel != 0 (AddWordInsPenToCompactLattice applies)
+// bit  30     NIL   padding term, contributes log-zero
+static const uint32_t kRelMask = (1u << 27) - 1u;
+static const uint32_t kFar = 1u << 27;
+static const uint32_t kLast = 1u << 28;
+static const uint32_t kWord = 1u << 29;
+static const uint32_t kNil = 1u << 30;
+
+static const int kChunkRounds = 4;    // rounds per 16-byte lane load
+static const int kPrefetchChunks = 4; // register prefetch depth of the sweep kernel
+static const int kExpMin = -(1 << 29); // exponent tag of log-zero (mantissa 0)
+
+// One wave of the sweep kernel.
+struct SweepJob {
+  int64_t chunk_off;  // first chunk of this job's stream (chunk = 64 lanes x 4 rounds)
+  int32_t nchunks;    // multiple of kPrefetchChunks
+  int32_t dir;        // 0 forward, 1 backward
+  int32_t lane_tab;   // first LaneInfo of this job (64/G entries)
+  int32_t pad;
+};
+
+// One lattice inside a job.
+struct LaneInfo {
+  int64_t state_base;  // state_off[u]; -1 for an empty slot
+  int32_t num_states;  // S
+  int32_t lattice;     // u
+};
+
+// Work item of the posterior kernel: <=kPostItemArcs consecutive arcs of one lattice.
+struct PostItem {
+  int64_t arc_begin;
+  int32_t count;
+  int32_t lattice;
+};
+static const int kPostItemArcs = 1024;
+
+}  // namespace klat
+#endif

@@ -1,0 +1,91 @@
+// klat_internal.h -- definitions behind the opaque handles of include/klat.h.
+#ifndef KLAT_INTERNAL_H_
+#define KLAT_INTERNAL_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/klat.h"
+#include "klat_device.h"
+#include "klat_kernels.h"
+#include "klat_pack.h"
+
+namespace klat {
+
+int set_error(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define KLAT_HIP(expr)                                        \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) return ::klat::hip_fail(_e, #expr); \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) count = 1;  // keep pointers non-null for empty batches
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      return hip_fail(e, "hipMalloc");
+    }
+    return KLAT_OK;
+  }
+  int upload(const T* host, size_t count, hipStream_t s) {
+    int rc = alloc(count);
+    if (rc != KLAT_OK) return rc;
+    if (count == 0) return KLAT_OK;
+    hipError_t e = hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(H2D)");
+    return KLAT_OK;
+  }
+};
+
+}  // namespace klat
+
+struct klat_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+struct klat_batch {
+  klat_ctx* ctx = nullptr;
+  int64_t U = 0, S = 0, A = 0;
+  int G = 1, W = 8, num_jobs = 0, num_items = 0;
+  bool swept = false;
+  klat_scales scales = {1.f, 1.f, 0.f};
+  klat_batch_info info = {};
+  std::vector<int64_t> h_state_off, h_arc_off;
+  // caller-order CSR/SoA batch
+  klat::DevBuf<int64_t> state_off, arc_off;
+  klat::DevBuf<int32_t> src, dst, ilabel, olabel, state_time;
+  klat::DevBuf<float> graph, acoustic;
+  // lockstep streams
+  klat::DevBuf<int32_t> sw;
+  klat::DevBuf<float> sg, sa;
+  klat::DevBuf<klat::SweepJob> jobs;
+  klat::DevBuf<klat::LaneInfo> lanes;
+  klat::DevBuf<klat::PostItem> items;
+  // results
+  klat::DevBuf<double> fm, bm, totf_m, total, tot_fwd, tot_bwd, alpha, beta, logpost;
+  klat::DevBuf<int32_t> fe, be, totf_e;
+};
+
+#endif

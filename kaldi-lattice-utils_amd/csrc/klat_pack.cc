@@ -1,0 +1,321 @@
+// klat_pack.cc -- builds the forward / backward lockstep arc streams from the CSR batch.
+//
+// This is the "flatten" stage: it runs once per batch on the host, outside the timed region,
+// like the preprocessing the reference's own timers exclude
+// (kwsbin2/lattice-word-index-segment.cc:140-141 "Timer does not include preprocessing time").
+//
+// Forward stream of one lattice: for every position p = 0..S (p == S is a virtual super-final
+// state whose value is tot_forward), the terms (source position, cost) that feed it:
+//   p == 0        : the constant-one term (alpha[start] = 0)
+//   0 < p < S     : one term per in-arc (src -> p)
+//   p == S        : one term per final state s, cost = final weight
+// Backward stream: position q stands for state s = S-1-q; terms are the out-arcs of s (source
+// = position of dst) plus, if s is final, a constant-one term carrying the final cost.
+// A position with no term gets one NIL term so that every state is finalised exactly once.
+// Terms of a position are dealt to the lattice's G lanes round by round; the last round of a
+// position carries LAST on all G lanes.
+#include "klat_pack.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <thread>
+
+namespace klat {
+
+namespace {
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <class F>
+void parallel_for(int64_t n, int threads, F f) {
+  if (threads <= 1 || n < 2) {
+    for (int64_t i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::atomic<int64_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      int64_t i = next.fetch_add(1);
+      if (i >= n) break;
+      f(i);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+  for (auto& t : pool) t.join();
+}
+
+inline bool is_final(const klat_batch_desc& d, int64_t gs) {
+  return !(d.final_graph[gs] == INFINITY && d.final_acoustic[gs] == INFINITY);
+}
+
+}  // namespace
+
+int choose_lanes_per_lattice(int64_t U, int64_t S, int64_t A) {
+  if (U <= 0 || S <= 0) return 1;
+  // Enough lattices to give every SIMD several lane-per-lattice waves: no padding, G = 1.
+  const int64_t waves_g1 = 2 * ceil_div(U, 64);
+  if (waves_g1 >= 4096) return 1;
+  // Otherwise spread each state's terms over G lanes (shorter dependency chain per lattice).
+  const double fan = (double)A / (double)S;
+  int G = 1;
+  while (G < fan && G < 64) G *= 2;
+  while (G > 1 && 2 * ceil_div(U, 64 / G) > 8192) G /= 2;
+  return G;
+}
+
+int choose_ring_slots(int G, int64_t max_rel) {
+  const int LPW = 64 / G;
+  int cap = 8;
+  while (cap * 2 * LPW * 12 <= 24 * 1024 && cap < 1024) cap *= 2;  // <= 24 KiB LDS per wave
+  int W = 8;
+  while (W <= max_rel && W < cap) W *= 2;
+  return W;
+}
+
+int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBatch* out,
+               std::string* err) {
+  const int64_t U = d.num_lattices;
+  if (U < 0 || (U > 0 && (!d.state_off || !d.arc_off))) {
+    *err = "klat_batch_desc: null offsets";
+    return KLAT_ERR_INVALID_ARG;
+  }
+  const int64_t S_tot = U ? d.state_off[U] : 0, A_tot = U ? d.arc_off[U] : 0;
+  if (A_tot > 0 && (!d.src || !d.dst || !d.graph || !d.acoustic || !d.ilabel)) {
+    *err = "klat_batch_desc: null arc arrays";
+    return KLAT_ERR_INVALID_ARG;
+  }
+  if (S_tot > 0 && (!d.final_graph || !d.final_acoustic)) {
+    *err = "klat_batch_desc: null final-weight arrays";
+    return KLAT_ERR_INVALID_ARG;
+  }
+  int threads = opt.host_threads > 0 ? opt.host_threads : (int)std::thread::hardware_concurrency();
+  if (threads < 1) threads = 1;
+
+  int G = opt.lanes_per_lattice;
+  if (G == 0) G = choose_lanes_per_lattice(U, S_tot, A_tot);
+  if (G < 1 || G > 64 || (G & (G - 1))) {
+    *err = "lanes_per_lattice must be a power of two in [1,64]";
+    return KLAT_ERR_INVALID_ARG;
+  }
+  if (opt.ring_slots != 0 &&
+      (opt.ring_slots < 8 || opt.ring_slots > 1024 || (opt.ring_slots & (opt.ring_slots - 1)))) {
+    *err = "ring_slots must be a power of two in [8,1024]";
+    return KLAT_ERR_INVALID_ARG;
+  }
+  const int LPW = 64 / G;
+  const int D = kPrefetchChunks;
+
+  // ---- pass 1: validate, count rounds per lattice and direction ----
+  std::vector<int64_t> rf(U, 0), rb(U, 0);
+  std::atomic<int64_t> max_rel(1);
+  std::atomic<int> bad(0);
+  std::atomic<int64_t> bad_lat(-1);
+  parallel_for(U, threads, [&](int64_t u) {
+    const int64_t s0 = d.state_off[u], a0 = d.arc_off[u];
+    const int64_t S = d.state_off[u + 1] - s0, A = d.arc_off[u + 1] - a0;
+    if (S < 0 || A < 0 || S >= (int64_t)kRelMask || (S == 0 && A > 0)) {
+      bad = KLAT_ERR_INVALID_ARG;
+      bad_lat = u;
+      return;
+    }
+    if (S == 0) return;
+    std::vector<int32_t> in_cnt(S, 0), out_cnt(S, 0);
+    int64_t mr = 1;
+    int32_t prev_src = 0;
+    for (int64_t i = 0; i < A; ++i) {
+      const int32_t s = d.src[a0 + i], t = d.dst[a0 + i];
+      if (s < 0 || s >= S || t <= s || t >= S || s < prev_src) {
+        bad = (s < prev_src || s < 0 || s >= S) ? KLAT_ERR_INVALID_ARG : KLAT_ERR_BAD_TOPOLOGY;
+        bad_lat = u;
+        return;
+      }
+      prev_src = s;
+      in_cnt[t]++;
+      out_cnt[s]++;
+      mr = std::max<int64_t>(mr, t - s);
+    }
+    int64_t nfinal = 0, f = 0, b = 0;
+    for (int64_t s = 0; s < S; ++s) {
+      const bool fin = is_final(d, s0 + s);
+      if (fin) {
+        nfinal++;
+        mr = std::max<int64_t>(mr, S - s);
+      }
+      const int64_t nf = (s == 0) ? in_cnt[0] + 1 : std::max<int64_t>(in_cnt[s], 1);
+      const int64_t nb = std::max<int64_t>(out_cnt[s] + (fin ? 1 : 0), 1);
+      f += ceil_div(nf, G);
+      b += ceil_div(nb, G);
+    }
+    f += ceil_div(std::max<int64_t>(nfinal, 1), G);
+    rf[u] = f;
+    rb[u] = b;
+    int64_t cur = max_rel.load();
+    while (mr > cur && !max_rel.compare_exchange_weak(cur, mr)) {
+    }
+  });
+  if (bad.load() != 0) {
+    *err = "lattice " + std::to_string(bad_lat.load()) +
+           (bad.load() == KLAT_ERR_BAD_TOPOLOGY
+                ? ": arc with dst <= src or out of range (lattice is not topologically sorted)"
+                : ": malformed CSR (state ids out of range or arcs not grouped by source)");
+    return bad.load();
+  }
+  // The ring only has to cover arcs; final terms (rel = S - s) may be far without harm, so the
+  // automatic W follows the arcs' span, which pass 1 folded into max_rel together with finals.
+  int W = opt.ring_slots ? opt.ring_slots : choose_ring_slots(G, max_rel.load());
+
+  // ---- slicing: lattices of similar length share a wave ----
+  std::vector<int64_t> live;
+  for (int64_t u = 0; u < U; ++u)
+    if (d.state_off[u + 1] > d.state_off[u]) live.push_back(u);
+  struct ProtoJob {
+    int dir;
+    int64_t rounds;
+    std::vector<int64_t> lat;
+  };
+  std::vector<ProtoJob> proto;
+  for (int dir = 0; dir < 2; ++dir) {
+    const std::vector<int64_t>& r = dir ? rb : rf;
+    std::vector<int64_t> order(live);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r[a] > r[b]; });
+    for (size_t i = 0; i < order.size(); i += LPW) {
+      ProtoJob pj;
+      pj.dir = dir;
+      pj.rounds = r[order[i]];
+      for (size_t j = i; j < std::min(order.size(), i + (size_t)LPW); ++j) pj.lat.push_back(order[j]);
+      proto.push_back(std::move(pj));
+    }
+  }
+  std::stable_sort(proto.begin(), proto.end(),
+                   [](const ProtoJob& a, const ProtoJob& b) { return a.rounds > b.rounds; });
+
+  PackedBatch& P = *out;
+  P.G = G;
+  P.W = W;
+  P.jobs.resize(proto.size());
+  P.lanes.assign(proto.size() * LPW, LaneInfo{-1, 0, -1});
+  int64_t chunk_total = 0;
+  for (size_t j = 0; j < proto.size(); ++j) {
+    int64_t nch = ceil_div(proto[j].rounds, kChunkRounds);
+    nch = ceil_div(nch, D) * D;
+    P.jobs[j].chunk_off = chunk_total;
+    P.jobs[j].nchunks = (int32_t)nch;
+    P.jobs[j].dir = proto[j].dir;
+    P.jobs[j].lane_tab = (int32_t)(j * LPW);
+    P.jobs[j].pad = 0;
+    chunk_total += nch;
+    (proto[j].dir ? P.bwd_slots : P.fwd_slots) += nch * kChunkRounds * 64;
+    P.max_rounds = std::max<int32_t>(P.max_rounds, (int32_t)(nch * kChunkRounds));
+    for (size_t k = 0; k < proto[j].lat.size(); ++k) {
+      const int64_t u = proto[j].lat[k];
+      LaneInfo& li = P.lanes[j * LPW + k];
+      li.state_base = d.state_off[u];
+      li.num_states = (int32_t)(d.state_off[u + 1] - d.state_off[u]);
+      li.lattice = (int32_t)u;
+    }
+  }
+  const size_t nslots = (size_t)chunk_total * 64 * kChunkRounds;
+  P.sw.resize(nslots);
+  P.sg.resize(nslots);
+  P.sa.resize(nslots);
+
+  // ---- pass 2: fill ----
+  std::atomic<int64_t> far(0);
+  parallel_for((int64_t)proto.size(), threads, [&](int64_t j) {
+    const SweepJob& job = P.jobs[j];
+    const size_t b0 = (size_t)job.chunk_off * 64 * kChunkRounds;
+    const size_t n = (size_t)job.nchunks * 64 * kChunkRounds;
+    for (size_t i = 0; i < n; ++i) P.sw[b0 + i] = (int32_t)kNil;
+    std::memset(&P.sg[b0], 0, n * sizeof(float));
+    std::memset(&P.sa[b0], 0, n * sizeof(float));
+    int64_t far_local = 0;
+    auto slot_index = [&](int64_t r, int lane) -> size_t {
+      return b0 + (((size_t)(r / kChunkRounds) * 64 + lane) * kChunkRounds + (size_t)(r % kChunkRounds));
+    };
+    std::vector<int64_t> in_begin;
+    std::vector<int32_t> in_arc;
+    for (size_t k = 0; k < proto[j].lat.size(); ++k) {
+      const int64_t u = proto[j].lat[k];
+      const int64_t s0 = d.state_off[u], a0 = d.arc_off[u];
+      const int64_t S = d.state_off[u + 1] - s0, A = d.arc_off[u + 1] - a0;
+      const int lane0 = (int)k * G;
+      int64_t r = 0;  // next free round of this lattice
+      int64_t nterm = 0;
+      auto begin_pos = [&]() { nterm = 0; };
+      auto emit = [&](int64_t rel, bool word, float g, float a, bool nil) {
+        const int64_t rr = r + nterm / G;
+        const int lane = lane0 + (int)(nterm % G);
+        uint32_t w = nil ? kNil : (uint32_t)rel;
+        if (!nil && rel >= W) {
+          w |= kFar;
+          far_local++;
+        }
+        if (word) w |= kWord;
+        const size_t ix = slot_index(rr, lane);
+        P.sw[ix] = (int32_t)w;
+        P.sg[ix] = g;
+        P.sa[ix] = a;
+        nterm++;
+      };
+      auto end_pos = [&]() {
+        if (nterm == 0) emit(0, false, 0.f, 0.f, true);
+        const int64_t nr = ceil_div(nterm, G);
+        const int64_t lastr = r + nr - 1;
+        for (int g = 0; g < G; ++g) P.sw[slot_index(lastr, lane0 + g)] |= (int32_t)kLast;
+        r += nr;
+      };
+      if (job.dir == 0) {
+        // in-arc lists by counting sort on dst (stable: sources ascending)
+        in_begin.assign(S + 1, 0);
+        for (int64_t i = 0; i < A; ++i) in_begin[d.dst[a0 + i] + 1]++;
+        for (int64_t s = 0; s < S; ++s) in_begin[s + 1] += in_begin[s];
+        in_arc.resize(A);
+        {
+          std::vector<int64_t> cur(in_begin.begin(), in_begin.end() - 1);
+          for (int64_t i = 0; i < A; ++i) in_arc[cur[d.dst[a0 + i]]++] = (int32_t)i;
+        }
+        for (int64_t p = 0; p < S; ++p) {
+          begin_pos();
+          if (p == 0) emit(0, false, 0.f, 0.f, false);  // alpha[start] = 0
+          for (int64_t q = in_begin[p]; q < in_begin[p + 1]; ++q) {
+            const int64_t i = a0 + in_arc[q];
+            emit(p - d.src[i], d.ilabel[i] != 0, d.graph[i], d.acoustic[i], false);
+          }
+          end_pos();
+        }
+        begin_pos();  // virtual super-final state
+        for (int64_t s = 0; s < S; ++s)
+          if (is_final(d, s0 + s)) emit(S - s, false, d.final_graph[s0 + s], d.final_acoustic[s0 + s], false);
+        end_pos();
+      } else {
+        int64_t hi = A;  // arcs of state s are [lo,hi) scanning sources downwards
+        for (int64_t s = S - 1; s >= 0; --s) {
+          int64_t lo = hi;
+          while (lo > 0 && d.src[a0 + lo - 1] == s) --lo;
+          begin_pos();
+          if (is_final(d, s0 + s)) emit(0, false, d.final_graph[s0 + s], d.final_acoustic[s0 + s], false);
+          for (int64_t i = lo; i < hi; ++i)
+            emit(d.dst[a0 + i] - s, d.ilabel[a0 + i] != 0, d.graph[a0 + i], d.acoustic[a0 + i], false);
+          end_pos();
+          hi = lo;
+        }
+      }
+    }
+    far += far_local;
+  });
+  P.far_terms = far.load();
+
+  // ---- posterior work items ----
+  for (int64_t u = 0; u < U; ++u) {
+    const int64_t a0 = d.arc_off[u], a1 = d.arc_off[u + 1];
+    for (int64_t a = a0; a < a1; a += kPostItemArcs)
+      P.items.push_back(PostItem{a, (int32_t)std::min<int64_t>(kPostItemArcs, a1 - a), (int32_t)u});
+  }
+  return KLAT_OK;
+}
+
+}  // namespace klat

@@ -1,0 +1,164 @@
+"""GPU parity tests proper: every call goes through the C ABI (libklat.so) and is compared
+with the CPU oracle on the same inputs.  Tolerance: |delta log-prob| <= 1e-4 as north_star
+states (we assert 1e-8, the HIP path carries doubles); integer fields bit-exact."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import latfmt
+from oracle import oracle as orc
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kaldi-lattice-utils_amd", "python"))
+import klat_amd  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+GOLDEN = ["egs_word_lattice.ark.txt", "egs_expand_lattice.char.txt", "egs_expand_lattice2.char.txt",
+          "egs_char_lattice.lattice-format.ark.txt", "egs_ctc_input.lattice-format.txt"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert klat_amd.device_count() >= 1, "GPU tests need a GPU; there is no CPU fallback to hide behind"
+    c = klat_amd.Ctx(0)
+    yield c
+    c.close()
+
+
+def _arc_begin(arrays):
+    S = int(arrays["state_off"][-1])
+    gsrc = arrays["src"] + np.repeat(arrays["state_off"][:-1], np.diff(arrays["arc_off"]))
+    return np.concatenate([[0], np.cumsum(np.bincount(gsrc, minlength=S))]).astype(np.int64)
+
+
+def _oracle_batch(arrays, gs, as_, pen):
+    wa, wb, wt, wthr = orc.batch_fb_post(arrays["state_off"], arrays["arc_off"], _arc_begin(arrays), arrays["dst"],
+                                         arrays["ilabel"], arrays["graph"], arrays["acoustic"],
+                                         arrays["final_graph"], arrays["final_acoustic"], gs, as_, pen)
+    return wa, wb, wt, wthr - np.repeat(wt, np.diff(arrays["arc_off"]))
+
+
+def _check(got, want, tol=TOL):
+    assert got.shape == want.shape
+    assert np.array_equal(np.isneginf(got), np.isneginf(want)), "log-zero pattern differs"
+    assert not np.any(np.isnan(got))
+    fin = np.isfinite(want)
+    assert np.max(np.abs(got[fin] - want[fin]), initial=0.0) <= tol
+
+
+def _run_and_compare(ctx, arrays, G, W, scales):
+    batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=G, ring_slots=W)
+    batch.forward_backward(*scales)
+    alpha, beta = batch.alpha_beta()
+    total, tf, tb = batch.totals()
+    post = batch.arc_logpost()
+    info = batch.info()
+    batch.close()
+    wa, wb, wt, wpost = _oracle_batch(arrays, *scales)
+    _check(alpha, wa), _check(beta, wb), _check(total, wt), _check(post, wpost)
+    return info
+
+
+@pytest.mark.parametrize("G,W", [(1, 8), (2, 8), (4, 8), (8, 16), (16, 8), (32, 8), (64, 64), (0, 0)])
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (0.7, 0.1, 0.5)])
+def test_golden_lattices(ctx, golden_dir, G, W, scales):
+    lats = []
+    for name in GOLDEN:
+        lats += [latfmt.prepare(l) for l in latfmt.read_text_archive(os.path.join(golden_dir, name))]
+    _run_and_compare(ctx, klat_amd.concat_lattices(lats), G, W, scales)
+
+
+@pytest.mark.parametrize("G,W", [(1, 8), (1, 16), (4, 8), (4, 32), (16, 16), (64, 128)])
+def test_synthetic_ragged_batch(ctx, G, W):
+    rng = np.random.RandomState(7)
+    ns = np.concatenate([[1, 2, 3], rng.randint(4, 700, size=197)]).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4, 6], size=len(ns)).astype(np.int32)
+    arrays = klat_amd.synth(20260004, ns, fo)
+    info = _run_and_compare(ctx, arrays, G, W, (1.0, 0.1, 0.0))
+    if W == 8:
+        assert info["far_terms"] > 0  # the HBM re-read path for sources outside the ring ran
+
+
+def test_log_zero_states_and_infinite_costs(ctx):
+    """Unreachable and non-coaccessible states keep -inf (Appendix A.1); a +inf arc cost is a
+    zero weight; a lattice without any final state has total -inf."""
+    inf = np.inf
+    # lattice 0: 0->1->3(final), 0->2 (dead end), state 4 isolated; lattice 1: no finals
+    l0 = orc.lat_from_arcs(5, [(0, 1, 1, 1, 0.5, 0.25, 1), (0, 2, 2, 2, 1.0, 0.0, 1), (1, 3, 3, 3, 0.1, 0.2, 2),
+                               (1, 3, 4, 4, inf, inf, 2)], {3: (0.3, 0.0, 0)})
+    l1 = orc.lat_from_arcs(3, [(0, 1, 1, 1, 1.0, 0.0, 1), (1, 2, 2, 2, 1.0, 0.0, 1)], {})
+    arrays = klat_amd.concat_lattices([l0, l1])
+    for G in (1, 4):
+        batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=G, ring_slots=8)
+        batch.forward_backward()
+        alpha, beta = batch.alpha_beta()
+        total, tf, tb = batch.totals()
+        post = batch.arc_logpost()
+        batch.close()
+        wa, wb, wt, wpost = _oracle_batch(arrays, 1.0, 1.0, 0.0)
+        n0 = int(arrays["arc_off"][1])  # lattice 1 has total -inf: its posteriors are -inf - -inf in the reference
+        _check(alpha, wa), _check(beta, wb), _check(post[:n0], wpost[:n0])
+        assert np.all(np.isneginf(post[n0:]))
+        assert np.isneginf(alpha[4]) and np.isneginf(beta[2]) and np.isneginf(beta[4])
+        assert np.isneginf(post[3])
+        assert np.isneginf(total[1]) and np.isneginf(wt[1])
+        assert abs(total[0] - wt[0]) < TOL
+
+
+def test_bad_topology_is_reported(ctx):
+    arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
+    arrays["dst"][3] = 0
+    with pytest.raises(klat_amd.KlatError) as e:
+        klat_amd.Batch(ctx, arrays)
+    assert e.value.code == klat_amd.ERR_BAD_TOPOLOGY
+
+
+def test_results_before_sweep_is_an_error(ctx):
+    arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
+    b = klat_amd.Batch(ctx, arrays)
+    with pytest.raises(klat_amd.KlatError) as e:
+        b.alpha_beta()
+    assert e.value.code == klat_amd.ERR_STATE
+    b.close()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 2 shape (scaled to 2k lattices to keep the test short): size-independent
+    properties -- tot_fwd == tot_bwd, posterior flow conservation at every state, arcs out of
+    the start state carry total mass 1 -- plus oracle parity on a 64-lattice sample."""
+    U = 2000
+    ns = np.full(U, 2000, np.int32)
+    fo = np.full(U, 3, np.int32)
+    arrays = klat_amd.synth(20260001, ns, fo)
+    batch = klat_amd.Batch(ctx, arrays)
+    batch.forward_backward(1.0, 0.1, 0.0)
+    alpha, beta = batch.alpha_beta()
+    total, tf, tb = batch.totals()
+    post = batch.arc_logpost()
+    batch.close()
+    assert np.max(np.abs(tf - tb)) < 1e-7
+    S = int(arrays["state_off"][-1])
+    lat_of_arc = np.repeat(np.arange(U), np.diff(arrays["arc_off"]))
+    gsrc = arrays["src"] + arrays["state_off"][lat_of_arc]
+    gdst = arrays["dst"] + arrays["state_off"][lat_of_arc]
+    p = np.exp(post)
+    outflow = np.bincount(gsrc, weights=p, minlength=S)
+    inflow = np.bincount(gdst, weights=p, minlength=S)
+    gamma = np.exp(alpha + beta - np.repeat(total, np.diff(arrays["state_off"])))
+    last = arrays["state_off"][1:] - 1
+    first = arrays["state_off"][:-1]
+    interior = np.ones(S, bool)
+    interior[last] = False
+    assert np.max(np.abs(outflow[interior] - gamma[interior])) < 1e-9
+    interior[last] = True
+    interior[first] = False
+    assert np.max(np.abs(inflow[interior] - gamma[interior])) < 1e-9
+    assert np.max(np.abs(outflow[first] - 1.0)) < 1e-9
+    # oracle parity on a sample
+    sub = klat_amd.synth(20260001, ns[:64], fo[:64])
+    wa, wb, wt, wpost = _oracle_batch(sub, 1.0, 0.1, 0.0)
+    n_s, n_a = int(sub["state_off"][-1]), int(sub["arc_off"][-1])
+    _check(alpha[:n_s], wa, 1e-7), _check(beta[:n_s], wb, 1e-7), _check(post[:n_a], wpost, 1e-7)

@@ -1,0 +1,98 @@
+"""CPU-side checks of the host packer and of the scaled-linear sweep arithmetic: the packed
+streams (klat_pack_host, no GPU) are interpreted in Python and compared with the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import latfmt
+import stream_sim
+from oracle import oracle as orc
+
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kaldi-lattice-utils_amd", "python"))
+import klat_amd  # noqa: E402
+
+GOLDEN = ["egs_word_lattice.ark.txt", "egs_expand_lattice.char.txt", "egs_expand_lattice2.char.txt",
+          "egs_char_lattice.lattice-format.ark.txt", "egs_ctc_input.lattice-format.txt"]
+
+
+def _golden_lats(golden_dir):
+    lats = []
+    for name in GOLDEN:
+        for lat in latfmt.read_text_archive(os.path.join(golden_dir, name)):
+            lats.append(latfmt.prepare(lat))
+    return lats
+
+
+def _oracle(lats, gs=1.0, as_=1.0, pen=0.0):
+    al, be, tf, tb = [], [], [], []
+    for lat in lats:
+        sl = orc.scale_and_penalize(lat, gs, as_, pen)
+        a, b, tot, f, bw = orc.alphas_betas(sl)
+        al.append(a), be.append(b), tf.append(f), tb.append(bw)
+    return np.concatenate(al), np.concatenate(be), np.array(tf), np.array(tb)
+
+
+def _close(got, want, tol=1e-9):
+    assert got.shape == want.shape
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isneginf(got), np.isneginf(want))
+    assert np.max(np.abs(got[fin] - want[fin]), initial=0.0) < tol
+
+
+@pytest.mark.parametrize("G", [1, 2, 4, 16, 64])
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (0.7, 0.1, 0.5)])
+def test_golden_lattices_through_streams(golden_dir, G, scales):
+    lats = _golden_lats(golden_dir)
+    arrays = klat_amd.concat_lattices(lats)
+    packed = klat_amd.pack_host(arrays, lanes_per_lattice=G, ring_slots=8)
+    a, b, tf, tb = stream_sim.run(packed, arrays["state_off"], *scales)
+    wa, wb, wtf, wtb = _oracle(lats, *scales)
+    _close(a, wa), _close(b, wb), _close(tf, wtf), _close(tb, wtb)
+
+
+@pytest.mark.parametrize("G,W", [(1, 8), (4, 8), (4, 16), (8, 32)])
+def test_synthetic_lattices_through_streams(G, W):
+    ns = np.array([1, 2, 3, 40, 57, 64, 9, 33, 120], np.int32)
+    fo = np.array([3, 3, 2, 3, 4, 6, 1, 3, 3], np.int32)
+    arrays = klat_amd.synth(20260001, ns, fo)
+    packed = klat_amd.pack_host(arrays, lanes_per_lattice=G, ring_slots=W)
+    if W == 8:
+        assert packed["info"]["far_terms"] > 0  # span 8 arcs exercise the FAR path
+    a, b, tf, tb = stream_sim.run(packed, arrays["state_off"], 1.0, 0.1, 0.0)
+    ab = np.concatenate([[0], np.cumsum(np.bincount(arrays["src"] + np.repeat(arrays["state_off"][:-1], np.diff(arrays["arc_off"])),
+                                                 minlength=int(arrays["state_off"][-1])))]).astype(np.int64)
+    wa, wb, wt, wthr = orc.batch_fb_post(arrays["state_off"], arrays["arc_off"], ab, arrays["dst"], arrays["ilabel"],
+                                         arrays["graph"], arrays["acoustic"], arrays["final_graph"],
+                                         arrays["final_acoustic"], 1.0, 0.1, 0.0)
+    _close(a, wa, 1e-8), _close(b, wb, 1e-8)
+    _close(0.5 * (tf + tb), wt, 1e-8)
+
+
+def test_packer_rejects_bad_topology():
+    arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
+    bad = dict(arrays)
+    bad["dst"] = arrays["dst"].copy()
+    bad["dst"][3] = 0  # arc going backwards
+    with pytest.raises(klat_amd.KlatError) as e:
+        klat_amd.pack_host(bad, 1, 8)
+    assert e.value.code == klat_amd.ERR_BAD_TOPOLOGY
+    with pytest.raises(klat_amd.KlatError) as e:
+        klat_amd.pack_host(arrays, 3, 8)
+    assert e.value.code == klat_amd.ERR_INVALID_ARG
+
+
+def test_empty_batch_and_empty_lattice():
+    z = lambda dt: np.zeros(0, dt)
+    arrays = {"state_off": np.zeros(1, np.int64), "arc_off": np.zeros(1, np.int64), "src": z(np.int32),
+              "dst": z(np.int32), "ilabel": z(np.int32), "olabel": z(np.int32), "graph": z(np.float32),
+              "acoustic": z(np.float32), "final_graph": z(np.float32), "final_acoustic": z(np.float32)}
+    p = klat_amd.pack_host(arrays, 1, 8)
+    assert p["info"]["num_jobs"] == 0
+    # an empty lattice between two real ones gets no stream and no posterior items
+    a = klat_amd.synth(3, np.array([4, 6], np.int32), np.array([2, 2], np.int32))
+    a["state_off"] = np.array([0, 4, 4, 10], np.int64)
+    a["arc_off"] = np.array([0, int(a["arc_off"][1]), int(a["arc_off"][1]), int(a["arc_off"][2])], np.int64)
+    p = klat_amd.pack_host(a, 2, 8)
+    assert set(p["lanes"]["lattice"][p["lanes"]["state_base"] >= 0]) == {0, 2}
