@@ -162,12 +162,8 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   UP(jobs, P.jobs.data(), P.jobs.size());
   UP(lanes, P.lanes.data(), P.lanes.size());
   UP(items, P.items.data(), P.items.size());
-  AL(fm, b->S);
-  AL(fe, b->S);
-  AL(bm, b->S);
-  AL(be, b->S);
-  AL(totf_m, b->U);
-  AL(totf_e, b->U);
+  AL(fme, b->S + b->U);
+  AL(bme, b->S + b->U);
   AL(total, b->U);
   AL(tot_fwd, b->U);
   AL(tot_bwd, b->U);
@@ -205,8 +201,8 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
   ScaleParams sp;
-  sp.gs = (double)s.graph_scale;
-  sp.as = (double)s.acoustic_scale;
+  sp.gs_f = s.graph_scale;
+  sp.as_f = s.acoustic_scale;
   sp.pen = s.insertion_penalty;
   sp.scaled = (s.acoustic_scale != 1.0f || s.graph_scale != 1.0f) ? 1 : 0;
   sp.penalized = (s.insertion_penalty != 0.0f) ? 1 : 0;
@@ -218,22 +214,16 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.sw = b->sw.p;
   sa.sg = b->sg.p;
   sa.sa = b->sa.p;
-  sa.fm = b->fm.p;
-  sa.fe = b->fe.p;
-  sa.bm = b->bm.p;
-  sa.be = b->be.p;
-  sa.totf_m = b->totf_m.p;
-  sa.totf_e = b->totf_e.p;
+  sa.fme = b->fme.p;
+  sa.bme = b->bme.p;
   sa.sp = sp;
   sa.ring_slots = b->W;
 
   TotalsArgs ta;
   ta.num_lattices = (int32_t)b->U;
   ta.state_off = b->state_off.p;
-  ta.totf_m = b->totf_m.p;
-  ta.totf_e = b->totf_e.p;
-  ta.bm = b->bm.p;
-  ta.be = b->be.p;
+  ta.fme = b->fme.p;
+  ta.bme = b->bme.p;
   ta.total = b->total.p;
   ta.tot_fwd = b->tot_fwd.p;
   ta.tot_bwd = b->tot_bwd.p;
@@ -246,22 +236,13 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   pa.ilabel = b->ilabel.p;
   pa.graph = b->graph.p;
   pa.acoustic = b->acoustic.p;
-  pa.fm = b->fm.p;
-  pa.fe = b->fe.p;
-  pa.bm = b->bm.p;
-  pa.be = b->be.p;
+  pa.fme = b->fme.p;
+  pa.bme = b->bme.p;
+  pa.alpha = b->alpha.p;
+  pa.beta = b->beta.p;
   pa.total = b->total.p;
   pa.logpost = b->logpost.p;
   pa.sp = sp;
-
-  ConvertArgs ca;
-  ca.num_states = b->S;
-  ca.fm = b->fm.p;
-  ca.fe = b->fe.p;
-  ca.bm = b->bm.p;
-  ca.be = b->be.p;
-  ca.alpha = b->alpha.p;
-  ca.beta = b->beta.p;
 
   KLAT_HIP(hipEventRecord(c->ev[0], c->stream));
   KLAT_HIP(launch_sweep(sa, b->num_jobs, b->G, c->stream));
@@ -270,8 +251,6 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   KLAT_HIP(hipEventRecord(c->ev[2], c->stream));
   KLAT_HIP(launch_posterior(pa, b->num_items, c->stream));
   KLAT_HIP(hipEventRecord(c->ev[3], c->stream));
-  KLAT_HIP(launch_convert(ca, c->stream));
-  KLAT_HIP(hipEventRecord(c->ev[4], c->stream));
   b->swept = true;
   return KLAT_OK;
 }
@@ -281,12 +260,12 @@ int klat_get_timings(const klat_batch* b, klat_timings* t) {
   if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
-  KLAT_HIP(hipEventSynchronize(c->ev[4]));
+  KLAT_HIP(hipEventSynchronize(c->ev[3]));
   KLAT_HIP(hipEventElapsedTime(&t->sweep_ms, c->ev[0], c->ev[1]));
   KLAT_HIP(hipEventElapsedTime(&t->totals_ms, c->ev[1], c->ev[2]));
   KLAT_HIP(hipEventElapsedTime(&t->posterior_ms, c->ev[2], c->ev[3]));
-  KLAT_HIP(hipEventElapsedTime(&t->convert_ms, c->ev[3], c->ev[4]));
-  KLAT_HIP(hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[4]));
+  t->convert_ms = 0.0f;  // alpha/beta conversion is fused into the posterior kernel
+  KLAT_HIP(hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[3]));
   return KLAT_OK;
 }
 

@@ -22,11 +22,13 @@ namespace klat {
 // bit  28     LAST  last round of this target state (uniform over the lattice's G lanes)
 // bit  29     WORD  ilabel != 0 (AddWordInsPenToCompactLattice applies)
 // bit  30     NIL   padding term, contributes log-zero
+// bit  31     FIRST first round of this target state (uniform over the lattice's G lanes)
 static const uint32_t kRelMask = (1u << 27) - 1u;
 static const uint32_t kFar = 1u << 27;
 static const uint32_t kLast = 1u << 28;
 static const uint32_t kWord = 1u << 29;
 static const uint32_t kNil = 1u << 30;
+static const uint32_t kFirst = 1u << 31;  // first round of this target state (all G lanes)
 
 static const int kChunkRounds = 4;    // rounds per 16-byte lane load
 static const int kPrefetchChunks = 4; // register prefetch depth of the sweep kernel
@@ -48,11 +50,23 @@ struct LaneInfo {
   int32_t lattice;     // u
 };
 
-// Work item of the posterior kernel: <=kPostItemArcs consecutive arcs of one lattice.
+// Work item of the posterior kernel: <=kPostItemArcs consecutive arcs of one lattice plus a
+// slice of that lattice's states (whose alpha/beta it converts to natural log).
 struct PostItem {
   int64_t arc_begin;
   int32_t count;
   int32_t lattice;
+  int32_t state_begin;  // lattice-local
+  int32_t state_count;
+};
+
+// Per-state value in the scaled-linear domain: m * 2^e (m == 0 encodes log-zero).  One 16-byte
+// cell so that a state's value moves with a single dwordx4 access.  Lattice u's cells start at
+// state_off[u] + u: S cells for its states plus one for the forward sweep's virtual
+// super-final state (tot_forward).
+struct __attribute__((aligned(16))) MECell {
+  double m;
+  int64_t e;
 };
 static const int kPostItemArcs = 1024;
 

@@ -84,8 +84,8 @@ struct klat_batch {
   klat::DevBuf<klat::LaneInfo> lanes;
   klat::DevBuf<klat::PostItem> items;
   // results
-  klat::DevBuf<double> fm, bm, totf_m, total, tot_fwd, tot_bwd, alpha, beta, logpost;
-  klat::DevBuf<int32_t> fe, be, totf_e;
+  klat::DevBuf<klat::MECell> fme, bme;  // scaled-linear values, S+1 cells per lattice
+  klat::DevBuf<double> total, tot_fwd, tot_bwd, alpha, beta, logpost;
 };
 
 #endif

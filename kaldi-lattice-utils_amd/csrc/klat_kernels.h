@@ -9,7 +9,7 @@
 namespace klat {
 
 struct ScaleParams {
-  double gs, as;  // (double)(float)graph_scale, acoustic_scale
+  float gs_f, as_f;  // graph_scale, acoustic_scale (BaseFloat in the reference)
   float pen;
   int scaled;     // graph_scale != 1 || acoustic_scale != 1 (the reference's own test)
   int penalized;  // insertion_penalty != 0
@@ -21,9 +21,8 @@ struct SweepArgs {
   const int32_t* sw;  // stream term words
   const float* sg;    // stream graph costs
   const float* sa;    // stream acoustic costs
-  double* fm; int32_t* fe;  // forward values per state (mantissa, exponent)
-  double* bm; int32_t* be;  // backward values per state
-  double* totf_m; int32_t* totf_e;  // forward total per lattice (virtual super-final state)
+  MECell* fme;  // forward values, S+1 cells per lattice (see MECell)
+  MECell* bme;  // backward values
   ScaleParams sp;
   int32_t ring_slots;
 };
@@ -31,8 +30,7 @@ struct SweepArgs {
 struct TotalsArgs {
   int32_t num_lattices;
   const int64_t* state_off;
-  const double* totf_m; const int32_t* totf_e;
-  const double* bm; const int32_t* be;
+  const MECell* fme; const MECell* bme;
   double* total; double* tot_fwd; double* tot_bwd;
 };
 
@@ -41,24 +39,16 @@ struct PosteriorArgs {
   const int64_t* state_off;
   const int32_t* src; const int32_t* dst; const int32_t* ilabel;
   const float* graph; const float* acoustic;
-  const double* fm; const int32_t* fe;
-  const double* bm; const int32_t* be;
+  const MECell* fme; const MECell* bme;
   const double* total;
   double* logpost;
+  double* alpha; double* beta;  // natural-log per-state outputs (B2 interface)
   ScaleParams sp;
-};
-
-struct ConvertArgs {
-  int64_t num_states;
-  const double* fm; const int32_t* fe;
-  const double* bm; const int32_t* be;
-  double* alpha; double* beta;
 };
 
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream);
 hipError_t launch_totals(const TotalsArgs& a, hipStream_t stream);
 hipError_t launch_posterior(const PosteriorArgs& a, int num_items, hipStream_t stream);
-hipError_t launch_convert(const ConvertArgs& a, hipStream_t stream);
 
 }  // namespace klat
 #endif

@@ -13,7 +13,8 @@
 // = position of dst) plus, if s is final, a constant-one term carrying the final cost.
 // A position with no term gets one NIL term so that every state is finalised exactly once.
 // Terms of a position are dealt to the lattice's G lanes round by round; the last round of a
-// position carries LAST on all G lanes.
+// position carries LAST on all G lanes, the first round FIRST.  Within a position the term whose
+// source was finished most recently comes last (it is the one on the dependency chain).
 #include "klat_pack.h"
 
 #include <algorithm>
@@ -70,7 +71,7 @@ int choose_lanes_per_lattice(int64_t U, int64_t S, int64_t A) {
 int choose_ring_slots(int G, int64_t max_rel) {
   const int LPW = 64 / G;
   int cap = 8;
-  while (cap * 2 * LPW * 12 <= 24 * 1024 && cap < 1024) cap *= 2;  // <= 24 KiB LDS per wave
+  while (cap * 2 * LPW * 16 <= 32 * 1024 && cap < 1024) cap *= 2;  // <= 32 KiB LDS per wave (16 B ring cells)
   int W = 8;
   while (W <= max_rel && W < cap) W *= 2;
   return W;
@@ -237,7 +238,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
       return b0 + (((size_t)(r / kChunkRounds) * 64 + lane) * kChunkRounds + (size_t)(r % kChunkRounds));
     };
     std::vector<int64_t> in_begin;
-    std::vector<int32_t> in_arc;
+    std::vector<int32_t> in_arc, out_ord;
     for (size_t k = 0; k < proto[j].lat.size(); ++k) {
       const int64_t u = proto[j].lat[k];
       const int64_t s0 = d.state_off[u], a0 = d.arc_off[u];
@@ -265,7 +266,10 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
         if (nterm == 0) emit(0, false, 0.f, 0.f, true);
         const int64_t nr = ceil_div(nterm, G);
         const int64_t lastr = r + nr - 1;
-        for (int g = 0; g < G; ++g) P.sw[slot_index(lastr, lane0 + g)] |= (int32_t)kLast;
+        for (int g = 0; g < G; ++g) {
+          P.sw[slot_index(r, lane0 + g)] |= (int32_t)kFirst;
+          P.sw[slot_index(lastr, lane0 + g)] |= (int32_t)kLast;
+        }
         r += nr;
       };
       if (job.dir == 0) {
@@ -298,7 +302,13 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
           while (lo > 0 && d.src[a0 + lo - 1] == s) --lo;
           begin_pos();
           if (is_final(d, s0 + s)) emit(0, false, d.final_graph[s0 + s], d.final_acoustic[s0 + s], false);
-          for (int64_t i = lo; i < hi; ++i)
+          // farthest destination first, nearest last: the term that depends on the most
+          // recently finished state is the last one to enter the accumulator
+          out_ord.resize(hi - lo);
+          for (int64_t i = lo; i < hi; ++i) out_ord[i - lo] = (int32_t)i;
+          std::stable_sort(out_ord.begin(), out_ord.end(),
+                           [&](int32_t x, int32_t y) { return d.dst[a0 + x] > d.dst[a0 + y]; });
+          for (int32_t i : out_ord)
             emit(d.dst[a0 + i] - s, d.ilabel[a0 + i] != 0, d.graph[a0 + i], d.acoustic[a0 + i], false);
           end_pos();
           hi = lo;
@@ -312,8 +322,16 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   // ---- posterior work items ----
   for (int64_t u = 0; u < U; ++u) {
     const int64_t a0 = d.arc_off[u], a1 = d.arc_off[u + 1];
-    for (int64_t a = a0; a < a1; a += kPostItemArcs)
-      P.items.push_back(PostItem{a, (int32_t)std::min<int64_t>(kPostItemArcs, a1 - a), (int32_t)u});
+    const int64_t S = d.state_off[u + 1] - d.state_off[u];
+    if (S == 0) continue;
+    const int64_t K = std::max<int64_t>(1, ceil_div(a1 - a0, kPostItemArcs));
+    const int64_t per = ceil_div(S, K);
+    for (int64_t k = 0; k < K; ++k) {
+      const int64_t a = a0 + k * kPostItemArcs;
+      const int64_t sb = std::min(S, k * per), se = std::min(S, (k + 1) * per);
+      P.items.push_back(PostItem{a, (int32_t)std::max<int64_t>(0, std::min<int64_t>(kPostItemArcs, a1 - a)),
+                                 (int32_t)u, (int32_t)sb, (int32_t)(se - sb)});
+    }
   }
   return KLAT_OK;
 }

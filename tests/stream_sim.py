@@ -8,7 +8,7 @@ import math
 import numpy as np
 
 REL_MASK = (1 << 27) - 1
-FAR, LAST, WORD, NIL = 1 << 27, 1 << 28, 1 << 29, 1 << 30
+FAR, LAST, WORD, NIL, FIRST = 1 << 27, 1 << 28, 1 << 29, 1 << 30, 1 << 31
 EXP_MIN = -(1 << 29)
 LOG2E = 1.4426950408889634
 LN2 = 0.6931471805599453
@@ -58,6 +58,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
             ring = {}
             p = 0
             accs = [(0.0, EXP_MIN)] * G
+            nround = 0
             for r in range(int(job["nchunks"]) * 4):
                 last = False
                 for sub in range(G):
@@ -67,6 +68,10 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                     if base < 0:
                         assert w == NIL, "empty slot must hold NIL terms only"
                         continue
+                    if p >= (S if d else S + 1):
+                        assert w == NIL, "padding after the last state must be plain NIL"
+                        continue
+                    assert bool(w & FIRST) == (nround == 0), "FIRST marks exactly the first round of a state"
                     c = _cost(sg[ix], sa[ix], bool(w & WORD), graph_scale, acoustic_scale, insertion_penalty)
                     rel = w & REL_MASK
                     dead = not (c < 1e30)
@@ -96,8 +101,10 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                         last = True
                     else:
                         assert not last, "LAST must be uniform over the G lanes of a lattice"
+                nround += 1
                 if base < 0 or not last:
                     continue
+                nround = 0
                 M, E = accs[0]
                 for sub in range(1, G):
                     M, E = _acc(M, E, accs[sub][0], accs[sub][1])
