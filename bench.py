@@ -63,6 +63,23 @@ def cpu_baseline(ns, fo, seed, scales, target_seconds=12.0):
                       % (per_thread * cores, int(ns[0]), int(fo[0]), arcs, cores, dt)}
 
 
+def measured_traffic(G):
+    """HBM bytes per sweep launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    separate rocprofv3 runs of this same command, corrected as MI355X_MICROARCH.md prescribes;
+    condensed by tools/prof_summarize.py into profiles/*_hbm_traffic.json).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)
+    for f in reversed(files):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in t.items():
+            if "sweep_kernel<%d>" % G in k:
+                return {"bytes": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT)}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +157,7 @@ def main():
         sweep_bytes = 32.0 * A + 32.0 * S
         achieved = sweep_bytes / (sweep_avg * 1e-3) / 1e9
         step_bytes = 56.0 * A + 48.0 * S  # fb + arc posterior: 72 B/arc at fanout 3
+        traffic = measured_traffic(info["lanes_per_lattice"])
         out = {
             "metric": "lattice-arcs/sec (whole node) on forward-backward + arc posteriors",
             "value": value, "unit": "lattice-arcs/s", "n_gpus": world, "steps": args.steps,
@@ -153,7 +171,9 @@ def main():
                        "topological_depth": args.states, "sharding": "utterances across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "klat::sweep_kernel (forward+backward lockstep sweep)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
                          "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_avg},
             "roofline_step": {"bound": "hbm", "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s",

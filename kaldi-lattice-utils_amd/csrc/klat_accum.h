@@ -1,0 +1,38 @@
+// klat_accum.h -- argument block and launchers of the accumulate stage (klat_accum.hip).
+#ifndef KLAT_ACCUM_H_
+#define KLAT_ACCUM_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace klat {
+
+struct AccumArgs {
+  const int64_t* state_off;
+  const int64_t* arc_off;
+  const int64_t* scratch_off;  // [U+1], per-lattice scratch capacity = next_pow2(arcs)
+  const int32_t* src;
+  const int32_t* dst;
+  const int32_t* olabel;
+  const int32_t* state_time;
+  const int32_t* state_len;  // position index only
+  const double* logpost;
+  const int32_t* include;
+  int32_t num_include;
+  const int32_t* exclude;
+  int32_t num_exclude;
+  void* key_scratch;  // 16 B per slot
+  void* rec_scratch;  // 24 B per slot
+  int32_t* num_records;  // [U]
+};
+
+struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)
+  int32_t f0, f1, f2, f3;
+  double logp;
+};
+
+hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hipStream_t stream);
+hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
+                               OutRecord* out, hipStream_t stream);
+
+}  // namespace klat
+#endif

@@ -1,0 +1,350 @@
+// klat_accum.hip -- second stage: the reference's key accumulators over the arc posteriors.
+//
+//   segment index  kwsbin2/lattice-word-index-segment.cc:143-174 (acc[label][(t0,t1)] = LogAdd)
+//                  and :98-126 (sort by logp desc, label, t0, t1)
+//   position index kwsbin2/lattice-word-index-position.cc:144-187 (key (label,pos); LogAdd sum
+//                  plus the (t0,t1) of the FIRST arc attaining the maximum, strict '>' :178)
+//                  and :100-127 (pos 1-based, sort by logp desc, label, pos)
+//
+// The reference does this with two-level std::map inserts per arc.  Here one workgroup owns one
+// lattice: (1) filter arcs and emit 16-byte keys (label,t0,t1 | label,pos ; arc index),
+// (2) bitonic sort of the keys (LDS tiles of 2048 keys, global passes above that),
+// (3) each run of equal keys is folded in arc order with the reference's LogAdd (cutoff
+// log(DBL_EPSILON) included), (4) the folded records are bitonic-sorted by the reference's output
+// comparator.  Utterance-level parallelism (thousands of lattices) fills the chip; there is no
+// inter-workgroup communication.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "klat_accum.h"
+
+namespace klat {
+
+static constexpr int kAccThreads = 512;
+static constexpr int kKeyTile = 2048;  // 16-byte keys per LDS tile  (32 KiB)
+static constexpr int kRecTile = 1024;  // 24-byte records per LDS tile (24 KiB)
+
+// LogAdd(double,double) of SURVEY.md A.2, as the reference's accumulators call it.
+__device__ __forceinline__ double log_add(double x, double y) {
+  double diff;
+  if (x < y) {
+    diff = x - y;
+    x = y;
+  } else {
+    diff = y - x;
+  }
+  if (diff >= -36.04365338911715) return x + log1p(exp(diff));  // log(DBL_EPSILON)
+  return x;
+}
+
+__device__ __forceinline__ uint32_t bias(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+__device__ __forceinline__ int32_t unbias(uint32_t v) { return (int32_t)(v ^ 0x80000000u); }
+
+// descending double -> ascending uint64
+__device__ __forceinline__ uint64_t desc_key(double x) {
+  uint64_t b = (uint64_t)__double_as_longlong(x);
+  b = (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);  // ascending order key
+  return ~b;                                                           // flip: descending
+}
+__device__ __forceinline__ double desc_unkey(uint64_t k) {
+  uint64_t b = ~k;
+  b = (b & 0x8000000000000000ull) ? (b & 0x7FFFFFFFFFFFFFFFull) : ~b;
+  return __longlong_as_double((long long)b);
+}
+
+struct Key {  // 16 B
+  uint64_t a;  // segment: label|t0     position: label|pos
+  uint64_t b;  // segment: t1|arc       position: 0|arc
+};
+struct Rec {  // 24 B
+  uint64_t k0;  // desc_key(logp)
+  uint64_t k1;  // segment: label|t0    position: label|pos
+  uint64_t k2;  // segment: t1|0        position: t0|t1 (payload, not compared)
+};
+
+struct KeyLess {
+  __device__ bool operator()(const Key& x, const Key& y) const { return x.a < y.a || (x.a == y.a && x.b < y.b); }
+};
+template <bool USE_K2>
+struct RecLess {
+  __device__ bool operator()(const Rec& x, const Rec& y) const {
+    if (x.k0 != y.k0) return x.k0 < y.k0;
+    if (x.k1 != y.k1) return x.k1 < y.k1;
+    return USE_K2 ? (x.k2 < y.k2) : false;
+  }
+};
+
+// In-place bitonic sort of n (power of two) elements at `data` (global) by one workgroup.
+// Passes with stride < TILE run inside an LDS tile.
+template <class T, int TILE, class Less>
+__device__ void block_bitonic_sort(T* data, int n, T* tile, Less less) {
+  const int tid = threadIdx.x;
+  if (n <= TILE) {  // whole sort inside LDS
+    for (int i = tid; i < n; i += kAccThreads) tile[i] = data[i];
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < n; i += kAccThreads) {
+          const int l = i ^ j;
+          if (l > i) {
+            const T x = tile[i], y = tile[l];
+            const bool up = (i & k) == 0;
+            if (up ? less(y, x) : less(x, y)) {
+              tile[i] = y;
+              tile[l] = x;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < n; i += kAccThreads) data[i] = tile[i];
+    __syncthreads();
+    return;
+  }
+  for (int k = 2; k <= n; k <<= 1) {
+    int j = k >> 1;
+    for (; j >= TILE; j >>= 1) {  // global passes
+      for (int i = tid; i < n; i += kAccThreads) {
+        const int l = i ^ j;
+        if (l > i) {
+          const T x = data[i], y = data[l];
+          const bool up = (i & k) == 0;
+          if (up ? less(y, x) : less(x, y)) {
+            data[i] = y;
+            data[l] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // remaining strides of this k inside LDS tiles
+    const int tl = TILE;
+    for (int base = 0; base < n; base += tl) {
+      for (int i = tid; i < tl; i += kAccThreads) tile[i] = data[base + i];
+      __syncthreads();
+      for (int jj = j; jj > 0; jj >>= 1) {
+        for (int i = tid; i < tl; i += kAccThreads) {
+          const int l = i ^ jj;
+          if (l > i) {
+            const T x = tile[i], y = tile[l];
+            const bool up = ((base + i) & k) == 0;
+            if (up ? less(y, x) : less(x, y)) {
+              tile[i] = y;
+              tile[l] = x;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      for (int i = tid; i < tl; i += kAccThreads) data[base + i] = tile[i];
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ bool in_sorted(const int32_t* set, int n, int32_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (set[mid] < v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < n && set[lo] == v;
+}
+
+// block-wide exclusive prefix of a 0/1 flag; returns the thread's offset, *total the block sum
+__device__ int block_compact_offset(bool flag, int* total, int* sh /* [kAccThreads/64 + 1] */) {
+  const uint64_t ballot = __ballot(flag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int within = __popcll(ballot & ((1ull << lane) - 1ull));
+  if (lane == 0) sh[wave] = __popcll(ballot);
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int w = 0; w < kAccThreads / 64; ++w) {
+    if (w < wave) off += sh[w];
+    tot += sh[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return off + within;
+}
+
+template <bool POSITION>
+__global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kKeyTile * sizeof(Key)];
+  __shared__ int sh[kAccThreads / 64 + 1];
+  __shared__ int s_count;
+  const int u = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t a0 = a.arc_off[u], a1 = a.arc_off[u + 1];
+  const int64_t s0 = a.state_off[u];
+  const int nA = (int)(a1 - a0);
+  Key* keys = reinterpret_cast<Key*>(a.key_scratch) + a.scratch_off[u];
+  Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + a.scratch_off[u];
+  const int cap = (int)(a.scratch_off[u + 1] - a.scratch_off[u]);  // power of two >= nA (or 0)
+
+  // ---- 1. filter + keys (compacted; order is fixed later by the arc index in the key) ----
+  int n = 0;
+  for (int base = 0; base < nA; base += kAccThreads) {
+    const int i = base + tid;
+    bool valid = false;
+    Key key;
+    key.a = key.b = 0;
+    if (i < nA) {
+      const int32_t label = a.olabel[a0 + i];
+      valid = label != 0 && ((a.num_include > 0 && in_sorted(a.include, a.num_include, label)) ||
+                             (a.num_include == 0 && !in_sorted(a.exclude, a.num_exclude, label)));
+      if (valid) {
+        const int32_t s = a.src[a0 + i], d = a.dst[a0 + i];
+        if (POSITION) {
+          key.a = ((uint64_t)bias(label) << 32) | bias(a.state_len[s0 + s]);
+          key.b = (uint32_t)i;
+        } else {
+          key.a = ((uint64_t)bias(label) << 32) | bias(a.state_time[s0 + s]);
+          key.b = ((uint64_t)bias(a.state_time[s0 + d]) << 32) | (uint32_t)i;
+        }
+      }
+    }
+    int tot;
+    const int off = block_compact_offset(valid, &tot, sh);
+    if (valid) keys[n + off] = key;
+    n += tot;
+  }
+  int np = 1;
+  while (np < n) np <<= 1;
+  if (n == 0) np = 0;
+  for (int i = n + tid; i < np; i += kAccThreads) {
+    Key pad;
+    pad.a = pad.b = ~0ull;
+    keys[i] = pad;
+  }
+  __syncthreads();
+  if (np > cap) {  // cannot happen: cap = next_pow2(arcs)
+    if (tid == 0) a.num_records[u] = -1;
+    return;
+  }
+
+  // ---- 2. sort keys ----
+  if (np > 1) block_bitonic_sort<Key, kKeyTile, KeyLess>(keys, np, reinterpret_cast<Key*>(smem), KeyLess());
+
+  // ---- 3. fold runs of equal keys in arc order ----
+  const uint64_t group_mask_b = POSITION ? 0ull : 0xFFFFFFFF00000000ull;
+  int m = 0;
+  for (int base = 0; base < n; base += kAccThreads) {
+    const int i = base + tid;
+    bool head = false;
+    Rec rec;
+    rec.k0 = rec.k1 = rec.k2 = 0;
+    if (i < n) {
+      const Key ki = keys[i];
+      head = (i == 0);
+      if (!head) {
+        const Key kp = keys[i - 1];
+        head = (kp.a != ki.a) || ((kp.b & group_mask_b) != (ki.b & group_mask_b));
+      }
+      if (head) {
+        int arc = (int)(uint32_t)ki.b;
+        double acc = a.logpost[a0 + arc];
+        double best = acc;
+        int best_arc = arc;
+        for (int j = i + 1; j < n; ++j) {
+          const Key kj = keys[j];
+          if (kj.a != ki.a || ((kj.b & group_mask_b) != (ki.b & group_mask_b))) break;
+          arc = (int)(uint32_t)kj.b;
+          const double x = a.logpost[a0 + arc];
+          acc = log_add(acc, x);
+          if (x > best) {  // strict: the first maximum in arc order wins
+            best = x;
+            best_arc = arc;
+          }
+        }
+        rec.k0 = desc_key(acc);
+        if (POSITION) {
+          const int32_t label = unbias((uint32_t)(ki.a >> 32));
+          const int32_t pos = unbias((uint32_t)ki.a) + 1;  // 1-based on output
+          rec.k1 = ((uint64_t)bias(label) << 32) | bias(pos);
+          const int32_t t0 = a.state_time[s0 + a.src[a0 + best_arc]];
+          const int32_t t1 = a.state_time[s0 + a.dst[a0 + best_arc]];
+          rec.k2 = ((uint64_t)(uint32_t)t0 << 32) | (uint32_t)t1;
+        } else {
+          rec.k1 = ki.a;
+          rec.k2 = ki.b & 0xFFFFFFFF00000000ull;
+        }
+      }
+    }
+    int tot;
+    const int off = block_compact_offset(head, &tot, sh);
+    if (head) recs[m + off] = rec;
+    m += tot;
+  }
+  int mp = 1;
+  while (mp < m) mp <<= 1;
+  if (m == 0) mp = 0;
+  for (int i = m + tid; i < mp; i += kAccThreads) {
+    Rec pad;
+    pad.k0 = pad.k1 = pad.k2 = ~0ull;
+    recs[i] = pad;
+  }
+  __syncthreads();
+
+  // ---- 4. sort by the reference's output comparator ----
+  if (mp > 1) {
+    if (POSITION)
+      block_bitonic_sort<Rec, kRecTile, RecLess<false>>(recs, mp, reinterpret_cast<Rec*>(smem), RecLess<false>());
+    else
+      block_bitonic_sort<Rec, kRecTile, RecLess<true>>(recs, mp, reinterpret_cast<Rec*>(smem), RecLess<true>());
+  }
+  if (tid == 0) a.num_records[u] = m;
+  (void)s_count;
+}
+
+// Gathers the per-lattice sorted records into the dense output (record_off computed on the host
+// from num_records).  Output record = {int32 f0,f1,f2,f3; double logp} (24 B):
+//   segment : label, t0, t1, 0        position : label, pos, t0, t1
+template <bool POSITION>
+__global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const int64_t* record_off, OutRecord* out) {
+  const int u = blockIdx.x;
+  const Rec* recs = reinterpret_cast<const Rec*>(a.rec_scratch) + a.scratch_off[u];
+  const int64_t o = record_off[u];
+  const int m = (int)(record_off[u + 1] - o);
+  for (int i = threadIdx.x; i < m; i += 256) {
+    const Rec r = recs[i];
+    OutRecord w;
+    w.logp = desc_unkey(r.k0);
+    w.f0 = unbias((uint32_t)(r.k1 >> 32));
+    w.f1 = unbias((uint32_t)r.k1);
+    if (POSITION) {
+      w.f2 = (int32_t)(uint32_t)(r.k2 >> 32);
+      w.f3 = (int32_t)(uint32_t)r.k2;
+    } else {
+      w.f2 = unbias((uint32_t)(r.k2 >> 32));
+      w.f3 = 0;
+    }
+    out[o + i] = w;
+  }
+}
+
+hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hipStream_t stream) {
+  if (num_lattices <= 0) return hipSuccess;
+  if (position)
+    hipLaunchKernelGGL(index_kernel<true>, dim3(num_lattices), dim3(kAccThreads), 0, stream, a);
+  else
+    hipLaunchKernelGGL(index_kernel<false>, dim3(num_lattices), dim3(kAccThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
+                               OutRecord* out, hipStream_t stream) {
+  if (num_lattices <= 0) return hipSuccess;
+  if (position)
+    hipLaunchKernelGGL(index_gather_kernel<true>, dim3(num_lattices), dim3(256), 0, stream, a, record_off, out);
+  else
+    hipLaunchKernelGGL(index_gather_kernel<false>, dim3(num_lattices), dim3(256), 0, stream, a, record_off, out);
+  return hipGetLastError();
+}
+
+}  // namespace klat

@@ -1,0 +1,141 @@
+// klat_accum_api.cc -- C ABI of the accumulate stage (segment / position index, frame
+// posteriors) declared in include/klat.h.  Device work is in klat_accum.hip; this file sizes
+// scratch, moves the small per-call inputs (label filter, state lengths) and the results.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/klat.h"
+#include "klat_accum.h"
+#include "klat_internal.h"
+
+using namespace klat;
+
+static_assert(sizeof(klat_segment_record) == 24 && sizeof(klat_position_record) == 24 &&
+                  sizeof(OutRecord) == 24,
+              "record layouts must agree");
+
+namespace {
+
+int64_t next_pow2(int64_t n) {
+  int64_t p = 1;
+  while (p < n) p <<= 1;
+  return n <= 0 ? 0 : p;
+}
+
+int ensure_index_scratch(klat_batch* b) {
+  klat_accum_state& st = b->accum;
+  if (st.scratch_ready) return KLAT_OK;
+  std::vector<int64_t> off(b->U + 1, 0);
+  for (int64_t u = 0; u < b->U; ++u) off[u + 1] = off[u] + next_pow2(b->h_arc_off[u + 1] - b->h_arc_off[u]);
+  st.scratch_slots = off[b->U];
+  int rc;
+  if ((rc = st.scratch_off.upload(off.data(), off.size(), b->ctx->stream))) return rc;
+  if ((rc = st.key_scratch.alloc((size_t)st.scratch_slots * 16))) return rc;
+  if ((rc = st.rec_scratch.alloc((size_t)st.scratch_slots * 24))) return rc;
+  if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
+  st.scratch_ready = true;
+  return KLAT_OK;
+}
+
+int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat_label_filter* f,
+              int64_t* record_off, void* records, int64_t capacity, int64_t* num_records) {
+  if (!b || !num_records || !record_off) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  if (b->S > 0 && b->state_time.n == 0)
+    return set_error(KLAT_ERR_INVALID_ARG, "the batch was created without state_time: the index accumulators need it");
+  if (b->A > 0 && b->olabel.n == 0)
+    return set_error(KLAT_ERR_INVALID_ARG, "the batch was created without olabel");
+  if (position && b->S > 0 && !state_len) return set_error(KLAT_ERR_INVALID_ARG, "state_len is null");
+  klat_ctx* c = b->ctx;
+  KLAT_HIP(hipSetDevice(c->device));
+  klat_accum_state& st = b->accum;
+  int rc = ensure_index_scratch(b);
+  if (rc != KLAT_OK) return rc;
+
+  AccumArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.state_off = b->state_off.p;
+  a.arc_off = b->arc_off.p;
+  a.scratch_off = st.scratch_off.p;
+  a.src = b->src.p;
+  a.dst = b->dst.p;
+  a.olabel = b->olabel.p;
+  a.state_time = b->state_time.p;
+  a.logpost = b->logpost.p;
+  a.key_scratch = st.key_scratch.p;
+  a.rec_scratch = st.rec_scratch.p;
+  a.num_records = st.num_records.p;
+
+  if (records == nullptr) {  // sizing call: compute and cache
+    klat_label_filter flt = {nullptr, 0, nullptr, 0};
+    if (f) flt = *f;
+    if (flt.num_include < 0 || flt.num_exclude < 0 || (flt.num_include > 0 && !flt.include) ||
+        (flt.num_exclude > 0 && !flt.exclude))
+      return set_error(KLAT_ERR_INVALID_ARG, "bad label filter");
+    std::vector<int32_t> inc(flt.include, flt.include + flt.num_include), exc(flt.exclude, flt.exclude + flt.num_exclude);
+    std::sort(inc.begin(), inc.end());
+    std::sort(exc.begin(), exc.end());
+    if ((rc = st.include.upload(inc.data(), inc.size(), c->stream))) return rc;
+    if ((rc = st.exclude.upload(exc.data(), exc.size(), c->stream))) return rc;
+    if (position && (rc = st.state_len.upload(state_len, (size_t)b->S, c->stream))) return rc;
+    a.include = st.include.p;
+    a.num_include = (int32_t)inc.size();
+    a.exclude = st.exclude.p;
+    a.num_exclude = (int32_t)exc.size();
+    a.state_len = st.state_len.p;
+    KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
+    std::vector<int32_t> counts((size_t)b->U);
+    if (b->U > 0)
+      KLAT_HIP(hipMemcpyAsync(counts.data(), st.num_records.p, sizeof(int32_t) * (size_t)b->U,
+                              hipMemcpyDeviceToHost, c->stream));
+    KLAT_HIP(hipStreamSynchronize(c->stream));
+    st.record_off.assign((size_t)b->U + 1, 0);
+    for (int64_t u = 0; u < b->U; ++u) {
+      if (counts[u] < 0) return set_error(KLAT_ERR_HIP, "index kernel: scratch overflow");
+      st.record_off[u + 1] = st.record_off[u] + counts[u];
+    }
+    st.cached_mode = position ? 2 : 1;
+    std::memcpy(record_off, st.record_off.data(), sizeof(int64_t) * ((size_t)b->U + 1));
+    *num_records = st.record_off[b->U];
+    return KLAT_OK;
+  }
+
+  // fetch call: gather the cached per-lattice records into the caller's dense array
+  if (st.cached_mode != (position ? 2 : 1))
+    return set_error(KLAT_ERR_STATE, "call with records == NULL first: it computes and sizes the index");
+  const int64_t total = st.record_off[b->U];
+  if (capacity < total) return set_error(KLAT_ERR_INVALID_ARG, "records capacity too small");
+  DevBuf<int64_t> d_off;
+  DevBuf<OutRecord> d_out;
+  if ((rc = d_off.upload(st.record_off.data(), st.record_off.size(), c->stream))) return rc;
+  if ((rc = d_out.alloc((size_t)total))) return rc;
+  KLAT_HIP(launch_index_gather(a, (int)b->U, position, d_off.p, d_out.p, c->stream));
+  if (total > 0)
+    KLAT_HIP(hipMemcpyAsync(records, d_out.p, sizeof(OutRecord) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipStreamSynchronize(c->stream));
+  std::memcpy(record_off, st.record_off.data(), sizeof(int64_t) * ((size_t)b->U + 1));
+  *num_records = total;
+  return KLAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int klat_segment_index(klat_batch* b, const klat_label_filter* f, int64_t* record_off,
+                       klat_segment_record* records, int64_t capacity, int64_t* num_records) {
+  return run_index(b, false, nullptr, f, record_off, records, capacity, num_records);
+}
+
+int klat_position_index(klat_batch* b, const int32_t* state_len, const klat_label_filter* f,
+                        int64_t* record_off, klat_position_record* records, int64_t capacity,
+                        int64_t* num_records) {
+  return run_index(b, true, state_len, f, record_off, records, capacity, num_records);
+}
+
+}  // extern "C"

@@ -65,7 +65,19 @@ struct klat_ctx {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
+// device scratch + cached result of the accumulate stage (klat_accum_api.cc)
+struct klat_accum_state {
+  bool scratch_ready = false;
+  int64_t scratch_slots = 0;
+  int cached_mode = 0;  // 0 none, 1 segment, 2 position
+  std::vector<int64_t> record_off;
+  klat::DevBuf<int64_t> scratch_off;
+  klat::DevBuf<unsigned char> key_scratch, rec_scratch;
+  klat::DevBuf<int32_t> num_records, include, exclude, state_len;
+};
+
 struct klat_batch {
+  klat_accum_state accum;
   klat_ctx* ctx = nullptr;
   int64_t U = 0, S = 0, A = 0;
   int G = 1, W = 8, num_jobs = 0, num_items = 0;

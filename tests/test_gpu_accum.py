@@ -1,0 +1,178 @@
+"""GPU parity of the accumulate stage (segment / position index, frame posteriors) through the
+C ABI, against the oracle and the reference's README vectors.  Comparison rule of SURVEY.md
+Appendix C.3: integer fields bit-exact, |delta logp| <= tol, order must be a valid sort under the
+reference comparator (records whose logp differ by <= tol may swap)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import latfmt
+from oracle import oracle as orc
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kaldi-lattice-utils_amd", "python"))
+import klat_amd  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert klat_amd.device_count() >= 1
+    c = klat_amd.Ctx(0)
+    yield c
+    c.close()
+
+
+def _fmt7(x):
+    s = "%.7g" % x
+    return "0" if float(s) == 0 else s
+
+
+def _split(arrays):
+    """klat_batch_desc arrays -> list of orc.Lat (for the oracle)."""
+    lats = []
+    for u in range(len(arrays["state_off"]) - 1):
+        s0, s1 = int(arrays["state_off"][u]), int(arrays["state_off"][u + 1])
+        a0, a1 = int(arrays["arc_off"][u]), int(arrays["arc_off"][u + 1])
+        S = s1 - s0
+        ab = np.concatenate([[0], np.cumsum(np.bincount(arrays["src"][a0:a1], minlength=S))]).astype(np.int64)
+        z = np.zeros(a1 - a0, np.int32)
+        lats.append(orc.Lat(ab, arrays["dst"][a0:a1].copy(), arrays["ilabel"][a0:a1].copy(),
+                            arrays["olabel"][a0:a1].copy(), arrays["graph"][a0:a1].copy(),
+                            arrays["acoustic"][a0:a1].copy(), z, arrays["final_graph"][s0:s1].copy(),
+                            arrays["final_acoustic"][s0:s1].copy(), np.zeros(S, np.int32)))
+    return lats
+
+
+def _check_sorted_records(got, want, nint, tol=TOL):
+    """got/want: lists of tuples (ints..., logp) for ONE lattice."""
+    assert len(got) == len(want)
+    gk = {g[:nint]: g[nint] for g in got}
+    assert len(gk) == len(got), "duplicate keys in GPU output"
+    for w in want:
+        assert w[:nint] in gk, "missing record %r" % (w[:nint],)
+        assert abs(gk[w[:nint]] - w[nint]) <= tol, (w, gk[w[:nint]])
+    # valid order: logp non-increasing up to tol, ties (within tol) may permute
+    for x, y in zip(got[:-1], got[1:]):
+        assert x[nint] >= y[nint] - tol
+        if x[nint] == y[nint]:
+            assert x[:nint] < y[:nint]
+
+
+def test_segment_index_readme_vector(ctx, golden_dir):
+    (lat,) = latfmt.read_text_archive(os.path.join(golden_dir, "egs_word_lattice.ark.txt"))
+    lat = latfmt.prepare(lat)
+    times, _, _ = orc.state_times(lat)
+    arrays = klat_amd.concat_lattices([lat], [times])
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward()
+    off, rec = b.segment_index()
+    b.close()
+    want = None
+    with open(os.path.join(golden_dir, "readme_expected.txt")) as f:
+        for line in f:
+            if line.startswith("segment "):
+                _, want = latfmt.parse_tuple_line(line.split(None, 1)[1], 3)
+    assert off.tolist() == [0, 10] and len(rec) == 10
+    # the 10 README records: integer fields exact, 7-digit text identical per key; records whose
+    # logp agree to rounding noise (the three P=0.8 arcs, ...) may swap
+    got = [(int(r["label"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in rec]
+    _check_sorted_records(got, want, 3, tol=5e-7)
+    gk = {g[:3]: g[3] for g in got}
+    for w in want:
+        assert _fmt7(gk[w[:3]]) == _fmt7(w[3]) or abs(gk[w[:3]] - w[3]) < 5e-8
+
+
+def test_position_index_readme_vector(ctx, golden_dir):
+    (lat,) = latfmt.read_text_archive(os.path.join(golden_dir, "egs_word_lattice.ark.txt"))
+    lat = latfmt.prepare(lat)
+    dlat, state_len, _ = orc.disambiguate_length(lat)  # host pre-pass a14 (oracle side in this test)
+    times, _, _ = orc.state_times(dlat)
+    arrays = klat_amd.concat_lattices([dlat], [times])
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward()
+    off, rec = b.position_index(state_len)
+    b.close()
+    with open(os.path.join(golden_dir, "readme_expected.txt")) as f:
+        for line in f:
+            if line.startswith("position "):
+                _, want = latfmt.parse_tuple_line(line.split(None, 1)[1], 4)
+    assert len(rec) == 9
+    got = sorted([(int(r["label"]), int(r["pos"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in rec])
+    for g, w in zip(got, sorted(want)):
+        assert g[:4] == w[:4]
+        assert abs(g[4] - w[4]) < 5e-7
+
+
+@pytest.mark.parametrize("G", [1, 4])
+@pytest.mark.parametrize("flt", [{}, {"exclude": [3, 7, 500]}, {"include": list(range(1, 200))}])
+def test_segment_index_synthetic(ctx, G, flt):
+    rng = np.random.RandomState(11)
+    ns = np.concatenate([[1, 2], rng.randint(3, 400, size=60), [5000]]).astype(np.int32)  # 5000x3 arcs > LDS tile
+    fo = rng.choice([1, 2, 3, 4], size=len(ns)).astype(np.int32)
+    fo[-1] = 3
+    arrays = klat_amd.synth(20260004, ns, fo)
+    # few distinct labels so that keys collide and runs get folded
+    arrays["olabel"] = (arrays["olabel"] % 7).astype(np.int32)
+    arrays["ilabel"] = arrays["olabel"].copy()
+    b = klat_amd.Batch(ctx, arrays, lanes_per_lattice=G)
+    b.forward_backward(1.0, 0.1, 0.0)
+    off, rec = b.segment_index(**flt)
+    b.close()
+    for u, lat in enumerate(_split(arrays)):
+        sl = orc.scale_and_penalize(lat, 1.0, 0.1, 0.0)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        t = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
+        want = orc.segment_index(sl, t, alpha, beta, total, **flt)
+        got = [(int(r["label"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in rec[off[u]:off[u + 1]]]
+        _check_sorted_records(got, want, 3)
+
+
+def test_position_index_synthetic(ctx):
+    rng = np.random.RandomState(5)
+    ns = rng.randint(2, 60, size=40).astype(np.int32)
+    fo = rng.choice([1, 2, 3], size=len(ns)).astype(np.int32)
+    arrays = klat_amd.synth(99, ns, fo)
+    arrays["olabel"] = (arrays["olabel"] % 5).astype(np.int32)
+    arrays["ilabel"] = arrays["olabel"].copy()
+    # disambiguate every lattice on the host (oracle side), rebuild the batch
+    dl, sls, tms = [], [], []
+    for u, lat in enumerate(_split(arrays)):
+        lat.dur[:] = (arrays["state_time"][arrays["state_off"][u] + lat.dst] -
+                      arrays["state_time"][arrays["state_off"][u] + lat.src()])
+        d, sl, _ = orc.disambiguate_length(lat)
+        t, _, _ = orc.state_times(d)
+        dl.append(d), sls.append(sl), tms.append(t)
+    darr = klat_amd.concat_lattices(dl, tms)
+    b = klat_amd.Batch(ctx, darr)
+    b.forward_backward(1.0, 0.1, 0.0)
+    off, rec = b.position_index(np.concatenate(sls))
+    b.close()
+    for u, d in enumerate(dl):
+        sl = orc.scale_and_penalize(d, 1.0, 0.1, 0.0)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        want = orc.position_index(sl, tms[u], sls[u], alpha, beta, total)
+        got = [(int(r["label"]), int(r["pos"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in rec[off[u]:off[u + 1]]]
+        # (t0,t1) is payload: it must match exactly unless two arcs tie for the maximum within tol
+        assert len(got) == len(want)
+        gk = {g[:2]: g for g in got}
+        for w in want:
+            g = gk[w[:2]]
+            assert abs(g[4] - w[4]) <= TOL
+            assert g[2:4] == w[2:4]
+        for x, y in zip(got[:-1], got[1:]):
+            assert x[4] >= y[4] - TOL
+
+
+def test_index_needs_state_time(ctx):
+    arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
+    del arrays["state_time"]
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward()
+    with pytest.raises(klat_amd.KlatError) as e:
+        b.segment_index()
+    assert e.value.code == klat_amd.ERR_INVALID_ARG
+    b.close()

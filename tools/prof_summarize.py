@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output (gpurun_out/prof_{stats,fetch,write}) into the files kept under
+profiles/: the --kernel-trace --stats table, and per-kernel HBM traffic from the PMC passes
+(FETCH_SIZE and WRITE_SIZE collected in separate runs; both in KiB; FETCH_SIZE doubled as
+/opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes for 16 B/lane streaming reads on gfx950).
+
+usage: tools/prof_summarize.py <round-tag>   e.g. r01
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "gpurun_out")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
+
+traffic = collections.defaultdict(dict)
+for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    files = glob.glob(os.path.join(src, "prof_%s" % name, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        traffic[k][counter + "_KiB_mean"] = sum(v) / len(v)
+        traffic[k]["launches_" + name] = len(v)
+out = {}
+for k, t in traffic.items():
+    rd = 2.0 * 1024.0 * t.get("FETCH_SIZE_KiB_mean", 0.0)  # gfx950: FETCH_SIZE counts 128-B requests as 64 B
+    wr = 1024.0 * t.get("WRITE_SIZE_KiB_mean", 0.0)
+    out[k] = dict(t, hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr,
+                  hbm_bytes_per_launch=rd + wr)
+json.dump(out, open(os.path.join(dst, "%s_hbm_traffic.json" % tag), "w"), indent=1, sort_keys=True)
+for k, t in out.items():
+    print("%-60s read %.3f GB  write %.3f GB" % (k[:60], t["hbm_read_bytes_per_launch"] / 1e9, t["hbm_write_bytes_per_launch"] / 1e9))
