@@ -1,8 +1,11 @@
-// klat_accum.h -- argument block and launchers of the accumulate stage (klat_accum.hip).
+// klat_accum.h -- argument blocks and launchers of the accumulate stage
+// (klat_accum.hip: segment / position index; klat_frame.hip: frame posteriors).
 #ifndef KLAT_ACCUM_H_
 #define KLAT_ACCUM_H_
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "klat_kernels.h"
 
 namespace klat {
 
@@ -33,6 +36,32 @@ struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)
 hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hipStream_t stream);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
                                OutRecord* out, hipStream_t stream);
+
+struct FrameArgs {
+  const int64_t* state_off;
+  const int64_t* arc_off;
+  const int64_t* scratch_off;  // [U+1], per-lattice capacity = next_pow2(expansions)
+  const int32_t* src;
+  const int32_t* dst;
+  const int32_t* ilabel;
+  const float* graph;
+  const float* acoustic;
+  const int32_t* state_time;
+  const int32_t* num_frames;  // [U]
+  const double* logpost;
+  const double* total;
+  void* key_scratch;  // 16 B per slot
+  void* rec_scratch;  // 16 B per slot
+  int64_t* num_expansions;  // [U] (count kernel)
+  int32_t* num_records;     // [U]
+  ScaleParams sp;
+};
+
+hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t stream);
+hipError_t launch_frame(const FrameArgs& a, int num_lattices, hipStream_t stream);
+hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
+                               const int64_t* frame_base, int64_t* frame_off, int32_t* labels, float* logps,
+                               hipStream_t stream);
 
 }  // namespace klat
 #endif

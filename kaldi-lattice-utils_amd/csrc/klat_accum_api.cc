@@ -3,6 +3,7 @@
 // scratch, moves the small per-call inputs (label filter, state lengths) and the results.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -136,6 +137,105 @@ int klat_position_index(klat_batch* b, const int32_t* state_len, const klat_labe
                         int64_t* record_off, klat_position_record* records, int64_t capacity,
                         int64_t* num_records) {
   return run_index(b, true, state_len, f, record_off, records, capacity, num_records);
+}
+
+int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off, int32_t* labels,
+                    float* logps, int64_t capacity, int64_t* num_entries) {
+  if (!b || !num_entries || !frame_off || (b->U > 0 && !num_frames))
+    return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  if (b->S > 0 && b->state_time.n == 0)
+    return set_error(KLAT_ERR_INVALID_ARG, "the batch was created without state_time: frame posteriors need it");
+  klat_ctx* c = b->ctx;
+  KLAT_HIP(hipSetDevice(c->device));
+  klat_frame_state& st = b->frame;
+  int rc;
+
+  FrameArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.state_off = b->state_off.p;
+  a.arc_off = b->arc_off.p;
+  a.src = b->src.p;
+  a.dst = b->dst.p;
+  a.ilabel = b->ilabel.p;
+  a.graph = b->graph.p;
+  a.acoustic = b->acoustic.p;
+  a.state_time = b->state_time.p;
+  a.logpost = b->logpost.p;
+  a.total = b->total.p;
+  a.sp.gs_f = b->scales.graph_scale;
+  a.sp.as_f = b->scales.acoustic_scale;
+  a.sp.pen = b->scales.insertion_penalty;
+  a.sp.scaled = (b->scales.acoustic_scale != 1.0f || b->scales.graph_scale != 1.0f) ? 1 : 0;
+  a.sp.penalized = (b->scales.insertion_penalty != 0.0f) ? 1 : 0;
+
+  if (labels == nullptr || logps == nullptr) {  // sizing call: compute and cache
+    st.ready = false;
+    st.frame_base.assign((size_t)b->U + 1, 0);
+    for (int64_t u = 0; u < b->U; ++u) {
+      if (num_frames[u] < 0) return set_error(KLAT_ERR_INVALID_ARG, "negative num_frames");
+      st.frame_base[u + 1] = st.frame_base[u] + num_frames[u];
+    }
+    if ((rc = st.num_frames.upload(num_frames, (size_t)b->U, c->stream))) return rc;
+    if ((rc = st.num_expansions.alloc((size_t)b->U))) return rc;
+    if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
+    a.num_frames = st.num_frames.p;
+    a.num_expansions = st.num_expansions.p;
+    a.num_records = st.num_records.p;
+    KLAT_HIP(launch_frame_count(a, (int)b->U, c->stream));
+    std::vector<int64_t> nexp((size_t)b->U);
+    if (b->U > 0)
+      KLAT_HIP(hipMemcpyAsync(nexp.data(), st.num_expansions.p, sizeof(int64_t) * (size_t)b->U,
+                              hipMemcpyDeviceToHost, c->stream));
+    KLAT_HIP(hipStreamSynchronize(c->stream));
+    std::vector<int64_t> off((size_t)b->U + 1, 0);
+    for (int64_t u = 0; u < b->U; ++u) {
+      if (nexp[u] > (int64_t)1 << 30) return set_error(KLAT_ERR_OOM, "lattice has more than 2^30 (frame,word) expansions");
+      off[u + 1] = off[u] + next_pow2(nexp[u]);
+    }
+    if ((rc = st.scratch_off.upload(off.data(), off.size(), c->stream))) return rc;
+    if ((rc = st.key_scratch.alloc((size_t)off[b->U] * 16))) return rc;
+    if ((rc = st.rec_scratch.alloc((size_t)off[b->U] * 16))) return rc;
+    a.scratch_off = st.scratch_off.p;
+    a.key_scratch = st.key_scratch.p;
+    a.rec_scratch = st.rec_scratch.p;
+    KLAT_HIP(launch_frame(a, (int)b->U, c->stream));
+    std::vector<int32_t> counts((size_t)b->U);
+    if (b->U > 0)
+      KLAT_HIP(hipMemcpyAsync(counts.data(), st.num_records.p, sizeof(int32_t) * (size_t)b->U,
+                              hipMemcpyDeviceToHost, c->stream));
+    KLAT_HIP(hipStreamSynchronize(c->stream));
+    st.entry_off.assign((size_t)b->U + 1, 0);
+    for (int64_t u = 0; u < b->U; ++u) st.entry_off[u + 1] = st.entry_off[u] + counts[u];
+    st.ready = true;
+    *num_entries = st.entry_off[b->U];
+    return KLAT_OK;
+  }
+
+  if (!st.ready) return set_error(KLAT_ERR_STATE, "call with labels == NULL first: it computes and sizes the posteriors");
+  const int64_t total = st.entry_off[b->U], T = st.frame_base[b->U];
+  if (capacity < total) return set_error(KLAT_ERR_INVALID_ARG, "capacity too small");
+  a.num_frames = st.num_frames.p;
+  a.scratch_off = st.scratch_off.p;
+  a.rec_scratch = st.rec_scratch.p;
+  DevBuf<int64_t> d_eoff, d_fbase, d_foff;
+  DevBuf<int32_t> d_lab;
+  DevBuf<float> d_lp;
+  if ((rc = d_eoff.upload(st.entry_off.data(), st.entry_off.size(), c->stream))) return rc;
+  if ((rc = d_fbase.upload(st.frame_base.data(), st.frame_base.size(), c->stream))) return rc;
+  if ((rc = d_foff.alloc((size_t)T + 1))) return rc;
+  if ((rc = d_lab.alloc((size_t)total))) return rc;
+  if ((rc = d_lp.alloc((size_t)total))) return rc;
+  KLAT_HIP(launch_frame_gather(a, (int)b->U, d_eoff.p, d_fbase.p, d_foff.p, d_lab.p, d_lp.p, c->stream));
+  if (T > 0) KLAT_HIP(hipMemcpyAsync(frame_off, d_foff.p, sizeof(int64_t) * (size_t)T, hipMemcpyDeviceToHost, c->stream));
+  if (total > 0) {
+    KLAT_HIP(hipMemcpyAsync(labels, d_lab.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    KLAT_HIP(hipMemcpyAsync(logps, d_lp.p, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+  }
+  KLAT_HIP(hipStreamSynchronize(c->stream));
+  frame_off[T] = total;
+  *num_entries = total;
+  return KLAT_OK;
 }
 
 }  // extern "C"

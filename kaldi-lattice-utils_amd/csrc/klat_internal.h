@@ -76,8 +76,17 @@ struct klat_accum_state {
   klat::DevBuf<int32_t> num_records, include, exclude, state_len;
 };
 
+struct klat_frame_state {
+  bool ready = false;
+  std::vector<int64_t> frame_base, entry_off;
+  klat::DevBuf<int64_t> scratch_off, num_expansions;
+  klat::DevBuf<int32_t> num_frames, num_records;
+  klat::DevBuf<unsigned char> key_scratch, rec_scratch;
+};
+
 struct klat_batch {
   klat_accum_state accum;
+  klat_frame_state frame;
   klat_ctx* ctx = nullptr;
   int64_t U = 0, S = 0, A = 0;
   int G = 1, W = 8, num_jobs = 0, num_items = 0;

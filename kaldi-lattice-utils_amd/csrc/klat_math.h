@@ -28,13 +28,21 @@ static constexpr double kLog2e = 1.442695040888963407359924681002;
 // that single rounding is one IEEE float multiply; Value1 == +inf stays Zero;
 // AddWordInsPenToCompactLattice adds pen (float) to Value1 of word arcs; ConvertToCost sums the
 // two floats in double.
-__device__ __forceinline__ double arc_cost(float g, float a, bool word, const ScaleParams& sp) {
+__device__ __forceinline__ void arc_cost_parts(float g, float a, bool word, const ScaleParams& sp,
+                                               float& g_out, float& a_out) {
   if (sp.scaled) {
     a = (g == INFINITY) ? INFINITY : sp.as_f * a;
     g = (g == INFINITY) ? INFINITY : sp.gs_f * g;
   }
   if (sp.penalized && word) g = g + sp.pen;
-  return (double)g + (double)a;
+  g_out = g;
+  a_out = a;
+}
+
+__device__ __forceinline__ double arc_cost(float g, float a, bool word, const ScaleParams& sp) {
+  float g2, a2;
+  arc_cost_parts(g, a, word, sp, g2, a2);
+  return (double)g2 + (double)a2;
 }
 
 // v_fma_f64 with the addend taken from a scalar register pair: keeps the polynomial a pure

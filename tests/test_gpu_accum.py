@@ -176,3 +176,59 @@ def test_index_needs_state_time(ctx):
         b.segment_index()
     assert e.value.code == klat_amd.ERR_INVALID_ARG
     b.close()
+
+
+def _check_frames(off, labels, logps, fb, want_frames, tol=2e-6):
+    for k, want in enumerate(want_frames):
+        lo, hi = int(off[fb + k]), int(off[fb + k + 1])
+        got = [(int(labels[i]), float(logps[i])) for i in range(lo, hi)]
+        assert sorted(g[0] for g in got) == sorted(w[0] for w in want), (k, got, want)
+        gk = dict(got)
+        for lab, lp in want:
+            assert abs(gk[lab] - float(lp)) <= tol * max(1.0, abs(float(lp)))
+        for x, y in zip(got[:-1], got[1:]):  # float logp descending, then label ascending
+            assert x[1] > y[1] or (x[1] == y[1] and x[0] < y[0])
+
+
+def test_frame_post_word_lattice(ctx, golden_dir):
+    """No reference known-answer exists for lattice-to-word-frame-post ("parity unpinned");
+    checked against the oracle and, through it, the analytic table of SURVEY.md App. C.2."""
+    (lat,) = latfmt.read_text_archive(os.path.join(golden_dir, "egs_word_lattice.ark.txt"))
+    lat = latfmt.prepare(lat)
+    times, T, _ = orc.state_times(lat)
+    arrays = klat_amd.concat_lattices([lat], [times])
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward()
+    off, labels, logps = b.frame_post([T])
+    b.close()
+    alpha, beta, total, _, _ = orc.alphas_betas(lat)
+    want, _ = orc.frame_post(lat, times, T, alpha, beta, total)
+    assert len(off) == T + 1 and T == 33
+    _check_frames(off, labels, logps, 0, want)
+    assert [int(x) for x in labels[off[0]:off[1]]] == [2, 1]
+    assert [int(x) for x in labels[off[9]:off[10]]] == [5]
+
+
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (1.0, 0.1, 0.5)])
+def test_frame_post_synthetic(ctx, scales):
+    rng = np.random.RandomState(3)
+    ns = np.concatenate([[1, 2], rng.randint(3, 300, size=30), [1500]]).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4], size=len(ns)).astype(np.int32)
+    arrays = klat_amd.synth(20260004, ns, fo)
+    arrays["olabel"] = (arrays["olabel"] % 9).astype(np.int32)
+    arrays["ilabel"] = arrays["olabel"].copy()
+    lats = _split(arrays)
+    nframes = [int(arrays["state_time"][arrays["state_off"][u + 1] - 1]) for u in range(len(ns))]
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(*scales)
+    off, labels, logps = b.frame_post(nframes)
+    b.close()
+    fb = 0
+    for u, lat in enumerate(lats):
+        sl = orc.scale_and_penalize(lat, *scales)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        t = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
+        want, mis = orc.frame_post(sl, t, nframes[u], alpha, beta, total)
+        _check_frames(off, labels, logps, fb, want)
+        fb += nframes[u]
+    assert off[-1] == len(labels)
