@@ -1,0 +1,66 @@
+// tool-common.h -- what the three tools share: the scale / filter options of SURVEY.md 2.3 plus
+// the two knobs this implementation adds (--batch-size lattices per GPU batch, --device).
+#ifndef KLAT_HOST_TOOL_COMMON_H_
+#define KLAT_HOST_TOOL_COMMON_H_
+#include <limits>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../kaldi-io.h"
+
+namespace klat {
+
+struct CommonOptions {
+  float acoustic_scale = 1.0f, graph_scale = 1.0f, insertion_penalty = 0.0f;
+  int32_t batch_size = 4096;      // lattices per GPU batch
+  int32_t max_batch_arcs = 64 << 20;
+  int32_t device = 0;
+  int32_t lanes_per_lattice = 0;  // 0 = automatic
+  void Register(ParseOptions* po) {
+    po->Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic likelihoods in the lattices.");
+    po->Register("graph-scale", &graph_scale, "Scaling factor for graph probabilities in the lattices.");
+    po->Register("insertion-penalty", &insertion_penalty,
+                 "Add this penalty to the lattice arcs with non-epsilon output label (typically, equivalent to word insertion penalty).");
+    po->Register("batch-size", &batch_size, "Number of lattices processed per GPU batch.");
+    po->Register("max-batch-arcs", &max_batch_arcs, "Upper bound on arcs per GPU batch.");
+    po->Register("device", &device, "GPU device index.");
+    po->Register("lanes-per-lattice", &lanes_per_lattice, "Lanes per lattice of the sweep kernel (0 = choose from the batch).");
+  }
+};
+
+struct IndexOptions {
+  float beam = std::numeric_limits<float>::infinity();
+  std::string exclude_str, include_str;
+  int32_t num_threads = 1, num_threads_total = -1;
+  void Register(ParseOptions* po) {
+    po->Register("beam", &beam, "Pruning beam (applied after acoustic scaling and adding the insertion penalty).");
+    po->Register("exclude-words", &exclude_str, "Space-separated list of integers representing the words to exclude from the index.");
+    po->Register("include-words", &include_str, "Space-separated list of integers representing the words to include in the index.");
+    // TaskSequencerConfig options of the reference: accepted for command-line compatibility; the
+    // GPU batch replaces the thread pool (one lattice per wave group instead of one per thread).
+    po->Register("num-threads", &num_threads, "Accepted for compatibility; lattices are batched on the GPU instead.");
+    po->Register("num-threads-total", &num_threads_total, "Accepted for compatibility.");
+  }
+  void Check() const {
+    if (beam != std::numeric_limits<float>::infinity())
+      KLAT_ERR("--beam: PruneLattice is not part of this build (SURVEY.md 8f item f2); run without --beam");
+  }
+};
+
+inline std::vector<int32_t> ParseIntList(const std::string& s, const char* what) {
+  std::set<int32_t> out;
+  std::istringstream is(s);
+  std::string tok;
+  while (is >> tok) {
+    char* end = nullptr;
+    const long v = std::strtol(tok.c_str(), &end, 10);
+    if (end == tok.c_str() || *end) KLAT_ERR("Invalid integer \"" << tok << "\" in " << what);
+    out.insert((int32_t)v);
+  }
+  return std::vector<int32_t>(out.begin(), out.end());
+}
+
+}  // namespace klat
+#endif

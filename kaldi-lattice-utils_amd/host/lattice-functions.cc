@@ -1,0 +1,225 @@
+// lattice-functions.cc -- see lattice-functions.h.
+#include "lattice-functions.h"
+
+#include <algorithm>
+#include <map>
+#include <queue>
+#include <tuple>
+
+namespace klat {
+
+void Check(int rc, const char* what) {
+  if (rc != KLAT_OK) KLAT_ERR(what << ": " << klat_last_error());
+}
+
+static bool IsTopSorted(const CompactLattice& clat) {
+  for (int32_t s = 0; s < clat.NumStates(); ++s)
+    for (const auto& arc : clat.State(s).arcs)
+      if (arc.nextstate <= s) return false;
+  return true;
+}
+
+void TopSortCompactLatticeIfNeeded(CompactLattice* clat) {
+  const int32_t S = clat->NumStates();
+  if (S == 0 || clat->Start() == CompactLattice::kNoStateId) return;
+  if (clat->Start() == 0 && IsTopSorted(*clat)) return;
+  // DFS from the start state, then from every unvisited state in numeric order; new id = rank in
+  // reverse finishing order (what fst::TopSort produces).
+  std::vector<uint8_t> color(S, 0);
+  std::vector<int32_t> finish;
+  finish.reserve(S);
+  std::vector<std::pair<int32_t, size_t>> stack;
+  for (int32_t pass = -1; pass < S; ++pass) {
+    const int32_t root = pass < 0 ? clat->Start() : pass;
+    if (color[root]) continue;
+    color[root] = 1;
+    stack.emplace_back(root, 0);
+    while (!stack.empty()) {
+      auto& top = stack.back();
+      const auto& arcs = clat->State(top.first).arcs;
+      if (top.second < arcs.size()) {
+        const int32_t v = arcs[top.second++].nextstate;
+        if (color[v] == 1) KLAT_ERR("Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles).");
+        if (color[v] == 0) {
+          color[v] = 1;
+          stack.emplace_back(v, 0);
+        }
+      } else {
+        color[top.first] = 2;
+        finish.push_back(top.first);
+        stack.pop_back();
+      }
+    }
+  }
+  std::vector<int32_t> order(S);
+  for (int32_t k = 0; k < S; ++k) order[finish[S - 1 - k]] = k;
+  std::vector<CompactLatticeState> ns(S);
+  for (int32_t s = 0; s < S; ++s) {
+    ns[order[s]] = std::move(clat->State(s));
+    for (auto& arc : ns[order[s]].arcs) arc.nextstate = order[arc.nextstate];
+  }
+  clat->States() = std::move(ns);
+  clat->SetStart(order[clat->Start()]);
+}
+
+int32_t CompactLatticeStateTimes(const CompactLattice& clat, std::vector<int32_t>* times) {
+  if (!IsTopSorted(clat)) KLAT_ERR("Input lattice must be topologically sorted.");
+  const int32_t S = clat.NumStates();
+  times->clear();
+  if (S == 0) return 0;
+  if (clat.Start() != 0) KLAT_ERR("CompactLatticeStateTimes: start state must be 0");
+  times->assign(S, -1);
+  (*times)[0] = 0;
+  int32_t utt_len = -1;
+  for (int32_t s = 0; s < S; ++s) {
+    const int32_t cur = (*times)[s];
+    const CompactLatticeState& st = clat.State(s);
+    for (const auto& arc : st.arcs) {
+      if ((*times)[arc.nextstate] == -1) (*times)[arc.nextstate] = cur + arc.string_len;
+      else if ((*times)[arc.nextstate] != cur + arc.string_len)
+        KLAT_ERR("CompactLatticeStateTimes: inconsistent times at state " << arc.nextstate << " (lattice is not aligned)");
+    }
+    if (st.IsFinal()) {
+      const int32_t this_len = cur + st.final_string_len;
+      if (utt_len == -1) {
+        utt_len = this_len;
+      } else if (this_len != utt_len) {
+        KLAT_WARN("Utterance does not seem to have a consistent length.");
+        utt_len = std::max(utt_len, this_len);
+      }
+    }
+  }
+  if (utt_len == -1) {
+    KLAT_WARN("Utterance does not have a final-state.");
+    return 0;
+  }
+  return utt_len;
+}
+
+int32_t DisambiguateStateInputSequenceLength(const CompactLattice& ifst, CompactLattice* ofst,
+                                             std::vector<int32_t>* state_input_length, bool use_input) {
+  ofst->DeleteStates();
+  if (state_input_length) state_input_length->clear();
+  if (ifst.Start() < 0) return 0;
+  typedef std::tuple<int32_t, int32_t> Pair;  // (length, old state)
+  std::map<Pair, int32_t> state_map;
+  std::queue<Pair> q;
+  state_map[Pair(0, ifst.Start())] = -1;
+  q.push(Pair(0, ifst.Start()));
+  int32_t max_len = 0;
+  while (!q.empty()) {
+    const int32_t len = std::get<0>(q.front()), u = std::get<1>(q.front());
+    q.pop();
+    max_len = std::max(max_len, len);
+    for (const auto& arc : ifst.State(u).arcs) {
+      const int32_t nl = ((use_input ? arc.ilabel : arc.olabel) == 0) ? len : len + 1;
+      if (state_map.emplace(Pair(nl, arc.nextstate), -1).second) q.push(Pair(nl, arc.nextstate));
+    }
+  }
+  // ids = rank in (length, state) order; state_input_length follows the same order
+  int32_t next_id = 0;
+  for (auto& kv : state_map) {
+    kv.second = next_id++;
+    ofst->AddState();
+    if (state_input_length) state_input_length->push_back(std::get<0>(kv.first));
+  }
+  ofst->SetStart(0);
+  for (const auto& kv : state_map) {
+    const int32_t len = std::get<0>(kv.first), u = std::get<1>(kv.first), u2 = kv.second;
+    const CompactLatticeState& in = ifst.State(u);
+    CompactLatticeState& out = ofst->State(u2);
+    out.final_graph = in.final_graph;
+    out.final_acoustic = in.final_acoustic;
+    out.final_string_len = in.final_string_len;
+    out.arcs.reserve(in.arcs.size());
+    for (auto arc : in.arcs) {
+      const int32_t nl = ((use_input ? arc.ilabel : arc.olabel) == 0) ? len : len + 1;
+      arc.nextstate = state_map[Pair(nl, arc.nextstate)];
+      if (arc.nextstate <= u2) KLAT_ERR("DisambiguateStateInputSequenceLength: output would not be topologically sorted (cyclic input?)");
+      out.arcs.push_back(arc);
+    }
+  }
+  return max_len;
+}
+
+// ---- LatticeBatch ----
+void LatticeBatch::Clear() {
+  state_off_.assign(1, 0);
+  arc_off_.assign(1, 0);
+  src_.clear(), dst_.clear(), ilabel_.clear(), olabel_.clear(), state_time_.clear();
+  graph_.clear(), acoustic_.clear(), final_graph_.clear(), final_acoustic_.clear();
+  has_times_ = true;
+}
+
+void LatticeBatch::Add(const CompactLattice& clat, const std::vector<int32_t>* times) {
+  const int32_t S = clat.Start() == CompactLattice::kNoStateId ? 0 : clat.NumStates();
+  if (S > 0 && clat.Start() != 0) KLAT_ERR("LatticeBatch::Add: lattice must be top-sorted with start state 0");
+  if (!times) has_times_ = false;
+  for (int32_t s = 0; s < S; ++s) {
+    const CompactLatticeState& st = clat.State(s);
+    final_graph_.push_back(st.final_graph);
+    final_acoustic_.push_back(st.final_acoustic);
+    if (times) state_time_.push_back((*times)[s]);
+    for (const auto& arc : st.arcs) {
+      src_.push_back(s);
+      dst_.push_back(arc.nextstate);
+      ilabel_.push_back(arc.ilabel);
+      olabel_.push_back(arc.olabel);
+      graph_.push_back(arc.graph);
+      acoustic_.push_back(arc.acoustic);
+    }
+  }
+  state_off_.push_back((int64_t)final_graph_.size());
+  arc_off_.push_back((int64_t)src_.size());
+}
+
+klat_batch_desc LatticeBatch::Desc() const {
+  klat_batch_desc d;
+  d.num_lattices = NumLattices();
+  d.state_off = state_off_.data();
+  d.arc_off = arc_off_.data();
+  d.src = src_.data();
+  d.dst = dst_.data();
+  d.ilabel = ilabel_.data();
+  d.olabel = olabel_.data();
+  d.graph = graph_.data();
+  d.acoustic = acoustic_.data();
+  d.final_graph = final_graph_.data();
+  d.final_acoustic = final_acoustic_.data();
+  d.state_time = (has_times_ && (int64_t)state_time_.size() == NumStates()) ? state_time_.data() : nullptr;
+  return d;
+}
+
+Context::Context(int device) { Check(klat_ctx_create(device, &ctx_), "klat_ctx_create"); }
+Context::~Context() { klat_ctx_destroy(ctx_); }
+
+DeviceBatch::DeviceBatch(Context& ctx, const LatticeBatch& batch, const klat_pack_options* opt) {
+  const klat_batch_desc d = batch.Desc();
+  Check(klat_batch_create(ctx.get(), &d, opt, &b_), "klat_batch_create");
+}
+DeviceBatch::~DeviceBatch() { klat_batch_destroy(b_); }
+void DeviceBatch::ForwardBackward(float graph_scale, float acoustic_scale, float insertion_penalty) {
+  const klat_scales s = {graph_scale, acoustic_scale, insertion_penalty};
+  Check(klat_forward_backward(b_, &s), "klat_forward_backward");
+}
+
+double ComputeLatticeAlphasAndBetas(const CompactLattice& clat, bool viterbi, std::vector<double>* alpha,
+                                    std::vector<double>* beta) {
+  if (viterbi) KLAT_ERR("ComputeLatticeAlphasAndBetas: viterbi=true is not on the accelerated path");
+  if (clat.NumStates() == 0 || clat.Start() != 0) KLAT_ERR("ComputeLatticeAlphasAndBetas: lattice must be top-sorted with start state 0");
+  static thread_local Context ctx(0);  // one HIP stream per calling thread (re-entrant, B2 contract)
+  LatticeBatch lb;
+  lb.Add(clat, nullptr);
+  DeviceBatch db(ctx, lb);
+  db.ForwardBackward(1.0f, 1.0f, 0.0f);
+  alpha->assign(clat.NumStates(), 0.0);
+  beta->assign(clat.NumStates(), 0.0);
+  double total = 0.0, tf = 0.0, tb = 0.0;
+  Check(klat_get_alpha_beta(db.get(), alpha->data(), beta->data()), "klat_get_alpha_beta");
+  Check(klat_get_totals(db.get(), &total, &tf, &tb), "klat_get_totals");
+  if (std::abs(tf - tb) > 1e-8 * std::max(std::abs(tf), std::abs(tb)))
+    KLAT_WARN("Total forward probability over lattice = " << tf << ", while total backward probability = " << tb);
+  return total;
+}
+
+}  // namespace klat

@@ -1,0 +1,83 @@
+// lattice-functions.h -- host-side mirror of the Kaldi functions the reference tools call on the
+// hot path, with the reference's own names and argument meaning (interface B2), on
+// top of the C ABI of include/klat.h.  The integer graph work (top-sort, state times, length
+// disambiguation, flattening) runs on the host; everything numeric runs on the GPU.
+#ifndef KLAT_HOST_LATTICE_FUNCTIONS_H_
+#define KLAT_HOST_LATTICE_FUNCTIONS_H_
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/klat.h"
+#include "compact-lattice.h"
+
+namespace klat {
+
+// TopSortCompactLatticeIfNeeded (latbin/lattice-to-word-frame-post.cc:80): if some arc has
+// nextstate <= state or Start() != 0, renumber states in topological order (reverse DFS finishing
+// order, start first).  Throws (KLAT_ERR) on a cyclic lattice, as the reference does.
+void TopSortCompactLatticeIfNeeded(CompactLattice* clat);
+
+// CompactLatticeStateTimes (latbin/lattice-to-word-frame-post.cc:84-85): times[0]=0,
+// times[dst]=times[src]+len(arc string); returns the utterance length (max over final states of
+// times[s]+len(final string); 0 with a warning if there is no final state).  Throws if the
+// lattice is not top-sorted or the times are inconsistent (KALDI_ERR / KALDI_ASSERT upstream).
+int32_t CompactLatticeStateTimes(const CompactLattice& clat, std::vector<int32_t>* times);
+
+// DisambiguateStateInputSequenceLength (fstext/fstext-utils2.h:109-215): equivalent lattice in
+// which all paths reaching a state carry the same number of non-epsilon labels; new state ids are
+// the ranks of the (length, old state) pairs; returns the maximum length.
+int32_t DisambiguateStateInputSequenceLength(const CompactLattice& ifst, CompactLattice* ofst,
+                                             std::vector<int32_t>* state_input_length, bool use_input = false);
+
+// A batch of top-sorted lattices flattened to the CSR/SoA layout of klat_batch_desc.
+class LatticeBatch {
+ public:
+  void Clear();
+  // appends clat (must be top-sorted with Start()==0, or empty); times may be null
+  void Add(const CompactLattice& clat, const std::vector<int32_t>* times);
+  int32_t NumLattices() const { return (int32_t)state_off_.size() - 1; }
+  int64_t NumArcs() const { return arc_off_.back(); }
+  int64_t NumStates() const { return state_off_.back(); }
+  klat_batch_desc Desc() const;
+  const std::vector<int64_t>& StateOff() const { return state_off_; }
+  const std::vector<int64_t>& ArcOff() const { return arc_off_; }
+
+ private:
+  std::vector<int64_t> state_off_{0}, arc_off_{0};
+  std::vector<int32_t> src_, dst_, ilabel_, olabel_, state_time_;
+  std::vector<float> graph_, acoustic_, final_graph_, final_acoustic_;
+  bool has_times_ = true;
+};
+
+// RAII over klat_ctx / klat_batch; failures become exceptions carrying klat_last_error().
+class Context {
+ public:
+  explicit Context(int device = 0);
+  ~Context();
+  klat_ctx* get() const { return ctx_; }
+
+ private:
+  klat_ctx* ctx_ = nullptr;
+};
+class DeviceBatch {
+ public:
+  DeviceBatch(Context& ctx, const LatticeBatch& batch, const klat_pack_options* opt = nullptr);
+  ~DeviceBatch();
+  klat_batch* get() const { return b_; }
+  void ForwardBackward(float graph_scale, float acoustic_scale, float insertion_penalty);
+
+ private:
+  klat_batch* b_ = nullptr;
+};
+void Check(int rc, const char* what);
+
+// ComputeLatticeAlphasAndBetas (latbin/lattice-to-word-frame-post.cc:88-90): same signature and
+// return value (0.5*(tot_forward+tot_backward)); viterbi must be false (every call site of the
+// reference passes false).  Runs the lattice as a one-element batch on the calling thread's GPU
+// context; batch callers should use LatticeBatch/DeviceBatch directly.
+double ComputeLatticeAlphasAndBetas(const CompactLattice& clat, bool viterbi, std::vector<double>* alpha,
+                                    std::vector<double>* beta);
+
+}  // namespace klat
+#endif

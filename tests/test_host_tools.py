@@ -1,0 +1,169 @@
+"""The C++ host side: command-line surface of the three tools (SURVEY.md 2.3 / interface B1),
+archive formats, and -- on the GPU box -- their output against the reference's README vectors."""
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import latfmt
+from oracle import oracle as orc
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+BIN = os.path.join(ROOT, "kaldi-lattice-utils_amd", "bin")
+sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
+import klat_amd  # noqa: E402
+
+TOOLS = ["lattice-to-word-frame-post", "lattice-word-index-segment", "lattice-word-index-position"]
+
+
+def run(tool, *args, stdin=None):
+    p = subprocess.run([os.path.join(BIN, tool)] + list(args), input=stdin, capture_output=True, timeout=300)
+    return p.returncode, p.stdout, p.stderr.decode(errors="replace")
+
+
+# ------------------------------------------------------------------ CPU-side (no GPU needed)
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "klat.h")).read()
+    names = sorted(set(re.findall(r"\b(klat_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    lib = klat_amd.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, "declared in include/klat.h but not exported: %s" % missing
+    assert b"gfx950" in lib.klat_version()
+
+
+@pytest.mark.parametrize("tool", TOOLS)
+def test_usage_and_exit_codes(tool):
+    rc, out, err = run(tool)  # wrong number of arguments -> usage, exit(1)
+    assert rc == 1 and "Usage: " + tool in err
+    rc, out, err = run(tool, "--help")
+    assert rc == 0 and "--acoustic-scale" in err
+    rc, out, err = run(tool, "--no-such-option=1", "ark:a", "ark:b")
+    assert rc == 255 and "Invalid option" in err  # exception path: return -1
+
+
+def test_beam_is_refused_loudly(tmp_path):
+    rc, out, err = run("lattice-word-index-segment", "--beam=5", "ark:/dev/null", "ark,t:-")
+    assert rc == 255 and "PruneLattice" in err
+
+
+def test_binary_archive_round_trip(tmp_path, golden_dir):
+    """The binary CompactLattice reader (Appendix B.4) against this build's own writer, and the
+    exact byte layout of the stream header."""
+    src = os.path.join(golden_dir, "egs_expand_lattice2.char.txt")
+    b = str(tmp_path / "x.ark")
+    rc, _, err = run("klat-lattice-copy", "ark:" + src, "ark:" + b)
+    assert rc == 0, err
+    raw = open(b, "rb").read()
+    assert raw.startswith(b"lat2 ")
+    magic, n1 = struct.unpack_from("<ii", raw, 5)
+    assert magic == 2125659606 and raw[13:13 + n1] == b"vector"
+    t = str(tmp_path / "x.txt")
+    rc, _, err = run("klat-lattice-copy", "ark:" + b, "ark,t:" + t)
+    assert rc == 0, err
+    (a,) = latfmt.read_text_archive(src)
+    (c,) = latfmt.read_text_archive(t)
+    assert a.key == c.key == "lat2"
+    for f in ("arc_begin", "dst", "ilabel", "graph", "acoustic", "dur", "final_graph", "final_acoustic"):
+        assert np.array_equal(getattr(a, f), getattr(c, f)), f
+    # piped specifiers
+    rc, out, err = run("klat-lattice-copy", "ark:cat %s |" % b, "ark,t:| cat")
+    assert rc == 0 and b"lat2" in out
+
+
+# ------------------------------------------------------------------ GPU box
+def _readme(golden_dir, kind):
+    with open(os.path.join(golden_dir, "readme_expected.txt")) as f:
+        for line in f:
+            if line.startswith(kind + " "):
+                return line.split(None, 1)[1].strip()
+
+
+@pytest.mark.gpu
+def test_segment_tool_matches_readme(golden_dir):
+    rc, out, err = run("lattice-word-index-segment", "ark:" + os.path.join(golden_dir, "egs_word_lattice.ark.txt"), "ark,t:-")
+    assert rc == 0, err
+    line = out.decode().strip("\n")
+    assert line.endswith(" ") and "; " in line  # holder text format: fields end with a space
+    key, got = latfmt.parse_tuple_line(line, 3)
+    _, want = latfmt.parse_tuple_line(_readme(golden_dir, "segment"), 3)
+    assert key == "lat1" and sorted(g[:3] for g in got) == sorted(w[:3] for w in want)
+    # text identity with the README line up to the order of records whose logp tie
+    canon = lambda recs: sorted("%d %d %d %s" % (r[0], r[1], r[2], ("%.7g" % r[3]) if abs(r[3]) > 5e-8 else "0") for r in recs)
+    assert canon(got) == canon(want)
+    lps = [g[3] for g in got]
+    assert all(x >= y - 1e-7 for x, y in zip(lps[:-1], lps[1:]))
+
+
+@pytest.mark.gpu
+def test_position_tool_matches_readme(golden_dir):
+    rc, out, err = run("lattice-word-index-position", "ark:" + os.path.join(golden_dir, "egs_word_lattice.ark.txt"), "ark,t:-")
+    assert rc == 0, err
+    key, got = latfmt.parse_tuple_line(out.decode(), 4)
+    _, want = latfmt.parse_tuple_line(_readme(golden_dir, "position"), 4)
+    canon = lambda recs: sorted("%d %d %d %d %s" % (r[0], r[1], r[2], r[3], ("%.7g" % r[4]) if abs(r[4]) > 5e-8 else "0") for r in recs)
+    assert key == "lat1" and canon(got) == canon(want)
+
+
+@pytest.mark.gpu
+def test_frame_post_tool_text_and_binary(tmp_path, golden_dir):
+    src = "ark:" + os.path.join(golden_dir, "egs_word_lattice.ark.txt")
+    rc, out, err = run("lattice-to-word-frame-post", src, "ark,t:-")
+    assert rc == 0, err
+    key, frames = latfmt.parse_posterior_line(out.decode())
+    assert key == "lat1" and len(frames) == 33
+    assert [l for l, _ in frames[0]] == [2, 1] and [l for l, _ in frames[8]] == [5, 4] and [l for l, _ in frames[20]] == [6]
+    assert abs(frames[0][0][1] - np.log(0.8)) < 1e-6 and abs(frames[0][1][1] - np.log(0.2)) < 1e-6
+    b = str(tmp_path / "post.ark")
+    rc, _, err = run("lattice-to-word-frame-post", src, "ark:" + b)
+    assert rc == 0, err
+    raw = open(b, "rb").read()
+    assert raw.startswith(b"lat1 \x00B\x04" + struct.pack("<i", 33))  # key, binary marker, size-tagged int32 T
+
+
+@pytest.mark.gpu
+def test_tools_on_a_multi_lattice_archive(tmp_path):
+    """Input order is kept, empty lattices still produce a record, batching does not change the
+    output, binary input gives the same result as text input, scales reach the GPU."""
+    ns = np.array([30, 1, 17, 64, 5], np.int32)
+    fo = np.array([3, 1, 2, 3, 1], np.int32)
+    arrays = klat_amd.synth(4242, ns, fo)
+    txt = str(tmp_path / "in.txt")
+    with open(txt, "w") as f:
+        for u in range(len(ns)):
+            s0, a0, a1 = arrays["state_off"][u], arrays["arc_off"][u], arrays["arc_off"][u + 1]
+            f.write("utt%07d\n" % u)
+            for i in range(a0, a1):
+                s, d = arrays["src"][i], arrays["dst"][i]
+                dur = arrays["state_time"][s0 + d] - arrays["state_time"][s0 + s]
+                f.write("%d\t%d\t%d\t%.9g,%.9g,%s\n" % (s, d, arrays["ilabel"][i], arrays["graph"][i], arrays["acoustic"][i],
+                                                        "_".join(["7"] * dur)))
+            f.write("%d\n\n" % (ns[u] - 1))
+            if u == 2:
+                f.write("empty_utt\n\n")
+    args = ["--acoustic-scale=0.1", "--insertion-penalty=0.25"]
+    rc, out1, err = run("lattice-word-index-segment", *args, "ark:" + txt, "ark,t:-")
+    assert rc == 0, err
+    lines = out1.decode().strip("\n").split("\n")
+    assert [l.split()[0] if l.split() else "" for l in lines][:4] == ["utt0000000", "utt0000001", "utt0000002", "empty_utt"]
+    assert lines[3].strip() == "empty_utt" and lines[1].strip() == "utt0000001"  # no arcs -> empty record
+    rc, out2, err = run("lattice-word-index-segment", *args, "--batch-size=1", "ark:" + txt, "ark,t:-")
+    assert rc == 0 and out2 == out1
+    b = str(tmp_path / "in.ark")
+    assert run("klat-lattice-copy", "ark:" + txt, "ark:" + b)[0] == 0
+    rc, out3, err = run("lattice-word-index-segment", *args, "ark:" + b, "ark,t:-")
+    assert rc == 0 and out3 == out1
+    # against the oracle for utterance 3
+    lat = [l for l in latfmt.read_text_archive(txt) if l.key == "utt0000003"][0]
+    sl = orc.scale_and_penalize(lat, 1.0, 0.1, 0.25)
+    times, _, _ = orc.state_times(sl)
+    alpha, beta, total, _, _ = orc.alphas_betas(sl)
+    want = orc.segment_index(sl, times, alpha, beta, total)
+    _, got = latfmt.parse_tuple_line([l for l in lines if l.startswith("utt0000003")][0], 3)
+    assert sorted(g[:3] for g in got) == sorted(w[:3] for w in want)
+    wk = {w[:3]: w[3] for w in want}
+    assert all(abs(g[3] - wk[g[:3]]) < 1e-5 for g in got)
