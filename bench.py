@@ -113,10 +113,12 @@ def main():
     ns = np.full(U, args.states, np.int32)
     fo = np.full(U, args.fanout, np.int32)
     scales = (1.0, 0.1, 0.0)
-    arrays = klat_amd.synth(args.seed, ns, fo, first_utt=rank * U)
+    host_threads = max(1, (os.cpu_count() or 1) // max(1, world))  # ranks share the host cores
+    arrays = klat_amd.synth(args.seed, ns, fo, first_utt=rank * U, host_threads=host_threads)
     ctx = klat_amd.Ctx(local_rank)
     t0 = time.perf_counter()
-    batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=args.lanes_per_lattice, ring_slots=args.ring_slots)
+    batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=args.lanes_per_lattice, ring_slots=args.ring_slots,
+                           host_threads=host_threads)
     pack_s = time.perf_counter() - t0
     info = batch.info()
     A, S = info["num_arcs"], info["num_states"]
