@@ -122,6 +122,10 @@ int klat_batch_get_info(const klat_batch* batch, klat_batch_info* info);
  * ctx stream; results stay on the device until fetched. */
 int klat_forward_backward(klat_batch* batch, const klat_scales* scales);
 int klat_get_timings(const klat_batch* batch, klat_timings* t);
+/* Number of sweep jobs (waves) of the last klat_forward_backward that left the fast sweep's
+ * exponent window and were recomputed by the exact sweep (0 for ordinary lattices; non-zero when
+ * the terms entering one state are hundreds of nats apart).  Results are exact either way. */
+int klat_get_exact_sweep_jobs(klat_batch* batch, int32_t* count);
 
 /* Synchronising fetches (device -> caller's host buffers); any pointer may be NULL.
  * alpha/beta: [S] doubles, -inf for unreachable / non-coaccessible states.

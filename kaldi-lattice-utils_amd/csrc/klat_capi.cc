@@ -164,6 +164,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   UP(items, P.items.data(), P.items.size());
   AL(fme, b->S + b->U);
   AL(bme, b->S + b->U);
+  AL(job_flags, P.jobs.size());
   AL(total, b->U);
   AL(tot_fwd, b->U);
   AL(tot_bwd, b->U);
@@ -216,6 +217,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.sa = b->sa.p;
   sa.fme = b->fme.p;
   sa.bme = b->bme.p;
+  sa.job_flags = b->job_flags.p;
   sa.sp = sp;
   sa.ring_slots = b->W;
 
@@ -266,6 +268,21 @@ int klat_get_timings(const klat_batch* b, klat_timings* t) {
   KLAT_HIP(hipEventElapsedTime(&t->posterior_ms, c->ev[2], c->ev[3]));
   t->convert_ms = 0.0f;  // alpha/beta conversion is fused into the posterior kernel
   KLAT_HIP(hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[3]));
+  return KLAT_OK;
+}
+
+int klat_get_exact_sweep_jobs(klat_batch* b, int32_t* count) {
+  if (!b || !count) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  std::vector<int32_t> flags((size_t)b->num_jobs);
+  if (b->num_jobs > 0)
+    KLAT_HIP(hipMemcpyAsync(flags.data(), b->job_flags.p, sizeof(int32_t) * flags.size(), hipMemcpyDeviceToHost,
+                            b->ctx->stream));
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
+  int32_t n = 0;
+  for (int32_t f : flags) n += f != 0;
+  *count = n;
   return KLAT_OK;
 }
 

@@ -23,6 +23,7 @@ struct SweepArgs {
   const float* sa;    // stream acoustic costs
   MECell* fme;  // forward values, S+1 cells per lattice (see MECell)
   MECell* bme;  // backward values
+  int32_t* job_flags;  // [num_jobs] set by the fast sweep when a job needs the exact sweep
   ScaleParams sp;
   int32_t ring_slots;
 };

@@ -199,6 +199,11 @@ class Batch:
         _check(lib().klat_get_timings(self.h, C.byref(t)))
         return t.as_dict()
 
+    def exact_sweep_jobs(self):
+        n = C.c_int32(0)
+        _check(lib().klat_get_exact_sweep_jobs(self.h, C.byref(n)))
+        return n.value
+
     def alpha_beta(self):
         a = np.empty(self.S, np.float64)
         b = np.empty(self.S, np.float64)

@@ -108,6 +108,44 @@ def test_log_zero_states_and_infinite_costs(ctx):
         assert abs(total[0] - wt[0]) < TOL
 
 
+@pytest.mark.parametrize("G", [1, 4, 16])
+def test_exact_sweep_takes_over_outside_the_fast_window(ctx, G):
+    """Terms entering one state that are thousands of nats apart leave the fast sweep's +-900
+    binary-exponent window: the job is flagged and recomputed by the exact sweep.  Ordinary
+    lattices in the same batch stay on the fast path.  Results match the oracle either way."""
+    arcs, S = [], 40
+    for s in range(S - 1):
+        arcs.append((s, s + 1, 1 + s % 5, 1 + s % 5, 0.25 + 0.1 * (s % 3), 0.5, 1))
+        arcs.append((s, s + 1, 2, 2, 3000.0 if s % 2 else 1.0e-3, 2500.0 * (s % 3), 1))  # far-apart parallel arc
+        if s + 2 < S:
+            arcs.append((s, s + 2, 3, 3, 700.0 * (s % 4), 0.0, 2))
+    wild = orc.lat_from_arcs(S, arcs, {S - 1: (0.0, 0.0, 0), S - 3: (4000.0, 0.0, 0)})
+    tame = klat_amd.synth(5, np.array([50, 70], np.int32), np.array([3, 3], np.int32))
+    w = klat_amd.concat_lattices([wild])
+    arrays = {}
+    for k in w:  # tame lattices first, the wild one last (no state_time needed here)
+        if k in ("state_off", "arc_off"):
+            arrays[k] = np.concatenate([tame[k], w[k][1:] + tame[k][-1]])
+        else:
+            arrays[k] = np.concatenate([tame[k], w[k]])
+    batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=G, ring_slots=8)
+    batch.forward_backward(1.0, 1.0, 0.0)
+    alpha, beta = batch.alpha_beta()
+    total, tf, tb = batch.totals()
+    post = batch.arc_logpost()
+    flagged = batch.exact_sweep_jobs()
+    njobs = batch.info()["num_jobs"]
+    batch.close()
+    assert 1 <= flagged <= njobs
+    wa, wb, wt, wpost = _oracle_batch(arrays, 1.0, 1.0, 0.0)
+    _check(alpha, wa, 1e-7), _check(beta, wb, 1e-7), _check(total, wt, 1e-7), _check(post, wpost, 1e-7)
+    # the tame lattices alone never need the exact sweep
+    b2 = klat_amd.Batch(ctx, tame, lanes_per_lattice=G)
+    b2.forward_backward(1.0, 0.1, 0.0)
+    assert b2.exact_sweep_jobs() == 0
+    b2.close()
+
+
 def test_bad_topology_is_reported(ctx):
     arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
     arrays["dst"][3] = 0
