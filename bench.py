@@ -83,8 +83,8 @@ def measured_traffic(G):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--lattices", type=int, default=10000, help="lattices per GPU")
     ap.add_argument("--states", type=int, default=2000)
     ap.add_argument("--fanout", type=int, default=3)

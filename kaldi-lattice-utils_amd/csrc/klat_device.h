@@ -17,18 +17,31 @@
 namespace klat {
 
 // ---- stream term word -------------------------------------------------------------------
-// bits 0..26  rel   = target position - source position (>=1); 0 = constant-one source
-// bit  27     FAR   source is outside the LDS ring -> fetched from HBM/L2
+// Everything about a term that does not depend on state values is resolved by the packer,
+// which knows the layout (G, W) the stream is built for:
+// bits 0..10  RD    ring cell ((target position - rel) mod W) * (64/G) + lattice slot to read
+// bits 11..21 WR    ring cell of the target state (only on the COMMIT lane)
+// bit  22     COMMIT  LAST round and this lane (first of the lattice's G) stores the result
+// bit  23     BYPASS  source = state finished by the previous round (first round, rel == 1):
+//                     its value is taken from registers, not from the ring
+// bit  24     ONE   constant-one source (alpha[start] = 0, final weights)
+// bit  27     FAR   source older than the ring: bits 0..26 then hold rel = target position -
+//                   source position and RD/WR/COMMIT are resolved by the kernel
 // bit  28     LAST  last round of this target state (uniform over the lattice's G lanes)
 // bit  29     WORD  ilabel != 0 (AddWordInsPenToCompactLattice applies)
 // bit  30     NIL   padding term, contributes log-zero
 // bit  31     FIRST first round of this target state (uniform over the lattice's G lanes)
-static const uint32_t kRelMask = (1u << 27) - 1u;
+static const uint32_t kCellMask = 0x7FFu;  // ring cells per workgroup <= 2048
+static const int kWrShift = 11;
+static const uint32_t kCommit = 1u << 22;
+static const uint32_t kBypass = 1u << 23;
+static const uint32_t kOne = 1u << 24;
+static const uint32_t kRelMask = (1u << 27) - 1u;  // FAR terms only
 static const uint32_t kFar = 1u << 27;
 static const uint32_t kLast = 1u << 28;
 static const uint32_t kWord = 1u << 29;
 static const uint32_t kNil = 1u << 30;
-static const uint32_t kFirst = 1u << 31;  // first round of this target state (all G lanes)
+static const uint32_t kFirst = 1u << 31;
 
 static const int kChunkRounds = 4;    // rounds per 16-byte lane load
 static const int kPrefetchChunks = 4; // register prefetch depth of the sweep kernel

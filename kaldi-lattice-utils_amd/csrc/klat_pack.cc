@@ -168,6 +168,10 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   // The ring only has to cover arcs; final terms (rel = S - s) may be far without harm, so the
   // automatic W follows the arcs' span, which pass 1 folded into max_rel together with finals.
   int W = opt.ring_slots ? opt.ring_slots : choose_ring_slots(G, max_rel.load());
+  if ((int64_t)W * LPW > 2048) {
+    *err = "ring_slots * (64 / lanes_per_lattice) must not exceed 2048 ring cells per workgroup";
+    return KLAT_ERR_INVALID_ARG;
+  }
 
   // ---- slicing: lattices of similar length share a wave ----
   std::vector<int64_t> live;
@@ -246,14 +250,26 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
       const int lane0 = (int)k * G;
       int64_t r = 0;  // next free round of this lattice
       int64_t nterm = 0;
-      auto begin_pos = [&]() { nterm = 0; };
+      int64_t pos = 0;  // stream position of the state being fed (forward: state id; backward: S-1-id)
+      auto begin_pos = [&](int64_t p) {
+        nterm = 0;
+        pos = p;
+      };
+      auto ring_cell = [&](int64_t p) -> uint32_t { return (uint32_t)((p & (W - 1)) * LPW + (int64_t)k); };
       auto emit = [&](int64_t rel, bool word, float g, float a, bool nil) {
         const int64_t rr = r + nterm / G;
         const int lane = lane0 + (int)(nterm % G);
-        uint32_t w = nil ? kNil : (uint32_t)rel;
-        if (!nil && rel >= W) {
-          w |= kFar;
+        uint32_t w;
+        if (nil) {
+          w = kNil | ring_cell(pos);  // reads a valid cell; the weight is zero
+        } else if (rel == 0) {
+          w = kOne | ring_cell(pos);
+        } else if (rel >= W) {
+          w = kFar | (uint32_t)rel;  // the kernel resolves the cells of FAR terms
           far_local++;
+        } else {
+          w = ring_cell(pos - rel);
+          if (rel == 1 && nterm < G) w |= kBypass;  // first round: the source was finished just before
         }
         if (word) w |= kWord;
         const size_t ix = slot_index(rr, lane);
@@ -270,6 +286,9 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
           P.sw[slot_index(r, lane0 + g)] |= (int32_t)kFirst;
           P.sw[slot_index(lastr, lane0 + g)] |= (int32_t)kLast;
         }
+        // the lattice's first lane stores the state's value at the end of its last round
+        int32_t& cw = P.sw[slot_index(lastr, lane0)];
+        if (((uint32_t)cw & kFar) == 0) cw |= (int32_t)(kCommit | (ring_cell(pos) << kWrShift));
         r += nr;
       };
       if (job.dir == 0) {
@@ -283,7 +302,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
           for (int64_t i = 0; i < A; ++i) in_arc[cur[d.dst[a0 + i]]++] = (int32_t)i;
         }
         for (int64_t p = 0; p < S; ++p) {
-          begin_pos();
+          begin_pos(p);
           if (p == 0) emit(0, false, 0.f, 0.f, false);  // alpha[start] = 0
           for (int64_t q = in_begin[p]; q < in_begin[p + 1]; ++q) {
             const int64_t i = a0 + in_arc[q];
@@ -291,7 +310,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
           }
           end_pos();
         }
-        begin_pos();  // virtual super-final state
+        begin_pos(S);  // virtual super-final state
         for (int64_t s = 0; s < S; ++s)
           if (is_final(d, s0 + s)) emit(S - s, false, d.final_graph[s0 + s], d.final_acoustic[s0 + s], false);
         end_pos();
@@ -300,7 +319,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
         for (int64_t s = S - 1; s >= 0; --s) {
           int64_t lo = hi;
           while (lo > 0 && d.src[a0 + lo - 1] == s) --lo;
-          begin_pos();
+          begin_pos(S - 1 - s);
           if (is_final(d, s0 + s)) emit(0, false, d.final_graph[s0 + s], d.final_acoustic[s0 + s], false);
           // farthest destination first, nearest last: the term that depends on the most
           // recently finished state is the last one to enter the accumulator

@@ -55,33 +55,44 @@ __device__ __forceinline__ double group_sum(double v) {
 
 // One staged term: what the producer wave hands to the consumer wave through LDS.
 struct __attribute__((aligned(16))) StagedTerm {
-  double wm;   // 2^frac part of exp(-cost); 0 for dead / padding terms
-  int32_t k;   // binary exponent of exp(-cost)
-  uint32_t w;  // stream word (NIL also set for zero-weight terms)
+  double wm;     // 2^frac part of exp(-cost); 0 for dead / padding terms
+  int32_t k;     // binary exponent of exp(-cost)
+  uint32_t ctl;  // the stream word (klat_device.h) with FAR terms resolved and NIL set on zero weights
 };
+static constexpr uint32_t kCtlFirst = kFirst;
+static constexpr uint32_t kCtlLast = kLast;
+static constexpr uint32_t kCtlCommit = kCommit;
+static constexpr uint32_t kCtlBypass = kBypass;
+static constexpr uint32_t kCtlOne = kOne;
+static constexpr uint32_t kCtlFar = kFar;   // source cell index (relative to the lattice) is in far[]
+static constexpr uint32_t kCtlZero = kNil;  // padding or zero-weight term
 
 // ---------------------------------------------------------------------------------------------
 // Lockstep sweep.  One workgroup of TWO waves per job; a job is 64/G lattices, G lanes each,
 // walking the forward (dir 0) or backward (dir 1) arc stream of those lattices round by round.
 //
-//   wave 0, PRODUCER  reads the arc stream -- the only HBM stream: 12 B per term, read once, as
-//                     1 KiB dwordx4 wave loads, prefetched kPrefetchChunks chunks (16 rounds) ahead
-//                     in registers -- and evaluates, per term, the cost (ScaleLattice / insertion
-//                     penalty fused) and the 2^k * wm split of exp(-cost).  None of this depends
-//                     on state values.  It leaves {wm, k, word} of the next chunk (4 rounds) in an
-//                     LDS stage buffer.
-//   wave 1, CONSUMER  owns the serial dependency chain: value of the source state -> multiply ->
-//                     ldexp -> add into the lane's accumulator -> (G lanes combined with DPP) ->
-//                     frexp; the result is forwarded IN REGISTERS to the next round.
+//   wave 0, PRODUCER  does everything that does not depend on state values: reads the arc stream
+//                     (the only HBM read stream: 12 B per term, read once, 1 KiB dwordx4 wave loads,
+//                     prefetched kPrefetchChunks chunks = 16 rounds ahead in registers); evaluates
+//                     per term the cost (ScaleLattice / insertion penalty fused) and the 2^k * wm
+//                     split of exp(-cost); tracks each lattice's position counter and turns the
+//                     stream word into ring-cell addresses and control bits; and copies the states
+//                     the consumer finished one chunk ago from the LDS ring to HBM (all G lanes of
+//                     a lattice store in parallel, 16 B each).  It stages {wm, k, ctl} of the next
+//                     chunk (4 rounds) in LDS.
+//   wave 1, CONSUMER  owns the serial dependency chain and touches only LDS: value of the source
+//                     state -> multiply -> ldexp -> add into the lane's accumulator -> (G lanes
+//                     combined with DPP) -> frexp -> ring cell; the result is also forwarded IN
+//                     REGISTERS to the next round.
 // The two waves sit on different SIMDs of one CU and meet at one workgroup barrier per chunk
-// (double-buffered stage), so the chain wave issues only the chain.
+// (double-buffered stage).
 //
 // The values of the last W visited states of each lattice live in an LDS ring of 16-byte cells
-// ([slot][lattice]).  The ring read of round r+1 is issued before round r's result is written
-// and is patched from registers when it names the state round r just finished, so the LDS
-// write->read latency is off the chain.  Chunks in which some lane has a constant-one source
-// (start state / final weight) or a source older than W states (FAR: re-read from the cells
-// this kernel itself wrote) take a slower instantiation of the same round.
+// ([slot][lattice]).  The ring read of round r+1 is issued before round r's result is written and
+// is patched from registers when it names the state round r just finished (BYPASS), so the LDS
+// write->read latency is off the chain.  Chunks in which some lane has a constant-one source or
+// a source older than W states (FAR: re-read from the cells already copied out) take a slower
+// instantiation of the same round.
 //
 // Two instantiations share this body:
 //   FAST   every term of a state is aligned to ONE reference exponent -- that of the lattice's
@@ -98,15 +109,24 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   const int W = args.ring_slots;
   if (!FAST && args.job_flags[blockIdx.x] == 0) return;  // workgroup-uniform
 
-  MECell* ring = smem;                                                  // [W][LPW]
+  MECell* ring = smem;                                                        // [W][LPW]
   StagedTerm* stage = reinterpret_cast<StagedTerm*>(smem + (size_t)W * LPW);  // [2][4][64]
+  int32_t* far = reinterpret_cast<int32_t*>(stage + 2 * 4 * 64);              // [2][4][64]
   const int lane = threadIdx.x & 63;
+  const int slot = lane / G;
+  const int sub = lane % G;
   const bool producer = threadIdx.x < 64;  // wave 0
   const SweepJob job = args.jobs[blockIdx.x];
   const int nchunks = job.nchunks;
+  const LaneInfo li = args.lanes[job.lane_tab + slot];
+  const int S = li.num_states;
+  const bool bwd = job.dir != 0;
+  // position p of the stream -> cell: forward walks the lattice's cells upwards (position S, the
+  // virtual super-final state, is the extra cell), backward downwards from state S-1
+  MECell* cells = (bwd ? args.bme : args.fme) + li.state_base + li.lattice;  // state_off[u] + u
 
   if (producer) {
-    // ------------------------------------------------------------------ wave 0: weights
+    // ------------------------------------------------------------------ wave 0
     const ScaleParams sp = args.sp;
     const int4* __restrict__ sw = reinterpret_cast<const int4*>(args.sw) + job.chunk_off * 64 + lane;
     const float4* __restrict__ sg = reinterpret_cast<const float4*>(args.sg) + job.chunk_off * 64 + lane;
@@ -120,12 +140,34 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       gb[j] = sg[cn * 64];
       ab[j] = sa[cn * 64];
     }
-    auto put = [&](StagedTerm* dst, uint32_t w, float g, float a) {
+    int p = 0;                  // position the lattice is accumulating at the current round
+    int out_p0 = 0, out_n = 0;  // states the consumer finished in the chunk before the last barrier
+    const bool live = li.state_base >= 0;
+
+    auto put = [&](StagedTerm* dst, int32_t* fdst, uint32_t w, float g, float a) {
       StagedTerm t;
       bool dead;
       arc_weight(arc_cost(g, a, (w & kWord) != 0, sp), (w & kNil) != 0, t.wm, t.k, dead);
-      t.w = dead ? (w | kNil) : w;
+      const bool last = (w & kLast) != 0;
+      uint32_t ctl = dead ? (w | kNil) : w;
+      if (__any((w & kFar) != 0)) {  // rare: the packer left this term's cells to the kernel
+        if (w & kFar) {
+          const int q = p - (int)(w & kRelMask);
+          *fdst = bwd ? (S - 1 - q) : q;
+          ctl &= ~kRelMask;  // reads ring cell 0 (ignored), source comes from far[]
+          if (last && sub == 0) ctl |= kCommit | ((uint32_t)((p & (W - 1)) * LPW + slot) << kWrShift);
+        }
+      }
+      t.ctl = ctl;
       *dst = t;
+      p += last ? 1 : 0;
+    };
+    // copies the states finished during the previous chunk from the ring to HBM
+    auto copy_out = [&]() {
+      for (int j = sub; j < out_n; j += G) {
+        const int q = out_p0 + j;
+        if (live) cells[bwd ? (S - 1 - q) : q] = ring[(q & (W - 1)) * LPW + slot];
+      }
     };
     // chunk c is staged during the consumer's chunk c-1; nchunks is a multiple of D
     for (int c = 0; c < nchunks; c += D) {
@@ -139,28 +181,27 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         gb[j] = sg[cn * 64];
         ab[j] = sa[cn * 64];
         StagedTerm* st = stage + ((c + j) & 1) * 256 + lane;
-        put(st, (uint32_t)w4.x, g4.x, a4.x);
-        put(st + 64, (uint32_t)w4.y, g4.y, a4.y);
-        put(st + 128, (uint32_t)w4.z, g4.z, a4.z);
-        put(st + 192, (uint32_t)w4.w, g4.w, a4.w);
-        __syncthreads();  // chunk c+j staged; the consumer has finished chunk c+j-1
+        int32_t* fs = far + ((c + j) & 1) * 256 + lane;
+        const int p0 = p;
+        put(st, fs, (uint32_t)w4.x, g4.x, a4.x);
+        put(st + 64, fs + 64, (uint32_t)w4.y, g4.y, a4.y);
+        put(st + 128, fs + 128, (uint32_t)w4.z, g4.z, a4.z);
+        put(st + 192, fs + 192, (uint32_t)w4.w, g4.w, a4.w);
+        __syncthreads();  // chunk c+j is staged; the consumer has finished chunk c+j-1
+        copy_out();       // ... whose states are now stable in the ring (W >= 8 >= 2 chunks)
+        out_p0 = p0;
+        out_n = p - p0;
       }
     }
+    __syncthreads();  // the consumer has finished the last chunk
+    copy_out();
     return;
   }
 
   // -------------------------------------------------------------------- wave 1: the chain
-  const int slot = lane / G;
-  const int sub = lane % G;
-  const LaneInfo li = args.lanes[job.lane_tab + slot];
-  const int S = li.num_states;
-  const bool bwd = job.dir != 0;
-  MECell* cells = bwd ? args.bme : args.fme;
-  // position p of the stream -> cell: forward walks the lattice's cells upwards (position S,
-  // the virtual super-final state, is the extra cell), backward downwards from state S-1
-  const int64_t cbase = li.state_base + li.lattice;  // state_off[u] + u
-  MECell* out = cells + (li.state_base < 0 ? 0 : (bwd ? cbase + S - 1 : cbase));
-  const int ostep = bwd ? -1 : 1;
+  // the chain wave is the critical path of its job: let it win issue arbitration against the
+  // producer waves (of other jobs) that share its SIMD -- those spend part of their time at barriers
+  __builtin_amdgcn_s_setprio(2);
 
   // every ring cell starts as log-zero so that padding terms read something well-defined
   for (int i = lane; i < W * LPW; i += 64) {
@@ -168,52 +209,43 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     ring[i].e = kExpMin;
   }
 
-  int p = 0;           // position of the state this lattice is currently accumulating
   double accM = 0.0;   // lane accumulator: mantissa scaled by 2^accE (!FAST) or 2^refE (FAST)
   int accE = kExpMin;
   int refE = 0;        // FAST: exponent of the lattice's previous non-zero state
   bool sticky = false; // FAST: some term left the safe exponent window
   double lastM = 0.0;  // value of the state finished by the previous round (register bypass)
   int lastE = kExpMin;
-  bool prevLast = false;
-
-  // ring read for the upcoming round, software-pipelined one round ahead
-  MECell pre;
-  auto preload = [&](uint32_t wnext, int pnext) {
-    const int rs = (pnext - (int)(wnext & kRelMask)) & (W - 1);
-    pre = ring[rs * LPW + slot];
-  };
+  MECell pre;          // ring read for the upcoming round, software-pipelined one round ahead
 
   // SPECIAL = this chunk may hold constant-one or FAR sources; PRE = issue the next round's ring
   // read (the last round of a chunk cannot: its successor is staged behind the barrier)
-  auto round = [&](auto special, auto do_pre, uint32_t w, double wm, int k, uint32_t wnext) {
-    const int rel = (int)(w & kRelMask);
-    const bool last = (w & kLast) != 0;
-    const bool first = (w & kFirst) != 0;
+  auto round = [&](auto special, auto do_pre, const StagedTerm& t, uint32_t ctl_next, int far_cell) {
+    const uint32_t ctl = t.ctl;
+    const bool last = (ctl & kCtlLast) != 0;
+    const bool first = (ctl & kCtlFirst) != 0;
     double sm = pre.m;
     int se = (int)pre.e;
     // issue next round's ring read now, ahead of this round's ring write
-    if (decltype(do_pre)::value) preload(wnext, p + (last ? 1 : 0));
-    const bool bypass = prevLast & (rel == 1);
+    if (decltype(do_pre)::value) pre = ring[ctl_next & kCellMask];
+    const bool bypass = (ctl & kCtlBypass) != 0;
     sm = bypass ? lastM : sm;
     se = bypass ? lastE : se;
     if (decltype(special)::value) {
-      const bool one = (rel == 0) & ((w & kNil) == 0);  // constant one = 0.5 * 2^1
+      const bool one = (ctl & kCtlOne) != 0;  // constant one = 0.5 * 2^1
       sm = one ? 0.5 : sm;
       se = one ? 1 : se;
-      if (w & kFar) {
-        const int q = p - rel;
-        const MECell* src = cells + cbase + (bwd ? (int64_t)(S - 1 - q) : (int64_t)q);
+      if (ctl & kCtlFar) {
+        const MECell* src = cells + far_cell;
         sm = __hip_atomic_load(&src->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         se = (int)__hip_atomic_load(&src->e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     // dead (zero weight / padding) terms have wm == 0 and zero sources sm == 0: tm is then 0
-    const double tm = sm * wm;
+    const double tm = sm * t.wm;
     double cM;
     int cE;
     if (FAST) {
-      const int shift = se + k - refE;
+      const int shift = se + t.k - refE;
       sticky |= (tm != 0.0) & ((unsigned)(shift + 900) > 1800u);
       const double add = ldexp(tm, shift);
       accM = first ? add : accM + add;
@@ -221,7 +253,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       cE = refE;
     } else {
       // only the exponent tag needs forcing so that a zero never becomes a reference exponent
-      const int te = (((w & kNil) != 0) | (sm == 0.0)) ? kExpMin : se + k;
+      const int te = (((ctl & kCtlZero) != 0) | (sm == 0.0)) ? kExpMin : se + t.k;
       const int ref = first ? te : accE;
       const int shift = te - ref;
       if (__any(shift > 900)) {
@@ -249,16 +281,12 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     const int e = nz ? cE + __builtin_amdgcn_frexp_exp(cM) : kExpMin;
     lastM = m;
     lastE = e;
-    prevLast = last;
-    if (last && sub == 0) {
+    if (ctl & kCtlCommit) {
       MECell cell;
       cell.m = m;
       cell.e = e;
-      ring[(p & (W - 1)) * LPW + slot] = cell;
-      *out = cell;
+      ring[(ctl >> 11) & kCellMask] = cell;
     }
-    p += last ? 1 : 0;
-    out += last ? ostep : 0;
     if (FAST) refE = (last & nz) ? e : refE;
   };
 
@@ -266,24 +294,25 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     __syncthreads();  // chunk c is staged (and, for c == 0, the ring is initialised)
     const StagedTerm* st = stage + (c & 1) * 256 + lane;
     const StagedTerm t0 = st[0], t1 = st[64], t2 = st[128], t3 = st[192];
-    preload(t0.w, p);  // after the previous chunk's last ring write: reads the fresh value
-    constexpr uint32_t kOneMask = kRelMask | kNil;  // rel == 0 on a real term = constant one
-    const bool sp0 = ((t0.w & kOneMask) == 0) | ((t0.w & kFar) != 0), sp1 = ((t1.w & kOneMask) == 0) | ((t1.w & kFar) != 0);
-    const bool sp2 = ((t2.w & kOneMask) == 0) | ((t2.w & kFar) != 0), sp3 = ((t3.w & kOneMask) == 0) | ((t3.w & kFar) != 0);
+    pre = ring[t0.ctl & kCellMask];  // after the previous chunk's last ring write: the fresh value
     const std::true_type yes;
     const std::false_type no;
-    if (__any(sp0 | sp1 | sp2 | sp3)) {
-      round(yes, yes, t0.w, t0.wm, t0.k, t1.w);
-      round(yes, yes, t1.w, t1.wm, t1.k, t2.w);
-      round(yes, yes, t2.w, t2.wm, t2.k, t3.w);
-      round(yes, no, t3.w, t3.wm, t3.k, 0u);
+    if (__any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & (kCtlOne | kCtlFar)) != 0)) {
+      const int32_t* fs = far + (c & 1) * 256 + lane;
+      const bool anyfar = __any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & kCtlFar) != 0);
+      const int f0 = anyfar ? fs[0] : 0, f1 = anyfar ? fs[64] : 0, f2 = anyfar ? fs[128] : 0, f3 = anyfar ? fs[192] : 0;
+      round(yes, yes, t0, t1.ctl, f0);
+      round(yes, yes, t1, t2.ctl, f1);
+      round(yes, yes, t2, t3.ctl, f2);
+      round(yes, no, t3, 0u, f3);
     } else {
-      round(no, yes, t0.w, t0.wm, t0.k, t1.w);
-      round(no, yes, t1.w, t1.wm, t1.k, t2.w);
-      round(no, yes, t2.w, t2.wm, t2.k, t3.w);
-      round(no, no, t3.w, t3.wm, t3.k, 0u);
+      round(no, yes, t0, t1.ctl, 0);
+      round(no, yes, t1, t2.ctl, 0);
+      round(no, yes, t2, t3.ctl, 0);
+      round(no, no, t3, 0u, 0);
     }
   }
+  __syncthreads();  // lets the producer copy out the last chunk's states
   if (FAST) {
     if (__any(sticky) && lane == 0) args.job_flags[blockIdx.x] = 1;
   }
@@ -300,7 +329,8 @@ static void launch_pair(const SweepArgs& args, int num_jobs, size_t lds, hipStre
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream) {
   if (num_jobs <= 0) return hipSuccess;
   const int LPW = 64 / G;
-  const size_t lds = (size_t)args.ring_slots * LPW * sizeof(MECell) + 2 * 4 * 64 * sizeof(StagedTerm);
+  if ((size_t)args.ring_slots * LPW > kCellMask + 1) return hipErrorInvalidValue;
+  const size_t lds = (size_t)args.ring_slots * LPW * sizeof(MECell) + 2 * 4 * 64 * (sizeof(StagedTerm) + sizeof(int32_t));
   hipError_t e = hipMemsetAsync(args.job_flags, 0, sizeof(int32_t) * (size_t)num_jobs, stream);
   if (e != hipSuccess) return e;
   switch (G) {

@@ -1,12 +1,15 @@
 """Pure-Python interpreter of the packed lockstep arc streams (test infrastructure).
 
-Mirrors sweep_kernel in kaldi-lattice-utils_amd/csrc/klat_kernels.hip term by term, so the
-host packer and the scaled-linear arithmetic can be checked against the oracle on the CPU,
-before GPU time is spent.  Never used by the product."""
+Mirrors the producer/consumer pair of sweep_kernel (kaldi-lattice-utils_amd/csrc/klat_sweep.hip)
+term by term -- ring cells, register bypass, constant-one and FAR sources, per-round commit --
+so the host packer and the scaled-linear arithmetic can be checked against the oracle on the
+CPU, before GPU time is spent.  Never used by the product."""
 import math
 
 import numpy as np
 
+CELL_MASK, WR_SHIFT = 0x7FF, 11
+COMMIT, BYPASS, ONE = 1 << 22, 1 << 23, 1 << 24
 REL_MASK = (1 << 27) - 1
 FAR, LAST, WORD, NIL, FIRST = 1 << 27, 1 << 28, 1 << 29, 1 << 30, 1 << 31
 EXP_MIN = -(1 << 29)
@@ -42,6 +45,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
     info = packed["info"]
     G, W = info["lanes_per_lattice"], info["ring_slots"]
     LPW = 64 // G
+    assert W * LPW <= CELL_MASK + 1
     sw = packed["sw"].view(np.uint32)
     sg, sa = packed["sg"], packed["sa"]
     S_tot = int(state_off[-1])
@@ -52,28 +56,27 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
     totf = np.full(U, np.nan)
     for job in packed["jobs"]:
         d = int(job["dir"])
+        ring = {}  # cell index -> (m, e); shared by the job's lattices like the LDS ring
         for slot in range(LPW):
             li = packed["lanes"][int(job["lane_tab"]) + slot]
             base, S, u = int(li["state_base"]), int(li["num_states"]), int(li["lattice"])
-            ring = {}
+            npos = S if d else S + 1
             p = 0
             accs = [(0.0, EXP_MIN)] * G
+            last_val = (0.0, EXP_MIN)
             nround = 0
             for r in range(int(job["nchunks"]) * 4):
                 last = False
+                commit = None
                 for sub in range(G):
                     lane = slot * G + sub
                     ix = ((int(job["chunk_off"]) + r // 4) * 64 + lane) * 4 + r % 4
                     w = int(sw[ix])
-                    if base < 0:
-                        assert w == NIL, "empty slot must hold NIL terms only"
-                        continue
-                    if p >= (S if d else S + 1):
-                        assert w == NIL, "padding after the last state must be plain NIL"
+                    if base < 0 or p >= npos:
+                        assert w & NIL and not (w & (LAST | FIRST | COMMIT | FAR)), "padding must be plain NIL"
                         continue
                     assert bool(w & FIRST) == (nround == 0), "FIRST marks exactly the first round of a state"
                     c = _cost(sg[ix], sa[ix], bool(w & WORD), graph_scale, acoustic_scale, insertion_penalty)
-                    rel = w & REL_MASK
                     dead = not (c < 1e30)
                     if not dead:
                         t = -c * LOG2E
@@ -83,26 +86,41 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                         k, wm = 0, 0.0
                     if w & NIL:
                         sm, se = 0.0, EXP_MIN
-                    elif rel == 0:
-                        sm, se = 0.5, 1
+                        assert not (w & (ONE | BYPASS | FAR))
                     elif w & FAR:
-                        assert rel >= W
+                        rel = w & REL_MASK
+                        assert rel >= W and not (w & (ONE | BYPASS))
                         q = p - rel
                         idx = base + (S - 1 - q if d else q)
                         sm, se = vm[d][idx], int(ve[d][idx])
+                    elif w & ONE:
+                        sm, se = 0.5, 1
+                    elif w & BYPASS:
+                        assert nround == 0 and p > 0, "BYPASS only in the first round of a state"
+                        sm, se = last_val
+                        assert ring[w & CELL_MASK] == last_val, "bypassed source must equal the ring cell"
                     else:
-                        assert 1 <= rel <= W - 1, (rel, W)
-                        sm, se = ring[(p - rel) & (W - 1)]
+                        cell = w & CELL_MASK
+                        assert cell % LPW == slot, "ring cell belongs to another lattice"
+                        sm, se = ring[cell]
                     zero = bool(w & NIL) or dead or sm == 0.0
                     tm = 0.0 if zero else sm * wm
                     te = EXP_MIN if zero else se + k
-                    accs[sub] = _acc(accs[sub][0], accs[sub][1], tm, te)
+                    accs[sub] = (tm, te) if nround == 0 else _acc(accs[sub][0], accs[sub][1], tm, te)
                     if w & LAST:
                         last = True
                     else:
                         assert not last, "LAST must be uniform over the G lanes of a lattice"
+                    if w & COMMIT:
+                        assert sub == 0 and (w & LAST)
+                        commit = (w >> WR_SHIFT) & CELL_MASK
+                    elif (w & LAST) and sub == 0:
+                        assert w & FAR, "the first lane of a LAST round commits (FAR terms: resolved by the kernel)"
+                        commit = (p & (W - 1)) * LPW + slot
+                if base < 0 or p >= npos:
+                    continue
                 nround += 1
-                if base < 0 or not last:
+                if not last:
                     continue
                 nround = 0
                 M, E = accs[0]
@@ -110,7 +128,9 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                     M, E = _acc(M, E, accs[sub][0], accs[sub][1])
                 m, ex = math.frexp(M)
                 e = EXP_MIN if M == 0.0 else E + ex
-                ring[p & (W - 1)] = (m, e)
+                assert commit == (p & (W - 1)) * LPW + slot, "commit cell must be the target state's ring cell"
+                ring[commit] = (m, e)
+                last_val = (m, e)
                 if d == 0 and p == S:
                     totf[u] = _ln(m, e)
                 else:
@@ -119,8 +139,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                     val[d][idx] = _ln(m, e)
                     vm[d][idx], ve[d][idx] = m, e
                 p += 1
-                accs = [(0.0, EXP_MIN)] * G
             if base >= 0:
-                assert p == (S + 1 if d == 0 else S), (p, S, d)
+                assert p == npos, (p, S, d)
     totb = np.array([val[1][int(state_off[u])] if state_off[u + 1] > state_off[u] else 0.0 for u in range(U)])
     return val[0], val[1], totf, totb
