@@ -75,7 +75,7 @@ def measured_traffic(G):
         except Exception:
             continue
         for k, v in t.items():
-            if "sweep_kernel<%d>" % G in k:
+            if "sweep_kernel<%d, true" % G in k or "sweep_kernel<%d>" % G in k:  # the fast sweep
                 return {"bytes": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT)}
     return None
 

@@ -53,6 +53,15 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// One ring cell in LDS.  The consumer reads m and e as separate 8- and 4-byte accesses: a 16-byte
+// read would leave a dead register that the allocator reuses at once, forcing an immediate
+// s_waitcnt on the software-pipelined read.
+struct __attribute__((aligned(16))) RingCell {
+  double m;
+  int32_t e;
+  int32_t pad;
+};
+
 // One staged term: what the producer wave hands to the consumer wave through LDS.
 struct __attribute__((aligned(16))) StagedTerm {
   double wm;     // 2^frac part of exp(-cost); 0 for dead / padding terms
@@ -101,17 +110,17 @@ static constexpr uint32_t kCtlZero = kNil;  // padding or zero-weight term
 //          (arc costs hundreds of nats apart inside one state) sets the job's flag.
 //   !FAST  exact for any input: every lane carries its own (mantissa, exponent) accumulator and
 //          re-references on demand.  It runs afterwards and only for flagged jobs.
-template <int G, bool FAST>
+template <int G, bool FAST, int CPB>  // CPB = stream chunks (of 4 rounds) staged per barrier: 2 when W >= 16, else 1
 __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
-  extern __shared__ MECell smem[];
+  extern __shared__ RingCell smem[];
   constexpr int LPW = 64 / G;
   constexpr int D = kPrefetchChunks;
   const int W = args.ring_slots;
   if (!FAST && args.job_flags[blockIdx.x] == 0) return;  // workgroup-uniform
 
-  MECell* ring = smem;                                                        // [W][LPW]
-  StagedTerm* stage = reinterpret_cast<StagedTerm*>(smem + (size_t)W * LPW);  // [2][4][64]
-  int32_t* far = reinterpret_cast<int32_t*>(stage + 2 * 4 * 64);              // [2][4][64]
+  RingCell* ring = smem;                                                      // [W][LPW]
+  StagedTerm* stage = reinterpret_cast<StagedTerm*>(smem + (size_t)W * LPW);  // [2][CPB][4][64]
+  int32_t* far = reinterpret_cast<int32_t*>(stage + 2 * CPB * 256);          // [2][CPB][4][64]
   const int lane = threadIdx.x & 63;
   const int slot = lane / G;
   const int sub = lane % G;
@@ -141,7 +150,8 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       ab[j] = sa[cn * 64];
     }
     int p = 0;                  // position the lattice is accumulating at the current round
-    int out_p0 = 0, out_n = 0;  // states the consumer finished in the chunk before the last barrier
+    int out_p0 = 0, out_n = 0;  // states the consumer finished in the period before the last barrier
+    int period_p0 = 0;
     const bool live = li.state_base >= 0;
 
     auto put = [&](StagedTerm* dst, int32_t* fdst, uint32_t w, float g, float a) {
@@ -166,7 +176,13 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     auto copy_out = [&]() {
       for (int j = sub; j < out_n; j += G) {
         const int q = out_p0 + j;
-        if (live) cells[bwd ? (S - 1 - q) : q] = ring[(q & (W - 1)) * LPW + slot];
+        if (live) {
+          const RingCell* rc = ring + (q & (W - 1)) * LPW + slot;
+          MECell cell;
+          cell.m = rc->m;
+          cell.e = rc->e;
+          cells[bwd ? (S - 1 - q) : q] = cell;
+        }
       }
     };
     // chunk c is staged during the consumer's chunk c-1; nchunks is a multiple of D
@@ -180,20 +196,24 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         wb[j] = sw[cn * 64];
         gb[j] = sg[cn * 64];
         ab[j] = sa[cn * 64];
-        StagedTerm* st = stage + ((c + j) & 1) * 256 + lane;
-        int32_t* fs = far + ((c + j) & 1) * 256 + lane;
-        const int p0 = p;
+        // stage buffer: [barrier period parity][chunk within the period][round][lane]
+        const int sidx = ((((c + j) / CPB) & 1) * CPB + ((c + j) % CPB)) * 256 + lane;
+        StagedTerm* st = stage + sidx;
+        int32_t* fs = far + sidx;
+        if ((c + j) % CPB == 0) period_p0 = p;
         put(st, fs, (uint32_t)w4.x, g4.x, a4.x);
         put(st + 64, fs + 64, (uint32_t)w4.y, g4.y, a4.y);
         put(st + 128, fs + 128, (uint32_t)w4.z, g4.z, a4.z);
         put(st + 192, fs + 192, (uint32_t)w4.w, g4.w, a4.w);
-        __syncthreads();  // chunk c+j is staged; the consumer has finished chunk c+j-1
-        copy_out();       // ... whose states are now stable in the ring (W >= 8 >= 2 chunks)
-        out_p0 = p0;
-        out_n = p - p0;
+        if ((c + j) % CPB == CPB - 1) {
+          __syncthreads();  // this period is staged; the consumer has finished the previous one
+          copy_out();       // ... whose states are stable in the ring (W >= 2 periods of states)
+          out_p0 = period_p0;
+          out_n = p - period_p0;
+        }
       }
     }
-    __syncthreads();  // the consumer has finished the last chunk
+    __syncthreads();  // the consumer has finished the last period
     copy_out();
     return;
   }
@@ -215,7 +235,8 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   bool sticky = false; // FAST: some term left the safe exponent window
   double lastM = 0.0;  // value of the state finished by the previous round (register bypass)
   int lastE = kExpMin;
-  MECell pre;          // ring read for the upcoming round, software-pipelined one round ahead
+  double preM = 0.0;   // ring read for the upcoming round, software-pipelined one round ahead
+  int preE = kExpMin;
 
   // SPECIAL = this chunk may hold constant-one or FAR sources; PRE = issue the next round's ring
   // read (the last round of a chunk cannot: its successor is staged behind the barrier)
@@ -223,10 +244,14 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     const uint32_t ctl = t.ctl;
     const bool last = (ctl & kCtlLast) != 0;
     const bool first = (ctl & kCtlFirst) != 0;
-    double sm = pre.m;
-    int se = (int)pre.e;
+    double sm = preM;
+    int se = preE;
     // issue next round's ring read now, ahead of this round's ring write
-    if (decltype(do_pre)::value) pre = ring[ctl_next & kCellMask];
+    if (decltype(do_pre)::value) {
+      const RingCell* rc = ring + (ctl_next & kCellMask);
+      preM = rc->m;
+      preE = rc->e;
+    }
     const bool bypass = (ctl & kCtlBypass) != 0;
     sm = bypass ? lastM : sm;
     se = bypass ? lastE : se;
@@ -282,23 +307,27 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     lastM = m;
     lastE = e;
     if (ctl & kCtlCommit) {
-      MECell cell;
-      cell.m = m;
-      cell.e = e;
-      ring[(ctl >> 11) & kCellMask] = cell;
+      RingCell* rc = ring + ((ctl >> kWrShift) & kCellMask);
+      rc->m = m;
+      rc->e = e;
     }
     if (FAST) refE = (last & nz) ? e : refE;
   };
 
   for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();  // chunk c is staged (and, for c == 0, the ring is initialised)
-    const StagedTerm* st = stage + (c & 1) * 256 + lane;
+    if (c % CPB == 0) __syncthreads();  // the period is staged (and, for c == 0, the ring is initialised)
+    const int sidx = (((c / CPB) & 1) * CPB + (c % CPB)) * 256 + lane;
+    const StagedTerm* st = stage + sidx;
     const StagedTerm t0 = st[0], t1 = st[64], t2 = st[128], t3 = st[192];
-    pre = ring[t0.ctl & kCellMask];  // after the previous chunk's last ring write: the fresh value
+    {  // after the previous chunk's last ring write: the fresh value
+      const RingCell* rc = ring + (t0.ctl & kCellMask);
+      preM = rc->m;
+      preE = rc->e;
+    }
     const std::true_type yes;
     const std::false_type no;
     if (__any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & (kCtlOne | kCtlFar)) != 0)) {
-      const int32_t* fs = far + (c & 1) * 256 + lane;
+      const int32_t* fs = far + sidx;
       const bool anyfar = __any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & kCtlFar) != 0);
       const int f0 = anyfar ? fs[0] : 0, f1 = anyfar ? fs[64] : 0, f2 = anyfar ? fs[128] : 0, f3 = anyfar ? fs[192] : 0;
       round(yes, yes, t0, t1.ctl, f0);
@@ -312,16 +341,25 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       round(no, no, t3, 0u, 0);
     }
   }
-  __syncthreads();  // lets the producer copy out the last chunk's states
+  __syncthreads();  // lets the producer copy out the last period's states
   if (FAST) {
     if (__any(sticky) && lane == 0) args.job_flags[blockIdx.x] = 1;
   }
 }
 
 template <int G>
-static void launch_pair(const SweepArgs& args, int num_jobs, size_t lds, hipStream_t stream) {
-  hipLaunchKernelGGL((sweep_kernel<G, true>), dim3(num_jobs), dim3(128), lds, stream, args);
-  hipLaunchKernelGGL((sweep_kernel<G, false>), dim3(num_jobs), dim3(128), lds, stream, args);
+static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream) {
+  const int LPW = 64 / G;
+  // the producer copies a period's states out one period later: the ring must hold two periods
+  const int cpb = args.ring_slots >= 16 ? 2 : 1;
+  const size_t lds = (size_t)args.ring_slots * LPW * sizeof(RingCell) + (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t));
+  if (cpb == 2) {
+    hipLaunchKernelGGL((sweep_kernel<G, true, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
+    hipLaunchKernelGGL((sweep_kernel<G, false, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
+  } else {
+    hipLaunchKernelGGL((sweep_kernel<G, true, 1>), dim3(num_jobs), dim3(128), lds, stream, args);
+    hipLaunchKernelGGL((sweep_kernel<G, false, 1>), dim3(num_jobs), dim3(128), lds, stream, args);
+  }
 }
 
 // Clears the job flags, runs the fast sweep over every job and the exact sweep over the jobs the
@@ -330,17 +368,16 @@ hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t 
   if (num_jobs <= 0) return hipSuccess;
   const int LPW = 64 / G;
   if ((size_t)args.ring_slots * LPW > kCellMask + 1) return hipErrorInvalidValue;
-  const size_t lds = (size_t)args.ring_slots * LPW * sizeof(MECell) + 2 * 4 * 64 * (sizeof(StagedTerm) + sizeof(int32_t));
   hipError_t e = hipMemsetAsync(args.job_flags, 0, sizeof(int32_t) * (size_t)num_jobs, stream);
   if (e != hipSuccess) return e;
   switch (G) {
-    case 1: launch_pair<1>(args, num_jobs, lds, stream); break;
-    case 2: launch_pair<2>(args, num_jobs, lds, stream); break;
-    case 4: launch_pair<4>(args, num_jobs, lds, stream); break;
-    case 8: launch_pair<8>(args, num_jobs, lds, stream); break;
-    case 16: launch_pair<16>(args, num_jobs, lds, stream); break;
-    case 32: launch_pair<32>(args, num_jobs, lds, stream); break;
-    case 64: launch_pair<64>(args, num_jobs, lds, stream); break;
+    case 1: launch_pair<1>(args, num_jobs, stream); break;
+    case 2: launch_pair<2>(args, num_jobs, stream); break;
+    case 4: launch_pair<4>(args, num_jobs, stream); break;
+    case 8: launch_pair<8>(args, num_jobs, stream); break;
+    case 16: launch_pair<16>(args, num_jobs, stream); break;
+    case 32: launch_pair<32>(args, num_jobs, stream); break;
+    case 64: launch_pair<64>(args, num_jobs, stream); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
