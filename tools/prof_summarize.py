@@ -20,13 +20,14 @@ src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
+newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]
+stats = newest(glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv")))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
 
 traffic = collections.defaultdict(dict)
 for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    files = glob.glob(os.path.join(src, "prof_%s" % name, "*", "*_counter_collection.csv"))
+    files = newest(glob.glob(os.path.join(src, "prof_%s" % name, "*", "*_counter_collection.csv")))
     if not files:
         continue
     acc = collections.defaultdict(list)
