@@ -71,7 +71,7 @@ int choose_lanes_per_lattice(int64_t U, int64_t S, int64_t A) {
 int choose_ring_slots(int G, int64_t max_rel) {
   const int LPW = 64 / G;
   int cap = 8;
-  while (cap * 2 * LPW * 16 <= 32 * 1024 && cap < 1024) cap *= 2;  // <= 32 KiB LDS per wave (16 B ring cells)
+  while (cap * 2 * LPW <= 1024 && cap < 1024) cap *= 2;  // <= 1024 ring cells (16 KiB) per workgroup
   int W = 8;
   while (W <= max_rel && W < cap) W *= 2;
   return W;
@@ -168,8 +168,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   // The ring only has to cover arcs; final terms (rel = S - s) may be far without harm, so the
   // automatic W follows the arcs' span, which pass 1 folded into max_rel together with finals.
   int W = opt.ring_slots ? opt.ring_slots : choose_ring_slots(G, max_rel.load());
-  if ((int64_t)W * LPW > 2048) {
-    *err = "ring_slots * (64 / lanes_per_lattice) must not exceed 2048 ring cells per workgroup";
+  if ((int64_t)W * LPW > 1024) {
+    *err = "ring_slots * (64 / lanes_per_lattice) must not exceed 1024 ring cells per workgroup";
     return KLAT_ERR_INVALID_ARG;
   }
 
@@ -234,7 +234,10 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
     const SweepJob& job = P.jobs[j];
     const size_t b0 = (size_t)job.chunk_off * 64 * kChunkRounds;
     const size_t n = (size_t)job.nchunks * 64 * kChunkRounds;
-    for (size_t i = 0; i < n; ++i) P.sw[b0 + i] = (int32_t)kNil;
+    // padding: zero-weight terms that read cell 0 and park their (unused) result in the lane's
+    // own dummy cell behind the ring, so that the consumer's ring write needs no predicate
+    for (size_t i = 0; i < n; ++i)
+      P.sw[b0 + i] = (int32_t)(kNil | ((uint32_t)(W * LPW + (int)((i / kChunkRounds) % 64)) << kWrShift));
     std::memset(&P.sg[b0], 0, n * sizeof(float));
     std::memset(&P.sa[b0], 0, n * sizeof(float));
     int64_t far_local = 0;
@@ -272,6 +275,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
           if (rel == 1 && nterm < G) w |= kBypass;  // first round: the source was finished just before
         }
         if (word) w |= kWord;
+        if ((w & kFar) == 0) w |= (uint32_t)(W * LPW + lane) << kWrShift;  // dummy cell unless COMMIT (end_pos)
         const size_t ix = slot_index(rr, lane);
         P.sw[ix] = (int32_t)w;
         P.sg[ix] = g;
@@ -288,7 +292,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
         }
         // the lattice's first lane stores the state's value at the end of its last round
         int32_t& cw = P.sw[slot_index(lastr, lane0)];
-        if (((uint32_t)cw & kFar) == 0) cw |= (int32_t)(kCommit | (ring_cell(pos) << kWrShift));
+        if (((uint32_t)cw & kFar) == 0)
+          cw = (int32_t)((((uint32_t)cw) & ~(kCellMask << kWrShift)) | kCommit | (ring_cell(pos) << kWrShift));
         r += nr;
       };
       if (job.dir == 0) {

@@ -53,6 +53,23 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// Workgroup barriers of the producer/consumer pair.  __syncthreads() would drain vmcnt(0): the
+// producer would then wait at every barrier for the stream loads it has just prefetched (a full
+// HBM latency per period).  Only LDS has to be ordered here, so the producer keeps its newest
+// KEEP global operations (the period's prefetch loads) in flight; everything older -- including
+// the previous period's copy-out stores, which FAR reads two periods later rely on -- is done.
+template <int KEEP>
+__device__ __forceinline__ void producer_barrier() {
+  static_assert(KEEP == 3 || KEEP == 6, "three stream loads per chunk");
+  if (KEEP == 6)
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void consumer_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // One ring cell in LDS.  The consumer reads m and e as separate 8- and 4-byte accesses: a 16-byte
 // read would leave a dead register that the allocator reuses at once, forcing an immediate
 // s_waitcnt on the software-pipelined read.
@@ -119,7 +136,8 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   if (!FAST && args.job_flags[blockIdx.x] == 0) return;  // workgroup-uniform
 
   RingCell* ring = smem;                                                      // [W][LPW]
-  StagedTerm* stage = reinterpret_cast<StagedTerm*>(smem + (size_t)W * LPW);  // [2][CPB][4][64]
+  // 64 dummy cells (one per lane) follow the ring, then the stage buffers [2][CPB][4][64]
+  StagedTerm* stage = reinterpret_cast<StagedTerm*>(smem + (size_t)W * LPW + 64);
   int32_t* far = reinterpret_cast<int32_t*>(stage + 2 * CPB * 256);          // [2][CPB][4][64]
   const int lane = threadIdx.x & 63;
   const int slot = lane / G;
@@ -165,7 +183,10 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           const int q = p - (int)(w & kRelMask);
           *fdst = bwd ? (S - 1 - q) : q;
           ctl &= ~kRelMask;  // reads ring cell 0 (ignored), source comes from far[]
-          if (last && sub == 0) ctl |= kCommit | ((uint32_t)((p & (W - 1)) * LPW + slot) << kWrShift);
+          if (last && sub == 0)
+            ctl |= kCommit | ((uint32_t)((p & (W - 1)) * LPW + slot) << kWrShift);
+          else
+            ctl |= (uint32_t)(W * LPW + lane) << kWrShift;  // the lane's dummy cell
         }
       }
       t.ctl = ctl;
@@ -206,7 +227,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         put(st + 128, fs + 128, (uint32_t)w4.z, g4.z, a4.z);
         put(st + 192, fs + 192, (uint32_t)w4.w, g4.w, a4.w);
         if ((c + j) % CPB == CPB - 1) {
-          __syncthreads();  // this period is staged; the consumer has finished the previous one
+          producer_barrier<3 * CPB>();  // this period is staged; the consumer has finished the previous one
           copy_out();       // ... whose states are stable in the ring (W >= 2 periods of states)
           out_p0 = period_p0;
           out_n = p - period_p0;
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     const int e = nz ? cE + __builtin_amdgcn_frexp_exp(cM) : kExpMin;
     lastM = m;
     lastE = e;
-    if (ctl & kCtlCommit) {
+    {  // unpredicated: lanes that do not commit a state write their own dummy cell behind the ring
       RingCell* rc = ring + ((ctl >> kWrShift) & kCellMask);
       rc->m = m;
       rc->e = e;
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   };
 
   for (int c = 0; c < nchunks; ++c) {
-    if (c % CPB == 0) __syncthreads();  // the period is staged (and, for c == 0, the ring is initialised)
+    if (c % CPB == 0) consumer_barrier();  // the period is staged (and, for c == 0, the ring is initialised)
     const int sidx = (((c / CPB) & 1) * CPB + (c % CPB)) * 256 + lane;
     const StagedTerm* st = stage + sidx;
     const StagedTerm t0 = st[0], t1 = st[64], t2 = st[128], t3 = st[192];
@@ -352,7 +373,7 @@ static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream)
   const int LPW = 64 / G;
   // the producer copies a period's states out one period later: the ring must hold two periods
   const int cpb = args.ring_slots >= 16 ? 2 : 1;
-  const size_t lds = (size_t)args.ring_slots * LPW * sizeof(RingCell) + (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t));
+  const size_t lds = ((size_t)args.ring_slots * LPW + 64) * sizeof(RingCell) + (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t));
   if (cpb == 2) {
     hipLaunchKernelGGL((sweep_kernel<G, true, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
     hipLaunchKernelGGL((sweep_kernel<G, false, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
@@ -367,7 +388,7 @@ static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream)
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream) {
   if (num_jobs <= 0) return hipSuccess;
   const int LPW = 64 / G;
-  if ((size_t)args.ring_slots * LPW > kCellMask + 1) return hipErrorInvalidValue;
+  if ((size_t)args.ring_slots * LPW + 64 > kCellMask + 1) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(args.job_flags, 0, sizeof(int32_t) * (size_t)num_jobs, stream);
   if (e != hipSuccess) return e;
   switch (G) {

@@ -45,7 +45,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
     info = packed["info"]
     G, W = info["lanes_per_lattice"], info["ring_slots"]
     LPW = 64 // G
-    assert W * LPW <= CELL_MASK + 1
+    assert W * LPW + 64 <= CELL_MASK + 1
     sw = packed["sw"].view(np.uint32)
     sg, sa = packed["sg"], packed["sa"]
     S_tot = int(state_off[-1])
@@ -74,6 +74,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                     w = int(sw[ix])
                     if base < 0 or p >= npos:
                         assert w & NIL and not (w & (LAST | FIRST | COMMIT | FAR)), "padding must be plain NIL"
+                        assert (w >> WR_SHIFT) & CELL_MASK == W * LPW + lane
                         continue
                     assert bool(w & FIRST) == (nround == 0), "FIRST marks exactly the first round of a state"
                     c = _cost(sg[ix], sa[ix], bool(w & WORD), graph_scale, acoustic_scale, insertion_penalty)
@@ -114,6 +115,8 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                     if w & COMMIT:
                         assert sub == 0 and (w & LAST)
                         commit = (w >> WR_SHIFT) & CELL_MASK
+                    elif not (w & FAR):
+                        assert (w >> WR_SHIFT) & CELL_MASK == W * LPW + lane, "non-commit lanes write their dummy cell"
                     elif (w & LAST) and sub == 0:
                         assert w & FAR, "the first lane of a LAST round commits (FAR terms: resolved by the kernel)"
                         commit = (p & (W - 1)) * LPW + slot
