@@ -26,6 +26,7 @@ struct AccumArgs {
   void* key_scratch;  // 16 B per slot
   void* rec_scratch;  // 24 B per slot
   int32_t* num_records;  // [U]
+  int32_t tile_bytes;    // dynamic LDS per workgroup (sort tile), <= 128 KiB
 };
 
 struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)

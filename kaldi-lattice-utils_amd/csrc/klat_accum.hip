@@ -8,10 +8,12 @@
 //
 // The reference does this with two-level std::map inserts per arc.  Here one workgroup owns one
 // lattice: (1) filter arcs and emit 16-byte keys (label,t0,t1 | label,pos ; arc index),
-// (2) bitonic sort of the keys (LDS tiles of 2048 keys, global passes above that),
-// (3) each run of equal keys is folded in arc order with the reference's LogAdd (cutoff
-// log(DBL_EPSILON) included), (4) the folded records are bitonic-sorted by the reference's output
-// comparator.  Utterance-level parallelism (thousands of lattices) fills the chip; there is no
+// (2) bitonic sort of the keys, (3) each run of equal keys is folded in arc order with the
+// reference's LogAdd (cutoff log(DBL_EPSILON) included), (4) the folded records are
+// bitonic-sorted by the reference's output comparator.  The sorts run in a dynamic LDS tile sized
+// by the host for the largest lattice of the batch (up to 128 KiB: 8192 keys), so a C2-sized
+// lattice is sorted with one load and one store; larger lattices sort tile by tile and merge with
+// global passes.  Utterance-level parallelism (thousands of lattices) fills the chip; there is no
 // inter-workgroup communication.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -21,9 +23,7 @@
 
 namespace klat {
 
-static constexpr int kAccThreads = 512;
-static constexpr int kKeyTile = 2048;  // 16-byte keys per LDS tile  (32 KiB)
-static constexpr int kRecTile = 1024;  // 24-byte records per LDS tile (24 KiB)
+static constexpr int kAccThreads = 1024;
 
 // LogAdd(double,double) of SURVEY.md A.2, as the reference's accumulators call it.
 __device__ __forceinline__ double log_add(double x, double y) {
@@ -75,37 +75,43 @@ struct RecLess {
   }
 };
 
-// In-place bitonic sort of n (power of two) elements at `data` (global) by one workgroup.
-// Passes with stride < TILE run inside an LDS tile.
-template <class T, int TILE, class Less>
-__device__ void block_bitonic_sort(T* data, int n, T* tile, Less less) {
-  const int tid = threadIdx.x;
-  if (n <= TILE) {  // whole sort inside LDS
-    for (int i = tid; i < n; i += kAccThreads) tile[i] = data[i];
-    __syncthreads();
-    for (int k = 2; k <= n; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < n; i += kAccThreads) {
-          const int l = i ^ j;
-          if (l > i) {
-            const T x = tile[i], y = tile[l];
-            const bool up = (i & k) == 0;
-            if (up ? less(y, x) : less(x, y)) {
-              tile[i] = y;
-              tile[l] = x;
-            }
-          }
-        }
-        __syncthreads();
+// one compare-exchange pass of stride j inside an LDS tile of tl elements starting at global
+// index `base`; k is the bitonic block size that fixes the direction
+template <class T, class Less>
+__device__ __forceinline__ void tile_pass(T* tile, int tl, int base, int k, int j, Less less) {
+  for (int i = threadIdx.x; i < tl; i += kAccThreads) {
+    const int l = i ^ j;
+    if (l > i) {
+      const T x = tile[i], y = tile[l];
+      const bool up = ((base + i) & k) == 0;
+      if (up ? less(y, x) : less(x, y)) {
+        tile[i] = y;
+        tile[l] = x;
       }
     }
-    for (int i = tid; i < n; i += kAccThreads) data[i] = tile[i];
-    __syncthreads();
-    return;
   }
-  for (int k = 2; k <= n; k <<= 1) {
-    int j = k >> 1;
-    for (; j >= TILE; j >>= 1) {  // global passes
+  __syncthreads();
+}
+
+// In-place bitonic sort of n (power of two) elements at `data` (global) by one workgroup, with an
+// LDS tile of `tile_elems` (power of two) elements.
+template <class T, class Less>
+__device__ void block_bitonic_sort(T* data, int n, T* tile, int tile_elems, Less less) {
+  const int tid = threadIdx.x;
+  const int tl = n < tile_elems ? n : tile_elems;
+  // phase 1: every tile is sorted completely in LDS (all k <= tl), directions as in the full network
+  for (int base = 0; base < n; base += tl) {
+    for (int i = tid; i < tl; i += kAccThreads) tile[i] = data[base + i];
+    __syncthreads();
+    for (int k = 2; k <= tl; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) tile_pass(tile, tl, base, k, j, less);
+    for (int i = tid; i < tl; i += kAccThreads) data[base + i] = tile[i];
+    __syncthreads();
+  }
+  // phase 2: merge levels above the tile size: global passes for strides >= tl, then one LDS
+  // visit per tile for the strides below
+  for (int k = tl << 1; k <= n; k <<= 1) {
+    for (int j = k >> 1; j >= tl; j >>= 1) {
       for (int i = tid; i < n; i += kAccThreads) {
         const int l = i ^ j;
         if (l > i) {
@@ -119,25 +125,10 @@ __device__ void block_bitonic_sort(T* data, int n, T* tile, Less less) {
       }
       __syncthreads();
     }
-    // remaining strides of this k inside LDS tiles
-    const int tl = TILE;
     for (int base = 0; base < n; base += tl) {
       for (int i = tid; i < tl; i += kAccThreads) tile[i] = data[base + i];
       __syncthreads();
-      for (int jj = j; jj > 0; jj >>= 1) {
-        for (int i = tid; i < tl; i += kAccThreads) {
-          const int l = i ^ jj;
-          if (l > i) {
-            const T x = tile[i], y = tile[l];
-            const bool up = ((base + i) & k) == 0;
-            if (up ? less(y, x) : less(x, y)) {
-              tile[i] = y;
-              tile[l] = x;
-            }
-          }
-        }
-        __syncthreads();
-      }
+      for (int j = tl >> 1; j > 0; j >>= 1) tile_pass(tile, tl, base, k, j, less);
       for (int i = tid; i < tl; i += kAccThreads) data[base + i] = tile[i];
       __syncthreads();
     }
@@ -157,7 +148,7 @@ __device__ __forceinline__ bool in_sorted(const int32_t* set, int n, int32_t v) 
 }
 
 // block-wide exclusive prefix of a 0/1 flag; returns the thread's offset, *total the block sum
-__device__ int block_compact_offset(bool flag, int* total, int* sh /* [kAccThreads/64 + 1] */) {
+__device__ int block_compact_offset(bool flag, int* total, int* sh /* [kAccThreads/64] */) {
   const uint64_t ballot = __ballot(flag);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int within = __popcll(ballot & ((1ull << lane) - 1ull));
@@ -175,9 +166,8 @@ __device__ int block_compact_offset(bool flag, int* total, int* sh /* [kAccThrea
 
 template <bool POSITION>
 __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kKeyTile * sizeof(Key)];
-  __shared__ int sh[kAccThreads / 64 + 1];
-  __shared__ int s_count;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int sh[kAccThreads / 64];
   const int u = blockIdx.x;
   const int tid = threadIdx.x;
   const int64_t a0 = a.arc_off[u], a1 = a.arc_off[u + 1];
@@ -186,6 +176,10 @@ __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
   Key* keys = reinterpret_cast<Key*>(a.key_scratch) + a.scratch_off[u];
   Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + a.scratch_off[u];
   const int cap = (int)(a.scratch_off[u + 1] - a.scratch_off[u]);  // power of two >= nA (or 0)
+  // LDS tile capacities (powers of two) for the two element sizes
+  int key_tile = 1, rec_tile = 1;
+  while ((size_t)key_tile * 2 * sizeof(Key) <= (size_t)a.tile_bytes) key_tile <<= 1;
+  while ((size_t)rec_tile * 2 * sizeof(Rec) <= (size_t)a.tile_bytes) rec_tile <<= 1;
 
   // ---- 1. filter + keys (compacted; order is fixed later by the arc index in the key) ----
   int n = 0;
@@ -229,7 +223,7 @@ __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
   }
 
   // ---- 2. sort keys ----
-  if (np > 1) block_bitonic_sort<Key, kKeyTile, KeyLess>(keys, np, reinterpret_cast<Key*>(smem), KeyLess());
+  if (np > 1) block_bitonic_sort<Key, KeyLess>(keys, np, reinterpret_cast<Key*>(smem), key_tile, KeyLess());
 
   // ---- 3. fold runs of equal keys in arc order ----
   const uint64_t group_mask_b = POSITION ? 0ull : 0xFFFFFFFF00000000ull;
@@ -294,12 +288,11 @@ __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
   // ---- 4. sort by the reference's output comparator ----
   if (mp > 1) {
     if (POSITION)
-      block_bitonic_sort<Rec, kRecTile, RecLess<false>>(recs, mp, reinterpret_cast<Rec*>(smem), RecLess<false>());
+      block_bitonic_sort<Rec, RecLess<false>>(recs, mp, reinterpret_cast<Rec*>(smem), rec_tile, RecLess<false>());
     else
-      block_bitonic_sort<Rec, kRecTile, RecLess<true>>(recs, mp, reinterpret_cast<Rec*>(smem), RecLess<true>());
+      block_bitonic_sort<Rec, RecLess<true>>(recs, mp, reinterpret_cast<Rec*>(smem), rec_tile, RecLess<true>());
   }
   if (tid == 0) a.num_records[u] = m;
-  (void)s_count;
 }
 
 // Gathers the per-lattice sorted records into the dense output (record_off computed on the host
@@ -330,10 +323,16 @@ __global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const in
 
 hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
-  if (position)
-    hipLaunchKernelGGL(index_kernel<true>, dim3(num_lattices), dim3(kAccThreads), 0, stream, a);
-  else
-    hipLaunchKernelGGL(index_kernel<false>, dim3(num_lattices), dim3(kAccThreads), 0, stream, a);
+  hipError_t e;
+  if (position) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(index_kernel<true>, dim3(num_lattices), dim3(kAccThreads), (size_t)a.tile_bytes, stream, a);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(index_kernel<false>, dim3(num_lattices), dim3(kAccThreads), (size_t)a.tile_bytes, stream, a);
+  }
   return hipGetLastError();
 }
 

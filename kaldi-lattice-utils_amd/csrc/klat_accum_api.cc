@@ -71,6 +71,13 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
   a.key_scratch = st.key_scratch.p;
   a.rec_scratch = st.rec_scratch.p;
   a.num_records = st.num_records.p;
+  {
+    // sort tile: big enough for the largest lattice's keys if that fits 128 KiB of LDS
+    int64_t max_arcs = 0;
+    for (int64_t u = 0; u < b->U; ++u) max_arcs = std::max(max_arcs, b->h_arc_off[u + 1] - b->h_arc_off[u]);
+    const int64_t want = next_pow2(max_arcs) * 24;
+    a.tile_bytes = (int32_t)std::min<int64_t>(128 * 1024, std::max<int64_t>(4096, want));
+  }
 
   if (records == nullptr) {  // sizing call: compute and cache
     klat_label_filter flt = {nullptr, 0, nullptr, 0};
