@@ -60,6 +60,9 @@ int main(int argc, char* argv[]) {
       CompactLattice& clat = reader.Value();
       CompactLattice dlat;
       std::vector<int32_t> times, state_len;
+      // Lattice pruning (applied after acoustic scaling and adding the insertion penalty)
+      if (io.Prunes() && clat.Start() != CompactLattice::kNoStateId)
+        PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &clat);
       if (clat.Start() != CompactLattice::kNoStateId) {
         TopSortCompactLatticeIfNeeded(&clat);
         DisambiguateStateInputSequenceLength(clat, &dlat, &state_len, false);

@@ -59,6 +59,9 @@ int main(int argc, char* argv[]) {
       CompactLattice& clat = reader.Value();
       KLAT_VLOG(1, "Lattice " << reader.Key() << ": #states " << clat.NumStates() << " #arcs " << clat.NumArcs());
       std::vector<int32_t> times;
+      // Lattice pruning (applied after acoustic scaling and adding the insertion penalty)
+      if (io.Prunes() && clat.Start() != CompactLattice::kNoStateId)
+        PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &clat);
       if (clat.Start() != CompactLattice::kNoStateId) {
         TopSortCompactLatticeIfNeeded(&clat);
         CompactLatticeStateTimes(clat, &times);

@@ -43,9 +43,9 @@ struct IndexOptions {
     po->Register("num-threads", &num_threads, "Accepted for compatibility; lattices are batched on the GPU instead.");
     po->Register("num-threads-total", &num_threads_total, "Accepted for compatibility.");
   }
+  bool Prunes() const { return beam != std::numeric_limits<float>::infinity(); }
   void Check() const {
-    if (beam != std::numeric_limits<float>::infinity())
-      KLAT_ERR("--beam: PruneLattice is not part of this build (SURVEY.md 8f item f2); run without --beam");
+    if (Prunes() && !(beam > 0.0f)) KLAT_ERR("--beam must be positive");
   }
 };
 

@@ -142,6 +142,107 @@ int32_t DisambiguateStateInputSequenceLength(const CompactLattice& ifst, Compact
   return max_len;
 }
 
+namespace {
+// ConvertToCost of a weight after ScaleLattice / AddWordInsPen, with the reference's rounding:
+// products formed in double and stored as float, penalty added in float, sum in double.
+inline double ScaledCost(float g, float a, bool word, float gs, float as, float pen) {
+  const float inf = std::numeric_limits<float>::infinity();
+  if (as != 1.0f || gs != 1.0f) {
+    if (g == inf) {
+      a = inf;
+    } else {
+      g = (float)((double)gs * (double)g);
+      a = (float)((double)as * (double)a);
+    }
+  }
+  if (pen != 0.0f && word) g = g + pen;
+  return (double)g + (double)a;
+}
+}  // namespace
+
+bool PruneLattice(float beam, float gs, float as, float pen, CompactLattice* clat) {
+  if (!(beam > 0.0f)) KLAT_ERR("PruneLattice: beam must be positive");
+  TopSortCompactLatticeIfNeeded(clat);
+  const int32_t S = clat->NumStates();
+  if (S == 0 || clat->Start() == CompactLattice::kNoStateId) return false;
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<double> cost(S, inf);  // Viterbi forward, then shared with the backward costs
+  cost[clat->Start()] = 0.0;
+  double best_final = inf;
+  for (int32_t s = 0; s < S; ++s) {
+    const CompactLatticeState& st = clat->State(s);
+    const double fc = cost[s];
+    for (const auto& arc : st.arcs) {
+      const double nc = fc + ScaledCost(arc.graph, arc.acoustic, arc.ilabel != 0, gs, as, pen);
+      if (cost[arc.nextstate] > nc) cost[arc.nextstate] = nc;
+    }
+    const double tf = fc + ScaledCost(st.final_graph, st.final_acoustic, false, gs, as, 0.0f);
+    if (tf < best_final) best_final = tf;
+  }
+  const double cutoff = best_final + beam;
+  std::vector<std::vector<uint8_t>> keep(S);
+  for (int32_t s = S - 1; s >= 0; --s) {
+    CompactLatticeState& st = clat->State(s);
+    const double fc = cost[s];
+    double bc = ScaledCost(st.final_graph, st.final_acoustic, false, gs, as, 0.0f);
+    if (bc + fc > cutoff && bc != inf) {
+      st.final_graph = st.final_acoustic = std::numeric_limits<float>::infinity();
+      st.final_string_len = 0;
+    }
+    keep[s].assign(st.arcs.size(), 1);
+    for (size_t i = 0; i < st.arcs.size(); ++i) {
+      const auto& arc = st.arcs[i];
+      const double abc = ScaledCost(arc.graph, arc.acoustic, arc.ilabel != 0, gs, as, pen) + cost[arc.nextstate];
+      if (abc < bc) bc = abc;
+      if (fc + abc > cutoff) keep[s][i] = 0;  // the reference redirects the arc to a dead state
+    }
+    cost[s] = bc;
+  }
+  // Connect(): keep states that are accessible from the start and co-accessible to a final state
+  std::vector<uint8_t> acc(S, 0), coacc(S, 0);
+  acc[clat->Start()] = 1;
+  for (int32_t s = 0; s < S; ++s) {
+    if (!acc[s]) continue;
+    const auto& arcs = clat->State(s).arcs;
+    for (size_t i = 0; i < arcs.size(); ++i)
+      if (keep[s][i]) acc[arcs[i].nextstate] = 1;
+  }
+  for (int32_t s = S - 1; s >= 0; --s) {
+    const CompactLatticeState& st = clat->State(s);
+    bool c = st.IsFinal();
+    for (size_t i = 0; i < st.arcs.size() && !c; ++i)
+      if (keep[s][i] && coacc[st.arcs[i].nextstate]) c = true;
+    coacc[s] = c;
+  }
+  std::vector<int32_t> newid(S, -1);
+  int32_t n = 0;
+  for (int32_t s = 0; s < S; ++s)
+    if (acc[s] && coacc[s]) newid[s] = n++;
+  if (n == 0 || newid[clat->Start()] < 0) {
+    clat->DeleteStates();
+    return false;
+  }
+  std::vector<CompactLatticeState> ns(n);
+  for (int32_t s = 0; s < S; ++s) {
+    if (newid[s] < 0) continue;
+    CompactLatticeState& src = clat->State(s);
+    CompactLatticeState& dst = ns[newid[s]];
+    dst.final_graph = src.final_graph;
+    dst.final_acoustic = src.final_acoustic;
+    dst.final_string_len = src.final_string_len;
+    for (size_t i = 0; i < src.arcs.size(); ++i) {
+      if (!keep[s][i] || newid[src.arcs[i].nextstate] < 0) continue;
+      CompactLatticeArc arc = src.arcs[i];
+      arc.nextstate = newid[arc.nextstate];
+      dst.arcs.push_back(arc);
+    }
+  }
+  const int32_t new_start = newid[clat->Start()];
+  clat->States() = std::move(ns);
+  clat->SetStart(new_start);
+  return true;
+}
+
 // ---- LatticeBatch ----
 void LatticeBatch::Clear() {
   state_off_.assign(1, 0);

@@ -30,6 +30,17 @@ int32_t CompactLatticeStateTimes(const CompactLattice& clat, std::vector<int32_t
 int32_t DisambiguateStateInputSequenceLength(const CompactLattice& ifst, CompactLattice* ofst,
                                              std::vector<int32_t>* state_input_length, bool use_input = false);
 
+// PruneLattice(beam, &clat) as the kwsbin2 tools apply it after ScaleLattice and
+// AddWordInsPenToCompactLattice (kwsbin2/lattice-word-index-segment.cc:41-51): Viterbi forward /
+// backward costs (structure mirrored in-repo at latbin/lattice-prune-dyn-beam.cc:35-87), final
+// weights and arcs whose best path through them costs more than best + beam are dropped, then
+// Connect() removes states that are no longer accessible and co-accessible (ids stay in order).
+// The lattice keeps its ORIGINAL costs (the GPU applies the scales later); the pruning decision
+// uses the costs the reference would see, i.e. scaled and penalised with its float rounding.
+// Host-side graph surgery.  Returns false if the result is empty.
+bool PruneLattice(float beam, float graph_scale, float acoustic_scale, float insertion_penalty,
+                  CompactLattice* clat);
+
 // A batch of top-sorted lattices flattened to the CSR/SoA layout of klat_batch_desc.
 class LatticeBatch {
  public:

@@ -666,6 +666,72 @@ int32_t kor_disambiguate_length(int32_t S, int32_t start, const int64_t *arc_beg
   return max_len;
 }
 
+/* ---- A.4  PruneLattice(beam, lat) [UPSTREAM lat/lattice-functions.cc]; call sites
+ * kwsbin2/lattice-word-index-segment.cc:49-51, kwsbin2/lattice-word-index-position.cc:49-51;
+ * loop structure corroborated by the in-repo latbin/lattice-prune-dyn-beam.cc:35-87.
+ * Input costs are the ones the tool holds at that point (already scaled / penalised).
+ * Outputs: keep_arc[A] (0 = arc redirected to the dead state), final weights set to Zero in
+ * place where pruned, keep_state[S] = accessible and co-accessible after Connect().
+ * Returns the number of kept states. */
+int32_t kor_prune_lattice(int32_t S, const int64_t *arc_begin, const int32_t *dst, const float *graph,
+                          const float *acoustic, float *final_graph, float *final_acoustic,
+                          double beam, uint8_t *keep_arc, uint8_t *keep_state) {
+  if (S == 0) return 0;
+  double *cost = (double *)malloc(sizeof(double) * (size_t)S);
+  for (int32_t s = 0; s < S; ++s) cost[s] = INFINITY;
+  cost[0] = 0.0;
+  double best_final = INFINITY;
+  for (int32_t s = 0; s < S; ++s) {
+    double fc = cost[s];
+    for (int64_t i = arc_begin[s]; i < arc_begin[s + 1]; ++i) {
+      double nc = fc + ((double)graph[i] + (double)acoustic[i]);
+      if (cost[dst[i]] > nc) cost[dst[i]] = nc;
+    }
+    double tf = fc + ((double)final_graph[s] + (double)final_acoustic[s]);
+    if (tf < best_final) best_final = tf;
+  }
+  double cutoff = best_final + beam;
+  for (int32_t s = S - 1; s >= 0; --s) {
+    double fc = cost[s];
+    double bc = (double)final_graph[s] + (double)final_acoustic[s];
+    if (bc + fc > cutoff && bc != INFINITY) {
+      final_graph[s] = INFINITY;
+      final_acoustic[s] = INFINITY;
+    }
+    for (int64_t i = arc_begin[s]; i < arc_begin[s + 1]; ++i) {
+      double abc = ((double)graph[i] + (double)acoustic[i]) + cost[dst[i]];
+      if (abc < bc) bc = abc;
+      keep_arc[i] = (fc + abc > cutoff) ? 0 : 1;
+    }
+    cost[s] = bc;
+  }
+  free(cost);
+  uint8_t *acc = (uint8_t *)calloc((size_t)S, 1), *co = (uint8_t *)calloc((size_t)S, 1);
+  acc[0] = 1;
+  for (int32_t s = 0; s < S; ++s)
+    if (acc[s])
+      for (int64_t i = arc_begin[s]; i < arc_begin[s + 1]; ++i)
+        if (keep_arc[i]) acc[dst[i]] = 1;
+  for (int32_t s = S - 1; s >= 0; --s) {
+    int c = !(final_graph[s] == INFINITY && final_acoustic[s] == INFINITY);
+    for (int64_t i = arc_begin[s]; i < arc_begin[s + 1] && !c; ++i)
+      if (keep_arc[i] && co[dst[i]]) c = 1;
+    co[s] = (uint8_t)c;
+  }
+  int32_t n = 0;
+  for (int32_t s = 0; s < S; ++s) {
+    keep_state[s] = acc[s] && co[s];
+    n += keep_state[s];
+  }
+  free(acc);
+  free(co);
+  if (!keep_state[0]) {
+    memset(keep_state, 0, (size_t)S);
+    n = 0;
+  }
+  return n;
+}
+
 /* ---- timed CPU baseline for bench.py ("port"): fb + arc through-likelihood over a batch
  * of lattices held as one flat CSR (state_off/arc_off per lattice, arc_begin global per
  * state, lattice-local dst).  Scales are applied to private copies first (a2/a3), as the

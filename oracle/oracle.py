@@ -263,6 +263,30 @@ def disambiguate_length(lat, start=0, use_input=False):
     return out, state_len, max_len
 
 
+def prune_lattice(lat, beam):
+    """A.4 on an already scaled lattice.  Returns the pruned, connected lattice (state ids in
+    order) or None if nothing survives; `extra` holds the kept old state / arc indices."""
+    out = lat.copy()
+    keep_arc = np.zeros(max(lat.A, 1), np.uint8)
+    keep_state = np.zeros(max(lat.S, 1), np.uint8)
+    n = lib().kor_prune_lattice(C.c_int32(lat.S), _p(out.arc_begin), _p(out.dst), _p(out.graph), _p(out.acoustic),
+                                _p(out.final_graph), _p(out.final_acoustic), C.c_double(beam), _p(keep_arc), _p(keep_state))
+    if n == 0:
+        return None
+    ks = keep_state[:lat.S].astype(bool)
+    newid = np.cumsum(ks) - 1
+    src = lat.src()
+    ka = keep_arc[:lat.A].astype(bool) & ks[src] & ks[lat.dst]
+    idx = np.nonzero(ka)[0]
+    counts = np.bincount(newid[src[idx]], minlength=n)
+    ab = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    res = Lat(ab, newid[lat.dst[idx]].astype(np.int32), lat.ilabel[idx], lat.olabel[idx], lat.graph[idx], lat.acoustic[idx],
+              lat.dur[idx], out.final_graph[ks], out.final_acoustic[ks], lat.final_dur[ks], key=lat.key)
+    res.extra["arc_old"] = idx
+    res.extra["state_old"] = np.nonzero(ks)[0]
+    return res
+
+
 def batch_fb_post(state_off, arc_off, arc_begin_global, dst, ilabel, graph, acoustic, final_graph,
                   final_acoustic, graph_scale, acoustic_scale, insertion_penalty):
     """Timed CPU baseline body (bench.py cpu_baseline) and batch parity checker."""

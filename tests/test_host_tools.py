@@ -46,9 +46,54 @@ def test_usage_and_exit_codes(tool):
     assert rc == 255 and "Invalid option" in err  # exception path: return -1
 
 
-def test_beam_is_refused_loudly(tmp_path):
-    rc, out, err = run("lattice-word-index-segment", "--beam=5", "ark:/dev/null", "ark,t:-")
-    assert rc == 255 and "PruneLattice" in err
+def test_bad_beam_is_refused_loudly(tmp_path):
+    rc, out, err = run("lattice-word-index-segment", "--beam=-5", "ark:/dev/null", "ark,t:-")
+    assert rc == 255 and "--beam must be positive" in err
+
+
+def _write_text_archive(path, arrays, ns):
+    with open(path, "w") as f:
+        for u in range(len(ns)):
+            s0, a0, a1 = arrays["state_off"][u], arrays["arc_off"][u], arrays["arc_off"][u + 1]
+            f.write("utt%07d\n" % u)
+            for i in range(a0, a1):
+                s, d = arrays["src"][i], arrays["dst"][i]
+                dur = arrays["state_time"][s0 + d] - arrays["state_time"][s0 + s]
+                f.write("%d\t%d\t%d\t%.9g,%.9g,%s\n" % (s, d, arrays["ilabel"][i], arrays["graph"][i], arrays["acoustic"][i],
+                                                        "_".join(["7"] * dur)))
+            f.write("%d\n\n" % (ns[u] - 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beam", [1.5, 6.0])
+def test_segment_tool_with_beam_matches_oracle_pipeline(tmp_path, beam):
+    """--beam: ScaleLattice -> AddWordInsPen -> PruneLattice -> TopSort -> times -> sweep -> index
+    (kwsbin2/lattice-word-index-segment.cc:41-63); the pruning is host-side graph surgery."""
+    ns = np.array([40, 25, 60], np.int32)
+    fo = np.array([3, 2, 4], np.int32)
+    arrays = klat_amd.synth(99, ns, fo)
+    txt = str(tmp_path / "in.txt")
+    _write_text_archive(txt, arrays, ns)
+    args = ["--acoustic-scale=0.1", "--insertion-penalty=0.5", "--beam=%g" % beam]
+    rc, out, err = run("lattice-word-index-segment", *args, "ark:" + txt, "ark,t:-")
+    assert rc == 0, err
+    lines = out.decode().strip("\n").split("\n")
+    assert len(lines) == 3
+    npruned = 0
+    for lat, line in zip(latfmt.read_text_archive(txt), lines):
+        sl = orc.scale_and_penalize(lat, 1.0, 0.1, 0.5)
+        pl = orc.prune_lattice(sl, beam)
+        assert pl is not None
+        npruned += pl.A < lat.A
+        times, _, _ = orc.state_times(pl)
+        alpha, beta, total, _, _ = orc.alphas_betas(pl)
+        want = orc.segment_index(pl, times, alpha, beta, total)
+        key, got = latfmt.parse_tuple_line(line, 3)
+        assert key == lat.key
+        assert sorted(g[:3] for g in got) == sorted(w[:3] for w in want)
+        wk = {w[:3]: w[3] for w in want}
+        assert all(abs(g[3] - wk[g[:3]]) < 1e-5 for g in got)
+    assert npruned >= 2 or beam > 5  # the small beam really removes arcs
 
 
 def test_binary_archive_round_trip(tmp_path, golden_dir):
