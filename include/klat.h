@@ -173,7 +173,7 @@ int klat_frame_post(klat_batch* batch, const int32_t* num_frames, int64_t* frame
 /* Host-only view of the packed lockstep streams (no device needed): what klat_batch_create
  * uploads.  jobs: 24-byte records {int64 chunk_off; int32 nchunks, dir, lane_tab, pad};
  * lanes: 16-byte records {int64 state_base; int32 num_states, lattice};
- * items: 24-byte records {int64 arc_begin; int32 count, lattice, state_begin, state_count}.  Stream slot of
+ * items: 16-byte records {int64 arc_begin; int32 count, lattice}.  Stream slot of
  * (chunk c, lane l, round r) is ((chunk_off + c) * 64 + l) * 4 + r. */
 typedef struct klat_packed klat_packed;
 int klat_pack_host(const klat_batch_desc* desc, const klat_pack_options* opt, klat_packed** out);

@@ -162,8 +162,6 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   UP(jobs, P.jobs.data(), P.jobs.size());
   UP(lanes, P.lanes.data(), P.lanes.size());
   UP(items, P.items.data(), P.items.size());
-  AL(fme, b->S + b->U);
-  AL(bme, b->S + b->U);
   AL(job_flags, P.jobs.size());
   AL(total, b->U);
   AL(tot_fwd, b->U);
@@ -215,8 +213,9 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.sw = b->sw.p;
   sa.sg = b->sg.p;
   sa.sa = b->sa.p;
-  sa.fme = b->fme.p;
-  sa.bme = b->bme.p;
+  sa.alpha = b->alpha.p;
+  sa.beta = b->beta.p;
+  sa.tot_fwd = b->tot_fwd.p;
   sa.job_flags = b->job_flags.p;
   sa.sp = sp;
   sa.ring_slots = b->W;
@@ -224,8 +223,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   TotalsArgs ta;
   ta.num_lattices = (int32_t)b->U;
   ta.state_off = b->state_off.p;
-  ta.fme = b->fme.p;
-  ta.bme = b->bme.p;
+  ta.beta = b->beta.p;
   ta.total = b->total.p;
   ta.tot_fwd = b->tot_fwd.p;
   ta.tot_bwd = b->tot_bwd.p;
@@ -238,8 +236,6 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   pa.ilabel = b->ilabel.p;
   pa.graph = b->graph.p;
   pa.acoustic = b->acoustic.p;
-  pa.fme = b->fme.p;
-  pa.bme = b->bme.p;
   pa.alpha = b->alpha.p;
   pa.beta = b->beta.p;
   pa.total = b->total.p;

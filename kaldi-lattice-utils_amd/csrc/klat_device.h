@@ -8,8 +8,7 @@
 //     wide: a wave owns 64/G lattices, G lanes each; one *round* is one term per lane; four
 //     rounds of one lane are contiguous (16 B) so that every stream load is a 1 KiB
 //     dwordx4 wave access;
-//   * per-state scaled-linear values (mantissa double + int32 binary exponent) for both
-//     directions, natural-log alpha/beta, per-arc log posterior.
+//   * natural-log alpha/beta per state (written by the sweep itself), per-arc log posterior.
 #ifndef KLAT_DEVICE_H_
 #define KLAT_DEVICE_H_
 #include <stdint.h>
@@ -63,24 +62,13 @@ struct LaneInfo {
   int32_t lattice;     // u
 };
 
-// Work item of the posterior kernel: <=kPostItemArcs consecutive arcs of one lattice plus a
-// slice of that lattice's states (whose alpha/beta it converts to natural log).
+// Work item of the posterior kernel: <=kPostItemArcs consecutive arcs of one lattice.
 struct PostItem {
   int64_t arc_begin;
   int32_t count;
   int32_t lattice;
-  int32_t state_begin;  // lattice-local
-  int32_t state_count;
 };
 
-// Per-state value in the scaled-linear domain: m * 2^e (m == 0 encodes log-zero).  One 16-byte
-// cell so that a state's value moves with a single dwordx4 access.  Lattice u's cells start at
-// state_off[u] + u: S cells for its states plus one for the forward sweep's virtual
-// super-final state (tot_forward).
-struct __attribute__((aligned(16))) MECell {
-  double m;
-  int64_t e;
-};
 static const int kPostItemArcs = 1024;
 
 }  // namespace klat

@@ -105,7 +105,6 @@ struct klat_batch {
   klat::DevBuf<klat::LaneInfo> lanes;
   klat::DevBuf<klat::PostItem> items;
   // results
-  klat::DevBuf<klat::MECell> fme, bme;  // scaled-linear values, S+1 cells per lattice
   klat::DevBuf<int32_t> job_flags;      // fast sweep -> exact sweep hand-over
   klat::DevBuf<double> total, tot_fwd, tot_bwd, alpha, beta, logpost;
 };

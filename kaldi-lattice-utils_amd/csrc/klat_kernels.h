@@ -21,8 +21,9 @@ struct SweepArgs {
   const int32_t* sw;  // stream term words
   const float* sg;    // stream graph costs
   const float* sa;    // stream acoustic costs
-  MECell* fme;  // forward values, S+1 cells per lattice (see MECell)
-  MECell* bme;  // backward values
+  double* alpha;      // [S] natural-log forward values  (vector<double>* alpha of B2)
+  double* beta;       // [S] natural-log backward values (vector<double>* beta of B2)
+  double* tot_fwd;    // [U] forward total: the value of the virtual super-final state
   int32_t* job_flags;  // [num_jobs] set by the fast sweep when a job needs the exact sweep
   ScaleParams sp;
   int32_t ring_slots;
@@ -31,8 +32,9 @@ struct SweepArgs {
 struct TotalsArgs {
   int32_t num_lattices;
   const int64_t* state_off;
-  const MECell* fme; const MECell* bme;
-  double* total; double* tot_fwd; double* tot_bwd;
+  const double* beta;
+  double* tot_fwd;  // in: as written by the sweep; rewritten to 0 for empty lattices
+  double* total; double* tot_bwd;
 };
 
 struct PosteriorArgs {
@@ -40,10 +42,9 @@ struct PosteriorArgs {
   const int64_t* state_off;
   const int32_t* src; const int32_t* dst; const int32_t* ilabel;
   const float* graph; const float* acoustic;
-  const MECell* fme; const MECell* bme;
+  const double* alpha; const double* beta;
   const double* total;
   double* logpost;
-  double* alpha; double* beta;  // natural-log per-state outputs (B2 interface)
   ScaleParams sp;
 };
 

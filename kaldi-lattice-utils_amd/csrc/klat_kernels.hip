@@ -1,7 +1,7 @@
 // klat_kernels.hip -- the fully parallel kernels around the sweep: per-lattice totals and the
 // per-arc log posteriors (a8 of SURVEY.md 8a: kwsbin2/lattice-word-index-segment.cc:160-163,
-// latbin/lattice-to-word-frame-post.cc:102-104) fused with the natural-log alpha/beta outputs
-// of the B2 interface.
+// latbin/lattice-to-word-frame-post.cc:102-104).  The sweep itself leaves alpha and beta in
+// natural log, so this stage is a pure streaming pass.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -22,10 +22,8 @@ __global__ __launch_bounds__(256) void totals_kernel(TotalsArgs a) {
   const int64_t S = a.state_off[u + 1] - s0;
   double tf = 0.0, tb = 0.0;
   if (S > 0) {
-    const MECell f = a.fme[s0 + u + S];  // virtual super-final state of the forward sweep
-    const MECell b = a.bme[s0 + u];      // beta[start]
-    tf = me_to_ln(f.m, (int)f.e);
-    tb = me_to_ln(b.m, (int)b.e);
+    tf = a.tot_fwd[u];  // value of the forward sweep's virtual super-final state
+    tb = a.beta[s0];    // beta[start]
   }
   a.tot_fwd[u] = tf;
   a.tot_bwd[u] = tb;
@@ -33,16 +31,14 @@ __global__ __launch_bounds__(256) void totals_kernel(TotalsArgs a) {
 }
 
 // a8 + normalisation: logpost[i] = alpha[src] - cost + beta[dst] - total, fully parallel over
-// arcs in caller order.  Reads src,dst,graph,acoustic (16 B/arc, coalesced), gathers the 16-byte
-// cells of the two end states (L2-resident: arcs are grouped by source), writes 8 B/arc; each
-// work item also turns a slice of its lattice's cells into natural-log alpha/beta
-// (vector<double>* alpha, *beta of the B2 interface), 16 B/state written.
+// arcs in caller order.  Reads src,dst,graph,acoustic (16 B/arc, coalesced), gathers alpha[src]
+// and beta[dst] (8 B each, L2-resident: arcs are grouped by source), writes 8 B/arc.
 template <bool PEN>
 __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
   const PostItem item = a.items[blockIdx.x];
   const int64_t base = a.state_off[item.lattice];
-  const MECell* __restrict__ fme = a.fme + base + item.lattice;
-  const MECell* __restrict__ bme = a.bme + base + item.lattice;
+  const double* __restrict__ alpha = a.alpha + base;
+  const double* __restrict__ beta = a.beta + base;
   const double tot = a.total[item.lattice];
   const ScaleParams sp = a.sp;
   for (int t = threadIdx.x; t < item.count; t += 256) {
@@ -51,20 +47,9 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
     const int d = a.dst[i];
     const bool word = PEN ? (a.ilabel[i] != 0) : false;
     const double c = arc_cost(a.graph[i], a.acoustic[i], word, sp);
-    const MECell f = fme[s];
-    const MECell b = bme[d];
-    const double prod = f.m * b.m;
-    const int e = (int)f.e + (int)b.e;
-    double r = -INFINITY;
-    if (prod != 0.0 && c < 1.0e30) r = fma((double)e, kLn2, log(prod)) - c - tot;
-    a.logpost[i] = r;
-  }
-  for (int t = threadIdx.x; t < item.state_count; t += 256) {
-    const int s = item.state_begin + t;
-    const MECell f = fme[s];
-    const MECell b = bme[s];
-    a.alpha[base + s] = me_to_ln(f.m, (int)f.e);
-    a.beta[base + s] = me_to_ln(b.m, (int)b.e);
+    const double through = alpha[s] + beta[d] - c;
+    // log-zero stays log-zero (also when the lattice has no path at all: total == -inf)
+    a.logpost[i] = (through > -INFINITY) ? through - tot : -INFINITY;
   }
 }
 

@@ -346,16 +346,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   // ---- posterior work items ----
   for (int64_t u = 0; u < U; ++u) {
     const int64_t a0 = d.arc_off[u], a1 = d.arc_off[u + 1];
-    const int64_t S = d.state_off[u + 1] - d.state_off[u];
-    if (S == 0) continue;
-    const int64_t K = std::max<int64_t>(1, ceil_div(a1 - a0, kPostItemArcs));
-    const int64_t per = ceil_div(S, K);
-    for (int64_t k = 0; k < K; ++k) {
-      const int64_t a = a0 + k * kPostItemArcs;
-      const int64_t sb = std::min(S, k * per), se = std::min(S, (k + 1) * per);
-      P.items.push_back(PostItem{a, (int32_t)std::max<int64_t>(0, std::min<int64_t>(kPostItemArcs, a1 - a)),
-                                 (int32_t)u, (int32_t)sb, (int32_t)(se - sb)});
-    }
+    for (int64_t a = a0; a < a1; a += kPostItemArcs)
+      P.items.push_back(PostItem{a, (int32_t)std::min<int64_t>(kPostItemArcs, a1 - a), (int32_t)u});
   }
   return KLAT_OK;
 }

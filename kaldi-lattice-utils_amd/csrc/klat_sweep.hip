@@ -79,6 +79,28 @@ struct __attribute__((aligned(16))) RingCell {
   int32_t pad;
 };
 
+// ln(m * 2^e) for a normalised mantissa m in [0.5,1) (or 0 = log-zero) with a 64-entry table in
+// LDS instead of the library log (~50 instructions): 2m = c_i * (1 + r), |r| <= 1/128, and
+// log1p(r) by its degree-7 series (next term < 2e-18).  About 20 instructions.
+struct __attribute__((aligned(16))) LnTabEntry {
+  double inv2;  // 2 / c_i
+  double lnc;   // ln(c_i / 2)
+};
+__device__ __forceinline__ double table_ln(double m, int e, const LnTabEntry* tab) {
+  const int i = (__double2hiint(m) >> 14) & 63;  // top six mantissa bits
+  const LnTabEntry t = tab[i];
+  const double r = fma(m, t.inv2, -1.0);
+  double p = 1.0 / 7.0;
+  p = fma(p, r, -1.0 / 6.0);
+  p = fma(p, r, 1.0 / 5.0);
+  p = fma(p, r, -1.0 / 4.0);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  p = fma(p, r, 1.0);
+  const double v = fma((double)e, kLn2, fma(p, r, t.lnc));
+  return (m == 0.0) ? -INFINITY : v;
+}
+
 // One staged term: what the producer wave hands to the consumer wave through LDS.
 struct __attribute__((aligned(16))) StagedTerm {
   double wm;     // 2^frac part of exp(-cost); 0 for dead / padding terms
@@ -139,6 +161,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   // 64 dummy cells (one per lane) follow the ring, then the stage buffers [2][CPB][4][64]
   StagedTerm* stage = reinterpret_cast<StagedTerm*>(smem + (size_t)W * LPW + 64);
   int32_t* far = reinterpret_cast<int32_t*>(stage + 2 * CPB * 256);          // [2][CPB][4][64]
+  LnTabEntry* lntab = reinterpret_cast<LnTabEntry*>(far + 2 * CPB * 256);   // [64], producer only
   const int lane = threadIdx.x & 63;
   const int slot = lane / G;
   const int sub = lane % G;
@@ -148,9 +171,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   const LaneInfo li = args.lanes[job.lane_tab + slot];
   const int S = li.num_states;
   const bool bwd = job.dir != 0;
-  // position p of the stream -> cell: forward walks the lattice's cells upwards (position S, the
-  // virtual super-final state, is the extra cell), backward downwards from state S-1
-  MECell* cells = (bwd ? args.bme : args.fme) + li.state_base + li.lattice;  // state_off[u] + u
+  // position p of the stream -> state: forward walks the lattice's states upwards (position S is
+  // the virtual super-final state, whose value is tot_forward), backward downwards from S-1
+  double* vals = (bwd ? args.beta : args.alpha) + li.state_base;
 
   if (producer) {
     // ------------------------------------------------------------------ wave 0
@@ -168,6 +191,11 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       ab[j] = sa[cn * 64];
     }
     int p = 0;                  // position the lattice is accumulating at the current round
+    {  // table for ln of a mantissa in [0.5,1): interval i covers 2m in [1 + i/64, 1 + (i+1)/64)
+      const double c = 1.0 + ((double)lane + 0.5) * (1.0 / 64.0);
+      lntab[lane].inv2 = 2.0 / c;
+      lntab[lane].lnc = log(0.5 * c);
+    }
     int out_p0 = 0, out_n = 0;  // states the consumer finished in the period before the last barrier
     int period_p0 = 0;
     const bool live = li.state_base >= 0;
@@ -193,16 +221,18 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       *dst = t;
       p += last ? 1 : 0;
     };
-    // copies the states finished during the previous chunk from the ring to HBM
+    // turns the states finished during the previous period into natural log (the only log of
+    // the sweep, off the chain, spread over the lattice's G lanes) and writes them to HBM
     auto copy_out = [&]() {
       for (int j = sub; j < out_n; j += G) {
         const int q = out_p0 + j;
         if (live) {
           const RingCell* rc = ring + (q & (W - 1)) * LPW + slot;
-          MECell cell;
-          cell.m = rc->m;
-          cell.e = rc->e;
-          cells[bwd ? (S - 1 - q) : q] = cell;
+          const double v = table_ln(rc->m, rc->e, lntab);
+          if (!bwd && q == S)
+            args.tot_fwd[li.lattice] = v;
+          else
+            vals[bwd ? (S - 1 - q) : q] = v;
         }
       }
     };
@@ -281,9 +311,12 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       sm = one ? 0.5 : sm;
       se = one ? 1 : se;
       if (ctl & kCtlFar) {
-        const MECell* src = cells + far_cell;
-        sm = __hip_atomic_load(&src->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        se = (int)__hip_atomic_load(&src->e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the source left the ring: re-read its natural-log value (copied out at least two
+        // periods ago) and split it back into mantissa and exponent
+        const double v = __hip_atomic_load(&vals[far_cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool zero_src;
+        arc_weight(-v, false, sm, se, zero_src);
+        se = zero_src ? kExpMin : se;
       }
     }
     // dead (zero weight / padding) terms have wm == 0 and zero sources sm == 0: tm is then 0
@@ -373,7 +406,7 @@ static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream)
   const int LPW = 64 / G;
   // the producer copies a period's states out one period later: the ring must hold two periods
   const int cpb = args.ring_slots >= 16 ? 2 : 1;
-  const size_t lds = ((size_t)args.ring_slots * LPW + 64) * sizeof(RingCell) + (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t));
+  const size_t lds = ((size_t)args.ring_slots * LPW + 64) * sizeof(RingCell) + (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t)) + 64 * sizeof(LnTabEntry);
   if (cpb == 2) {
     hipLaunchKernelGGL((sweep_kernel<G, true, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
     hipLaunchKernelGGL((sweep_kernel<G, false, 2>), dim3(num_jobs), dim3(128), lds, stream, args);

@@ -68,7 +68,7 @@ SEGMENT_DTYPE = np.dtype([("label", "<i4"), ("t0", "<i4"), ("t1", "<i4"), ("pad"
 POSITION_DTYPE = np.dtype([("label", "<i4"), ("pos", "<i4"), ("t0", "<i4"), ("t1", "<i4"), ("logp", "<f8")])
 JOB_DTYPE = np.dtype([("chunk_off", "<i8"), ("nchunks", "<i4"), ("dir", "<i4"), ("lane_tab", "<i4"), ("pad", "<i4")])
 LANE_DTYPE = np.dtype([("state_base", "<i8"), ("num_states", "<i4"), ("lattice", "<i4")])
-ITEM_DTYPE = np.dtype([("arc_begin", "<i8"), ("count", "<i4"), ("lattice", "<i4"), ("state_begin", "<i4"), ("state_count", "<i4")])
+ITEM_DTYPE = np.dtype([("arc_begin", "<i8"), ("count", "<i4"), ("lattice", "<i4")])
 
 _lib = None
 
