@@ -93,7 +93,7 @@ typedef struct {
   float sweep_ms;      /* forward+backward lockstep sweep kernel */
   float totals_ms;     /* per-lattice total kernel */
   float posterior_ms;  /* arc posterior kernel */
-  float convert_ms;    /* alpha/beta natural-log conversion kernel */
+  float convert_ms;    /* always 0: the sweep writes natural-log alpha/beta itself (kept for ABI stability) */
   float total_ms;      /* first event to last event */
 } klat_timings;
 

@@ -262,7 +262,7 @@ int klat_get_timings(const klat_batch* b, klat_timings* t) {
   KLAT_HIP(hipEventElapsedTime(&t->sweep_ms, c->ev[0], c->ev[1]));
   KLAT_HIP(hipEventElapsedTime(&t->totals_ms, c->ev[1], c->ev[2]));
   KLAT_HIP(hipEventElapsedTime(&t->posterior_ms, c->ev[2], c->ev[3]));
-  t->convert_ms = 0.0f;  // alpha/beta conversion is fused into the posterior kernel
+  t->convert_ms = 0.0f;  // the sweep's producer wave writes natural-log alpha/beta itself
   KLAT_HIP(hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[3]));
   return KLAT_OK;
 }

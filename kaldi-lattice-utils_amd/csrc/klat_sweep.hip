@@ -139,7 +139,7 @@ static constexpr uint32_t kCtlZero = kNil;  // padding or zero-weight term
 // ([slot][lattice]).  The ring read of round r+1 is issued before round r's result is written and
 // is patched from registers when it names the state round r just finished (BYPASS), so the LDS
 // write->read latency is off the chain.  Chunks in which some lane has a constant-one source or
-// a source older than W states (FAR: re-read from the cells already copied out) take a slower
+// a source older than W states (FAR: re-read from the alpha/beta values already copied out) take a slower
 // instantiation of the same round.
 //
 // Two instantiations share this body:
