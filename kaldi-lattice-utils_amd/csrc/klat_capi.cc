@@ -74,6 +74,16 @@ int klat_ctx_create(int device, klat_ctx** out) {
       return hip_fail(e, "hipEventCreate");
     }
   }
+  {
+    std::vector<LnTabEntry> tab((size_t)kLnTabSize);
+    fill_ln_table(tab.data());
+    int rc = c->ln_table.upload(tab.data(), tab.size(), c->stream);
+    if (rc == KLAT_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = set_error(KLAT_ERR_HIP, "ln table upload");
+    if (rc != KLAT_OK) {
+      klat_ctx_destroy(c);
+      return rc;
+    }
+  }
   *out = c;
   return KLAT_OK;
 }
@@ -166,8 +176,8 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   AL(total, b->U);
   AL(tot_fwd, b->U);
   AL(tot_bwd, b->U);
-  AL(alpha, b->S);
-  AL(beta, b->S);
+  AL(alpha, b->S + b->U);
+  AL(beta, b->S + b->U);
   AL(logpost, b->A);
 #undef UP
 #undef AL
@@ -215,14 +225,16 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.sa = b->sa.p;
   sa.alpha = b->alpha.p;
   sa.beta = b->beta.p;
-  sa.tot_fwd = b->tot_fwd.p;
   sa.job_flags = b->job_flags.p;
+  sa.ln_table = c->ln_table.p;
   sa.sp = sp;
+  sa.sc = make_stream_cost(sp);
   sa.ring_slots = b->W;
 
   TotalsArgs ta;
   ta.num_lattices = (int32_t)b->U;
   ta.state_off = b->state_off.p;
+  ta.alpha = b->alpha.p;
   ta.beta = b->beta.p;
   ta.total = b->total.p;
   ta.tot_fwd = b->tot_fwd.p;
@@ -293,8 +305,19 @@ int klat_get_alpha_beta(klat_batch* b, double* alpha, double* beta) {
   if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
   KLAT_HIP(hipSetDevice(b->ctx->device));
   int rc;
-  if ((rc = fetch(b, alpha, b->alpha.p, sizeof(double) * (size_t)b->S))) return rc;
-  if ((rc = fetch(b, beta, b->beta.p, sizeof(double) * (size_t)b->S))) return rc;
+  // the device keeps both arrays padded (one extra slot per lattice): compact, then copy
+  if (b->dense.n < (size_t)b->S && (rc = b->dense.alloc((size_t)b->S))) return rc;
+  for (int which = 0; which < 2; ++which) {
+    double* host = which ? beta : alpha;
+    if (!host || b->S == 0) continue;
+    UnpadArgs ua;
+    ua.num_lattices = (int32_t)b->U;
+    ua.state_off = b->state_off.p;
+    ua.padded = which ? b->beta.p : b->alpha.p;
+    ua.dense = b->dense.p;
+    KLAT_HIP(launch_unpad(ua, b->ctx->stream));
+    if ((rc = fetch(b, host, b->dense.p, sizeof(double) * (size_t)b->S))) return rc;
+  }
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   return KLAT_OK;
 }

@@ -27,8 +27,10 @@ namespace klat {
 // bit  27     FAR   source older than the ring: bits 0..26 then hold rel = target position -
 //                   source position and RD/WR/COMMIT are resolved by the kernel
 // bit  28     LAST  last round of this target state (uniform over the lattice's G lanes)
-// bit  29     WORD  ilabel != 0 (AddWordInsPenToCompactLattice applies)
-// bit  30     NIL   padding term, contributes log-zero
+// bit  29     NIL   padding term, contributes log-zero; its graph cost in the stream is +inf, so
+//                   the kernel needs no test of this bit to give it weight zero
+// bit  30     WORD  ilabel != 0 (AddWordInsPenToCompactLattice applies).  Bit 30 alone is the
+//                   float 2.0f: the kernel adds the penalty as fma(bits, pen/2, graph)
 // bit  31     FIRST first round of this target state (uniform over the lattice's G lanes)
 static const uint32_t kCellMask = 0x7FFu;  // ring cells per workgroup <= 2048
 static const int kWrShift = 11;
@@ -38,8 +40,8 @@ static const uint32_t kOne = 1u << 24;
 static const uint32_t kRelMask = (1u << 27) - 1u;  // FAR terms only
 static const uint32_t kFar = 1u << 27;
 static const uint32_t kLast = 1u << 28;
-static const uint32_t kWord = 1u << 29;
-static const uint32_t kNil = 1u << 30;
+static const uint32_t kNil = 1u << 29;
+static const uint32_t kWord = 1u << 30;
 static const uint32_t kFirst = 1u << 31;
 
 static const int kChunkRounds = 4;    // rounds per 16-byte lane load

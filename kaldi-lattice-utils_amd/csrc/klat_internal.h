@@ -63,6 +63,7 @@ struct klat_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  klat::DevBuf<klat::LnTabEntry> ln_table;  // table behind the sweep's natural log
 };
 
 // device scratch + cached result of the accumulate stage (klat_accum_api.cc)
@@ -106,7 +107,9 @@ struct klat_batch {
   klat::DevBuf<klat::PostItem> items;
   // results
   klat::DevBuf<int32_t> job_flags;      // fast sweep -> exact sweep hand-over
-  klat::DevBuf<double> total, tot_fwd, tot_bwd, alpha, beta, logpost;
+  klat::DevBuf<double> total, tot_fwd, tot_bwd, logpost;
+  klat::DevBuf<double> alpha, beta;     // padded: S + U entries (klat_kernels.h)
+  klat::DevBuf<double> dense;           // scratch of klat_get_alpha_beta
 };
 
 #endif

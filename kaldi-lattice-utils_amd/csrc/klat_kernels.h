@@ -15,26 +15,64 @@ struct ScaleParams {
   int penalized;  // insertion_penalty != 0
 };
 
+// Scales and penalty in the form the sweep's fast cost evaluation wants (klat_math.h stream_cost).
+struct StreamCost {
+  float gs, as, half_pen;
+  int general;  // graph_scale < 0 or NaN, or pen/2 not exact: the sweep uses arc_cost() instead
+};
+inline StreamCost make_stream_cost(const ScaleParams& sp) {
+  StreamCost c;
+  c.gs = sp.scaled ? sp.gs_f : 1.0f;
+  c.as = sp.scaled ? sp.as_f : 1.0f;
+  c.half_pen = sp.penalized ? 0.5f * sp.pen : 0.0f;
+  c.general = (!(c.gs >= 0.0f) || 2.0f * c.half_pen != (sp.penalized ? sp.pen : 0.0f)) ? 1 : 0;
+  return c;
+}
+
+// The per-state outputs are kept "padded" on the device: lattice u owns alpha[state_off[u] + u ..
+// state_off[u+1] + u], one slot more than its states.  The extra slot is position S of the
+// forward sweep, the virtual super-final state whose value is tot_forward, so that the sweep
+// stores every position it finishes through one address computation.  beta is padded the same
+// way (its extra slot is unused).
+__host__ __device__ inline int64_t padded_state_base(int64_t state_off_u, int64_t u) { return state_off_u + u; }
+
+// One entry of the table behind the sweep's natural log: interval i of 256 covers mantissas with
+// 2m in [1 + i/256, 1 + (i+1)/256); c is its midpoint.
+struct __attribute__((aligned(16))) LnTabEntry {
+  double inv2;  // 2 / c
+  double lnc;   // ln(c / 2)
+};
+static const int kLnTabSize = 256;
+
 struct SweepArgs {
   const SweepJob* jobs;
   const LaneInfo* lanes;
   const int32_t* sw;  // stream term words
   const float* sg;    // stream graph costs
   const float* sa;    // stream acoustic costs
-  double* alpha;      // [S] natural-log forward values  (vector<double>* alpha of B2)
-  double* beta;       // [S] natural-log backward values (vector<double>* beta of B2)
-  double* tot_fwd;    // [U] forward total: the value of the virtual super-final state
+  double* alpha;      // [S+U] padded natural-log forward values  (vector<double>* alpha of B2)
+  double* beta;       // [S+U] padded natural-log backward values (vector<double>* beta of B2)
   int32_t* job_flags;  // [num_jobs] set by the fast sweep when a job needs the exact sweep
+  const LnTabEntry* ln_table;  // [kLnTabSize]
   ScaleParams sp;
+  StreamCost sc;  // = make_stream_cost(sp)
   int32_t ring_slots;
 };
 
 struct TotalsArgs {
   int32_t num_lattices;
   const int64_t* state_off;
-  const double* beta;
-  double* tot_fwd;  // in: as written by the sweep; rewritten to 0 for empty lattices
-  double* total; double* tot_bwd;
+  const double* alpha;  // padded
+  const double* beta;   // padded
+  double* total; double* tot_fwd; double* tot_bwd;
+};
+
+// Copies a padded per-state array into the caller's contiguous [S] layout.
+struct UnpadArgs {
+  int32_t num_lattices;
+  const int64_t* state_off;
+  const double* padded;
+  double* dense;
 };
 
 struct PosteriorArgs {
@@ -42,7 +80,7 @@ struct PosteriorArgs {
   const int64_t* state_off;
   const int32_t* src; const int32_t* dst; const int32_t* ilabel;
   const float* graph; const float* acoustic;
-  const double* alpha; const double* beta;
+  const double* alpha; const double* beta;  // padded
   const double* total;
   double* logpost;
   ScaleParams sp;
@@ -50,6 +88,8 @@ struct PosteriorArgs {
 
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream);
 hipError_t launch_totals(const TotalsArgs& a, hipStream_t stream);
+hipError_t launch_unpad(const UnpadArgs& a, hipStream_t stream);
+void fill_ln_table(LnTabEntry* host_table);  // kLnTabSize entries
 hipError_t launch_posterior(const PosteriorArgs& a, int num_items, hipStream_t stream);
 
 }  // namespace klat

@@ -22,8 +22,9 @@ __global__ __launch_bounds__(256) void totals_kernel(TotalsArgs a) {
   const int64_t S = a.state_off[u + 1] - s0;
   double tf = 0.0, tb = 0.0;
   if (S > 0) {
-    tf = a.tot_fwd[u];  // value of the forward sweep's virtual super-final state
-    tb = a.beta[s0];    // beta[start]
+    const int64_t base = padded_state_base(s0, u);
+    tf = a.alpha[base + S];  // value of the forward sweep's virtual super-final state
+    tb = a.beta[base];       // beta[start]
   }
   a.tot_fwd[u] = tf;
   a.tot_bwd[u] = tb;
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void totals_kernel(TotalsArgs a) {
 template <bool PEN>
 __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
   const PostItem item = a.items[blockIdx.x];
-  const int64_t base = a.state_off[item.lattice];
+  const int64_t base = padded_state_base(a.state_off[item.lattice], item.lattice);
   const double* __restrict__ alpha = a.alpha + base;
   const double* __restrict__ beta = a.beta + base;
   const double tot = a.total[item.lattice];
@@ -50,6 +51,30 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
     const double through = alpha[s] + beta[d] - c;
     // log-zero stays log-zero (also when the lattice has no path at all: total == -inf)
     a.logpost[i] = (through > -INFINITY) ? through - tot : -INFINITY;
+  }
+}
+
+// one workgroup per lattice: dense[state_off[u] + s] = padded[state_off[u] + u + s]
+__global__ __launch_bounds__(256) void unpad_kernel(UnpadArgs a) {
+  for (int u = blockIdx.x; u < a.num_lattices; u += gridDim.x) {
+    const int64_t s0 = a.state_off[u];
+    const int64_t S = a.state_off[u + 1] - s0;
+    const double* __restrict__ src = a.padded + padded_state_base(s0, u);
+    for (int64_t s = threadIdx.x; s < S; s += 256) a.dense[s0 + s] = src[s];
+  }
+}
+
+hipError_t launch_unpad(const UnpadArgs& a, hipStream_t stream) {
+  if (a.num_lattices <= 0) return hipSuccess;
+  hipLaunchKernelGGL(unpad_kernel, dim3(a.num_lattices < 65535 ? a.num_lattices : 65535), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+void fill_ln_table(LnTabEntry* t) {
+  for (int i = 0; i < kLnTabSize; ++i) {
+    const double c = 1.0 + ((double)i + 0.5) / (double)kLnTabSize;
+    t[i].inv2 = 2.0 / c;
+    t[i].lnc = log(0.5 * c);
   }
 }
 

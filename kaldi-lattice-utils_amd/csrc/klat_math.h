@@ -6,9 +6,9 @@
 // carried as (mantissa m in [0.5,1) or 0, binary exponent e): value = m * 2^e,
 // log-value = ln2*e + ln m.  An arc weight exp(-cost) is split the same way (2^k * wm,
 // wm = 2^frac) off the chain; the chain itself is multiply + ldexp + add + frexp.  Natural-log
-// doubles are produced once per state / arc by the fully parallel kernels.  The result equals
-// the log-semiring sum the reference computes to ~1e-12 (the reference's own LogAdd drops
-// terms below exp(-36.04); we keep them).
+// doubles are produced once per state by the sweep's producer wave.  The result equals the
+// log-semiring sum the reference computes to ~1e-11 (the reference's own LogAdd drops terms
+// below exp(-36.04); we keep them).
 #ifndef KLAT_MATH_H_
 #define KLAT_MATH_H_
 #include <hip/hip_runtime.h>
@@ -45,42 +45,47 @@ __device__ __forceinline__ double arc_cost(float g, float a, bool word, const Sc
   return (double)g2 + (double)a2;
 }
 
-// v_fma_f64 with the addend taken from a scalar register pair: keeps the polynomial a pure
-// 3-address FMA chain (hipcc otherwise emits v_mov_b64 + v_fmac_f64 per step for a live
-// VGPR constant).
-__device__ __forceinline__ double fma_sconst(double a, double b, double c) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-  return r;
+// The same cost for a stream term in seven instructions, valid whenever graph_scale >= 0 (see
+// StreamCost::general): with a non-negative scale, scale * inf is inf or NaN and the arc stays
+// dead either way, so ScaleLattice's special case for Zero needs no test; multiplying by 1 is the
+// identity, so "not scaled" needs none; and the word bit of the stream word is bit 30 -- the
+// float 2.0f -- so the penalty is fma(2 or 0, pen/2, g): one rounding of g + pen, like the
+// reference's float add, and g itself when pen is 0.  (StreamCost: klat_kernels.h)
+__device__ __forceinline__ double stream_cost(uint32_t w, float g, float a, const StreamCost& sc) {
+  const float g2 = __fmaf_rn(__uint_as_float(w & kWord), sc.half_pen, sc.gs * g);
+  return (double)g2 + (double)(sc.as * a);
 }
 
-// exp(-c) = wm * 2^k with wm = 2^f, |f| <= 1/2.  dead = the weight is exactly zero
-// (cost +inf or NaN, or a padding term), returned as wm = 0.  2^f by a degree-12 Taylor polynomial in f (coefficients ln2^n/n!):
-// |f ln2| <= 0.3466 -> truncation error < 2e-16 relative.
-__device__ __forceinline__ void arc_weight(double c, bool nil, double& wm, int& k, bool& dead) {
-  dead = !(c < 1.0e30) | nil;
-  const double cc = dead ? 0.0 : fmax(c, -1.0e8);
+// exp(-c) = wm * 2^k with wm = 2^f, |f| <= 1/2.  dead = the weight is exactly zero (cost +inf or
+// NaN; padding terms carry an infinite cost), returned as wm = 0 with an unspecified k.
+// 2^f by the degree-9 polynomial of tools/exp2_poly.py (Chebyshev interpolant, relative error
+// < 1.9e-14), evaluated as one block of nine v_fma_f64 with the coefficients in scalar
+// registers: hipcc otherwise keeps them in VGPRs and emits v_mov_b64 + v_fmac_f64 per step.
+__device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& dead) {
+  dead = !(c < 1.0e30);
+  const double cc = fmax(c, -1.0e8);  // NaN -> -1e8; +inf stays (wm is forced to 0 below)
   const double kf = rint(-cc * kLog2e);
   const double f = fma(-cc, kLog2e, -kf);
-  k = (int)kf;
-  double p = 2.5678435993488205142e-11;    // ln2^12/12!
-  p = fma_sconst(p, f, 4.4455382718708114976e-10);  // ln2^11/11!
-  p = fma_sconst(p, f, 7.05491162080112333e-09);   // ln2^10/10!
-  p = fma_sconst(p, f, 1.01780860092396997e-07);   // ln2^9/9!
-  p = fma_sconst(p, f, 1.32154867901443095e-06);   // ln2^8/8!
-  p = fma_sconst(p, f, 1.52527338040598403e-05);   // ln2^7/7!
-  p = fma_sconst(p, f, 1.54035303933816099e-04);   // ln2^6/6!
-  p = fma_sconst(p, f, 1.33335581464284434e-03);   // ln2^5/5!
-  p = fma_sconst(p, f, 9.61812910762847716e-03);   // ln2^4/4!
-  p = fma_sconst(p, f, 5.55041086648215800e-02);   // ln2^3/3!
-  p = fma_sconst(p, f, 2.40226506959100712e-01);   // ln2^2/2!
-  p = fma_sconst(p, f, 6.93147180559945309e-01);   // ln2
-  p = fma(p, f, 1.0);
+  // the instruction saturates (kf is -inf for a dead term); a C++ cast would be undefined there
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(k) : "v"(kf));
+  double p;
+  const double c9 = 1.02059054137655954707e-07;
+  asm("v_fma_f64 %0, %1, %2, %3\n\t"
+      "v_fma_f64 %0, %0, %2, %4\n\t"
+      "v_fma_f64 %0, %0, %2, %5\n\t"
+      "v_fma_f64 %0, %0, %2, %6\n\t"
+      "v_fma_f64 %0, %0, %2, %7\n\t"
+      "v_fma_f64 %0, %0, %2, %8\n\t"
+      "v_fma_f64 %0, %0, %2, %9\n\t"
+      "v_fma_f64 %0, %0, %2, %10\n\t"
+      "v_fma_f64 %0, %0, %2, %11"
+      : "=&v"(p)
+      : "v"(c9), "v"(f), "s"(1.32596452448871106013e-06), "s"(1.52526729248507371552e-05),
+        "s"(1.54034337512510096551e-04), "s"(1.33335582007945924535e-03),
+        "s"(9.61812919393431262072e-03), "s"(5.55041086646516704239e-02),
+        "s"(2.40226506956403407234e-01), "s"(6.93147180559946174405e-01),
+        "s"(1.00000000000001354472e+00));
   wm = dead ? 0.0 : p;
-}
-
-__device__ __forceinline__ double me_to_ln(double m, int e) {
-  return (m == 0.0) ? -INFINITY : fma((double)e, kLn2, log(m));
 }
 
 // (M,E) += (tm,te) in the scaled-linear domain, safe for any exponent gap.

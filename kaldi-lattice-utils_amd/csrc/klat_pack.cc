@@ -18,6 +18,7 @@
 #include "klat_pack.h"
 
 #include <algorithm>
+#include <limits>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -238,7 +239,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
     // own dummy cell behind the ring, so that the consumer's ring write needs no predicate
     for (size_t i = 0; i < n; ++i)
       P.sw[b0 + i] = (int32_t)(kNil | ((uint32_t)(W * LPW + (int)((i / kChunkRounds) % 64)) << kWrShift));
-    std::memset(&P.sg[b0], 0, n * sizeof(float));
+    std::fill(P.sg.begin() + b0, P.sg.begin() + b0 + n, std::numeric_limits<float>::infinity());
     std::memset(&P.sa[b0], 0, n * sizeof(float));
     int64_t far_local = 0;
     auto slot_index = [&](int64_t r, int lane) -> size_t {
@@ -278,7 +279,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
         if ((w & kFar) == 0) w |= (uint32_t)(W * LPW + lane) << kWrShift;  // dummy cell unless COMMIT (end_pos)
         const size_t ix = slot_index(rr, lane);
         P.sw[ix] = (int32_t)w;
-        P.sg[ix] = g;
+        P.sg[ix] = nil ? std::numeric_limits<float>::infinity() : g;
         P.sa[ix] = a;
         nterm++;
       };

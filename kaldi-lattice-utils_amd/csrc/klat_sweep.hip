@@ -79,41 +79,38 @@ struct __attribute__((aligned(16))) RingCell {
   int32_t pad;
 };
 
-// ln(m * 2^e) for a normalised mantissa m in [0.5,1) (or 0 = log-zero) with a 64-entry table in
-// LDS instead of the library log (~50 instructions): 2m = c_i * (1 + r), |r| <= 1/128, and
-// log1p(r) by its degree-7 series (next term < 2e-18).  About 20 instructions.
-struct __attribute__((aligned(16))) LnTabEntry {
-  double inv2;  // 2 / c_i
-  double lnc;   // ln(c_i / 2)
-};
+// ln(m * 2^e) for a normalised mantissa m in [0.5,1) (or 0 = log-zero) with a 256-entry table in
+// LDS instead of the library log (~50 instructions): 2m = c_i * (1 + r), |r| <= 1/512, and
+// log1p(r) by its degree-5 series (next term < 1e-17).  The series runs as one block of
+// v_fma_f64 with its constants in scalar registers or inline (see arc_weight).
 __device__ __forceinline__ double table_ln(double m, int e, const LnTabEntry* tab) {
-  const int i = (__double2hiint(m) >> 14) & 63;  // top six mantissa bits
+  const int i = (__double2hiint(m) >> 12) & (kLnTabSize - 1);  // top eight mantissa bits
   const LnTabEntry t = tab[i];
   const double r = fma(m, t.inv2, -1.0);
-  double p = 1.0 / 7.0;
-  p = fma(p, r, -1.0 / 6.0);
-  p = fma(p, r, 1.0 / 5.0);
-  p = fma(p, r, -1.0 / 4.0);
-  p = fma(p, r, 1.0 / 3.0);
-  p = fma(p, r, -0.5);
-  p = fma(p, r, 1.0);
-  const double v = fma((double)e, kLn2, fma(p, r, t.lnc));
+  const double c5 = 0.2;
+  double p, v;
+  asm("v_fma_f64 %0, %1, %2, %3\n\t"
+      "v_fma_f64 %0, %0, %2, %4\n\t"
+      "v_fma_f64 %0, %0, %2, -0.5\n\t"
+      "v_fma_f64 %0, %0, %2, 1.0"
+      : "=&v"(p)
+      : "v"(c5), "v"(r), "s"(-0.25), "s"(1.0 / 3.0));
+  const double lnm = fma(p, r, t.lnc);
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(v) : "v"((double)e), "s"(kLn2), "v"(lnm));
   return (m == 0.0) ? -INFINITY : v;
 }
 
 // One staged term: what the producer wave hands to the consumer wave through LDS.
 struct __attribute__((aligned(16))) StagedTerm {
   double wm;     // 2^frac part of exp(-cost); 0 for dead / padding terms
-  int32_t k;     // binary exponent of exp(-cost)
-  uint32_t ctl;  // the stream word (klat_device.h) with FAR terms resolved and NIL set on zero weights
+  int32_t k;     // binary exponent of exp(-cost); unspecified when wm == 0
+  uint32_t ctl;  // the stream word (klat_device.h), FAR terms resolved
 };
 static constexpr uint32_t kCtlFirst = kFirst;
 static constexpr uint32_t kCtlLast = kLast;
-static constexpr uint32_t kCtlCommit = kCommit;
 static constexpr uint32_t kCtlBypass = kBypass;
 static constexpr uint32_t kCtlOne = kOne;
 static constexpr uint32_t kCtlFar = kFar;   // source cell index (relative to the lattice) is in far[]
-static constexpr uint32_t kCtlZero = kNil;  // padding or zero-weight term
 
 // ---------------------------------------------------------------------------------------------
 // Lockstep sweep.  One workgroup of TWO waves per job; a job is 64/G lattices, G lanes each,
@@ -123,24 +120,24 @@ static constexpr uint32_t kCtlZero = kNil;  // padding or zero-weight term
 //                     (the only HBM read stream: 12 B per term, read once, 1 KiB dwordx4 wave loads,
 //                     prefetched kPrefetchChunks chunks = 16 rounds ahead in registers); evaluates
 //                     per term the cost (ScaleLattice / insertion penalty fused) and the 2^k * wm
-//                     split of exp(-cost); tracks each lattice's position counter and turns the
-//                     stream word into ring-cell addresses and control bits; and copies the states
-//                     the consumer finished one chunk ago from the LDS ring to HBM (all G lanes of
-//                     a lattice store in parallel, 16 B each).  It stages {wm, k, ctl} of the next
-//                     chunk (4 rounds) in LDS.
+//                     split of exp(-cost); and turns the states the consumer finished one period
+//                     ago into natural log and stores them (all G lanes of a lattice in parallel).
+//                     It stages {wm, k, ctl} of the next period in LDS.  About 30 VALU
+//                     instructions per term: the kernel is bound by instruction issue, and every
+//                     one of them counts.
 //   wave 1, CONSUMER  owns the serial dependency chain and touches only LDS: value of the source
 //                     state -> multiply -> ldexp -> add into the lane's accumulator -> (G lanes
 //                     combined with DPP) -> frexp -> ring cell; the result is also forwarded IN
 //                     REGISTERS to the next round.
-// The two waves sit on different SIMDs of one CU and meet at one workgroup barrier per chunk
-// (double-buffered stage).
+// The two waves sit on different SIMDs of one CU and meet at one workgroup barrier per period of
+// CPB chunks (double-buffered stage).
 //
 // The values of the last W visited states of each lattice live in an LDS ring of 16-byte cells
 // ([slot][lattice]).  The ring read of round r+1 is issued before round r's result is written and
 // is patched from registers when it names the state round r just finished (BYPASS), so the LDS
 // write->read latency is off the chain.  Chunks in which some lane has a constant-one source or
-// a source older than W states (FAR: re-read from the alpha/beta values already copied out) take a slower
-// instantiation of the same round.
+// a source older than W states (FAR: re-read from the alpha/beta values already stored) take a
+// slower instantiation of the same round.
 //
 // Two instantiations share this body:
 //   FAST   every term of a state is aligned to ONE reference exponent -- that of the lattice's
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   // 64 dummy cells (one per lane) follow the ring, then the stage buffers [2][CPB][4][64]
   StagedTerm* stage = reinterpret_cast<StagedTerm*>(smem + (size_t)W * LPW + 64);
   int32_t* far = reinterpret_cast<int32_t*>(stage + 2 * CPB * 256);          // [2][CPB][4][64]
-  LnTabEntry* lntab = reinterpret_cast<LnTabEntry*>(far + 2 * CPB * 256);   // [64], producer only
+  LnTabEntry* lntab = reinterpret_cast<LnTabEntry*>(far + 2 * CPB * 256);   // [kLnTabSize], producer only
   const int lane = threadIdx.x & 63;
   const int slot = lane / G;
   const int sub = lane % G;
@@ -171,101 +168,126 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   const LaneInfo li = args.lanes[job.lane_tab + slot];
   const int S = li.num_states;
   const bool bwd = job.dir != 0;
-  // position p of the stream -> state: forward walks the lattice's states upwards (position S is
-  // the virtual super-final state, whose value is tot_forward), backward downwards from S-1
-  double* vals = (bwd ? args.beta : args.alpha) + li.state_base;
+  // position q of the stream -> element of the lattice's padded output row: forward walks the
+  // states upwards (position S is the virtual super-final state, whose value is tot_forward and
+  // lands in the row's extra slot), backward downwards from S-1
+  double* vals = (bwd ? args.beta : args.alpha) + padded_state_base(li.state_base, li.lattice);
+  const int q_off = bwd ? S - 1 : 0;
+  const int q_step = bwd ? -1 : 1;
 
   if (producer) {
     // ------------------------------------------------------------------ wave 0
-    const ScaleParams sp = args.sp;
-    const int4* __restrict__ sw = reinterpret_cast<const int4*>(args.sw) + job.chunk_off * 64 + lane;
-    const float4* __restrict__ sg = reinterpret_cast<const float4*>(args.sg) + job.chunk_off * 64 + lane;
-    const float4* __restrict__ sa = reinterpret_cast<const float4*>(args.sa) + job.chunk_off * 64 + lane;
-    int4 wb[D];
-    float4 gb[D], ab[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const int64_t cn = min(j, nchunks - 1);
-      wb[j] = sw[cn * 64];
-      gb[j] = sg[cn * 64];
-      ab[j] = sa[cn * 64];
-    }
-    int p = 0;                  // position the lattice is accumulating at the current round
-    {  // table for ln of a mantissa in [0.5,1): interval i covers 2m in [1 + i/64, 1 + (i+1)/64)
-      const double c = 1.0 + ((double)lane + 0.5) * (1.0 / 64.0);
-      lntab[lane].inv2 = 2.0 / c;
-      lntab[lane].lnc = log(0.5 * c);
-    }
-    int out_p0 = 0, out_n = 0;  // states the consumer finished in the period before the last barrier
-    int period_p0 = 0;
+    for (int i = lane; i < kLnTabSize; i += 64) lntab[i] = args.ln_table[i];
     const bool live = li.state_base >= 0;
 
-    auto put = [&](StagedTerm* dst, int32_t* fdst, uint32_t w, float g, float a) {
-      StagedTerm t;
-      bool dead;
-      arc_weight(arc_cost(g, a, (w & kWord) != 0, sp), (w & kNil) != 0, t.wm, t.k, dead);
-      const bool last = (w & kLast) != 0;
-      uint32_t ctl = dead ? (w | kNil) : w;
-      if (__any((w & kFar) != 0)) {  // rare: the packer left this term's cells to the kernel
+    auto run = [&](auto general_tag) {
+      constexpr bool GENERAL = decltype(general_tag)::value;
+      const ScaleParams sp = args.sp;
+      const StreamCost sc = args.sc;
+      const int4* __restrict__ sw = reinterpret_cast<const int4*>(args.sw) + job.chunk_off * 64 + lane;
+      const float4* __restrict__ sg = reinterpret_cast<const float4*>(args.sg) + job.chunk_off * 64 + lane;
+      const float4* __restrict__ sa = reinterpret_cast<const float4*>(args.sa) + job.chunk_off * 64 + lane;
+      int4 wb[D];
+      float4 gb[D], ab[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int64_t cn = min(j, nchunks - 1);
+        wb[j] = sw[cn * 64];
+        gb[j] = sg[cn * 64];
+        ab[j] = sa[cn * 64];
+      }
+      int p = 0;                  // position the lattice is accumulating at the current round
+      int out_p0 = 0, out_n = 0;  // states the consumer finished in the period before the last barrier
+      int period_p0 = 0;
+
+      auto weigh = [&](StagedTerm& t, uint32_t w, float g, float a) {
+        const double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : stream_cost(w, g, a, sc);
+        bool dead;
+        arc_weight(c, t.wm, t.k, dead);
+      };
+      auto put = [&](StagedTerm* dst, uint32_t w, float g, float a) {
+        StagedTerm t;
+        weigh(t, w, g, a);
+        t.ctl = w;
+        *dst = t;
+        p += (int)((w / kLast) & 1u);
+      };
+      // the same for a chunk in which some lane's source left the ring: the packer could not
+      // resolve that term's cells, the position counter can
+      auto put_far = [&](StagedTerm* dst, int32_t* fdst, uint32_t w, float g, float a) {
+        StagedTerm t;
+        weigh(t, w, g, a);
+        const bool last = (w & kLast) != 0;
+        uint32_t ctl = w;
         if (w & kFar) {
           const int q = p - (int)(w & kRelMask);
-          *fdst = bwd ? (S - 1 - q) : q;
-          ctl &= ~kRelMask;  // reads ring cell 0 (ignored), source comes from far[]
+          *fdst = q_off + q_step * q;
+          ctl &= ~kRelMask;  // reads ring cell 0 (ignored), the source comes through far[]
           if (last && sub == 0)
             ctl |= kCommit | ((uint32_t)((p & (W - 1)) * LPW + slot) << kWrShift);
           else
             ctl |= (uint32_t)(W * LPW + lane) << kWrShift;  // the lane's dummy cell
         }
-      }
-      t.ctl = ctl;
-      *dst = t;
-      p += last ? 1 : 0;
-    };
-    // turns the states finished during the previous period into natural log (the only log of
-    // the sweep, off the chain, spread over the lattice's G lanes) and writes them to HBM
-    auto copy_out = [&]() {
-      for (int j = sub; j < out_n; j += G) {
-        const int q = out_p0 + j;
-        if (live) {
-          const RingCell* rc = ring + (q & (W - 1)) * LPW + slot;
-          const double v = table_ln(rc->m, rc->e, lntab);
-          if (!bwd && q == S)
-            args.tot_fwd[li.lattice] = v;
-          else
-            vals[bwd ? (S - 1 - q) : q] = v;
-        }
-      }
-    };
-    // chunk c is staged during the consumer's chunk c-1; nchunks is a multiple of D
-    for (int c = 0; c < nchunks; c += D) {
+        t.ctl = ctl;
+        *dst = t;
+        p += last ? 1 : 0;
+      };
+      // turns the states finished during the previous period into natural log (the only log of
+      // the sweep, off the chain, spread over the lattice's G lanes) and writes them to HBM
+      auto copy_out = [&]() {
+        constexpr int kIters = (4 * CPB + G - 1) / G;  // a period finishes at most 4*CPB states
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const int4 w4 = wb[j];
-        const float4 g4 = gb[j];
-        const float4 a4 = ab[j];
-        const int64_t cn = min(c + j + D, nchunks - 1);
-        wb[j] = sw[cn * 64];
-        gb[j] = sg[cn * 64];
-        ab[j] = sa[cn * 64];
-        // stage buffer: [barrier period parity][chunk within the period][round][lane]
-        const int sidx = ((((c + j) / CPB) & 1) * CPB + ((c + j) % CPB)) * 256 + lane;
-        StagedTerm* st = stage + sidx;
-        int32_t* fs = far + sidx;
-        if ((c + j) % CPB == 0) period_p0 = p;
-        put(st, fs, (uint32_t)w4.x, g4.x, a4.x);
-        put(st + 64, fs + 64, (uint32_t)w4.y, g4.y, a4.y);
-        put(st + 128, fs + 128, (uint32_t)w4.z, g4.z, a4.z);
-        put(st + 192, fs + 192, (uint32_t)w4.w, g4.w, a4.w);
-        if ((c + j) % CPB == CPB - 1) {
-          producer_barrier<3 * CPB>();  // this period is staged; the consumer has finished the previous one
-          copy_out();       // ... whose states are stable in the ring (W >= 2 periods of states)
-          out_p0 = period_p0;
-          out_n = p - period_p0;
+        for (int it = 0; it < kIters; ++it) {
+          const int j = sub + it * G;
+          if (live && j < out_n) {
+            const int q = out_p0 + j;
+            const RingCell* rc = ring + (q & (W - 1)) * LPW + slot;
+            vals[q_off + q_step * q] = table_ln(rc->m, rc->e, lntab);
+          }
+        }
+      };
+      // chunk c is staged during the consumer's chunk c-1; nchunks is a multiple of D
+      for (int c = 0; c < nchunks; c += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const int4 w4 = wb[j];
+          const float4 g4 = gb[j];
+          const float4 a4 = ab[j];
+          const int64_t cn = min(c + j + D, nchunks - 1);
+          wb[j] = sw[cn * 64];
+          gb[j] = sg[cn * 64];
+          ab[j] = sa[cn * 64];
+          // stage buffer: [barrier period parity][chunk within the period][round][lane]
+          const int sidx = ((((c + j) / CPB) & 1) * CPB + ((c + j) % CPB)) * 256 + lane;
+          StagedTerm* st = stage + sidx;
+          if ((c + j) % CPB == 0) period_p0 = p;
+          if (__any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0)) {  // rare
+            int32_t* fs = far + sidx;
+            put_far(st, fs, (uint32_t)w4.x, g4.x, a4.x);
+            put_far(st + 64, fs + 64, (uint32_t)w4.y, g4.y, a4.y);
+            put_far(st + 128, fs + 128, (uint32_t)w4.z, g4.z, a4.z);
+            put_far(st + 192, fs + 192, (uint32_t)w4.w, g4.w, a4.w);
+          } else {
+            put(st, (uint32_t)w4.x, g4.x, a4.x);
+            put(st + 64, (uint32_t)w4.y, g4.y, a4.y);
+            put(st + 128, (uint32_t)w4.z, g4.z, a4.z);
+            put(st + 192, (uint32_t)w4.w, g4.w, a4.w);
+          }
+          if ((c + j) % CPB == CPB - 1) {
+            producer_barrier<3 * CPB>();  // this period is staged; the consumer has finished the previous one
+            copy_out();       // ... whose states are stable in the ring (W >= 2 periods of states)
+            out_p0 = period_p0;
+            out_n = p - period_p0;
+          }
         }
       }
-    }
-    __syncthreads();  // the consumer has finished the last period
-    copy_out();
+      __syncthreads();  // the consumer has finished the last period
+      copy_out();
+    };
+    if (args.sc.general)
+      run(std::true_type());
+    else
+      run(std::false_type());
     return;
   }
 
@@ -315,16 +337,18 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         // periods ago) and split it back into mantissa and exponent
         const double v = __hip_atomic_load(&vals[far_cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool zero_src;
-        arc_weight(-v, false, sm, se, zero_src);
+        arc_weight(-v, sm, se, zero_src);
         se = zero_src ? kExpMin : se;
       }
     }
-    // dead (zero weight / padding) terms have wm == 0 and zero sources sm == 0: tm is then 0
+    // dead (zero weight / padding) terms have wm == 0 and zero sources sm == 0: tm is then 0 and
+    // whatever the exponents hold is ignored (unsigned arithmetic: t.k is unspecified for them)
     const double tm = sm * t.wm;
+    const int te_raw = (int)((uint32_t)se + (uint32_t)t.k);
     double cM;
     int cE;
     if (FAST) {
-      const int shift = se + t.k - refE;
+      const int shift = (int)((uint32_t)te_raw - (uint32_t)refE);
       sticky |= (tm != 0.0) & ((unsigned)(shift + 900) > 1800u);
       const double add = ldexp(tm, shift);
       accM = first ? add : accM + add;
@@ -332,7 +356,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       cE = refE;
     } else {
       // only the exponent tag needs forcing so that a zero never becomes a reference exponent
-      const int te = (((ctl & kCtlZero) != 0) | (sm == 0.0)) ? kExpMin : se + t.k;
+      const int te = (tm == 0.0) ? kExpMin : te_raw;
       const int ref = first ? te : accE;
       const int shift = te - ref;
       if (__any(shift > 900)) {
@@ -355,9 +379,15 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       }
     }
     // close the state: computed every round (straight-line), committed when LAST
-    const bool nz = cM != 0.0;
     const double m = __builtin_amdgcn_frexp_mant(cM);
-    const int e = nz ? cE + __builtin_amdgcn_frexp_exp(cM) : kExpMin;
+    int e;
+    if (FAST) {
+      // a zero state keeps the reference exponent as its (irrelevant) exponent: frexp gives 0, 0
+      e = cE + __builtin_amdgcn_frexp_exp(cM);
+      refE = last ? e : refE;
+    } else {
+      e = (cM != 0.0) ? cE + __builtin_amdgcn_frexp_exp(cM) : kExpMin;
+    }
     lastM = m;
     lastE = e;
     {  // unpredicated: lanes that do not commit a state write their own dummy cell behind the ring
@@ -365,7 +395,6 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       rc->m = m;
       rc->e = e;
     }
-    if (FAST) refE = (last & nz) ? e : refE;
   };
 
   for (int c = 0; c < nchunks; ++c) {
@@ -401,12 +430,17 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   }
 }
 
+static size_t sweep_lds_bytes(int ring_slots, int LPW, int cpb) {
+  return ((size_t)ring_slots * LPW + 64) * sizeof(RingCell) +
+         (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t)) + kLnTabSize * sizeof(LnTabEntry);
+}
+
 template <int G>
 static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream) {
   const int LPW = 64 / G;
   // the producer copies a period's states out one period later: the ring must hold two periods
   const int cpb = args.ring_slots >= 16 ? 2 : 1;
-  const size_t lds = ((size_t)args.ring_slots * LPW + 64) * sizeof(RingCell) + (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t)) + 64 * sizeof(LnTabEntry);
+  const size_t lds = sweep_lds_bytes(args.ring_slots, LPW, cpb);
   if (cpb == 2) {
     hipLaunchKernelGGL((sweep_kernel<G, true, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
     hipLaunchKernelGGL((sweep_kernel<G, false, 2>), dim3(num_jobs), dim3(128), lds, stream, args);

@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(_PKG, "..", ".."))
-LIB_PATH = os.path.join(ROOT, "lib", "libklat.so")
+LIB_PATH = os.environ.get("KLAT_LIB_OVERRIDE") or os.path.join(ROOT, "lib", "libklat.so")  # override: kernel experiments only
 
 KLAT_OK = 0
 ERR_INVALID_ARG, ERR_BAD_TOPOLOGY, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_STATE, ERR_TIMES = range(1, 8)

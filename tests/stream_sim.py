@@ -11,7 +11,7 @@ import numpy as np
 CELL_MASK, WR_SHIFT = 0x7FF, 11
 COMMIT, BYPASS, ONE = 1 << 22, 1 << 23, 1 << 24
 REL_MASK = (1 << 27) - 1
-FAR, LAST, WORD, NIL, FIRST = 1 << 27, 1 << 28, 1 << 29, 1 << 30, 1 << 31
+FAR, LAST, NIL, WORD, FIRST = 1 << 27, 1 << 28, 1 << 29, 1 << 30, 1 << 31
 EXP_MIN = -(1 << 29)
 LOG2E = 1.4426950408889634
 LN2 = 0.6931471805599453
@@ -74,6 +74,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                     w = int(sw[ix])
                     if base < 0 or p >= npos:
                         assert w & NIL and not (w & (LAST | FIRST | COMMIT | FAR)), "padding must be plain NIL"
+                        assert sg[ix] == np.inf, "NIL terms carry an infinite graph cost"
                         assert (w >> WR_SHIFT) & CELL_MASK == W * LPW + lane
                         continue
                     assert bool(w & FIRST) == (nround == 0), "FIRST marks exactly the first round of a state"
@@ -86,6 +87,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                     else:
                         k, wm = 0, 0.0
                     if w & NIL:
+                        assert sg[ix] == np.inf and dead, "NIL terms carry an infinite graph cost"
                         sm, se = 0.0, EXP_MIN
                         assert not (w & (ONE | BYPASS | FAR))
                     elif w & FAR:
