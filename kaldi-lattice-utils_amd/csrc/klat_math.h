@@ -56,6 +56,33 @@ __device__ __forceinline__ double stream_cost(uint32_t w, float g, float a, cons
   return (double)g2 + (double)(sc.as * a);
 }
 
+// Per-lane selects with the lane mask in a scalar register pair and the VOP3 encoding of
+// v_cndmask_b32.  hipcc prefers the VOP2 encoding with the mask in VCC; runs of those cost ~16
+// cycles each once several waves share a CU (tools/ubench5.hip), the VOP3 form costs ~4.6.
+__device__ __forceinline__ uint64_t lane_mask(bool cond) { return __builtin_amdgcn_ballot_w64(cond); }
+__device__ __forceinline__ int select32(uint64_t mask, int if_set, int if_clear) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ double select64(uint64_t mask, double if_set, double if_clear) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, %2, %3, %6\n\t"
+      "v_cndmask_b32_e64 %1, %4, %5, %6"
+      : "=&v"(lo), "=v"(hi)
+      : "v"(__double2loint(if_clear)), "v"(__double2loint(if_set)), "v"(__double2hiint(if_clear)),
+        "v"(__double2hiint(if_set)), "s"(mask));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double select64_or_zero(uint64_t mask, double if_set) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, 0, %2, %4\n\t"
+      "v_cndmask_b32_e64 %1, 0, %3, %4"
+      : "=&v"(lo), "=v"(hi)
+      : "v"(__double2loint(if_set)), "v"(__double2hiint(if_set)), "s"(mask));
+  return __hiloint2double(hi, lo);
+}
+
 // exp(-c) = wm * 2^k with wm = 2^f, |f| <= 1/2.  dead = the weight is exactly zero (cost +inf or
 // NaN; padding terms carry an infinite cost), returned as wm = 0 with an unspecified k.
 // 2^f by the degree-9 polynomial of tools/exp2_poly.py (Chebyshev interpolant, relative error
@@ -85,7 +112,7 @@ __device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& d
         "s"(9.61812919393431262072e-03), "s"(5.55041086646516704239e-02),
         "s"(2.40226506956403407234e-01), "s"(6.93147180559946174405e-01),
         "s"(1.00000000000001354472e+00));
-  wm = dead ? 0.0 : p;
+  wm = select64_or_zero(lane_mask(c < 1.0e30), p);
 }
 
 // (M,E) += (tm,te) in the scaled-linear domain, safe for any exponent gap.

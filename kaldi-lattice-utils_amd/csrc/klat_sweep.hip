@@ -325,9 +325,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       preM = rc->m;
       preE = rc->e;
     }
-    const bool bypass = (ctl & kCtlBypass) != 0;
-    sm = bypass ? lastM : sm;
-    se = bypass ? lastE : se;
+    const uint64_t bypass = lane_mask((ctl & kCtlBypass) != 0);
+    sm = select64(bypass, lastM, sm);
+    se = select32(bypass, lastE, se);
     if (decltype(special)::value) {
       const bool one = (ctl & kCtlOne) != 0;  // constant one = 0.5 * 2^1
       sm = one ? 0.5 : sm;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       const int shift = (int)((uint32_t)te_raw - (uint32_t)refE);
       sticky |= (tm != 0.0) & ((unsigned)(shift + 900) > 1800u);
       const double add = ldexp(tm, shift);
-      accM = first ? add : accM + add;
+      accM = select64(lane_mask(first), add, accM + add);
       cM = G > 1 ? group_sum<G>(accM) : accM;
       cE = refE;
     } else {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     if (FAST) {
       // a zero state keeps the reference exponent as its (irrelevant) exponent: frexp gives 0, 0
       e = cE + __builtin_amdgcn_frexp_exp(cM);
-      refE = last ? e : refE;
+      refE = select32(lane_mask(last), e, refE);
     } else {
       e = (cM != 0.0) ? cE + __builtin_amdgcn_frexp_exp(cM) : kExpMin;
     }
