@@ -173,6 +173,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   UP(lanes, P.lanes.data(), P.lanes.size());
   UP(items, P.items.data(), P.items.size());
   AL(job_flags, P.jobs.size());
+  AL(sink, P.jobs.size() * 64);
   AL(total, b->U);
   AL(tot_fwd, b->U);
   AL(tot_bwd, b->U);
@@ -226,6 +227,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.alpha = b->alpha.p;
   sa.beta = b->beta.p;
   sa.job_flags = b->job_flags.p;
+  sa.sink = b->sink.p;
   sa.ln_table = c->ln_table.p;
   sa.sp = sp;
   sa.sc = make_stream_cost(sp);

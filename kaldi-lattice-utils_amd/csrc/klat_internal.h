@@ -110,6 +110,7 @@ struct klat_batch {
   klat::DevBuf<double> total, tot_fwd, tot_bwd, logpost;
   klat::DevBuf<double> alpha, beta;     // padded: S + U entries (klat_kernels.h)
   klat::DevBuf<double> dense;           // scratch of klat_get_alpha_beta
+  klat::DevBuf<double> sink;            // SweepArgs::sink
 };
 
 #endif

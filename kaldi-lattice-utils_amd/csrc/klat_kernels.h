@@ -36,13 +36,14 @@ inline StreamCost make_stream_cost(const ScaleParams& sp) {
 // way (its extra slot is unused).
 __host__ __device__ inline int64_t padded_state_base(int64_t state_off_u, int64_t u) { return state_off_u + u; }
 
-// One entry of the table behind the sweep's natural log: interval i of 256 covers mantissas with
-// 2m in [1 + i/256, 1 + (i+1)/256); c is its midpoint.
+// One entry of the table behind the sweep's natural log: interval i of 128 covers mantissas with
+// 2m in [1 + i/128, 1 + (i+1)/128); c is its midpoint.  (128 entries = 2 KiB of LDS: the sweep's
+// workgroup has to stay below 32 KiB for five of them to share a CU.)
 struct __attribute__((aligned(16))) LnTabEntry {
   double inv2;  // 2 / c
   double lnc;   // ln(c / 2)
 };
-static const int kLnTabSize = 256;
+static const int kLnTabSize = 128;
 
 struct SweepArgs {
   const SweepJob* jobs;
@@ -53,6 +54,7 @@ struct SweepArgs {
   double* alpha;      // [S+U] padded natural-log forward values  (vector<double>* alpha of B2)
   double* beta;       // [S+U] padded natural-log backward values (vector<double>* beta of B2)
   int32_t* job_flags;  // [num_jobs] set by the fast sweep when a job needs the exact sweep
+  double* sink;        // [num_jobs * 64] where lanes without a state to store park their write
   const LnTabEntry* ln_table;  // [kLnTabSize]
   ScaleParams sp;
   StreamCost sc;  // = make_stream_cost(sp)

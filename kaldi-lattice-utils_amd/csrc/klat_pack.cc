@@ -73,7 +73,10 @@ int choose_ring_slots(int G, int64_t max_rel) {
   const int LPW = 64 / G;
   int cap = 8;
   while (cap * 2 * LPW <= 1024 && cap < 1024) cap *= 2;  // <= 1024 ring cells (16 KiB) per workgroup
-  int W = 8;
+  // 32 slots where they fit: the sweep then stages two chunks per barrier and never has to wait
+  // for its own stores (klat_sweep.hip); 16 otherwise
+  int W = cap < 32 ? cap : 32;
+  if (W < 16) W = 16;
   while (W <= max_rel && W < cap) W *= 2;
   return W;
 }

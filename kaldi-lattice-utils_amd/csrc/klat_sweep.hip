@@ -60,44 +60,40 @@ __device__ __forceinline__ double group_sum(double v) {
 // the previous period's copy-out stores, which FAR reads two periods later rely on -- is done.
 template <int KEEP>
 __device__ __forceinline__ void producer_barrier() {
-  static_assert(KEEP == 3 || KEEP == 6, "three stream loads per chunk");
-  if (KEEP == 6)
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  static_assert(KEEP >= 3 && KEEP < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
 }
 __device__ __forceinline__ void consumer_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// One ring cell in LDS.  The consumer reads m and e as separate 8- and 4-byte accesses: a 16-byte
-// read would leave a dead register that the allocator reuses at once, forcing an immediate
-// s_waitcnt on the software-pipelined read.
-struct __attribute__((aligned(16))) RingCell {
-  double m;
-  int32_t e;
-  int32_t pad;
-};
+// RingLayout: a ring cell is a mantissa (double) and an exponent (int32) kept in two LDS arrays
+// indexed by the same cell number.  As 16-byte records (m, e, pad) the 64 lanes of a read hit only
+// a quarter of the banks -- the kernel ran with LDS 57 % busy, two thirds of it bank conflicts
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE); the split arrays spread a wave's cells over all banks.
 
-// ln(m * 2^e) for a normalised mantissa m in [0.5,1) (or 0 = log-zero) with a 256-entry table in
-// LDS instead of the library log (~50 instructions): 2m = c_i * (1 + r), |r| <= 1/512, and
-// log1p(r) by its degree-5 series (next term < 1e-17).  The series runs as one block of
+// ln(m * 2^e) for a normalised mantissa m in [0.5,1) (or 0 = log-zero) with a 128-entry table in
+// LDS instead of the library log (~50 instructions): 2m = c_i * (1 + r), |r| <= 1/256, and
+// log1p(r) by its degree-6 series (next term < 2e-18).  The series runs as one block of
 // v_fma_f64 with its constants in scalar registers or inline (see arc_weight).
-__device__ __forceinline__ double table_ln(double m, int e, const LnTabEntry* tab) {
-  const int i = (__double2hiint(m) >> 12) & (kLnTabSize - 1);  // top eight mantissa bits
-  const LnTabEntry t = tab[i];
+// The table read is a separate step so that callers can overlap its LDS latency with other work.
+__device__ __forceinline__ int ln_table_index(double m) {
+  return (__double2hiint(m) >> 13) & (kLnTabSize - 1);  // top seven mantissa bits
+}
+__device__ __forceinline__ double table_ln(double m, int e, const LnTabEntry& t) {
   const double r = fma(m, t.inv2, -1.0);
-  const double c5 = 0.2;
+  const double c6 = -1.0 / 6.0;
   double p, v;
   asm("v_fma_f64 %0, %1, %2, %3\n\t"
       "v_fma_f64 %0, %0, %2, %4\n\t"
+      "v_fma_f64 %0, %0, %2, %5\n\t"
       "v_fma_f64 %0, %0, %2, -0.5\n\t"
       "v_fma_f64 %0, %0, %2, 1.0"
       : "=&v"(p)
-      : "v"(c5), "v"(r), "s"(-0.25), "s"(1.0 / 3.0));
+      : "v"(c6), "v"(r), "s"(0.2), "s"(-0.25), "s"(1.0 / 3.0));
   const double lnm = fma(p, r, t.lnc);
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(v) : "v"((double)e), "s"(kLn2), "v"(lnm));
-  return (m == 0.0) ? -INFINITY : v;
+  return select64(lane_mask(m == 0.0), -INFINITY, v);
 }
 
 // One staged term: what the producer wave hands to the consumer wave through LDS.
@@ -106,6 +102,11 @@ struct __attribute__((aligned(16))) StagedTerm {
   int32_t k;     // binary exponent of exp(-cost); unspecified when wm == 0
   uint32_t ctl;  // the stream word (klat_device.h), FAR terms resolved
 };
+// one 16-byte LDS write (hipcc splits the struct assignment into two 8-byte halves, which hit the
+// banks with a two-way conflict)
+__device__ __forceinline__ void store_staged(StagedTerm* dst, const StagedTerm& t) {
+  *reinterpret_cast<int4*>(dst) = make_int4(__double2loint(t.wm), __double2hiint(t.wm), t.k, (int)t.ctl);
+}
 static constexpr uint32_t kCtlFirst = kFirst;
 static constexpr uint32_t kCtlLast = kLast;
 static constexpr uint32_t kCtlBypass = kBypass;
@@ -146,17 +147,20 @@ static constexpr uint32_t kCtlFar = kFar;   // source cell index (relative to th
 //          (arc costs hundreds of nats apart inside one state) sets the job's flag.
 //   !FAST  exact for any input: every lane carries its own (mantissa, exponent) accumulator and
 //          re-references on demand.  It runs afterwards and only for flagged jobs.
-template <int G, bool FAST, int CPB>  // CPB = stream chunks (of 4 rounds) staged per barrier: 2 when W >= 16, else 1
+template <int G, bool FAST, int CPB>  // CPB = stream chunks (of 4 rounds) staged per barrier: 2 when W >= 32, else 1
 __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
-  extern __shared__ RingCell smem[];
+  extern __shared__ double smem[];
   constexpr int LPW = 64 / G;
   constexpr int D = kPrefetchChunks;
   const int W = args.ring_slots;
   if (!FAST && args.job_flags[blockIdx.x] == 0) return;  // workgroup-uniform
 
-  RingCell* ring = smem;                                                      // [W][LPW]
-  // 64 dummy cells (one per lane) follow the ring, then the stage buffers [2][CPB][4][64]
-  StagedTerm* stage = reinterpret_cast<StagedTerm*>(smem + (size_t)W * LPW + 64);
+  // ring cells [W][LPW] plus 64 dummy cells (one per lane), mantissas and exponents in separate
+  // arrays (see RingLayout); then the stage buffers [2][CPB][4][64]
+  const int ncell = W * LPW + 64;
+  double* ringM = smem;
+  int32_t* ringE = reinterpret_cast<int32_t*>(smem + ncell);
+  StagedTerm* stage = reinterpret_cast<StagedTerm*>(ringE + ncell);
   int32_t* far = reinterpret_cast<int32_t*>(stage + 2 * CPB * 256);          // [2][CPB][4][64]
   LnTabEntry* lntab = reinterpret_cast<LnTabEntry*>(far + 2 * CPB * 256);   // [kLnTabSize], producer only
   const int lane = threadIdx.x & 63;
@@ -179,6 +183,8 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     // ------------------------------------------------------------------ wave 0
     for (int i = lane; i < kLnTabSize; i += 64) lntab[i] = args.ln_table[i];
     const bool live = li.state_base >= 0;
+    // how many periods of this wave's own stores and loads may still be in flight at a barrier
+    const int slack_periods = W >= 16 * CPB ? 2 : (W >= 12 * CPB ? 1 : 0);
 
     auto run = [&](auto general_tag) {
       constexpr bool GENERAL = decltype(general_tag)::value;
@@ -197,8 +203,10 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         ab[j] = sa[cn * 64];
       }
       int p = 0;                  // position the lattice is accumulating at the current round
-      int out_p0 = 0, out_n = 0;  // states the consumer finished in the period before the last barrier
-      int period_p0 = 0;
+      // The consumer works on period n between barriers n and n+1, so the iteration that stages
+      // period n can copy out the states of period n-2: out_* is that range, pend_* the range of
+      // period n-1 (still being worked on).
+      int out_p0 = 0, out_n = 0, pend_p0 = 0, pend_n = 0;
 
       auto weigh = [&](StagedTerm& t, uint32_t w, float g, float a) {
         const double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : stream_cost(w, g, a, sc);
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         StagedTerm t;
         weigh(t, w, g, a);
         t.ctl = w;
-        *dst = t;
+        store_staged(dst, t);
         p += (int)((w / kLast) & 1u);
       };
       // the same for a chunk in which some lane's source left the ring: the packer could not
@@ -229,60 +237,115 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
             ctl |= (uint32_t)(W * LPW + lane) << kWrShift;  // the lane's dummy cell
         }
         t.ctl = ctl;
-        *dst = t;
+        store_staged(dst, t);
         p += last ? 1 : 0;
       };
-      // turns the states finished during the previous period into natural log (the only log of
-      // the sweep, off the chain, spread over the lattice's G lanes) and writes them to HBM
-      auto copy_out = [&]() {
-        constexpr int kIters = (4 * CPB + G - 1) / G;  // a period finishes at most 4*CPB states
+      // Copy-out: turns the states the consumer finished during the previous period into natural
+      // log (the only log of the sweep, off the chain, spread over the lattice's G lanes) and
+      // stores them.  Three phases -- ring cells, table entries, arithmetic + store -- which the
+      // period schedule below interleaves with the staging work, so that the two dependent LDS
+      // round trips cost no waiting.
+      constexpr int kIters = (4 * CPB + G - 1) / G;  // a period finishes at most 4*CPB states
+      double cm[kIters];
+      int ce[kIters];
+      LnTabEntry ct[kIters];
+      auto copy_cells = [&]() {
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
           const int j = sub + it * G;
-          if (live && j < out_n) {
-            const int q = out_p0 + j;
-            const RingCell* rc = ring + (q & (W - 1)) * LPW + slot;
-            vals[q_off + q_step * q] = table_ln(rc->m, rc->e, lntab);
-          }
+          const int q = out_p0 + (j < out_n ? j : 0);  // idle lanes read some cell of their slot
+          const int cell = (q & (W - 1)) * LPW + slot;
+          cm[it] = ringM[cell];
+          ce[it] = ringE[cell];
         }
       };
-      // chunk c is staged during the consumer's chunk c-1; nchunks is a multiple of D
+      auto copy_table = [&]() {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) ct[it] = lntab[ln_table_index(cm[it])];
+      };
+      // exactly kIters store instructions per period (the barrier's vmcnt counts on it): lanes
+      // without a state park their value in the job's sink row
+      double* const sink = args.sink + (size_t)blockIdx.x * 64 + lane;
+      auto copy_store = [&]() {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+          const int j = sub + it * G;
+          const double v = table_ln(cm[it], ce[it], ct[it]);
+          double* dst = (live && j < out_n) ? vals + (q_off + q_step * (out_p0 + j)) : sink;
+          *dst = v;
+        }
+      };
+      auto stage_chunk = [&](int cj, const int4& w4, const float4& g4, const float4& a4) {
+        // stage buffer: [barrier period parity][chunk within the period][round][lane]
+        const int sidx = (((cj / CPB) & 1) * CPB + (cj % CPB)) * 256 + lane;
+        StagedTerm* st = stage + sidx;
+        if (__any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0)) {  // rare
+          int32_t* fs = far + sidx;
+          put_far(st, fs, (uint32_t)w4.x, g4.x, a4.x);
+          put_far(st + 64, fs + 64, (uint32_t)w4.y, g4.y, a4.y);
+          put_far(st + 128, fs + 128, (uint32_t)w4.z, g4.z, a4.z);
+          put_far(st + 192, fs + 192, (uint32_t)w4.w, g4.w, a4.w);
+        } else {
+          put(st, (uint32_t)w4.x, g4.x, a4.x);
+          put(st + 64, (uint32_t)w4.y, g4.y, a4.y);
+          put(st + 128, (uint32_t)w4.z, g4.z, a4.z);
+          put(st + 192, (uint32_t)w4.w, g4.w, a4.w);
+        }
+      };
+      // One period = CPB chunks, staged while the consumer works on the previous period:
+      //   ring cells of the states to copy out -> stage chunk 0 -> table entries -> stage chunk 1
+      //   -> logs + stores -> prefetch loads for D chunks ahead -> barrier.
+      // The iteration that stages period n stores the states of period n-2.  A state older than
+      // the ring (FAR) is re-read from these stores by the consumer, so they must be complete in
+      // time -- but vmcnt counts loads and stores together, in order: waiting for a store also
+      // waits for every older load, and a barrier that waits for this iteration's stores caps the
+      // stream prefetch at one period, less than the HBM latency under load.  A FAR term read in
+      // period n has at least W - 1 states, one commit round each, between its source and itself:
+      // with W >= 4*CPB*(k+2) rounds the source was finished in period n-k-2 or earlier and stored
+      // by iteration n-k or earlier, so barrier n may leave the newest k periods of operations
+      // (kIters stores + 3*CPB loads each) in flight.  k = 2 (W >= 16*CPB) never waits on a
+      // prefetch; a short ring (W = 8) gets k = 0 and waits for this iteration's stores
+      // (vmcnt(3*CPB): only the loads issued after them fly on).
+      // nchunks is a multiple of D, D of CPB.
+      static_assert(D % CPB == 0, "prefetch depth must be whole periods");
       for (int c = 0; c < nchunks; c += D) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const int4 w4 = wb[j];
-          const float4 g4 = gb[j];
-          const float4 a4 = ab[j];
-          const int64_t cn = min(c + j + D, nchunks - 1);
-          wb[j] = sw[cn * 64];
-          gb[j] = sg[cn * 64];
-          ab[j] = sa[cn * 64];
-          // stage buffer: [barrier period parity][chunk within the period][round][lane]
-          const int sidx = ((((c + j) / CPB) & 1) * CPB + ((c + j) % CPB)) * 256 + lane;
-          StagedTerm* st = stage + sidx;
-          if ((c + j) % CPB == 0) period_p0 = p;
-          if (__any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0)) {  // rare
-            int32_t* fs = far + sidx;
-            put_far(st, fs, (uint32_t)w4.x, g4.x, a4.x);
-            put_far(st + 64, fs + 64, (uint32_t)w4.y, g4.y, a4.y);
-            put_far(st + 128, fs + 128, (uint32_t)w4.z, g4.z, a4.z);
-            put_far(st + 192, fs + 192, (uint32_t)w4.w, g4.w, a4.w);
-          } else {
-            put(st, (uint32_t)w4.x, g4.x, a4.x);
-            put(st + 64, (uint32_t)w4.y, g4.y, a4.y);
-            put(st + 128, (uint32_t)w4.z, g4.z, a4.z);
-            put(st + 192, (uint32_t)w4.w, g4.w, a4.w);
+        for (int j0 = 0; j0 < D; j0 += CPB) {
+          const int period_p0 = p;
+          copy_cells();
+          stage_chunk(c + j0, wb[j0], gb[j0], ab[j0]);
+          copy_table();
+          if (CPB == 2) stage_chunk(c + j0 + 1, wb[j0 + 1], gb[j0 + 1], ab[j0 + 1]);
+          copy_store();
+#pragma unroll
+          for (int i = 0; i < CPB; ++i) {
+            const int64_t cn = min(c + j0 + i + D, nchunks - 1);
+            wb[j0 + i] = sw[cn * 64];
+            gb[j0 + i] = sg[cn * 64];
+            ab[j0 + i] = sa[cn * 64];
           }
-          if ((c + j) % CPB == CPB - 1) {
-            producer_barrier<3 * CPB>();  // this period is staged; the consumer has finished the previous one
-            copy_out();       // ... whose states are stable in the ring (W >= 2 periods of states)
-            out_p0 = period_p0;
-            out_n = p - period_p0;
-          }
+          // this period is staged; the consumer has finished the previous one,
+          if (slack_periods == 2)
+            producer_barrier<2 * (3 * CPB + kIters)>();
+          else if (slack_periods == 1)
+            producer_barrier<3 * CPB + kIters>();
+          else
+            producer_barrier<3 * CPB>();
+          out_p0 = pend_p0;             // whose states are now stable in the ring (W >= 2 periods of states)
+          out_n = pend_n;
+          pend_p0 = period_p0;
+          pend_n = p - period_p0;
         }
       }
+      copy_cells();
+      copy_table();
+      copy_store();
       __syncthreads();  // the consumer has finished the last period
-      copy_out();
+      out_p0 = pend_p0;
+      out_n = pend_n;
+      copy_cells();
+      copy_table();
+      copy_store();
     };
     if (args.sc.general)
       run(std::true_type());
@@ -298,8 +361,8 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 
   // every ring cell starts as log-zero so that padding terms read something well-defined
   for (int i = lane; i < W * LPW; i += 64) {
-    ring[i].m = 0.0;
-    ring[i].e = kExpMin;
+    ringM[i] = 0.0;
+    ringE[i] = kExpMin;
   }
 
   double accM = 0.0;   // lane accumulator: mantissa scaled by 2^accE (!FAST) or 2^refE (FAST)
@@ -321,9 +384,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     int se = preE;
     // issue next round's ring read now, ahead of this round's ring write
     if (decltype(do_pre)::value) {
-      const RingCell* rc = ring + (ctl_next & kCellMask);
-      preM = rc->m;
-      preE = rc->e;
+      const int cell = (int)(ctl_next & kCellMask);
+      preM = ringM[cell];
+      preE = ringE[cell];
     }
     const uint64_t bypass = lane_mask((ctl & kCtlBypass) != 0);
     sm = select64(bypass, lastM, sm);
@@ -391,9 +454,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     lastM = m;
     lastE = e;
     {  // unpredicated: lanes that do not commit a state write their own dummy cell behind the ring
-      RingCell* rc = ring + ((ctl >> kWrShift) & kCellMask);
-      rc->m = m;
-      rc->e = e;
+      const int cell = (int)((ctl >> kWrShift) & kCellMask);
+      ringM[cell] = m;
+      ringE[cell] = e;
     }
   };
 
@@ -403,9 +466,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     const StagedTerm* st = stage + sidx;
     const StagedTerm t0 = st[0], t1 = st[64], t2 = st[128], t3 = st[192];
     {  // after the previous chunk's last ring write: the fresh value
-      const RingCell* rc = ring + (t0.ctl & kCellMask);
-      preM = rc->m;
-      preE = rc->e;
+      const int cell = (int)(t0.ctl & kCellMask);
+      preM = ringM[cell];
+      preE = ringE[cell];
     }
     const std::true_type yes;
     const std::false_type no;
@@ -431,7 +494,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 }
 
 static size_t sweep_lds_bytes(int ring_slots, int LPW, int cpb) {
-  return ((size_t)ring_slots * LPW + 64) * sizeof(RingCell) +
+  return ((size_t)ring_slots * LPW + 64) * (sizeof(double) + sizeof(int32_t)) +
          (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t)) + kLnTabSize * sizeof(LnTabEntry);
 }
 
@@ -439,7 +502,7 @@ template <int G>
 static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream) {
   const int LPW = 64 / G;
   // the producer copies a period's states out one period later: the ring must hold two periods
-  const int cpb = args.ring_slots >= 16 ? 2 : 1;
+  const int cpb = args.ring_slots >= 32 ? 2 : 1;
   const size_t lds = sweep_lds_bytes(args.ring_slots, LPW, cpb);
   if (cpb == 2) {
     hipLaunchKernelGGL((sweep_kernel<G, true, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
