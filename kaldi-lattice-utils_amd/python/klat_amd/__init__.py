@@ -4,8 +4,10 @@ The product is the C/HIP library and the C++ tools; this module only moves numpy
 across the ABI.  It never computes anything itself and has no CPU fallback: if the HIP
 library is missing, or no GPU is present when a compute entry point is called, it raises.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -87,6 +89,7 @@ def lib():
         for name in ("klat_ctx_destroy", "klat_batch_destroy", "klat_packed_destroy"):
             getattr(_lib, name).restype = None
             getattr(_lib, name).argtypes = [C.c_void_p]
+        atexit.register(_close_all)  # after the HIP runtime registered its own handlers: runs before them
     return _lib
 
 
@@ -150,10 +153,23 @@ def concat_lattices(lats, times=None):
     return out
 
 
+# Handles still open when the interpreter exits are closed here, batches before contexts and both
+# before the HIP runtime's own exit handlers run (module teardown order is arbitrary, and
+# destroying a stream after the runtime is gone aborts the process).
+_live = weakref.WeakSet()
+
+
+def _close_all():
+    for kind in (Batch, Ctx):
+        for obj in [o for o in list(_live) if isinstance(o, kind)]:
+            obj.close()
+
+
 class Ctx:
     def __init__(self, device=0):
         self.h = C.c_void_p()
         _check(lib().klat_ctx_create(C.c_int(device), C.byref(self.h)))
+        _live.add(self)
 
     def sync(self):
         _check(lib().klat_ctx_sync(self.h))
@@ -177,6 +193,8 @@ class Ctx:
 class Batch:
     def __init__(self, ctx, arrays, lanes_per_lattice=0, ring_slots=0, host_threads=0):
         self.ctx = ctx
+        self.h = C.c_void_p()
+        _live.add(self)
         self.desc, self._keep = make_desc(arrays)
         self.U = self.desc.num_lattices
         self.S = int(self._keep["state_off"][-1]) if self.U else 0

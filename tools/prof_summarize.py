@@ -21,13 +21,13 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]
-stats = newest(glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv")))
+stats = newest(glob.glob(os.path.join(src, "prof_stats", "**", "*_kernel_stats.csv"), recursive=True))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
 
 traffic = collections.defaultdict(dict)
 for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    files = newest(glob.glob(os.path.join(src, "prof_%s" % name, "*", "*_counter_collection.csv")))
+    files = newest(glob.glob(os.path.join(src, "prof_%s" % name, "**", "*_counter_collection.csv"), recursive=True))
     if not files:
         continue
     acc = collections.defaultdict(list)
