@@ -34,25 +34,7 @@ int main(int argc, char* argv[]) {
     LatticeBatch batch;
     auto flush = [&]() {
       if (keys.empty()) return;
-      DeviceBatch db(ctx, batch, &popt);
-      db.ForwardBackward(co.graph_scale, co.acoustic_scale, co.insertion_penalty);
-      int64_t T = 0;
-      for (int32_t f : num_frames) T += f;
-      std::vector<int64_t> frame_off((size_t)T + 1, 0);
-      int64_t n = 0;
-      Check(klat_frame_post(db.get(), num_frames.data(), frame_off.data(), nullptr, nullptr, 0, &n), "klat_frame_post");
-      std::vector<int32_t> labels((size_t)std::max<int64_t>(n, 1));
-      std::vector<float> logps((size_t)std::max<int64_t>(n, 1));
-      Check(klat_frame_post(db.get(), num_frames.data(), frame_off.data(), labels.data(), logps.data(), (int64_t)labels.size(), &n),
-            "klat_frame_post");
-      int64_t fb = 0;
-      for (size_t u = 0; u < keys.size(); ++u) {
-        PosteriorWriter::T post((size_t)num_frames[u]);
-        for (int32_t k = 0; k < num_frames[u]; ++k)
-          for (int64_t i = frame_off[fb + k]; i < frame_off[fb + k + 1]; ++i) post[k].emplace_back(labels[i], logps[i]);
-        posterior_writer.Write(keys[u], post);
-        fb += num_frames[u];
-      }
+      WritePosteriors(ctx, batch, popt, co, keys, num_frames, &posterior_writer);
       keys.clear();
       num_frames.clear();
       batch.Clear();

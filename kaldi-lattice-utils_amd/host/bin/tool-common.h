@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "../kaldi-io.h"
+#include "../lattice-functions.h"
+#include "../table-writers.h"
 
 namespace klat {
 
@@ -48,6 +50,35 @@ struct IndexOptions {
     if (Prunes() && !(beam > 0.0f)) KLAT_ERR("--beam must be positive");
   }
 };
+
+// Forward-backward over one batch, then the per-frame word posteriors of every lattice written
+// as Posterior entries (latbin/lattice-to-word-frame-post.cc:93-139).  "Frames" are whatever the
+// batch carries as state times: frames for lattice-to-word-frame-post, word positions for
+// lattice-to-word-position-post.
+inline void WritePosteriors(Context& ctx, const LatticeBatch& batch, const klat_pack_options& popt,
+                            const CommonOptions& co, const std::vector<std::string>& keys,
+                            const std::vector<int32_t>& num_frames, PosteriorWriter* writer) {
+  DeviceBatch db(ctx, batch, &popt);
+  db.ForwardBackward(co.graph_scale, co.acoustic_scale, co.insertion_penalty);
+  int64_t T = 0;
+  for (int32_t f : num_frames) T += f;
+  std::vector<int64_t> frame_off((size_t)T + 1, 0);
+  int64_t n = 0;
+  Check(klat_frame_post(db.get(), num_frames.data(), frame_off.data(), nullptr, nullptr, 0, &n), "klat_frame_post");
+  std::vector<int32_t> labels((size_t)std::max<int64_t>(n, 1));
+  std::vector<float> logps((size_t)std::max<int64_t>(n, 1));
+  Check(klat_frame_post(db.get(), num_frames.data(), frame_off.data(), labels.data(), logps.data(),
+                        (int64_t)labels.size(), &n),
+        "klat_frame_post");
+  int64_t fb = 0;
+  for (size_t u = 0; u < keys.size(); ++u) {
+    PosteriorWriter::T post((size_t)num_frames[u]);
+    for (int32_t k = 0; k < num_frames[u]; ++k)
+      for (int64_t i = frame_off[fb + k]; i < frame_off[fb + k + 1]; ++i) post[k].emplace_back(labels[i], logps[i]);
+    writer->Write(keys[u], post);
+    fb += num_frames[u];
+  }
+}
 
 inline std::vector<int32_t> ParseIntList(const std::string& s, const char* what) {
   std::set<int32_t> out;

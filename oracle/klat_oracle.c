@@ -530,6 +530,67 @@ int64_t kor_frame_post(int32_t S, const int64_t *arc_begin, const int32_t *dst,
   return m;
 }
 
+/* ---- position posteriors, latbin/lattice-to-word-position-post.cc:100-135 (the "next" caller
+ * that a14 unlocks).  Over the length-disambiguated lattice: for every arc with
+ * ilabel != 0, pos = state_len[nextstate] :108 and acc[pos][word] = LogAdd(.., alpha[u] +
+ * beta[next] - (Value1 + Value2)) :110-116 (the cost is the float sum the reference writes);
+ * entry n-1 of the output holds position n, logp = (float)(acc - total) :122-124, sorted by
+ * (logp desc, label asc) on the float values :128-135.  pos_begin[max_len+1]. */
+int64_t kor_position_post(int32_t S, const int64_t *arc_begin, const int32_t *dst,
+                          const int32_t *ilabel, const float *graph, const float *acoustic,
+                          const int32_t *state_len, int32_t max_len, const double *alpha,
+                          const double *beta, double total, int64_t out_cap, int64_t *pos_begin,
+                          int32_t *out_label, float *out_logp) {
+  const int64_t A = S > 0 ? arc_begin[S] : 0;
+  kor_rec *r = (kor_rec *)malloc(sizeof(kor_rec) * (size_t)(A > 0 ? A : 1));
+  int64_t c = 0;
+  for (int32_t s = 0; s < S; ++s)
+    for (int64_t i = arc_begin[s]; i < arc_begin[s + 1]; ++i) {
+      if (ilabel[i] == 0) continue;
+      float fcost = graph[i] + acoustic[i];
+      r[c].k0 = state_len[dst[i]];
+      r[c].k1 = ilabel[i];
+      r[c].k2 = 0;
+      r[c].t0 = r[c].t1 = 0;
+      r[c].rank = c;
+      r[c].x = alpha[s] + beta[dst[i]] - fcost;
+      ++c;
+    }
+  qsort(r, (size_t)c, sizeof(kor_rec), cmp_key_rank);
+  for (int32_t n = 0; n <= max_len; ++n) pos_begin[n] = 0;
+  kor_post *p = (kor_post *)malloc(sizeof(kor_post) * (size_t)(c > 0 ? c : 1));
+  int64_t m = 0;
+  for (int64_t i = 0; i < c;) {
+    int64_t j = i + 1;
+    double acc = r[i].x;
+    while (j < c && r[j].k0 == r[i].k0 && r[j].k1 == r[i].k1) {
+      acc = kor_log_add(acc, r[j].x);
+      ++j;
+    }
+    if (r[i].k0 >= 1 && r[i].k0 <= max_len) { /* acc[0] is not used :101 */
+      p[m].label = r[i].k1;
+      p[m].logp = (float)(acc - total);
+      pos_begin[r[i].k0] += 1;
+      ++m;
+    }
+    i = j;
+  }
+  for (int32_t n = 0; n < max_len; ++n) pos_begin[n + 1] += pos_begin[n];
+  free(r);
+  if (m > out_cap) {
+    free(p);
+    return -1;
+  }
+  for (int32_t n = 0; n < max_len; ++n)
+    qsort(p + pos_begin[n], (size_t)(pos_begin[n + 1] - pos_begin[n]), sizeof(kor_post), cmp_post);
+  for (int64_t i = 0; i < m; ++i) {
+    out_label[i] = p[i].label;
+    out_logp[i] = p[i].logp;
+  }
+  free(p);
+  return m;
+}
+
 /* ---- a14  DisambiguateStateInputSequenceLength, fstext/fstext-utils2.h:109-215.
  * New states are the (len, old_state) pairs reachable from (0,start) :150-168; their ids
  * are the rank of the pair in std::map (lexicographic) order :164-166; state_len[new]=len

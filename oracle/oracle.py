@@ -34,6 +34,7 @@ def lib():
         _LIB.kor_segment_index.restype = C.c_int64
         _LIB.kor_position_index.restype = C.c_int64
         _LIB.kor_frame_post.restype = C.c_int64
+        _LIB.kor_position_post.restype = C.c_int64
         _LIB.kor_disambiguate_length.restype = C.c_int32
         _LIB.kor_free.argtypes = [C.c_void_p]
     return _LIB
@@ -227,6 +228,21 @@ def frame_post(lat, times, total_frames, alpha, beta, total):
     assert m >= 0
     out = [[(int(ol[i]), np.float32(lp[i])) for i in range(fb[f], fb[f + 1])] for f in range(total_frames)]
     return out, bool(mis.value)
+
+
+def position_post(lat, state_len, max_len, alpha, beta, total):
+    """latbin/lattice-to-word-position-post.cc over an already length-disambiguated lattice.
+    Returns a list per position 1..max_len of [(label, float32 logp)]."""
+    cap = lat.A + 1
+    pb = np.zeros(max_len + 1, np.int64)
+    ol = np.zeros(cap, np.int32)
+    lp = np.zeros(cap, np.float32)
+    m = lib().kor_position_post(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.ilabel),
+                                _p(lat.graph), _p(lat.acoustic), _p(np.ascontiguousarray(state_len, np.int32)),
+                                C.c_int32(max_len), _p(alpha), _p(beta), C.c_double(total), C.c_int64(cap),
+                                _p(pb), _p(ol), _p(lp))
+    assert m >= 0
+    return [[(int(ol[i]), np.float32(lp[i])) for i in range(pb[n], pb[n + 1])] for n in range(max_len)]
 
 
 def disambiguate_length(lat, start=0, use_input=False):

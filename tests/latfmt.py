@@ -135,6 +135,21 @@ def parse_posterior_line(line):
     return key, frames
 
 
+def write_synth_text(arrays, f, keys):
+    """Writes the lattices of a klat_amd.synth() batch as a text CompactLattice archive (arc
+    durations from the state times, transition id 7)."""
+    for u, key in enumerate(keys):
+        s0, a0, a1 = arrays["state_off"][u], arrays["arc_off"][u], arrays["arc_off"][u + 1]
+        n = arrays["state_off"][u + 1] - s0
+        f.write("%s\n" % key)
+        for i in range(a0, a1):
+            s, d = arrays["src"][i], arrays["dst"][i]
+            dur = arrays["state_time"][s0 + d] - arrays["state_time"][s0 + s]
+            f.write("%d\t%d\t%d\t%.9g,%.9g,%s\n" % (s, d, arrays["ilabel"][i], arrays["graph"][i], arrays["acoustic"][i],
+                                                    "_".join(["7"] * dur)))
+        f.write("%d\n\n" % (n - 1))
+
+
 def logsumexp(xs):
     xs = list(xs)
     if not xs:

@@ -171,6 +171,44 @@ def test_frame_post_tool_text_and_binary(tmp_path, golden_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (0.7, 0.1, 0.5)])
+def test_position_post_tool_matches_oracle(tmp_path, golden_dir, scales):
+    """lattice-to-word-position-post (latbin/lattice-to-word-position-post.cc): the golden word
+    lattice plus a synthetic archive, against the oracle's direct restatement."""
+    gs, ac, pen = scales
+    ns = np.array([25, 1, 40, 9], np.int32)
+    fo = np.array([3, 1, 2, 4], np.int32)
+    arrays = klat_amd.synth(777, ns, fo)
+    txt = str(tmp_path / "in.txt")
+    with open(txt, "w") as f:
+        f.write(open(os.path.join(golden_dir, "egs_word_lattice.ark.txt")).read().rstrip("\n") + "\n\n")
+        latfmt.write_synth_text(arrays, f, ["u%d" % i for i in range(len(ns))])
+    rc, out, err = run("lattice-to-word-position-post", "--graph-scale=%g" % gs, "--acoustic-scale=%g" % ac,
+                       "--insertion-penalty=%g" % pen, "ark:" + txt, "ark,t:-")
+    assert rc == 0, err
+    lines = [l for l in out.decode().splitlines() if l.strip()]
+    lats = latfmt.read_text_archive(txt)
+    assert len(lines) == len(lats) == 1 + len(ns)
+    for line, lat in zip(lines, lats):
+        key, got = latfmt.parse_posterior_line(line)
+        assert key == lat.key
+        slat = orc.scale_and_penalize(latfmt.prepare(lat), gs, ac, pen)
+        dlat, state_len, max_len = orc.disambiguate_length(slat)
+        if dlat.S == 0:
+            assert got == []
+            continue
+        alpha, beta, total, _, _ = orc.alphas_betas(dlat)
+        want = orc.position_post(dlat, state_len, max_len, alpha, beta, total)
+        assert len(got) == len(want) == max_len
+        for g, w in zip(got, want):
+            assert sorted(l for l, _ in g) == sorted(l for l, _ in w)
+            wd = dict(w)
+            for l, p in g:
+                assert abs(p - float(wd[l])) < 1e-4 * max(1.0, abs(p))
+            assert all(g[i][1] >= g[i + 1][1] - 1e-6 for i in range(len(g) - 1))
+
+
+@pytest.mark.gpu
 def test_tools_on_a_multi_lattice_archive(tmp_path):
     """Input order is kept, empty lattices still produce a record, batching does not change the
     output, binary input gives the same result as text input, scales reach the GPU."""

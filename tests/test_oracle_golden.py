@@ -69,6 +69,24 @@ def test_position_index_matches_readme(golden_dir):
         assert _fmt7(g[4]) == _fmt7(w[4]), (g, w)
 
 
+def test_position_post_agrees_with_the_readme_position_index(golden_dir):
+    """latbin/lattice-to-word-position-post.cc accumulates the same (word, position) sums as the
+    position index, whose output kwsbin2/README.md:122 pins: entry n-1 of the posterior must hold
+    exactly the README records with pos == n, as float32, best first."""
+    lat = _word_lattice(golden_dir)
+    dlat, state_len, max_len = orc.disambiguate_length(lat)
+    alpha, beta, total, _, _ = orc.alphas_betas(dlat)
+    post = orc.position_post(dlat, state_len, max_len, alpha, beta, total)
+    _, want = latfmt.parse_tuple_line(_expected(golden_dir)["position"], 4)
+    assert len(post) == max_len == 7
+    for n in range(1, max_len + 1):
+        ref = sorted([(w[0], w[4]) for w in want if w[1] == n], key=lambda r: (-r[1], r[0]))
+        got = post[n - 1]
+        assert [g[0] for g in got] == [r[0] for r in ref], (n, got, ref)
+        for g, r in zip(got, ref):
+            assert abs(float(g[1]) - r[1]) < 1e-6, (n, g, r)
+
+
 def test_utterance_total_matches_readme(golden_dir):
     """kwsbin2/README.md:25 pins the betas-only total: words on every path have logp 0."""
     lat = _word_lattice(golden_dir)
