@@ -228,9 +228,10 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
     }
   }
   const size_t nslots = (size_t)chunk_total * 64 * kChunkRounds;
-  P.sw.resize(nslots);
-  P.sg.resize(nslots);
-  P.sa.resize(nslots);
+  if (!P.sw.resize(nslots) || !P.sg.resize(nslots) || !P.sa.resize(nslots)) {
+    *err = "out of host memory for the arc streams";
+    return KLAT_ERR_OOM;
+  }
 
   // ---- pass 2: fill ----
   std::atomic<int64_t> far(0);
@@ -242,7 +243,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
     // own dummy cell behind the ring, so that the consumer's ring write needs no predicate
     for (size_t i = 0; i < n; ++i)
       P.sw[b0 + i] = (int32_t)(kNil | ((uint32_t)(W * LPW + (int)((i / kChunkRounds) % 64)) << kWrShift));
-    std::fill(P.sg.begin() + b0, P.sg.begin() + b0 + n, std::numeric_limits<float>::infinity());
+    std::fill(P.sg.data() + b0, P.sg.data() + b0 + n, std::numeric_limits<float>::infinity());
     std::memset(&P.sa[b0], 0, n * sizeof(float));
     int64_t far_local = 0;
     auto slot_index = [&](int64_t r, int lane) -> size_t {

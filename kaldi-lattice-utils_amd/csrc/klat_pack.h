@@ -3,6 +3,7 @@
 #define KLAT_PACK_H_
 #include <stdint.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -11,10 +12,37 @@
 
 namespace klat {
 
+// Uninitialised host array: the streams are hundreds of megabytes, and std::vector's value
+// initialisation would touch (page-fault) all of it on one thread before the packer's threads
+// overwrite it -- that fault-in, not the packing, dominated klat_batch_create.
+template <class T>
+class HostBuf {
+ public:
+  HostBuf() = default;
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+  ~HostBuf() { std::free(p_); }
+  bool resize(size_t n) {  // contents unspecified
+    std::free(p_);
+    p_ = n ? static_cast<T*>(std::malloc(n * sizeof(T))) : nullptr;
+    n_ = p_ ? n : 0;
+    return n == 0 || p_ != nullptr;
+  }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  size_t size() const { return n_; }
+  T& operator[](size_t i) { return p_[i]; }
+  const T& operator[](size_t i) const { return p_[i]; }
+
+ private:
+  T* p_ = nullptr;
+  size_t n_ = 0;
+};
+
 struct PackedBatch {
   int G = 0, W = 0;
-  std::vector<int32_t> sw;  // [chunks][64][4]
-  std::vector<float> sg, sa;
+  HostBuf<int32_t> sw;  // [chunks][64][4]
+  HostBuf<float> sg, sa;
   std::vector<SweepJob> jobs;    // sorted longest first
   std::vector<LaneInfo> lanes;
   std::vector<PostItem> items;
