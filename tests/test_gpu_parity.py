@@ -163,20 +163,10 @@ def test_results_before_sweep_is_an_error(ctx):
     b.close()
 
 
-def test_full_size_properties(ctx):
-    """BASELINE config 2 shape (scaled to 2k lattices to keep the test short): size-independent
-    properties -- tot_fwd == tot_bwd, posterior flow conservation at every state, arcs out of
-    the start state carry total mass 1 -- plus oracle parity on a 64-lattice sample."""
-    U = 2000
-    ns = np.full(U, 2000, np.int32)
-    fo = np.full(U, 3, np.int32)
-    arrays = klat_amd.synth(20260001, ns, fo)
-    batch = klat_amd.Batch(ctx, arrays)
-    batch.forward_backward(1.0, 0.1, 0.0)
-    alpha, beta = batch.alpha_beta()
-    total, tf, tb = batch.totals()
-    post = batch.arc_logpost()
-    batch.close()
+def _flow_properties(arrays, alpha, beta, total, tf, tb, post):
+    """Size-independent properties of a forward-backward result: tot_fwd == tot_bwd, posterior
+    flow conservation at every state, arcs out of the start state carry total mass 1."""
+    U = len(arrays["state_off"]) - 1
     assert np.max(np.abs(tf - tb)) < 1e-7
     S = int(arrays["state_off"][-1])
     lat_of_arc = np.repeat(np.arange(U), np.diff(arrays["arc_off"]))
@@ -195,8 +185,56 @@ def test_full_size_properties(ctx):
     interior[first] = False
     assert np.max(np.abs(inflow[interior] - gamma[interior])) < 1e-9
     assert np.max(np.abs(outflow[first] - 1.0)) < 1e-9
-    # oracle parity on a sample
-    sub = klat_amd.synth(20260001, ns[:64], fo[:64])
+
+
+def _run_and_check(ctx, arrays, sample, **kw):
+    batch = klat_amd.Batch(ctx, arrays, **kw)
+    batch.forward_backward(1.0, 0.1, 0.0)
+    alpha, beta = batch.alpha_beta()
+    total, tf, tb = batch.totals()
+    post = batch.arc_logpost()
+    info, exact = batch.info(), batch.exact_sweep_jobs()
+    batch.close()
+    _flow_properties(arrays, alpha, beta, total, tf, tb, post)
+    # oracle parity on the first lattices
+    sub = {k: v for k, v in arrays.items()}
+    n_s, n_a = int(arrays["state_off"][sample]), int(arrays["arc_off"][sample])
+    sub["state_off"], sub["arc_off"] = arrays["state_off"][:sample + 1], arrays["arc_off"][:sample + 1]
+    for k in ("src", "dst", "ilabel", "olabel", "graph", "acoustic"):
+        sub[k] = arrays[k][:n_a]
+    for k in ("final_graph", "final_acoustic", "state_time"):
+        sub[k] = arrays[k][:n_s]
     wa, wb, wt, wpost = _oracle_batch(sub, 1.0, 0.1, 0.0)
-    n_s, n_a = int(sub["state_off"][-1]), int(sub["arc_off"][-1])
     _check(alpha[:n_s], wa, 1e-7), _check(beta[:n_s], wb, 1e-7), _check(post[:n_a], wpost, 1e-7)
+    return info, exact
+
+
+def test_full_size_properties(ctx):
+    """BASELINE configs[1] at its full size (10 000 lattices x 2 000 states x fanout 3, the bench
+    workload): size-independent properties over all 60 M arcs plus oracle parity on 32 lattices."""
+    U = 10000
+    arrays = klat_amd.synth(20260001, np.full(U, 2000, np.int32), np.full(U, 3, np.int32))
+    info, exact = _run_and_check(ctx, arrays, 32)
+    assert info["lanes_per_lattice"] == 4 and exact == 0
+
+
+def test_c4_shape_properties(ctx):
+    """BASELINE configs[3] shape (5 000-state lattices) at 2 000 of its 100 000
+    lattices -- the shard one GPU of the node would take is 12 500."""
+    U = 2000
+    arrays = klat_amd.synth(20260003, np.full(U, 5000, np.int32), np.full(U, 3, np.int32))
+    _run_and_check(ctx, arrays, 8)
+
+
+def test_c5_skewed_mix_properties(ctx):
+    """BASELINE configs[4] shape (sizes log-uniform in [200, 20 000] states,
+    fanout in {2,3,4,6}) at 1 500 of its 20 000 lattices: jobs mix lattices of very different
+    lengths, automatic and forced layouts."""
+    U = 1500
+    rng = np.random.RandomState(20260004)
+    ns = np.exp(rng.uniform(np.log(200), np.log(20000), U)).astype(np.int32)
+    fo = rng.choice([2, 3, 4, 6], U).astype(np.int32)
+    arrays = klat_amd.synth(20260004, ns, fo)
+    _run_and_check(ctx, arrays, 2)
+    _run_and_check(ctx, arrays, 2, lanes_per_lattice=1)
+    _run_and_check(ctx, arrays, 2, lanes_per_lattice=8, ring_slots=16)
