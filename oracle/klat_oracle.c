@@ -591,6 +591,55 @@ int64_t kor_position_post(int32_t S, const int64_t *arc_begin, const int32_t *ds
   return m;
 }
 
+/* ---- transcript length distribution, latbin/lattice-to-transcript-length-dist.cc:96-124 (second
+ * adjacent caller behind a14).  Over the length-disambiguated lattice: for every final state u in
+ * state order, acc[state_len[u]] = LogAdd(.., alpha[u] - ConvertToCost(Final(u))) :99-108;
+ * logp = (float)(acc - total) :113-115; sorted by (logp desc, length asc) :117-124.
+ * Returns the number of pairs (<= out_cap). */
+int64_t kor_length_dist(int32_t S, const float *final_graph, const float *final_acoustic,
+                        const int32_t *state_len, const double *alpha, double total,
+                        int64_t out_cap, int32_t *out_len, float *out_logp) {
+  int32_t max_len = -1;
+  for (int32_t s = 0; s < S; ++s)
+    if (state_len[s] > max_len) max_len = state_len[s];
+  if (max_len < 0) return 0;
+  double *acc = (double *)malloc(sizeof(double) * (size_t)(max_len + 1));
+  char *seen = (char *)calloc((size_t)(max_len + 1), 1);
+  for (int32_t s = 0; s < S; ++s) {
+    if (isinf(final_graph[s]) && final_graph[s] > 0 && isinf(final_acoustic[s]) && final_acoustic[s] > 0)
+      continue; /* Final(u) == Zero */
+    const double lkh = alpha[s] - ((double)final_graph[s] + (double)final_acoustic[s]);
+    const int32_t L = state_len[s];
+    if (!seen[L]) {
+      seen[L] = 1;
+      acc[L] = lkh;
+    } else {
+      acc[L] = kor_log_add(acc[L], lkh);
+    }
+  }
+  kor_post *p = (kor_post *)malloc(sizeof(kor_post) * (size_t)(max_len + 1));
+  int64_t m = 0;
+  for (int32_t L = 0; L <= max_len; ++L)
+    if (seen[L]) {
+      p[m].label = L;
+      p[m].logp = (float)(acc[L] - total);
+      ++m;
+    }
+  qsort(p, (size_t)m, sizeof(kor_post), cmp_post);
+  free(acc);
+  free(seen);
+  if (m > out_cap) {
+    free(p);
+    return -1;
+  }
+  for (int64_t i = 0; i < m; ++i) {
+    out_len[i] = p[i].label;
+    out_logp[i] = p[i].logp;
+  }
+  free(p);
+  return m;
+}
+
 /* ---- a14  DisambiguateStateInputSequenceLength, fstext/fstext-utils2.h:109-215.
  * New states are the (len, old_state) pairs reachable from (0,start) :150-168; their ids
  * are the rank of the pair in std::map (lexicographic) order :164-166; state_len[new]=len

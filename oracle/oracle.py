@@ -35,6 +35,7 @@ def lib():
         _LIB.kor_position_index.restype = C.c_int64
         _LIB.kor_frame_post.restype = C.c_int64
         _LIB.kor_position_post.restype = C.c_int64
+        _LIB.kor_length_dist.restype = C.c_int64
         _LIB.kor_disambiguate_length.restype = C.c_int32
         _LIB.kor_free.argtypes = [C.c_void_p]
     return _LIB
@@ -243,6 +244,19 @@ def position_post(lat, state_len, max_len, alpha, beta, total):
                                 _p(pb), _p(ol), _p(lp))
     assert m >= 0
     return [[(int(ol[i]), np.float32(lp[i])) for i in range(pb[n], pb[n + 1])] for n in range(max_len)]
+
+
+def length_dist(lat, state_len, alpha, total):
+    """latbin/lattice-to-transcript-length-dist.cc over a length-disambiguated lattice (finals
+    already scaled).  Returns [(length, float32 logp)] best first."""
+    cap = lat.S + 1
+    ol = np.zeros(cap, np.int32)
+    lp = np.zeros(cap, np.float32)
+    m = lib().kor_length_dist(C.c_int32(lat.S), _p(lat.final_graph), _p(lat.final_acoustic),
+                              _p(np.ascontiguousarray(state_len, np.int32)), _p(alpha), C.c_double(total),
+                              C.c_int64(cap), _p(ol), _p(lp))
+    assert m >= 0
+    return [(int(ol[i]), np.float32(lp[i])) for i in range(m)]
 
 
 def disambiguate_length(lat, start=0, use_input=False):

@@ -209,6 +209,38 @@ def test_position_post_tool_matches_oracle(tmp_path, golden_dir, scales):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (0.7, 0.1, 0.5)])
+def test_length_dist_tool_matches_oracle(tmp_path, golden_dir, scales):
+    """lattice-to-transcript-length-dist (latbin/lattice-to-transcript-length-dist.cc) against the
+    oracle: a lattice with several final states and epsilon arcs, the golden word lattice and a
+    synthetic one in the same archive."""
+    gs, ac, pen = scales
+    arrays = klat_amd.synth(99, np.array([30, 1], np.int32), np.array([3, 1], np.int32))
+    txt = str(tmp_path / "in.txt")
+    with open(txt, "w") as f:
+        for name in ("multi_final_lattice.ark.txt", "egs_word_lattice.ark.txt"):
+            f.write(open(os.path.join(golden_dir, name)).read().rstrip("\n") + "\n\n")
+        latfmt.write_synth_text(arrays, f, ["u0", "u1"])
+    rc, out, err = run("lattice-to-transcript-length-dist", "--graph-scale=%g" % gs, "--acoustic-scale=%g" % ac,
+                       "--insertion-penalty=%g" % pen, "ark:" + txt, "ark,t:-")
+    assert rc == 0, err
+    lines = [l for l in out.decode().splitlines() if l.strip()]
+    lats = latfmt.read_text_archive(txt)
+    assert len(lines) == len(lats) == 4
+    for line, lat in zip(lines, lats):
+        key, got = latfmt.parse_posterior_line(line)
+        assert key == lat.key and len(got) == 1
+        slat = orc.scale_and_penalize(latfmt.prepare(lat), gs, ac, pen)
+        dlat, state_len, _ = orc.disambiguate_length(slat)
+        alpha, beta, total, _, _ = orc.alphas_betas(dlat)
+        want = orc.length_dist(dlat, state_len, alpha, total)
+        assert [g[0] for g in got[0]] == [w[0] for w in want], (key, got, want)
+        for g, w in zip(got[0], want):
+            assert abs(g[1] - float(w[1])) < 1e-4 * max(1.0, abs(g[1]))
+    assert len(latfmt.parse_posterior_line(lines[0])[1][0]) >= 3  # several lengths in the first lattice
+
+
+@pytest.mark.gpu
 def test_tools_on_a_multi_lattice_archive(tmp_path):
     """Input order is kept, empty lattices still produce a record, batching does not change the
     output, binary input gives the same result as text input, scales reach the GPU."""

@@ -87,6 +87,26 @@ def test_position_post_agrees_with_the_readme_position_index(golden_dir):
             assert abs(float(g[1]) - r[1]) < 1e-6, (n, g, r)
 
 
+def test_length_dist_equals_path_enumeration(golden_dir):
+    """latbin/lattice-to-transcript-length-dist.cc has no known-answer vector in the reference;
+    the oracle's restatement is checked against brute-force path enumeration (the reference's own
+    test idiom) on a lattice with epsilon arcs and final states at several depths."""
+    lat = latfmt.prepare(latfmt.read_text_archive(os.path.join(golden_dir, "multi_final_lattice.ark.txt"))[0])
+    dlat, state_len, max_len = orc.disambiguate_length(lat)
+    alpha, beta, total, _, _ = orc.alphas_betas(dlat)
+    got = orc.length_dist(dlat, state_len, alpha, total)
+    by_len = {}
+    for arcs, ll in latfmt.brute_force_paths(lat):
+        n = sum(1 for i in arcs if lat.olabel[i] != 0)
+        by_len.setdefault(n, []).append(ll)
+    tot = latfmt.logsumexp(x for v in by_len.values() for x in v)
+    want = sorted(((n, latfmt.logsumexp(v) - tot) for n, v in by_len.items()), key=lambda r: (-r[1], r[0]))
+    assert len(want) >= 3 and abs(tot - total) < 1e-9
+    assert [g[0] for g in got] == [w[0] for w in want]
+    for g, w in zip(got, want):
+        assert abs(float(g[1]) - w[1]) < 1e-6
+
+
 def test_utterance_total_matches_readme(golden_dir):
     """kwsbin2/README.md:25 pins the betas-only total: words on every path have logp 0."""
     lat = _word_lattice(golden_dir)
