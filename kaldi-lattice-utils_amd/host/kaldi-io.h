@@ -35,6 +35,12 @@ void LogMessage(const char* level, const std::string& msg);
     _os << msg;                                \
     ::klat::LogMessage("WARNING", _os.str());  \
   } while (0)
+#define KLAT_LOG(msg)                          \
+  do {                                         \
+    std::ostringstream _os;                    \
+    _os << msg;                                \
+    ::klat::LogMessage("LOG", _os.str());      \
+  } while (0)
 #define KLAT_ERR(msg)                          \
   do {                                         \
     std::ostringstream _os;                    \

@@ -142,6 +142,51 @@ int32_t DisambiguateStateInputSequenceLength(const CompactLattice& ifst, Compact
   return max_len;
 }
 
+void ArcSortByOlabel(CompactLattice* clat) {
+  for (auto& st : clat->States())
+    std::stable_sort(st.arcs.begin(), st.arcs.end(),
+                     [](const CompactLatticeArc& a, const CompactLatticeArc& b) { return a.olabel < b.olabel; });
+}
+
+void AddSequenceLengthDisambiguationSymbol(CompactLattice* clat, std::vector<int32_t>* state_input_length,
+                                           int32_t dis_label) {
+  if ((size_t)clat->NumStates() != state_input_length->size())
+    KLAT_ERR("AddSequenceLengthDisambiguationSymbol() expects the input length of every state ("
+             << state_input_length->size() << " vs. " << clat->NumStates() << ")");
+  if (clat->NumStates() == 0) return;
+  const int32_t num_orig = clat->NumStates();
+  const int32_t max_length = *std::max_element(state_input_length->begin(), state_input_length->end());
+  std::vector<int32_t> aux((size_t)max_length + 1);
+  for (int32_t k = 0; k <= max_length; ++k) aux[(size_t)k] = clat->AddState();
+  CompactLatticeState& last = clat->State(aux[(size_t)max_length]);
+  last.final_graph = last.final_acoustic = 0.0f;  // Weight::One()
+  last.final_string_len = 0;
+  for (int32_t k = 0; k <= max_length; ++k) {
+    state_input_length->push_back(k);
+    if (k < max_length) {
+      CompactLatticeArc arc;
+      arc.ilabel = arc.olabel = dis_label;
+      arc.graph = arc.acoustic = 0.0f;
+      arc.string_len = 0;
+      arc.nextstate = aux[(size_t)k + 1];
+      clat->State(aux[(size_t)k]).arcs.push_back(arc);
+    }
+  }
+  for (int32_t u = 0; u < num_orig; ++u) {
+    CompactLatticeState& st = clat->State(u);
+    if (!st.IsFinal()) continue;
+    CompactLatticeArc arc;
+    arc.ilabel = arc.olabel = 0;
+    arc.graph = st.final_graph;
+    arc.acoustic = st.final_acoustic;
+    arc.string_len = st.final_string_len;
+    arc.nextstate = aux[(size_t)(*state_input_length)[(size_t)u]];
+    st.arcs.push_back(arc);
+    st.final_graph = st.final_acoustic = std::numeric_limits<float>::infinity();
+    st.final_string_len = 0;
+  }
+}
+
 namespace {
 // ConvertToCost of a weight after ScaleLattice / AddWordInsPen, with the reference's rounding:
 // products formed in double and stored as float, penalty added in float, sum in double.

@@ -30,6 +30,18 @@ int32_t CompactLatticeStateTimes(const CompactLattice& clat, std::vector<int32_t
 int32_t DisambiguateStateInputSequenceLength(const CompactLattice& ifst, CompactLattice* ofst,
                                              std::vector<int32_t>* state_input_length, bool use_input = false);
 
+// ArcSort(&clat, OLabelCompare()) as latbin/lattice-best-path2.cc:103 applies it before the
+// disambiguation: the arcs of every state ordered by output label (stable).
+void ArcSortByOlabel(CompactLattice* clat);
+
+// AddSequenceLengthDismabiguationSymbol (fstext/fstext-utils2.h:219-271): appends the auxiliary
+// chain aux[0..max_len] (aux[k] -> aux[k+1] with label dis_label and weight One, aux[max_len]
+// final), and replaces every final weight by an epsilon arc carrying it to aux[length of the
+// state], so that every complete path has max_len labels.  state_input_length grows by the
+// auxiliary states (length k for aux[k]).
+void AddSequenceLengthDisambiguationSymbol(CompactLattice* clat, std::vector<int32_t>* state_input_length,
+                                           int32_t dis_label = -1);
+
 // PruneLattice(beam, &clat) as the kwsbin2 tools apply it after ScaleLattice and
 // AddWordInsPenToCompactLattice (kwsbin2/lattice-word-index-segment.cc:41-51): Viterbi forward /
 // backward costs (structure mirrored in-repo at latbin/lattice-prune-dyn-beam.cc:35-87), final

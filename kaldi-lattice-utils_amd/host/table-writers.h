@@ -65,6 +65,20 @@ class PosteriorWriter : public ArchiveWriter {
   }
 };
 
+// vector<int32> (Int32VectorWriter, latbin/lattice-best-path2.cc:75,199): BasicVectorHolder wire
+// format -- text: the values separated by spaces, newline; binary: int32 size, then the values.
+class Int32VectorWriter : public ArchiveWriter {
+ public:
+  using ArchiveWriter::ArchiveWriter;
+  void Write(const std::string& key, const std::vector<int32_t>& v) {
+    std::ostream& os = Begin(key);
+    if (binary()) WriteBasicType(os, true, (int32_t)v.size());
+    for (int32_t x : v) WriteBasicType(os, binary(), x);
+    if (!binary()) os << '\n';
+    End();
+  }
+};
+
 // vector<tuple<int32,int32,int32,double>> (segment index).
 class SegmentScoreWriter : public ArchiveWriter {
  public:

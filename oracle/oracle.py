@@ -293,6 +293,95 @@ def disambiguate_length(lat, start=0, use_input=False):
     return out, state_len, max_len
 
 
+def arc_sort_olabel(lat):
+    """ArcSort(&clat, OLabelCompare()) of latbin/lattice-best-path2.cc:103 (stable)."""
+    arcs, finals = [], {}
+    src = lat.src()
+    for s in range(lat.S):
+        idx = sorted(range(int(lat.arc_begin[s]), int(lat.arc_begin[s + 1])), key=lambda i: int(lat.olabel[i]))
+        for i in idx:
+            arcs.append((s, int(lat.dst[i]), int(lat.ilabel[i]), int(lat.olabel[i]), lat.graph[i], lat.acoustic[i], int(lat.dur[i])))
+        if not (np.isinf(lat.final_graph[s]) and np.isinf(lat.final_acoustic[s])):
+            finals[s] = (lat.final_graph[s], lat.final_acoustic[s], int(lat.final_dur[s]))
+    return lat_from_arcs(lat.S, arcs, finals, key=lat.key)
+
+
+def add_length_disambiguation(lat, state_len, dis_label=-1):
+    """AddSequenceLengthDismabiguationSymbol, fstext/fstext-utils2.h:219-271: auxiliary chain
+    aux[0..max_len] (label dis_label, weight One, last one final) and every final weight moved onto
+    an epsilon arc to aux[length of the state].  Returns (lattice, state_len incl. aux states)."""
+    S = lat.S
+    if S == 0:
+        return lat, np.asarray(state_len, np.int32)
+    max_len = int(np.max(state_len))
+    aux = [S + k for k in range(max_len + 1)]
+    arcs, finals = [], {aux[max_len]: (0.0, 0.0, 0)}
+    for s in range(S):
+        for i in range(int(lat.arc_begin[s]), int(lat.arc_begin[s + 1])):
+            arcs.append((s, int(lat.dst[i]), int(lat.ilabel[i]), int(lat.olabel[i]), lat.graph[i], lat.acoustic[i], int(lat.dur[i])))
+        if not (np.isinf(lat.final_graph[s]) and np.isinf(lat.final_acoustic[s])):
+            arcs.append((s, aux[int(state_len[s])], 0, 0, lat.final_graph[s], lat.final_acoustic[s], int(lat.final_dur[s])))
+    for k in range(max_len):
+        arcs.append((aux[k], aux[k + 1], dis_label, dis_label, 0.0, 0.0, 0))
+    out = lat_from_arcs(S + max_len + 1, arcs, finals, key=lat.key)
+    return out, np.concatenate([np.asarray(state_len, np.int32), np.arange(max_len + 1, dtype=np.int32)])
+
+
+def best_path2(lat):
+    """latbin/lattice-best-path2.cc:103-188 on a scaled, penalised, top-sorted lattice: returns
+    (transcript, cost as float32, number of distinct minimum-cost paths capped at 2).  Pure-Python
+    loops: for small lattices only.  Ties between equal-cost paths are kept in (state, arc) order;
+    the third value lets a test skip lattices whose answer depends on that."""
+    if lat.S == 0:
+        return [], np.float32(0.0), 1
+    dlat, state_len, _ = disambiguate_length(arc_sort_olabel(lat))
+    plat, plen = add_length_disambiguation(dlat, state_len)
+    alpha, beta, total, _, _ = alphas_betas(plat)
+    src = plat.src()
+    acc = {}
+    for i in range(plat.A):  # state order, arc order: the reference's two nested iterators
+        label = int(plat.olabel[i])
+        if label == 0:
+            continue
+        key = (label, int(plen[plat.dst[i]]))
+        w = alpha[src[i]] + beta[plat.dst[i]] - (float(plat.graph[i]) + float(plat.acoustic[i]))
+        acc[key] = w if key not in acc else log_add(acc[key], w)
+    post = {k: min(0.0, v - beta[0]) for k, v in acc.items()}
+    S = plat.S
+    inf = np.float32(np.inf)
+    dist = np.full(S, inf, np.float32)
+    ways = np.zeros(S, np.int64)
+    parent = [(-1, 0)] * S
+    dist[0], ways[0] = np.float32(0.0), 1
+    best, best_state, best_ways = inf, -1, 0
+    for s in range(S):
+        if dist[s] == inf:
+            continue
+        if not (np.isinf(plat.final_graph[s]) and np.isinf(plat.final_acoustic[s])):
+            if dist[s] < best:
+                best, best_state, best_ways = dist[s], s, int(ways[s])
+            elif dist[s] == best:
+                best_ways += int(ways[s])
+        for i in range(int(plat.arc_begin[s]), int(plat.arc_begin[s + 1])):
+            label, d = int(plat.olabel[i]), int(plat.dst[i])
+            w = np.float32(0.0)
+            if label != 0:
+                p = post[(label, int(plen[d]))]
+                w = np.float32(0.0 if p >= 0.0 else np.exp(np.log1p(-np.exp(p))))
+            nd = np.float32(dist[s] + w)
+            if nd < dist[d]:
+                dist[d], parent[d], ways[d] = nd, (s, label), ways[s]
+            elif nd == dist[d]:
+                ways[d] += ways[s]
+    out = []
+    s = best_state
+    while s >= 0 and parent[s][0] >= 0:
+        if parent[s][1] not in (0, -1):
+            out.append(parent[s][1])
+        s = parent[s][0]
+    return out[::-1], best, min(best_ways, 2)
+
+
 def prune_lattice(lat, beam):
     """A.4 on an already scaled lattice.  Returns the pruned, connected lattice (state ids in
     order) or None if nothing survives; `extra` holds the kept old state / arc indices."""

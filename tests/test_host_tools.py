@@ -241,6 +241,50 @@ def test_length_dist_tool_matches_oracle(tmp_path, golden_dir, scales):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (0.7, 0.1, 0.5)])
+def test_best_path2_tool_matches_oracle(tmp_path, golden_dir, scales):
+    """lattice-best-path2 (latbin/lattice-best-path2.cc) against the oracle: transcripts (integer
+    labels, exact) wherever the minimum-cost path is unique, and the logged costs."""
+    gs, ac, pen = scales
+    ns = np.array([30, 12, 1, 45], np.int32)
+    fo = np.array([3, 2, 1, 4], np.int32)
+    arrays = klat_amd.synth(2024, ns, fo)
+    txt = str(tmp_path / "in.txt")
+    with open(txt, "w") as f:
+        for name in ("egs_word_lattice.ark.txt", "multi_final_lattice.ark.txt"):
+            f.write(open(os.path.join(golden_dir, name)).read().rstrip("\n") + "\n\n")
+        latfmt.write_synth_text(arrays, f, ["u%d" % i for i in range(len(ns))])
+    rc, out, err = run("lattice-best-path2", "--graph-scale=%g" % gs, "--acoustic-scale=%g" % ac,
+                       "--insertion-penalty=%g" % pen, "ark:" + txt, "ark,t:-")
+    assert rc == 0, err
+    lines = out.decode().split("\n")[:-1]
+    lats = latfmt.read_text_archive(txt)
+    assert len(lines) == len(lats) == 2 + len(ns)
+    costs = [float(l.split("best cost is ")[1].split(" over ")[0]) for l in err.splitlines() if "best cost is" in l]
+    assert len(costs) == len(lats)
+    unique = 0
+    for line, lat, cost in zip(lines, lats, costs):
+        toks = line.split()
+        assert toks[0] == lat.key
+        got = [int(t) for t in toks[1:]]
+        want, wcost, ways = orc.best_path2(orc.scale_and_penalize(latfmt.prepare(lat), gs, ac, pen))
+        assert abs(cost - float(wcost)) < 1e-4 * max(1.0, abs(cost)), (lat.key, cost, wcost)
+        if ways == 1:
+            assert got == want, (lat.key, got, want)
+            unique += 1
+    assert unique >= 4
+    # binary output: BasicVectorHolder<int32>
+    b = str(tmp_path / "tra.ark")
+    rc, _, err = run("lattice-best-path2", "ark:" + txt, "ark:" + b)
+    assert rc == 0, err
+    raw = open(b, "rb").read()
+    n = len([int(t) for t in lines[0].split()[1:]]) if scales == (1.0, 1.0, 0.0) else None
+    assert raw.startswith(lats[0].key.encode() + b" \x00B\x04")
+    if n is not None:
+        assert struct.unpack("<i", raw[len(lats[0].key) + 4:len(lats[0].key) + 8])[0] == n
+
+
+@pytest.mark.gpu
 def test_tools_on_a_multi_lattice_archive(tmp_path):
     """Input order is kept, empty lattices still produce a record, batching does not change the
     output, binary input gives the same result as text input, scales reach the GPU."""

@@ -107,6 +107,32 @@ def test_length_dist_equals_path_enumeration(golden_dir):
         assert abs(float(g[1]) - w[1]) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["egs_word_lattice.ark.txt", "multi_final_lattice.ark.txt"])
+def test_best_path2_equals_path_enumeration(golden_dir, name):
+    """latbin/lattice-best-path2.cc has no known-answer vector in the reference (parity unpinned for
+    that tool): the oracle's restatement (position posteriors of the padded lattice, arc costs
+    1 - P, shortest path) is checked against enumerating every path of the padded lattice."""
+    lat = latfmt.prepare(latfmt.read_text_archive(os.path.join(golden_dir, name))[0])
+    got, cost, _ = orc.best_path2(lat)
+    dlat, state_len, _ = orc.disambiguate_length(orc.arc_sort_olabel(lat))
+    plat, plen = orc.add_length_disambiguation(dlat, state_len)
+    paths = latfmt.brute_force_paths(plat)
+    tot = latfmt.logsumexp(ll for _, ll in paths)
+    mass = {}
+    for arcs, ll in paths:
+        for i in arcs:
+            if plat.olabel[i] != 0:
+                mass.setdefault((int(plat.olabel[i]), int(plen[plat.dst[i]])), []).append(ll)
+    prob = {k: min(1.0, math.exp(latfmt.logsumexp(v) - tot)) for k, v in mass.items()}
+    scored = []
+    for arcs, _ in paths:
+        c = sum(1.0 - prob[(int(plat.olabel[i]), int(plen[plat.dst[i]]))] for i in arcs if plat.olabel[i] != 0)
+        scored.append((c, [int(plat.olabel[i]) for i in arcs if plat.olabel[i] not in (0, -1)]))
+    best = min(c for c, _ in scored)
+    assert abs(float(cost) - best) < 1e-5
+    assert got in [t for c, t in scored if c < best + 1e-5]
+
+
 def test_utterance_total_matches_readme(golden_dir):
     """kwsbin2/README.md:25 pins the betas-only total: words on every path have logp 0."""
     lat = _word_lattice(golden_dir)
