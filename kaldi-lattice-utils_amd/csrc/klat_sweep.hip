@@ -460,18 +460,12 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     }
   };
 
-  for (int c = 0; c < nchunks; ++c) {
-    if (c % CPB == 0) consumer_barrier();  // the period is staged (and, for c == 0, the ring is initialised)
-    const int sidx = (((c / CPB) & 1) * CPB + (c % CPB)) * 256 + lane;
-    const StagedTerm* st = stage + sidx;
-    const StagedTerm t0 = st[0], t1 = st[64], t2 = st[128], t3 = st[192];
-    {  // after the previous chunk's last ring write: the fresh value
-      const int cell = (int)(t0.ctl & kCellMask);
-      preM = ringM[cell];
-      preE = ringE[cell];
-    }
-    const std::true_type yes;
-    const std::false_type no;
+  const std::true_type yes;
+  const std::false_type no;
+  // four rounds; LAST_PRE = the chunk that follows belongs to the same period, so its first
+  // round's ring read (cell in next_ctl) can be issued from this chunk's last round
+  auto chunk = [&](const StagedTerm& t0, const StagedTerm& t1, const StagedTerm& t2, const StagedTerm& t3, int sidx,
+                   auto last_pre, uint32_t next_ctl) {
     if (__any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & (kCtlOne | kCtlFar)) != 0)) {
       const int32_t* fs = far + sidx;
       const bool anyfar = __any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & kCtlFar) != 0);
@@ -479,12 +473,31 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       round(yes, yes, t0, t1.ctl, f0);
       round(yes, yes, t1, t2.ctl, f1);
       round(yes, yes, t2, t3.ctl, f2);
-      round(yes, no, t3, 0u, f3);
+      round(yes, last_pre, t3, next_ctl, f3);
     } else {
       round(no, yes, t0, t1.ctl, 0);
       round(no, yes, t1, t2.ctl, 0);
       round(no, yes, t2, t3.ctl, 0);
-      round(no, no, t3, 0u, 0);
+      round(no, last_pre, t3, next_ctl, 0);
+    }
+  };
+  for (int c = 0; c < nchunks; c += CPB) {
+    consumer_barrier();  // the period is staged (and, for c == 0, the ring is initialised)
+    // the whole period's terms are read at once: one LDS round trip per period, not per chunk
+    const int sidx = ((c / CPB) & 1) * CPB * 256 + lane;
+    const StagedTerm* st = stage + sidx;
+    const StagedTerm a0 = st[0], a1 = st[64], a2 = st[128], a3 = st[192];
+    {  // after the previous period's last ring write: the fresh value
+      const int cell = (int)(a0.ctl & kCellMask);
+      preM = ringM[cell];
+      preE = ringE[cell];
+    }
+    if (CPB == 2) {
+      const StagedTerm b0 = st[256], b1 = st[320], b2 = st[384], b3 = st[448];
+      chunk(a0, a1, a2, a3, sidx, yes, b0.ctl);
+      chunk(b0, b1, b2, b3, sidx + 256, no, 0u);
+    } else {
+      chunk(a0, a1, a2, a3, sidx, no, 0u);
     }
   }
   __syncthreads();  // lets the producer copy out the last period's states
