@@ -35,6 +35,25 @@ struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)
 };
 
 hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hipStream_t stream);
+
+// Radix path (klat_accum_radix.hip): lattices of at most kRadixMaxArcs arcs whose index keys pack
+// into total_bits <= 62 bits -- (label - label_min) in label_bits, times / positions in time_bits
+// each.  The ranges come from range_kernel over the batch.
+static const int kRadixMaxArcs = 8192;
+struct RadixPack {
+  int32_t label_min;
+  int32_t label_bits, time_bits, total_bits;
+};
+struct RangeArgs {
+  int64_t num_arcs, num_states;
+  const int32_t* olabel;
+  const int32_t* state_time;
+  const int32_t* state_len;  // may be null
+  int32_t* out;              // [4]: label min, label max, time max, length max
+};
+hipError_t launch_range(const RangeArgs& a, hipStream_t stream);
+hipError_t launch_index_radix(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position,
+                              hipStream_t stream);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
                                OutRecord* out, hipStream_t stream);
 

@@ -321,6 +321,42 @@ __global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const in
   }
 }
 
+// label / time / length ranges of the batch (out[] preset to {INT_MAX, INT_MIN, 0, 0})
+__global__ __launch_bounds__(256) void range_kernel(RangeArgs a) {
+  int32_t lmin = 0x7FFFFFFF, lmax = (int32_t)0x80000000, tmax = 0, nmax = 0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.num_arcs; i += stride) {
+    const int32_t l = a.olabel[i];
+    lmin = min(lmin, l);
+    lmax = max(lmax, l);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.num_states; i += stride) {
+    const int32_t t = a.state_time[i];
+    tmax = max(tmax, t < 0 ? 0x7FFFFFFF : t);  // a negative time disables the radix path
+    if (a.state_len) {
+      const int32_t n = a.state_len[i];
+      nmax = max(nmax, n < 0 ? 0x7FFFFFFF : n);
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    lmin = min(lmin, __shfl_xor(lmin, d, 64));
+    lmax = max(lmax, __shfl_xor(lmax, d, 64));
+    tmax = max(tmax, __shfl_xor(tmax, d, 64));
+    nmax = max(nmax, __shfl_xor(nmax, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&a.out[0], lmin);
+    atomicMax(&a.out[1], lmax);
+    atomicMax(&a.out[2], tmax);
+    atomicMax(&a.out[3], nmax);
+  }
+}
+
+hipError_t launch_range(const RangeArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(range_kernel, dim3(1024), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
   hipError_t e;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -96,7 +97,38 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     a.exclude = st.exclude.p;
     a.num_exclude = (int32_t)exc.size();
     a.state_len = st.state_len.p;
-    KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
+    // lattices of up to 8192 arcs whose keys pack into 62 bits take the radix-sort kernel
+    bool radix = std::getenv("KLAT_INDEX_BITONIC") == nullptr;  // (test hook: force the general kernel)
+    RadixPack pk = {0, 0, 0, 0};
+    {
+      int64_t max_arcs = 0;
+      for (int64_t u = 0; u < b->U; ++u) max_arcs = std::max(max_arcs, b->h_arc_off[u + 1] - b->h_arc_off[u]);
+      radix = radix && max_arcs <= kRadixMaxArcs && b->A > 0;
+    }
+    if (radix) {
+      const int32_t init[4] = {0x7FFFFFFF, (int32_t)0x80000000, 0, 0};
+      int32_t range[4];
+      DevBuf<int32_t> d_range;
+      if ((rc = d_range.upload(init, 4, c->stream))) return rc;
+      RangeArgs ra = {b->A, b->S, b->olabel.p, b->state_time.p, position ? st.state_len.p : nullptr, d_range.p};
+      KLAT_HIP(launch_range(ra, c->stream));
+      KLAT_HIP(hipMemcpyAsync(range, d_range.p, sizeof(range), hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipStreamSynchronize(c->stream));
+      auto bits = [](uint64_t v) {
+        int n = 1;
+        while (n < 64 && (v >> n) != 0) ++n;
+        return n;
+      };
+      pk.label_min = range[0];
+      pk.label_bits = bits((uint64_t)((int64_t)range[1] - (int64_t)range[0]));
+      pk.time_bits = bits((uint64_t)(uint32_t)(position ? range[3] : range[2]));
+      pk.total_bits = pk.label_bits + (position ? 1 : 2) * pk.time_bits;
+      radix = pk.total_bits <= 62;
+    }
+    if (radix)
+      KLAT_HIP(launch_index_radix(a, pk, (int)b->U, position, c->stream));
+    else
+      KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
     std::vector<int32_t> counts((size_t)b->U);
     if (b->U > 0)
       KLAT_HIP(hipMemcpyAsync(counts.data(), st.num_records.p, sizeof(int32_t) * (size_t)b->U,

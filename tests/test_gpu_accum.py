@@ -109,9 +109,12 @@ def test_position_index_readme_vector(ctx, golden_dir):
 
 @pytest.mark.parametrize("G", [1, 4])
 @pytest.mark.parametrize("flt", [{}, {"exclude": [3, 7, 500]}, {"include": list(range(1, 200))}])
-def test_segment_index_synthetic(ctx, G, flt):
+@pytest.mark.parametrize("largest", [2700, 5000])
+def test_segment_index_synthetic(ctx, G, flt, largest):
+    """largest = 2700 states (8 097 arcs): every lattice fits the radix-sort kernel (<= 8 192 arcs);
+    5000 states (14 997 arcs): the batch takes the general kernel, whose sort leaves the LDS tile."""
     rng = np.random.RandomState(11)
-    ns = np.concatenate([[1, 2], rng.randint(3, 400, size=60), [5000]]).astype(np.int32)  # 5000x3 arcs > LDS tile
+    ns = np.concatenate([[1, 2], rng.randint(3, 400, size=60), [largest]]).astype(np.int32)
     fo = rng.choice([1, 2, 3, 4], size=len(ns)).astype(np.int32)
     fo[-1] = 3
     arrays = klat_amd.synth(20260004, ns, fo)
@@ -131,7 +134,12 @@ def test_segment_index_synthetic(ctx, G, flt):
         _check_sorted_records(got, want, 3)
 
 
-def test_position_index_synthetic(ctx):
+@pytest.mark.parametrize("kernel", ["radix", "general"])
+def test_position_index_synthetic(ctx, kernel, monkeypatch):
+    """Both index kernels: the radix-sort one these small lattices qualify for, and the general
+    (bitonic) one, forced through the library's test hook."""
+    if kernel == "general":
+        monkeypatch.setenv("KLAT_INDEX_BITONIC", "1")
     rng = np.random.RandomState(5)
     ns = rng.randint(2, 60, size=40).astype(np.int32)
     fo = rng.choice([1, 2, 3], size=len(ns)).astype(np.int32)
