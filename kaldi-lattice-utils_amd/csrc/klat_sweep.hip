@@ -111,7 +111,6 @@ static constexpr uint32_t kCtlFirst = kFirst;
 static constexpr uint32_t kCtlLast = kLast;
 static constexpr uint32_t kCtlBypass = kBypass;
 static constexpr uint32_t kCtlOne = kOne;
-static constexpr uint32_t kCtlFar = kFar;   // source cell index (relative to the lattice) is in far[]
 
 // ---------------------------------------------------------------------------------------------
 // Lockstep sweep.  One workgroup of TWO waves per job; a job is 64/G lattices, G lanes each,
@@ -161,8 +160,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   double* ringM = smem;
   int32_t* ringE = reinterpret_cast<int32_t*>(smem + ncell);
   StagedTerm* stage = reinterpret_cast<StagedTerm*>(ringE + ncell);
-  int32_t* far = reinterpret_cast<int32_t*>(stage + 2 * CPB * 256);          // [2][CPB][4][64]
-  LnTabEntry* lntab = reinterpret_cast<LnTabEntry*>(far + 2 * CPB * 256);   // [kLnTabSize], producer only
+  LnTabEntry* lntab = reinterpret_cast<LnTabEntry*>(stage + 2 * CPB * 256);  // [kLnTabSize], producer only
   const int lane = threadIdx.x & 63;
   const int slot = lane / G;
   const int sub = lane % G;
@@ -183,8 +181,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     // ------------------------------------------------------------------ wave 0
     for (int i = lane; i < kLnTabSize; i += 64) lntab[i] = args.ln_table[i];
     const bool live = li.state_base >= 0;
-    // how many periods of this wave's own stores and loads may still be in flight at a barrier
-    const int slack_periods = W >= 16 * CPB ? 2 : (W >= 12 * CPB ? 1 : 0);
+    const bool early_copy = W < 12 * CPB;  // see the period schedule below
 
     auto run = [&](auto general_tag) {
       constexpr bool GENERAL = decltype(general_tag)::value;
@@ -220,22 +217,28 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         store_staged(dst, t);
         p += (int)((w / kLast) & 1u);
       };
-      // the same for a chunk in which some lane's source left the ring: the packer could not
-      // resolve that term's cells, the position counter can
-      auto put_far = [&](StagedTerm* dst, int32_t* fdst, uint32_t w, float g, float a) {
+      // The same for a chunk in which some lane's source is older than the ring (FAR).  The
+      // source's natural-log value v is already in alpha / beta -- this very wave stored it, in
+      // program order before this load -- so the term becomes a constant-one source with the
+      // cost c - v: exp(-(c - v)) = exp(v) * exp(-c), formed off the chain with the same routine
+      // as every other weight.  The consumer never sees FAR.
+      auto put_far = [&](StagedTerm* dst, uint32_t w, float g, float a) {
         StagedTerm t;
-        weigh(t, w, g, a);
+        double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : stream_cost(w, g, a, sc);
         const bool last = (w & kLast) != 0;
         uint32_t ctl = w;
         if (w & kFar) {
           const int q = p - (int)(w & kRelMask);
-          *fdst = q_off + q_step * q;
-          ctl &= ~kRelMask;  // reads ring cell 0 (ignored), the source comes through far[]
+          const double v = __hip_atomic_load(&vals[q_off + q_step * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          c = (v == -INFINITY) ? INFINITY : c - v;  // a log-zero source kills the term
+          ctl = (w & ~(kRelMask | kFar)) | kOne;     // RD cell 0: ignored for a constant-one source
           if (last && sub == 0)
             ctl |= kCommit | ((uint32_t)((p & (W - 1)) * LPW + slot) << kWrShift);
           else
             ctl |= (uint32_t)(W * LPW + lane) << kWrShift;  // the lane's dummy cell
         }
+        bool dead;
+        arc_weight(c, t.wm, t.k, dead);
         t.ctl = ctl;
         store_staged(dst, t);
         p += last ? 1 : 0;
@@ -280,11 +283,10 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         const int sidx = (((cj / CPB) & 1) * CPB + (cj % CPB)) * 256 + lane;
         StagedTerm* st = stage + sidx;
         if (__any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0)) {  // rare
-          int32_t* fs = far + sidx;
-          put_far(st, fs, (uint32_t)w4.x, g4.x, a4.x);
-          put_far(st + 64, fs + 64, (uint32_t)w4.y, g4.y, a4.y);
-          put_far(st + 128, fs + 128, (uint32_t)w4.z, g4.z, a4.z);
-          put_far(st + 192, fs + 192, (uint32_t)w4.w, g4.w, a4.w);
+          put_far(st, (uint32_t)w4.x, g4.x, a4.x);
+          put_far(st + 64, (uint32_t)w4.y, g4.y, a4.y);
+          put_far(st + 128, (uint32_t)w4.z, g4.z, a4.z);
+          put_far(st + 192, (uint32_t)w4.w, g4.w, a4.w);
         } else {
           put(st, (uint32_t)w4.x, g4.x, a4.x);
           put(st + 64, (uint32_t)w4.y, g4.y, a4.y);
@@ -295,17 +297,13 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       // One period = CPB chunks, staged while the consumer works on the previous period:
       //   ring cells of the states to copy out -> stage chunk 0 -> table entries -> stage chunk 1
       //   -> logs + stores -> prefetch loads for D chunks ahead -> barrier.
-      // The iteration that stages period n stores the states of period n-2.  A state older than
-      // the ring (FAR) is re-read from these stores by the consumer, so they must be complete in
-      // time -- but vmcnt counts loads and stores together, in order: waiting for a store also
-      // waits for every older load, and a barrier that waits for this iteration's stores caps the
-      // stream prefetch at one period, less than the HBM latency under load.  A FAR term read in
-      // period n has at least W - 1 states, one commit round each, between its source and itself:
-      // with W >= 4*CPB*(k+2) rounds the source was finished in period n-k-2 or earlier and stored
-      // by iteration n-k or earlier, so barrier n may leave the newest k periods of operations
-      // (kIters stores + 3*CPB loads each) in flight.  k = 2 (W >= 16*CPB) never waits on a
-      // prefetch; a short ring (W = 8) gets k = 0 and waits for this iteration's stores
-      // (vmcnt(3*CPB): only the loads issued after them fly on).
+      // The iteration that stages period n stores the states of period n-2.  vmcnt counts loads
+      // and stores together, in order, so the barrier leaves the newest two periods of this
+      // wave's memory operations in flight (a fixed number: kIters stores + 3*CPB loads each) and
+      // never waits on a prefetch; nothing but this wave reads what it stores.  A FAR source of a
+      // term of period n has at least W - 1 commit rounds between itself and the term: with
+      // W >= 12*CPB it was finished in period n-3 or earlier and stored by iteration n-1.  A
+      // shorter ring (W = 8) may need a state of period n-2: its copy-out then runs first.
       // nchunks is a multiple of D, D of CPB.
       static_assert(D % CPB == 0, "prefetch depth must be whole periods");
       for (int c = 0; c < nchunks; c += D) {
@@ -313,10 +311,14 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         for (int j0 = 0; j0 < D; j0 += CPB) {
           const int period_p0 = p;
           copy_cells();
+          if (early_copy) {
+            copy_table();
+            copy_store();
+          }
           stage_chunk(c + j0, wb[j0], gb[j0], ab[j0]);
-          copy_table();
+          if (!early_copy) copy_table();
           if (CPB == 2) stage_chunk(c + j0 + 1, wb[j0 + 1], gb[j0 + 1], ab[j0 + 1]);
-          copy_store();
+          if (!early_copy) copy_store();
 #pragma unroll
           for (int i = 0; i < CPB; ++i) {
             const int64_t cn = min(c + j0 + i + D, nchunks - 1);
@@ -325,12 +327,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
             ab[j0 + i] = sa[cn * 64];
           }
           // this period is staged; the consumer has finished the previous one,
-          if (slack_periods == 2)
-            producer_barrier<2 * (3 * CPB + kIters)>();
-          else if (slack_periods == 1)
-            producer_barrier<3 * CPB + kIters>();
-          else
-            producer_barrier<3 * CPB>();
+          producer_barrier<2 * (3 * CPB + kIters)>();
           out_p0 = pend_p0;             // whose states are now stable in the ring (W >= 2 periods of states)
           out_n = pend_n;
           pend_p0 = period_p0;
@@ -374,9 +371,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   double preM = 0.0;   // ring read for the upcoming round, software-pipelined one round ahead
   int preE = kExpMin;
 
-  // SPECIAL = this chunk may hold constant-one or FAR sources; PRE = issue the next round's ring
+  // SPECIAL = this chunk may hold constant-one sources; PRE = issue the next round's ring
   // read (the last round of a chunk cannot: its successor is staged behind the barrier)
-  auto round = [&](auto special, auto do_pre, const StagedTerm& t, uint32_t ctl_next, int far_cell) {
+  auto round = [&](auto special, auto do_pre, const StagedTerm& t, uint32_t ctl_next) {
     const uint32_t ctl = t.ctl;
     const bool last = (ctl & kCtlLast) != 0;
     const bool first = (ctl & kCtlFirst) != 0;
@@ -395,14 +392,6 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       const bool one = (ctl & kCtlOne) != 0;  // constant one = 0.5 * 2^1
       sm = one ? 0.5 : sm;
       se = one ? 1 : se;
-      if (ctl & kCtlFar) {
-        // the source left the ring: re-read its natural-log value (copied out at least two
-        // periods ago) and split it back into mantissa and exponent
-        const double v = __hip_atomic_load(&vals[far_cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool zero_src;
-        arc_weight(-v, sm, se, zero_src);
-        se = zero_src ? kExpMin : se;
-      }
     }
     // dead (zero weight / padding) terms have wm == 0 and zero sources sm == 0: tm is then 0 and
     // whatever the exponents hold is ignored (unsigned arithmetic: t.k is unspecified for them)
@@ -464,21 +453,18 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   const std::false_type no;
   // four rounds; LAST_PRE = the chunk that follows belongs to the same period, so its first
   // round's ring read (cell in next_ctl) can be issued from this chunk's last round
-  auto chunk = [&](const StagedTerm& t0, const StagedTerm& t1, const StagedTerm& t2, const StagedTerm& t3, int sidx,
+  auto chunk = [&](const StagedTerm& t0, const StagedTerm& t1, const StagedTerm& t2, const StagedTerm& t3,
                    auto last_pre, uint32_t next_ctl) {
-    if (__any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & (kCtlOne | kCtlFar)) != 0)) {
-      const int32_t* fs = far + sidx;
-      const bool anyfar = __any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & kCtlFar) != 0);
-      const int f0 = anyfar ? fs[0] : 0, f1 = anyfar ? fs[64] : 0, f2 = anyfar ? fs[128] : 0, f3 = anyfar ? fs[192] : 0;
-      round(yes, yes, t0, t1.ctl, f0);
-      round(yes, yes, t1, t2.ctl, f1);
-      round(yes, yes, t2, t3.ctl, f2);
-      round(yes, last_pre, t3, next_ctl, f3);
+    if (__any(((t0.ctl | t1.ctl | t2.ctl | t3.ctl) & kCtlOne) != 0)) {
+      round(yes, yes, t0, t1.ctl);
+      round(yes, yes, t1, t2.ctl);
+      round(yes, yes, t2, t3.ctl);
+      round(yes, last_pre, t3, next_ctl);
     } else {
-      round(no, yes, t0, t1.ctl, 0);
-      round(no, yes, t1, t2.ctl, 0);
-      round(no, yes, t2, t3.ctl, 0);
-      round(no, last_pre, t3, next_ctl, 0);
+      round(no, yes, t0, t1.ctl);
+      round(no, yes, t1, t2.ctl);
+      round(no, yes, t2, t3.ctl);
+      round(no, last_pre, t3, next_ctl);
     }
   };
   for (int c = 0; c < nchunks; c += CPB) {
@@ -494,10 +480,10 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     }
     if (CPB == 2) {
       const StagedTerm b0 = st[256], b1 = st[320], b2 = st[384], b3 = st[448];
-      chunk(a0, a1, a2, a3, sidx, yes, b0.ctl);
-      chunk(b0, b1, b2, b3, sidx + 256, no, 0u);
+      chunk(a0, a1, a2, a3, yes, b0.ctl);
+      chunk(b0, b1, b2, b3, no, 0u);
     } else {
-      chunk(a0, a1, a2, a3, sidx, no, 0u);
+      chunk(a0, a1, a2, a3, no, 0u);
     }
   }
   __syncthreads();  // lets the producer copy out the last period's states
@@ -508,7 +494,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 
 static size_t sweep_lds_bytes(int ring_slots, int LPW, int cpb) {
   return ((size_t)ring_slots * LPW + 64) * (sizeof(double) + sizeof(int32_t)) +
-         (size_t)2 * cpb * 256 * (sizeof(StagedTerm) + sizeof(int32_t)) + kLnTabSize * sizeof(LnTabEntry);
+         (size_t)2 * cpb * 256 * sizeof(StagedTerm) + kLnTabSize * sizeof(LnTabEntry);
 }
 
 template <int G>

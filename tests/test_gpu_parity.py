@@ -146,6 +146,33 @@ def test_exact_sweep_takes_over_outside_the_fast_window(ctx, G):
     b2.close()
 
 
+@pytest.mark.parametrize("G,W", [(1, 16), (4, 16), (4, 32), (2, 8)])
+def test_long_span_arcs_take_the_far_path(ctx, G, W):
+    """Arcs that span more states than the ring holds: the producer re-reads their source's stored
+    natural-log value and folds it into the term's weight.  Synthetic lattices with every third
+    arc stretched to a span of up to 120 states."""
+    rng = np.random.RandomState(7)
+    ns = rng.randint(150, 700, size=40).astype(np.int32)
+    fo = rng.choice([2, 3, 4], size=len(ns)).astype(np.int32)
+    arrays = klat_amd.synth(4711, ns, fo)
+    lat = np.repeat(np.arange(len(ns)), np.diff(arrays["arc_off"]))
+    S_of = ns[lat]
+    src, dst = arrays["src"], arrays["dst"].copy()
+    stretch = (np.arange(len(dst)) % 3 == 1) & (dst != src + 1)
+    span = rng.randint(20, 121, size=len(dst))
+    dst[stretch] = np.minimum(src[stretch] + span[stretch], S_of[stretch] - 1)
+    arrays["dst"] = dst.astype(np.int32)
+    batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=G, ring_slots=W)
+    assert batch.info()["far_terms"] > 1000
+    batch.forward_backward(1.0, 0.1, 0.0)
+    alpha, beta = batch.alpha_beta()
+    total, tf, tb = batch.totals()
+    post = batch.arc_logpost()
+    batch.close()
+    wa, wb, wt, wpost = _oracle_batch(arrays, 1.0, 0.1, 0.0)
+    _check(alpha, wa, 1e-7), _check(beta, wb, 1e-7), _check(total, wt, 1e-7), _check(post, wpost, 1e-7)
+
+
 def test_bad_topology_is_reported(ctx):
     arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
     arrays["dst"][3] = 0
