@@ -75,7 +75,7 @@ typedef struct {
 /* Packing options (device layout of the lockstep arc streams, DESIGN.md "Data layout"). */
 typedef struct {
   int32_t lanes_per_lattice; /* G in {1,2,4,8,16,32,64}; 0 = choose from the batch shape */
-  int32_t ring_slots;        /* W, power of two in [8,1024]; 0 = choose from the batch */
+  int32_t ring_slots;        /* W, power of two in [8,1024] with W * (64/G) <= 4032; 0 = choose from the batch */
   int32_t host_threads;      /* threads used by the host packer; 0 = hardware concurrency */
 } klat_pack_options;
 

@@ -72,7 +72,7 @@ int choose_lanes_per_lattice(int64_t U, int64_t S, int64_t A) {
 int choose_ring_slots(int G, int64_t max_rel) {
   const int LPW = 64 / G;
   int cap = 8;
-  while (cap * 2 * LPW <= 1024 && cap < 1024) cap *= 2;  // <= 1024 ring cells (16 KiB) per workgroup
+  while (cap * 2 * LPW <= kMaxRingCells && cap < 1024) cap *= 2;  // ring + dummy cells fit 12-bit cell numbers (48 KiB)
   // 32 slots where they fit: the sweep then stages two chunks per barrier and never has to wait
   // for its own stores (klat_sweep.hip); 16 otherwise
   int W = cap < 32 ? cap : 32;
@@ -172,8 +172,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   // The ring only has to cover arcs; final terms (rel = S - s) may be far without harm, so the
   // automatic W follows the arcs' span, which pass 1 folded into max_rel together with finals.
   int W = opt.ring_slots ? opt.ring_slots : choose_ring_slots(G, max_rel.load());
-  if ((int64_t)W * LPW > 1024) {
-    *err = "ring_slots * (64 / lanes_per_lattice) must not exceed 1024 ring cells per workgroup";
+  if ((int64_t)W * LPW > kMaxRingCells) {
+    *err = "ring_slots * (64 / lanes_per_lattice) must not exceed 4032 ring cells per workgroup";
     return KLAT_ERR_INVALID_ARG;
   }
 

@@ -503,12 +503,18 @@ static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream)
   // the producer copies a period's states out one period later: the ring must hold two periods
   const int cpb = args.ring_slots >= 32 ? 2 : 1;
   const size_t lds = sweep_lds_bytes(args.ring_slots, LPW, cpb);
+  auto launch = [&](auto kernel) {
+    // the largest rings (4032 cells) take the workgroup past the default 64 KiB of dynamic LDS
+    if (lds > 60 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(num_jobs), dim3(128), lds, stream, args);
+  };
   if (cpb == 2) {
-    hipLaunchKernelGGL((sweep_kernel<G, true, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
-    hipLaunchKernelGGL((sweep_kernel<G, false, 2>), dim3(num_jobs), dim3(128), lds, stream, args);
+    launch(&sweep_kernel<G, true, 2>);
+    launch(&sweep_kernel<G, false, 2>);
   } else {
-    hipLaunchKernelGGL((sweep_kernel<G, true, 1>), dim3(num_jobs), dim3(128), lds, stream, args);
-    hipLaunchKernelGGL((sweep_kernel<G, false, 1>), dim3(num_jobs), dim3(128), lds, stream, args);
+    launch(&sweep_kernel<G, true, 1>);
+    launch(&sweep_kernel<G, false, 1>);
   }
 }
 

@@ -8,8 +8,8 @@ import math
 
 import numpy as np
 
-CELL_MASK, WR_SHIFT = 0x7FF, 11
-COMMIT, BYPASS, ONE = 1 << 22, 1 << 23, 1 << 24
+CELL_MASK, WR_SHIFT = 0xFFF, 12
+COMMIT, BYPASS, ONE = 1 << 24, 1 << 25, 1 << 26
 REL_MASK = (1 << 27) - 1
 FAR, LAST, NIL, WORD, FIRST = 1 << 27, 1 << 28, 1 << 29, 1 << 30, 1 << 31
 EXP_MIN = -(1 << 29)

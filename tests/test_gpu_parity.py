@@ -146,7 +146,7 @@ def test_exact_sweep_takes_over_outside_the_fast_window(ctx, G):
     b2.close()
 
 
-@pytest.mark.parametrize("G,W", [(1, 16), (4, 16), (4, 32), (2, 8)])
+@pytest.mark.parametrize("G,W", [(1, 16), (4, 16), (4, 32), (2, 8), (4, 128), (1, 32), (8, 256), (0, 0)])
 def test_long_span_arcs_take_the_far_path(ctx, G, W):
     """Arcs that span more states than the ring holds: the producer re-reads their source's stored
     natural-log value and folds it into the term's weight.  Synthetic lattices with every third
@@ -163,7 +163,11 @@ def test_long_span_arcs_take_the_far_path(ctx, G, W):
     dst[stretch] = np.minimum(src[stretch] + span[stretch], S_of[stretch] - 1)
     arrays["dst"] = dst.astype(np.int32)
     batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=G, ring_slots=W)
-    assert batch.info()["far_terms"] > 1000
+    info = batch.info()
+    if W and W < 120:
+        assert info["far_terms"] > 1000
+    if W == 0:  # automatic layout: the ring grows with the longest span where the cell numbers allow
+        assert info["ring_slots"] >= 64
     batch.forward_backward(1.0, 0.1, 0.0)
     alpha, beta = batch.alpha_beta()
     total, tf, tb = batch.totals()
