@@ -163,6 +163,14 @@ int klat_position_index(klat_batch* batch, const int32_t* state_len,
                         const klat_label_filter* filter, int64_t* record_off,
                         klat_position_record* records, int64_t capacity, int64_t* num_records);
 
+/* Utterance index (kwsbin2/lattice-word-index-utterance.cc:143-196; known answer
+ * kwsbin2/README.md:25): for lattice u and each of its query words words[word_off[u] ..
+ * word_off[u+1]) the log-probability that the word occurs at least once on the path,
+ * logp = b0[start] - beta[start] (:155,:177).  The caller chooses the words (the reference takes
+ * the lattice's distinct non-zero output labels through its include / exclude filter, :124-132)
+ * and sorts the records (:291-300).  Runs after klat_forward_backward with the same scales. */
+int klat_utterance_scores(klat_batch* batch, const int64_t* word_off, const int32_t* words, double* logp);
+
 /* Frame posteriors (latbin/lattice-to-word-frame-post.cc:93-135): for each lattice and frame
  * k < num_frames[u] the (label, float32 logp) entries sorted by (logp desc, label asc).
  * frame_off[sum(num_frames)+1] indexes entries; lattice u's frames start at

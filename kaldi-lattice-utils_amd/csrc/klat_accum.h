@@ -57,6 +57,27 @@ hipError_t launch_index_radix(const AccumArgs& a, const RadixPack& pk, int num_l
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
                                OutRecord* out, hipStream_t stream);
 
+// Utterance index (klat_utt.hip): one item = up to 64 query words of one lattice.
+struct UttItem {
+  int32_t lattice, word_begin, count, pad;
+};
+struct UttArgs {
+  const UttItem* items;
+  int32_t num_items;
+  int32_t* next_item;  // work queue head, zeroed before the launch
+  const int64_t* state_off;
+  const int64_t* arc_off;
+  const int32_t* src; const int32_t* dst; const int32_t* ilabel; const int32_t* olabel;
+  const float* graph; const float* acoustic;
+  const double* beta;    // padded (klat_kernels.h)
+  const int32_t* words;  // query words, lattice by lattice
+  double* logp;          // [number of words] out: log P(word occurs)
+  double* scratch;       // [workgroups][scratch_states][64]
+  int64_t scratch_states;
+  ScaleParams sp;
+};
+hipError_t launch_utterance(const UttArgs& a, int num_workgroups, hipStream_t stream);
+
 struct FrameArgs {
   const int64_t* state_off;
   const int64_t* arc_off;

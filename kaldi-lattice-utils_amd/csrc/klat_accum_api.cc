@@ -167,6 +167,64 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
 
 extern "C" {
 
+int klat_utterance_scores(klat_batch* b, const int64_t* word_off, const int32_t* words, double* logp) {
+  if (!b || !word_off) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  const int64_t nw = word_off[b->U];
+  if (nw < 0 || (nw > 0 && (!words || !logp))) return set_error(KLAT_ERR_INVALID_ARG, "bad word list");
+  if (nw == 0) return KLAT_OK;
+  if (b->olabel.n == 0) return set_error(KLAT_ERR_INVALID_ARG, "the batch was created without olabel");
+  klat_ctx* c = b->ctx;
+  KLAT_HIP(hipSetDevice(c->device));
+  std::vector<UttItem> items;
+  int64_t max_states = 1;
+  for (int64_t u = 0; u < b->U; ++u) {
+    if (word_off[u + 1] < word_off[u]) return set_error(KLAT_ERR_INVALID_ARG, "word_off must not decrease");
+    max_states = std::max(max_states, b->h_state_off[u + 1] - b->h_state_off[u]);
+    for (int64_t k = word_off[u]; k < word_off[u + 1]; k += 64)
+      items.push_back(UttItem{(int32_t)u, (int32_t)k, (int32_t)std::min<int64_t>(64, word_off[u + 1] - k), 0});
+  }
+  // persistent workgroups of one wave, each with its own [states][64] layer; at most 8 GiB of it
+  int64_t wgs = std::min<int64_t>((int64_t)items.size(), 256 * 8);
+  wgs = std::max<int64_t>(1, std::min<int64_t>(wgs, (8ll << 30) / (max_states * 64 * 8)));
+  DevBuf<UttItem> d_items;
+  DevBuf<int32_t> d_words, d_next;
+  DevBuf<double> d_logp, d_scratch;
+  int rc;
+  const int32_t zero = 0;
+  if ((rc = d_items.upload(items.data(), items.size(), c->stream))) return rc;
+  if ((rc = d_words.upload(words, (size_t)nw, c->stream))) return rc;
+  if ((rc = d_next.upload(&zero, 1, c->stream))) return rc;
+  if ((rc = d_logp.alloc((size_t)nw))) return rc;
+  if ((rc = d_scratch.alloc((size_t)(wgs * max_states * 64)))) return rc;
+  UttArgs a;
+  a.items = d_items.p;
+  a.num_items = (int32_t)items.size();
+  a.next_item = d_next.p;
+  a.state_off = b->state_off.p;
+  a.arc_off = b->arc_off.p;
+  a.src = b->src.p;
+  a.dst = b->dst.p;
+  a.ilabel = b->ilabel.p;
+  a.olabel = b->olabel.p;
+  a.graph = b->graph.p;
+  a.acoustic = b->acoustic.p;
+  a.beta = b->beta.p;
+  a.words = d_words.p;
+  a.logp = d_logp.p;
+  a.scratch = d_scratch.p;
+  a.scratch_states = max_states;
+  a.sp.gs_f = b->scales.graph_scale;
+  a.sp.as_f = b->scales.acoustic_scale;
+  a.sp.pen = b->scales.insertion_penalty;
+  a.sp.scaled = (b->scales.acoustic_scale != 1.0f || b->scales.graph_scale != 1.0f) ? 1 : 0;
+  a.sp.penalized = (b->scales.insertion_penalty != 0.0f) ? 1 : 0;
+  KLAT_HIP(launch_utterance(a, (int)wgs, c->stream));
+  KLAT_HIP(hipMemcpyAsync(logp, d_logp.p, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipStreamSynchronize(c->stream));
+  return KLAT_OK;
+}
+
 int klat_segment_index(klat_batch* b, const klat_label_filter* f, int64_t* record_off,
                        klat_segment_record* records, int64_t capacity, int64_t* num_records) {
   return run_index(b, false, nullptr, f, record_off, records, capacity, num_records);

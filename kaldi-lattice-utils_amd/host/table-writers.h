@@ -79,6 +79,23 @@ class Int32VectorWriter : public ArchiveWriter {
   }
 };
 
+// vector<tuple<int32,double>> (utterance index, kwsbin2/lattice-word-index-utterance.cc:267-268).
+class UtteranceScoreWriter : public ArchiveWriter {
+ public:
+  using ArchiveWriter::ArchiveWriter;
+  void Write(const std::string& key, const std::vector<std::pair<int32_t, double>>& rec) {
+    std::ostream& os = Begin(key);
+    if (binary()) WriteBasicType(os, true, (int32_t)rec.size());
+    for (size_t i = 0; i < rec.size(); ++i) {
+      WriteBasicType(os, binary(), rec[i].first);
+      WriteBasicType(os, binary(), rec[i].second);
+      if (!binary() && i + 1 < rec.size()) os << "; ";
+    }
+    if (!binary()) os << '\n';
+    End();
+  }
+};
+
 // vector<tuple<int32,int32,int32,double>> (segment index).
 class SegmentScoreWriter : public ArchiveWriter {
  public:

@@ -276,6 +276,14 @@ class Batch:
         _check(lib().klat_frame_post(self.h, _p(nf), _p(off), _p(labels), _p(logps), C.c_int64(len(labels)), C.byref(n)))
         return off, labels[:n.value], logps[:n.value]
 
+    def utterance_scores(self, word_off, words):
+        """log P(word occurs on the path) for the query words of every lattice (klat_utterance_scores)."""
+        wo = np.ascontiguousarray(word_off, np.int64)
+        ws = np.ascontiguousarray(words, np.int32)
+        out = np.zeros(max(len(ws), 1), np.float64)
+        _check(lib().klat_utterance_scores(self.h, _p(wo), _p(ws), _p(out)))
+        return out[:len(ws)]
+
     def close(self):
         if self.h:
             lib().klat_batch_destroy(self.h)

@@ -530,6 +530,81 @@ int64_t kor_frame_post(int32_t S, const int64_t *arc_begin, const int32_t *dst,
   return m;
 }
 
+typedef struct {
+  int32_t label;
+  double logp;
+} kor_post2;
+static int cmp_post2(const void *pa, const void *pb) {
+  const kor_post2 *a = (const kor_post2 *)pa, *b = (const kor_post2 *)pb;
+  if (a->logp != b->logp) return b->logp < a->logp ? -1 : 1;
+  if (a->label != b->label) return a->label < b->label ? -1 : 1;
+  return 0;
+}
+static int cmp_i32(const void *pa, const void *pb) {
+  const int32_t a = *(const int32_t *)pa, b = *(const int32_t *)pb;
+  return a < b ? -1 : (a > b ? 1 : 0);
+}
+
+/* ---- utterance index, kwsbin2/lattice-word-index-utterance.cc:117-135,143-196 (SURVEY.md 8f f4;
+ * pinned by kwsbin2/README.md:25).  For a query word w the reference composes the lattice with the
+ * two-state automaton Sigma* w Sigma* (CreateQueryFst :33-56, RhoCompose :171) and takes the betas
+ * of the result at its start state (:174-177).  The composed states are (s, q): q = 1 once w has
+ * been read.  (s,1) carries every continuation of s, i.e. beta[s] of the lattice itself; (s,0)
+ * is not final and follows an arc labelled w to (d,1), any other arc to (d,0):
+ *     b0[s] = LogAdd over the arcs of s of  (olabel == w ? beta[d] : b0[d]) - cost.
+ * score = b0[start] - total with total = beta[start] (:123, :155).  Words: the distinct non-zero
+ * output labels (GetOutputSymbols :124-125), filtered as :126-132.  Records sorted by (logp desc,
+ * label asc) :291-300.  beta: the betas of the lattice (kor_betas).  scratch: S doubles. */
+int64_t kor_utterance_index(int32_t S, const int64_t *arc_begin, const int32_t *dst,
+                            const int32_t *olabel, const float *graph, const float *acoustic,
+                            const double *beta, const int32_t *inc, int32_t ninc,
+                            const int32_t *exc, int32_t nexc, int64_t out_cap, int32_t *out_label,
+                            double *out_logp) {
+  if (S <= 0) return 0;
+  const int64_t A = arc_begin[S];
+  int32_t *labels = (int32_t *)malloc(sizeof(int32_t) * (size_t)(A > 0 ? A : 1));
+  int64_t nl = 0;
+  for (int64_t i = 0; i < A; ++i)
+    if (olabel[i] != 0) labels[nl++] = olabel[i];
+  qsort(labels, (size_t)nl, sizeof(int32_t), cmp_i32);
+  int64_t nu = 0;
+  for (int64_t i = 0; i < nl; ++i)
+    if (i == 0 || labels[i] != labels[i - 1]) labels[nu++] = labels[i];
+  double *b0 = (double *)malloc(sizeof(double) * (size_t)S);
+  kor_post2 *p = (kor_post2 *)malloc(sizeof(kor_post2) * (size_t)(nu > 0 ? nu : 1));
+  int64_t m = 0;
+  const double total = beta[0];
+  for (int64_t k = 0; k < nu; ++k) {
+    const int32_t w = labels[k];
+    const int keep = ninc > 0 ? in_sorted(inc, ninc, w) : !in_sorted(exc, nexc, w);
+    if (!keep) continue;
+    for (int32_t s = S - 1; s >= 0; --s) {
+      double acc = -INFINITY;
+      for (int64_t i = arc_begin[s]; i < arc_begin[s + 1]; ++i) {
+        const double arc_like = -((double)graph[i] + (double)acoustic[i]);
+        acc = kor_log_add(acc, (olabel[i] == w ? beta[dst[i]] : b0[dst[i]]) + arc_like);
+      }
+      b0[s] = acc;
+    }
+    p[m].label = w;
+    p[m].logp = b0[0] - total;
+    ++m;
+  }
+  qsort(p, (size_t)m, sizeof(kor_post2), cmp_post2);
+  free(labels);
+  free(b0);
+  if (m > out_cap) {
+    free(p);
+    return -1;
+  }
+  for (int64_t i = 0; i < m; ++i) {
+    out_label[i] = p[i].label;
+    out_logp[i] = p[i].logp;
+  }
+  free(p);
+  return m;
+}
+
 /* ---- position posteriors, latbin/lattice-to-word-position-post.cc:100-135 (the "next" caller
  * that a14 unlocks).  Over the length-disambiguated lattice: for every arc with
  * ilabel != 0, pos = state_len[nextstate] :108 and acc[pos][word] = LogAdd(.., alpha[u] +

@@ -36,6 +36,7 @@ def lib():
         _LIB.kor_frame_post.restype = C.c_int64
         _LIB.kor_position_post.restype = C.c_int64
         _LIB.kor_length_dist.restype = C.c_int64
+        _LIB.kor_utterance_index.restype = C.c_int64
         _LIB.kor_disambiguate_length.restype = C.c_int32
         _LIB.kor_free.argtypes = [C.c_void_p]
     return _LIB
@@ -172,6 +173,23 @@ def betas(lat):
     tot = lib().kor_betas(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.graph),
                           _p(lat.acoustic), _p(lat.final_graph), _p(lat.final_acoustic), _p(beta))
     return beta, tot
+
+
+def utterance_index(lat, include=None, exclude=None):
+    """kwsbin2/lattice-word-index-utterance.cc on a scaled, top-sorted lattice: [(label, logp)]
+    with logp = log P(label occurs somewhere on the path), best first."""
+    if lat.S == 0:
+        return []
+    beta, _ = betas(lat)
+    inc, exc = _sets(include, exclude)
+    cap = lat.A + 1
+    ol = np.zeros(cap, np.int32)
+    lp = np.zeros(cap, np.float64)
+    m = lib().kor_utterance_index(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.olabel),
+                                  _p(lat.graph), _p(lat.acoustic), _p(beta), _p(inc), C.c_int32(len(inc)),
+                                  _p(exc), C.c_int32(len(exc)), C.c_int64(cap), _p(ol), _p(lp))
+    assert m >= 0
+    return [(int(ol[i]), float(lp[i])) for i in range(m)]
 
 
 def arc_through(lat, alpha, beta):

@@ -285,6 +285,60 @@ def test_best_path2_tool_matches_oracle(tmp_path, golden_dir, scales):
 
 
 @pytest.mark.gpu
+def test_utterance_tool_matches_readme(golden_dir):
+    """kwsbin2/README.md:25, the known answer of lattice-word-index-utterance."""
+    rc, out, err = run("lattice-word-index-utterance", "ark:" + os.path.join(golden_dir, "egs_word_lattice.ark.txt"), "ark,t:-")
+    assert rc == 0, err
+    key, got = latfmt.parse_tuple_line(out.decode(), 1)
+    _, want = latfmt.parse_tuple_line(_readme(golden_dir, "utterance"), 1)
+    assert key == "lat1" and len(got) == len(want) == 8
+    assert sorted(g[0] for g in got) == sorted(w[0] for w in want)
+    wd = {w[0]: w[1] for w in want}
+    for g in got:
+        assert abs(g[1] - wd[g[0]]) < 5e-7, (g, wd[g[0]])
+    assert all(got[i][1] >= got[i + 1][1] - 1e-9 for i in range(len(got) - 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,flt", [([], {}), (["--acoustic-scale=0.1", "--insertion-penalty=0.5", "--exclude-words=3 7 11"], {"exclude": [3, 7, 11]}),
+                                      (["--graph-scale=0.7", "--include-words=" + " ".join(str(i) for i in range(1, 40))], {"include": list(range(1, 40))})])
+def test_utterance_tool_matches_oracle(tmp_path, golden_dir, args, flt):
+    """lattice-word-index-utterance on an archive of synthetic lattices (more than 64 distinct
+    words in one of them: several waves per lattice), the multi-final lattice and an empty one."""
+    ns = np.array([60, 1, 25, 9], np.int32)
+    fo = np.array([3, 1, 2, 4], np.int32)
+    arrays = klat_amd.synth(515, ns, fo)
+    arrays["olabel"][arrays["arc_off"][2]:arrays["arc_off"][3]] %= 5  # few words, many arcs each
+    arrays["ilabel"] = arrays["olabel"].copy()
+    txt = str(tmp_path / "in.txt")
+    with open(txt, "w") as f:
+        f.write(open(os.path.join(golden_dir, "multi_final_lattice.ark.txt")).read().rstrip("\n") + "\n\n")
+        f.write("empty_utt\n\n")
+        latfmt.write_synth_text(arrays, f, ["u%d" % i for i in range(len(ns))])
+    rc, out, err = run("lattice-word-index-utterance", *args, "ark:" + txt, "ark,t:-")
+    assert rc == 0, err
+    lines = out.decode().split("\n")[:-1]
+    lats = latfmt.read_text_archive(txt)
+    assert len(lines) == len(lats) == 2 + len(ns)
+    gs = float([a.split("=")[1] for a in args if a.startswith("--graph-scale")][0]) if any(a.startswith("--graph-scale") for a in args) else 1.0
+    ac = float([a.split("=")[1] for a in args if a.startswith("--acoustic-scale")][0]) if any(a.startswith("--acoustic-scale") for a in args) else 1.0
+    pen = float([a.split("=")[1] for a in args if a.startswith("--insertion-penalty")][0]) if any(a.startswith("--insertion-penalty") for a in args) else 0.0
+    many = 0
+    for line, lat in zip(lines, lats):
+        key, got = latfmt.parse_tuple_line(line, 1) if len(line.split()) > 1 else (line.split()[0], [])
+        assert key == lat.key
+        want = orc.utterance_index(orc.scale_and_penalize(latfmt.prepare(lat), gs, ac, pen), **flt)
+        assert sorted(g[0] for g in got) == sorted(w[0] for w in want), key
+        wd = dict(want)
+        for g in got:
+            assert abs(g[1] - wd[g[0]]) < 1e-6 * max(1.0, abs(g[1])), (key, g, wd[g[0]])
+        assert all(got[i][1] >= got[i + 1][1] - 1e-9 for i in range(len(got) - 1))
+        many = max(many, len(got))
+    if not flt:
+        assert many > 64
+
+
+@pytest.mark.gpu
 def test_tools_on_a_multi_lattice_archive(tmp_path):
     """Input order is kept, empty lattices still produce a record, batching does not change the
     output, binary input gives the same result as text input, scales reach the GPU."""

@@ -133,6 +133,17 @@ def test_best_path2_equals_path_enumeration(golden_dir, name):
     assert got in [t for c, t in scored if c < best + 1e-5]
 
 
+def test_utterance_index_matches_readme(golden_dir):
+    """kwsbin2/README.md:25: P(word occurs in the transcription), 8 records, printed order."""
+    lat = _word_lattice(golden_dir)
+    got = orc.utterance_index(lat)
+    _, want = latfmt.parse_tuple_line(_expected(golden_dir)["utterance"], 1)
+    assert len(got) == len(want) == 8
+    for g, w in zip(got, want):
+        assert g[0] == w[0]
+        assert _fmt7(g[1]) == _fmt7(w[1]) or abs(g[1] - w[1]) < 5e-8, (g, w)
+
+
 def test_utterance_total_matches_readme(golden_dir):
     """kwsbin2/README.md:25 pins the betas-only total: words on every path have logp 0."""
     lat = _word_lattice(golden_dir)
