@@ -134,6 +134,19 @@ int klat_get_alpha_beta(klat_batch* batch, double* alpha, double* beta);
 int klat_get_totals(klat_batch* batch, double* total, double* tot_fwd, double* tot_bwd);
 int klat_get_arc_logpost(klat_batch* batch, double* logpost /* [A] */);
 
+/* ---- tropical twin of the sweep ----
+ * Viterbi forward / backward costs (min,+) over the same batch and, from them, ComputeLatticeBeam
+ * (latbin/lattice-prune-dyn-beam.cc:27-90) and the decisions of PruneLattice(beam, &clat)
+ * [upstream Kaldi; kwsbin2/lattice-word-index-segment.cc:49-51]: an arc (a final weight) is kept
+ * iff the best complete path through it costs at most best + beam.  Costs are the ones the
+ * reference holds at that point: scaled and penalised.  The caller applies the masks and
+ * Connect()s (host-side graph surgery).  lattice_beam[u] is the beam at which lattice u loses
+ * nothing.  Any output pointer may be NULL. */
+int klat_viterbi(klat_batch* batch, const klat_scales* scales);
+int klat_get_viterbi(klat_batch* batch, double* fwd_cost /* [S] */, double* bwd_cost /* [S] */, double* best /* [U] */);
+int klat_prune_mask(klat_batch* batch, float beam, uint8_t* keep_arc /* [A] */, uint8_t* keep_final /* [S] */,
+                    double* lattice_beam /* [U] */);
+
 /* ---- second stage: the reference's accumulators over the same batch (a10/a11/a12) ----
  * Label filter of kwsbin2/lattice-word-index-segment.cc:148-154: label != 0 and
  * (include non-empty ? label in include : label not in exclude). */

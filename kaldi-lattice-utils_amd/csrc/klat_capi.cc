@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -166,6 +167,8 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   UP(graph, d->graph, b->A);
   UP(acoustic, d->acoustic, b->A);
   if (d->state_time) UP(state_time, d->state_time, b->S);
+  UP(final_graph, d->final_graph, b->S);
+  UP(final_acoustic, d->final_acoustic, b->S);
   UP(sw, P.sw.data(), P.sw.size());
   UP(sg, P.sg.data(), P.sg.size());
   UP(sa, P.sa.data(), P.sa.size());
@@ -264,6 +267,110 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   KLAT_HIP(launch_posterior(pa, b->num_items, c->stream));
   KLAT_HIP(hipEventRecord(c->ev[3], c->stream));
   b->swept = true;
+  return KLAT_OK;
+}
+
+static ScaleParams make_scale_params(const klat_scales& s) {
+  ScaleParams sp;
+  sp.gs_f = s.graph_scale;
+  sp.as_f = s.acoustic_scale;
+  sp.pen = s.insertion_penalty;
+  sp.scaled = (s.acoustic_scale != 1.0f || s.graph_scale != 1.0f) ? 1 : 0;
+  sp.penalized = (s.insertion_penalty != 0.0f) ? 1 : 0;
+  return sp;
+}
+
+int klat_viterbi(klat_batch* b, const klat_scales* sc) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  klat_scales s = {1.0f, 1.0f, 0.0f};
+  if (sc) s = *sc;
+  klat_ctx* c = b->ctx;
+  KLAT_HIP(hipSetDevice(c->device));
+  int rc;
+  if (b->fwd_cost.n == 0) {
+    if ((rc = b->fwd_cost.alloc((size_t)(b->S + b->U)))) return rc;
+    if ((rc = b->bwd_cost.alloc((size_t)(b->S + b->U)))) return rc;
+  }
+  b->viterbi_scales = s;
+  ViterbiArgs va;
+  va.jobs = b->jobs.p;
+  va.lanes = b->lanes.p;
+  va.sw = b->sw.p;
+  va.sg = b->sg.p;
+  va.sa = b->sa.p;
+  va.fwd_cost = b->fwd_cost.p;
+  va.bwd_cost = b->bwd_cost.p;
+  va.sp = make_scale_params(s);
+  va.sc = make_stream_cost(va.sp);
+  va.ring_slots = b->W;
+  KLAT_HIP(launch_viterbi(va, b->num_jobs, b->G, c->stream));
+  b->viterbi_done = true;
+  return KLAT_OK;
+}
+
+int klat_get_viterbi(klat_batch* b, double* fwd_cost, double* bwd_cost, double* best) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  if (!b->viterbi_done) return set_error(KLAT_ERR_STATE, "klat_viterbi has not run on this batch");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  int rc;
+  if (b->dense.n < (size_t)b->S && (rc = b->dense.alloc((size_t)b->S))) return rc;
+  for (int which = 0; which < 2; ++which) {
+    double* host = which ? bwd_cost : fwd_cost;
+    if (!host || b->S == 0) continue;
+    UnpadArgs ua;
+    ua.num_lattices = (int32_t)b->U;
+    ua.state_off = b->state_off.p;
+    ua.padded = which ? b->bwd_cost.p : b->fwd_cost.p;
+    ua.dense = b->dense.p;
+    KLAT_HIP(launch_unpad(ua, b->ctx->stream));
+    KLAT_HIP(hipMemcpyAsync(host, b->dense.p, sizeof(double) * (size_t)b->S, hipMemcpyDeviceToHost, b->ctx->stream));
+  }
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
+  if (best) {
+    // the best complete path of lattice u: the backward cost of its start state
+    std::vector<double> bw((size_t)(b->S + b->U));
+    if (!bw.empty())
+      KLAT_HIP(hipMemcpy(bw.data(), b->bwd_cost.p, sizeof(double) * bw.size(), hipMemcpyDeviceToHost));
+    for (int64_t u = 0; u < b->U; ++u)
+      best[u] = b->h_state_off[u + 1] > b->h_state_off[u] ? bw[(size_t)(b->h_state_off[u] + u)]
+                                                           : std::numeric_limits<double>::infinity();
+  }
+  return KLAT_OK;
+}
+
+int klat_prune_mask(klat_batch* b, float beam, uint8_t* keep_arc, uint8_t* keep_final, double* lattice_beam) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  if (!b->viterbi_done) return set_error(KLAT_ERR_STATE, "klat_viterbi has not run on this batch");
+  if (!(beam > 0.0f)) return set_error(KLAT_ERR_INVALID_ARG, "beam must be positive");
+  klat_ctx* c = b->ctx;
+  KLAT_HIP(hipSetDevice(c->device));
+  DevBuf<uint8_t> d_arc, d_fin;
+  DevBuf<double> d_beam;
+  int rc;
+  if ((rc = d_arc.alloc((size_t)b->A)) || (rc = d_fin.alloc((size_t)b->S)) || (rc = d_beam.alloc((size_t)b->U))) return rc;
+  PruneArgs pa;
+  pa.state_off = b->state_off.p;
+  pa.arc_off = b->arc_off.p;
+  pa.src = b->src.p;
+  pa.dst = b->dst.p;
+  pa.ilabel = b->ilabel.p;
+  pa.graph = b->graph.p;
+  pa.acoustic = b->acoustic.p;
+  pa.final_graph = b->final_graph.p;
+  pa.final_acoustic = b->final_acoustic.p;
+  pa.fwd_cost = b->fwd_cost.p;
+  pa.bwd_cost = b->bwd_cost.p;
+  pa.beam = (double)beam;
+  pa.keep_arc = d_arc.p;
+  pa.keep_final = d_fin.p;
+  pa.lattice_beam = d_beam.p;
+  pa.sp = make_scale_params(b->viterbi_scales);
+  KLAT_HIP(launch_prune(pa, (int)b->U, c->stream));
+  if (keep_arc && b->A > 0) KLAT_HIP(hipMemcpyAsync(keep_arc, d_arc.p, (size_t)b->A, hipMemcpyDeviceToHost, c->stream));
+  if (keep_final && b->S > 0) KLAT_HIP(hipMemcpyAsync(keep_final, d_fin.p, (size_t)b->S, hipMemcpyDeviceToHost, c->stream));
+  if (lattice_beam && b->U > 0)
+    KLAT_HIP(hipMemcpyAsync(lattice_beam, d_beam.p, sizeof(double) * (size_t)b->U, hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipStreamSynchronize(c->stream));
   return KLAT_OK;
 }
 

@@ -111,6 +111,10 @@ struct klat_batch {
   klat::DevBuf<double> alpha, beta;     // padded: S + U entries (klat_kernels.h)
   klat::DevBuf<double> dense;           // scratch of klat_get_alpha_beta
   klat::DevBuf<double> sink;            // SweepArgs::sink
+  klat::DevBuf<double> fwd_cost, bwd_cost;  // klat_viterbi (padded), allocated on first use
+  klat::DevBuf<float> final_graph, final_acoustic;
+  bool viterbi_done = false;
+  klat_scales viterbi_scales = {1.f, 1.f, 0.f};
 };
 
 #endif

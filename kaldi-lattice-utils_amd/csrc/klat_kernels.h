@@ -88,6 +88,31 @@ struct PosteriorArgs {
   ScaleParams sp;
 };
 
+// Tropical twin (klat_viterbi.hip): Viterbi costs over the same streams, then the beam decisions.
+struct ViterbiArgs {
+  const SweepJob* jobs;
+  const LaneInfo* lanes;
+  const int32_t* sw; const float* sg; const float* sa;
+  double* fwd_cost;  // [S+U] padded: best cost from the start; slot S = best complete path
+  double* bwd_cost;  // [S+U] padded: best cost to a final state (final weight included)
+  ScaleParams sp;
+  StreamCost sc;
+  int32_t ring_slots;
+};
+struct PruneArgs {
+  const int64_t* state_off; const int64_t* arc_off;
+  const int32_t* src; const int32_t* dst; const int32_t* ilabel;
+  const float* graph; const float* acoustic; const float* final_graph; const float* final_acoustic;
+  const double* fwd_cost; const double* bwd_cost;
+  double beam;
+  uint8_t* keep_arc;     // [A] or null
+  uint8_t* keep_final;   // [S] or null
+  double* lattice_beam;  // [U]
+  ScaleParams sp;
+};
+hipError_t launch_viterbi(const ViterbiArgs& a, int num_jobs, int G, hipStream_t stream);
+hipError_t launch_prune(const PruneArgs& a, int num_lattices, hipStream_t stream);
+
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream);
 hipError_t launch_totals(const TotalsArgs& a, hipStream_t stream);
 hipError_t launch_unpad(const UnpadArgs& a, hipStream_t stream);

@@ -56,13 +56,10 @@ int main(int argc, char* argv[]) {
       batch.Clear();
     };
 
-    for (SequentialCompactLatticeReader reader(po.GetArg(1)); !reader.Done(); reader.Next()) {
+    for (PrunedLatticeReader reader(po.GetArg(1), ctx, co, io); !reader.Done(); reader.Next()) {
       CompactLattice& clat = reader.Value();
       CompactLattice dlat;
       std::vector<int32_t> times, state_len;
-      // Lattice pruning (applied after acoustic scaling and adding the insertion penalty)
-      if (io.Prunes() && clat.Start() != CompactLattice::kNoStateId)
-        PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &clat);
       if (clat.Start() != CompactLattice::kNoStateId) {
         TopSortCompactLatticeIfNeeded(&clat);
         DisambiguateStateInputSequenceLength(clat, &dlat, &state_len, false);

@@ -55,13 +55,10 @@ int main(int argc, char* argv[]) {
     };
 
     int64_t num_lattices = 0;
-    for (SequentialCompactLatticeReader reader(po.GetArg(1)); !reader.Done(); reader.Next(), ++num_lattices) {
+    for (PrunedLatticeReader reader(po.GetArg(1), ctx, co, io); !reader.Done(); reader.Next(), ++num_lattices) {
       CompactLattice& clat = reader.Value();
       KLAT_VLOG(1, "Lattice " << reader.Key() << ": #states " << clat.NumStates() << " #arcs " << clat.NumArcs());
       std::vector<int32_t> times;
-      // Lattice pruning (applied after acoustic scaling and adding the insertion penalty)
-      if (io.Prunes() && clat.Start() != CompactLattice::kNoStateId)
-        PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &clat);
       if (clat.Start() != CompactLattice::kNoStateId) {
         TopSortCompactLatticeIfNeeded(&clat);
         CompactLatticeStateTimes(clat, &times);

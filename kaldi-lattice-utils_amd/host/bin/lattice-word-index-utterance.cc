@@ -74,10 +74,8 @@ int main(int argc, char* argv[]) {
       batch.Clear();
     };
 
-    for (SequentialCompactLatticeReader reader(po.GetArg(1)); !reader.Done(); reader.Next()) {
+    for (PrunedLatticeReader reader(po.GetArg(1), ctx, co, io); !reader.Done(); reader.Next()) {
       CompactLattice& clat = reader.Value();
-      if (io.Prunes() && clat.Start() != CompactLattice::kNoStateId)
-        PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &clat);
       std::set<int32_t> symbols;  // GetOutputSymbols(clat, false): distinct non-epsilon output labels
       if (clat.Start() != CompactLattice::kNoStateId) {
         TopSortCompactLatticeIfNeeded(&clat);

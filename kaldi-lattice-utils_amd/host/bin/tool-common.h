@@ -36,8 +36,11 @@ struct IndexOptions {
   float beam = std::numeric_limits<float>::infinity();
   std::string exclude_str, include_str;
   int32_t num_threads = 1, num_threads_total = -1;
+  bool device_prune = false;
   void Register(ParseOptions* po) {
     po->Register("beam", &beam, "Pruning beam (applied after acoustic scaling and adding the insertion penalty).");
+    po->Register("device-prune", &device_prune,
+                 "Take the --beam pruning decisions on the GPU (Viterbi sweep over the whole batch) instead of lattice by lattice on the host.");
     po->Register("exclude-words", &exclude_str, "Space-separated list of integers representing the words to exclude from the index.");
     po->Register("include-words", &include_str, "Space-separated list of integers representing the words to include in the index.");
     // TaskSequencerConfig options of the reference: accepted for command-line compatibility; the
@@ -79,6 +82,53 @@ inline void WritePosteriors(Context& ctx, const LatticeBatch& batch, const klat_
     fb += num_frames[u];
   }
 }
+
+// SequentialCompactLatticeReader with the reference's PruneLattice step applied
+// (kwsbin2/lattice-word-index-segment.cc:49-51): lattices are read a batch ahead so that
+// --device-prune can take the decisions of the whole batch in one Viterbi sweep on the GPU.
+class PrunedLatticeReader {
+ public:
+  PrunedLatticeReader(const std::string& rspecifier, Context& ctx, const CommonOptions& co, const IndexOptions& io)
+      : reader_(rspecifier), ctx_(ctx), co_(co), io_(io) {
+    Fill();
+  }
+  bool Done() const { return pos_ >= keys_.size(); }
+  const std::string& Key() const { return keys_[pos_]; }
+  CompactLattice& Value() { return lats_[pos_]; }
+  void FreeCurrent() { lats_[pos_].DeleteStates(); }
+  void Next() {
+    if (++pos_ >= keys_.size()) Fill();
+  }
+
+ private:
+  void Fill() {
+    keys_.clear();
+    lats_.clear();
+    pos_ = 0;
+    int64_t arcs = 0;
+    for (; !reader_.Done() && (int32_t)keys_.size() < co_.batch_size && arcs < co_.max_batch_arcs; reader_.Next()) {
+      keys_.push_back(reader_.Key());
+      arcs += reader_.Value().NumArcs();
+      lats_.push_back(std::move(reader_.Value()));
+      reader_.FreeCurrent();
+    }
+    if (!io_.Prunes() || keys_.empty()) return;
+    if (io_.device_prune) {
+      PruneLatticesOnDevice(ctx_, io_.beam, co_.graph_scale, co_.acoustic_scale, co_.insertion_penalty, &lats_);
+    } else {
+      for (auto& clat : lats_)
+        if (clat.Start() != CompactLattice::kNoStateId)
+          PruneLattice(io_.beam, co_.graph_scale, co_.acoustic_scale, co_.insertion_penalty, &clat);
+    }
+  }
+  SequentialCompactLatticeReader reader_;
+  Context& ctx_;
+  const CommonOptions& co_;
+  const IndexOptions& io_;
+  std::vector<std::string> keys_;
+  std::vector<CompactLattice> lats_;
+  size_t pos_ = 0;
+};
 
 inline std::vector<int32_t> ParseIntList(const std::string& s, const char* what) {
   std::set<int32_t> out;

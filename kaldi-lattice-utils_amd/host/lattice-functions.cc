@@ -243,6 +243,11 @@ bool PruneLattice(float beam, float gs, float as, float pen, CompactLattice* cla
     }
     cost[s] = bc;
   }
+  return ConnectKeeping(keep, clat);
+}
+
+bool ConnectKeeping(const std::vector<std::vector<uint8_t>>& keep, CompactLattice* clat) {
+  const int32_t S = clat->NumStates();
   // Connect(): keep states that are accessible from the start and co-accessible to a final state
   std::vector<uint8_t> acc(S, 0), coacc(S, 0);
   acc[clat->Start()] = 1;
@@ -286,6 +291,39 @@ bool PruneLattice(float beam, float gs, float as, float pen, CompactLattice* cla
   clat->States() = std::move(ns);
   clat->SetStart(new_start);
   return true;
+}
+
+void PruneLatticesOnDevice(Context& ctx, float beam, float gs, float as, float pen, std::vector<CompactLattice>* lats) {
+  if (!(beam > 0.0f)) KLAT_ERR("PruneLattice: beam must be positive");
+  LatticeBatch batch;
+  for (auto& clat : *lats) {
+    if (clat.Start() != CompactLattice::kNoStateId) TopSortCompactLatticeIfNeeded(&clat);
+    batch.Add(clat, nullptr);
+  }
+  if (batch.NumArcs() == 0 && batch.NumStates() == 0) return;
+  DeviceBatch db(ctx, batch, nullptr);
+  klat_scales sc = {gs, as, pen};
+  Check(klat_viterbi(db.get(), &sc), "klat_viterbi");
+  std::vector<uint8_t> keep_arc((size_t)std::max<int64_t>(batch.NumArcs(), 1)), keep_final((size_t)std::max<int64_t>(batch.NumStates(), 1));
+  Check(klat_prune_mask(db.get(), beam, keep_arc.data(), keep_final.data(), nullptr), "klat_prune_mask");
+  for (size_t u = 0; u < lats->size(); ++u) {
+    CompactLattice& clat = (*lats)[u];
+    const int32_t S = clat.NumStates();
+    if (S == 0) continue;
+    const int64_t s0 = batch.StateOff()[u];
+    int64_t a = batch.ArcOff()[u];
+    std::vector<std::vector<uint8_t>> keep((size_t)S);
+    for (int32_t s = 0; s < S; ++s) {
+      CompactLatticeState& st = clat.State(s);
+      if (st.IsFinal() && !keep_final[(size_t)(s0 + s)]) {
+        st.final_graph = st.final_acoustic = std::numeric_limits<float>::infinity();
+        st.final_string_len = 0;
+      }
+      keep[(size_t)s].assign(keep_arc.begin() + a, keep_arc.begin() + a + (int64_t)st.arcs.size());
+      a += (int64_t)st.arcs.size();
+    }
+    ConnectKeeping(keep, &clat);
+  }
 }
 
 // ---- LatticeBatch ----

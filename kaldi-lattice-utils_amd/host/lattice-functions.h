@@ -53,6 +53,11 @@ void AddSequenceLengthDisambiguationSymbol(CompactLattice* clat, std::vector<int
 bool PruneLattice(float beam, float graph_scale, float acoustic_scale, float insertion_penalty,
                   CompactLattice* clat);
 
+// Connect() after pruning: keep[s][i] == 0 drops arc i of state s; states that are no longer
+// accessible and co-accessible go, ids stay in order.  Returns false (and empties the lattice) if
+// nothing survives.
+bool ConnectKeeping(const std::vector<std::vector<uint8_t>>& keep, CompactLattice* clat);
+
 // A batch of top-sorted lattices flattened to the CSR/SoA layout of klat_batch_desc.
 class LatticeBatch {
  public:
@@ -94,6 +99,13 @@ class DeviceBatch {
   klat_batch* b_ = nullptr;
 };
 void Check(int rc, const char* what);
+
+// PruneLattice for a whole batch with the decisions taken on the GPU (klat_viterbi +
+// klat_prune_mask: the tropical twin of the sweep); the masks are applied and the
+// lattices Connect()ed here.  Same result as PruneLattice() lattice by lattice, except for arcs
+// whose best path lies within rounding of the cutoff.
+void PruneLatticesOnDevice(Context& ctx, float beam, float graph_scale, float acoustic_scale, float insertion_penalty,
+                           std::vector<CompactLattice>* lats);
 
 // ComputeLatticeAlphasAndBetas (latbin/lattice-to-word-frame-post.cc:88-90): same signature and
 // return value (0.5*(tot_forward+tot_backward)); viterbi must be false (every call site of the

@@ -276,6 +276,20 @@ class Batch:
         _check(lib().klat_frame_post(self.h, _p(nf), _p(off), _p(labels), _p(logps), C.c_int64(len(labels)), C.byref(n)))
         return off, labels[:n.value], logps[:n.value]
 
+    def viterbi(self, graph_scale=1.0, acoustic_scale=1.0, insertion_penalty=0.0):
+        s = Scales(graph_scale, acoustic_scale, insertion_penalty)
+        _check(lib().klat_viterbi(self.h, C.byref(s)))
+
+    def viterbi_costs(self):
+        fw, bw, best = np.zeros(max(self.S, 1)), np.zeros(max(self.S, 1)), np.zeros(max(self.U, 1))
+        _check(lib().klat_get_viterbi(self.h, _p(fw), _p(bw), _p(best)))
+        return fw[:self.S], bw[:self.S], best[:self.U]
+
+    def prune_mask(self, beam):
+        ka, kf, lb = np.zeros(max(self.A, 1), np.uint8), np.zeros(max(self.S, 1), np.uint8), np.zeros(max(self.U, 1))
+        _check(lib().klat_prune_mask(self.h, C.c_float(beam), _p(ka), _p(kf), _p(lb)))
+        return ka[:self.A], kf[:self.S], lb[:self.U]
+
     def utterance_scores(self, word_off, words):
         """log P(word occurs on the path) for the query words of every lattice (klat_utterance_scores)."""
         wo = np.ascontiguousarray(word_off, np.int64)

@@ -917,6 +917,43 @@ int32_t kor_prune_lattice(int32_t S, const int64_t *arc_begin, const int32_t *ds
   return n;
 }
 
+/* ---- ComputeLatticeBeam, latbin/lattice-prune-dyn-beam.cc:27-90: Viterbi forward costs :36-58,
+ * backward costs sharing the loop with the running cutoff :63-87, beam = cutoff - best :89.
+ * fwd / bwd receive the two cost vectors (the reference overwrites one with the other). */
+double kor_lattice_beam(int32_t S, const int64_t *arc_begin, const int32_t *dst, const float *graph,
+                        const float *acoustic, const float *final_graph, const float *final_acoustic,
+                        double *fwd, double *bwd) {
+  if (S == 0) return 0.0;
+  for (int32_t s = 0; s < S; ++s) fwd[s] = INFINITY;
+  fwd[0] = 0.0;
+  double best_final_cost = INFINITY;
+  for (int32_t s = 0; s < S; ++s) {
+    const double this_forward_cost = fwd[s];
+    for (int64_t i = arc_begin[s]; i < arc_begin[s + 1]; ++i) {
+      const double next_forward_cost = this_forward_cost + ((double)graph[i] + (double)acoustic[i]);
+      if (fwd[dst[i]] > next_forward_cost) fwd[dst[i]] = next_forward_cost;
+    }
+    const double this_final_cost = this_forward_cost + ((double)final_graph[s] + (double)final_acoustic[s]);
+    if (this_final_cost < best_final_cost) best_final_cost = this_final_cost;
+  }
+  double cutoff = best_final_cost;
+  for (int32_t s = S - 1; s >= 0; --s) {
+    const double this_forward_cost = fwd[s];
+    double this_backward_cost = (double)final_graph[s] + (double)final_acoustic[s];
+    if (this_backward_cost + this_forward_cost > cutoff && this_backward_cost != INFINITY)
+      cutoff = this_backward_cost + this_forward_cost;
+    for (int64_t i = arc_begin[s]; i < arc_begin[s + 1]; ++i) {
+      const double arc_cost = (double)graph[i] + (double)acoustic[i];
+      const double arc_backward_cost = arc_cost + bwd[dst[i]];
+      const double this_fb_cost = this_forward_cost + arc_backward_cost;
+      if (arc_backward_cost < this_backward_cost) this_backward_cost = arc_backward_cost;
+      if (this_fb_cost > cutoff) cutoff = this_fb_cost;
+    }
+    bwd[s] = this_backward_cost;
+  }
+  return cutoff - best_final_cost;
+}
+
 /* ---- timed CPU baseline for bench.py ("port"): fb + arc through-likelihood over a batch
  * of lattices held as one flat CSR (state_off/arc_off per lattice, arc_begin global per
  * state, lattice-local dst).  Scales are applied to private copies first (a2/a3), as the

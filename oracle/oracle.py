@@ -37,6 +37,7 @@ def lib():
         _LIB.kor_position_post.restype = C.c_int64
         _LIB.kor_length_dist.restype = C.c_int64
         _LIB.kor_utterance_index.restype = C.c_int64
+        _LIB.kor_lattice_beam.restype = C.c_double
         _LIB.kor_disambiguate_length.restype = C.c_int32
         _LIB.kor_free.argtypes = [C.c_void_p]
     return _LIB
@@ -398,6 +399,14 @@ def best_path2(lat):
             out.append(parent[s][1])
         s = parent[s][0]
     return out[::-1], best, min(best_ways, 2)
+
+
+def lattice_beam(lat):
+    """ComputeLatticeBeam (latbin/lattice-prune-dyn-beam.cc:27-90): (beam, fwd costs, bwd costs)."""
+    fw, bw = np.zeros(max(lat.S, 1)), np.zeros(max(lat.S, 1))
+    b = lib().kor_lattice_beam(C.c_int32(lat.S), _p(lat.arc_begin), _p(lat.dst), _p(lat.graph), _p(lat.acoustic),
+                               _p(lat.final_graph), _p(lat.final_acoustic), _p(fw), _p(bw))
+    return float(b), fw[:lat.S], bw[:lat.S]
 
 
 def prune_lattice(lat, beam):

@@ -66,15 +66,17 @@ def _write_text_archive(path, arrays, ns):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("beam", [1.5, 6.0])
-def test_segment_tool_with_beam_matches_oracle_pipeline(tmp_path, beam):
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_segment_tool_with_beam_matches_oracle_pipeline(tmp_path, beam, where):
     """--beam: ScaleLattice -> AddWordInsPen -> PruneLattice -> TopSort -> times -> sweep -> index
-    (kwsbin2/lattice-word-index-segment.cc:41-63); the pruning is host-side graph surgery."""
+    (kwsbin2/lattice-word-index-segment.cc:41-63).  The decisions are taken on the host lattice by
+    lattice, or with --device-prune by the Viterbi sweep on the GPU; Connect() is host-side."""
     ns = np.array([40, 25, 60], np.int32)
     fo = np.array([3, 2, 4], np.int32)
     arrays = klat_amd.synth(99, ns, fo)
     txt = str(tmp_path / "in.txt")
     _write_text_archive(txt, arrays, ns)
-    args = ["--acoustic-scale=0.1", "--insertion-penalty=0.5", "--beam=%g" % beam]
+    args = ["--acoustic-scale=0.1", "--insertion-penalty=0.5", "--beam=%g" % beam] + (["--device-prune=true"] if where == "device" else [])
     rc, out, err = run("lattice-word-index-segment", *args, "ark:" + txt, "ark,t:-")
     assert rc == 0, err
     lines = out.decode().strip("\n").split("\n")
