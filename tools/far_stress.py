@@ -1,4 +1,6 @@
-"""Stress test of the FAR path (sources older than the ring) under a full chip: 6 000 lattices with\nevery third arc stretched over 17-60 states, four layouts; flow properties over all arcs and oracle\nparity on a sample."""
+"""Stress test of the FAR path (sources older than the ring) under a full chip: 6 000 lattices with
+every third arc stretched over 17-60 states, four layouts; flow properties over all arcs and oracle
+parity on a sample."""
 import os, sys
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
