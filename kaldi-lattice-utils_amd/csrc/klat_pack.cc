@@ -58,14 +58,15 @@ inline bool is_final(const klat_batch_desc& d, int64_t gs) {
 
 int choose_lanes_per_lattice(int64_t U, int64_t S, int64_t A) {
   if (U <= 0 || S <= 0) return 1;
-  // Enough lattices to give every SIMD several lane-per-lattice waves: no padding, G = 1.
-  const int64_t waves_g1 = 2 * ceil_div(U, 64);
-  if (waves_g1 >= 4096) return 1;
-  // Otherwise spread each state's terms over G lanes (shorter dependency chain per lattice).
+  // Spread each state's terms over G ~ fanout lanes: the dependency chain of a lattice is then one
+  // round per state.  Very large batches halve G (more lattices per wave, fewer padded lanes), but
+  // not below 2: with one lane per lattice the chain is one round per ARC and the sweep is slower
+  // even when the chip is full many times over (tools/layout_scan.py: 140 000 lattices x 150
+  // states, G = 1: 92 G arcs/s, G = 2: 112, G = 4: 110).
   const double fan = (double)A / (double)S;
   int G = 1;
   while (G < fan && G < 64) G *= 2;
-  while (G > 1 && 2 * ceil_div(U, 64 / G) > 8192) G /= 2;
+  while (G > 2 && 2 * ceil_div(U, 64 / G) > 8192) G /= 2;
   return G;
 }
 
