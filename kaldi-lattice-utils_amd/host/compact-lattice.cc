@@ -17,7 +17,8 @@ int64_t CompactLattice::NumArcs() const {
 }
 
 // "g,a,t1_t2_.."  ->  graph, acoustic, number of transition ids.  Missing pieces = One.
-static bool ParseCompactWeight(const std::string& tok, float* g, float* a, int32_t* len) {
+static bool ParseCompactWeight(const std::string& tok, float* g, float* a, int32_t* len,
+                               std::vector<int32_t>* pool = nullptr, int32_t* off = nullptr) {
   *g = 0.f;
   *a = 0.f;
   *len = 0;
@@ -44,6 +45,16 @@ static bool ParseCompactWeight(const std::string& tok, float* g, float* a, int32
       else if (!(isdigit((unsigned char)ch) || ch == '-')) return false;
     }
     *len = n;
+    if (pool) {  // keep the ids themselves
+      *off = (int32_t)pool->size();
+      const char* c = s3.c_str();
+      for (int32_t i = 0; i < n; ++i) {
+        char* e = nullptr;
+        pool->push_back((int32_t)std::strtol(c, &e, 10));
+        if (e == c) return false;
+        c = (*e == '_') ? e + 1 : e;
+      }
+    }
   }
   return true;
 }
@@ -55,8 +66,9 @@ static bool IsInt(const std::string& s) {
   return *end == 0;
 }
 
-bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat) {
+bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat, bool keep_strings) {
   clat->DeleteStates();
+  std::vector<int32_t>* pool = keep_strings ? &clat->StringPool() : nullptr;
   std::string line;
   bool any = false;
   auto need_state = [&](int32_t s) {
@@ -81,7 +93,7 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat) {
       st.final_graph = 0.f;
       st.final_acoustic = 0.f;
       st.final_string_len = 0;
-      if (t.size() == 2 && !ParseCompactWeight(t[1], &st.final_graph, &st.final_acoustic, &st.final_string_len)) return false;
+      if (t.size() == 2 && !ParseCompactWeight(t[1], &st.final_graph, &st.final_acoustic, &st.final_string_len, pool, &st.final_string_off)) return false;
       continue;
     }
     if (!IsInt(t[1]) || !IsInt(t[2])) return false;
@@ -92,7 +104,7 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat) {
     if (t.size() == 3 || (t.size() == 4 && t[3].find(',') != std::string::npos)) {
       // CompactLattice (acceptor) format: src dst label [g,a,tids]
       arc.ilabel = arc.olabel = (int32_t)std::atol(t[2].c_str());
-      if (t.size() == 4 && !ParseCompactWeight(t[3], &arc.graph, &arc.acoustic, &arc.string_len)) return false;
+      if (t.size() == 4 && !ParseCompactWeight(t[3], &arc.graph, &arc.acoustic, &arc.string_len, pool, &arc.string_off)) return false;
     } else if (t.size() == 4 || t.size() == 5) {
       // Lattice format: src dst ilabel(transition-id) olabel(word) [g,a].  Converted arc by arc:
       // the word is the olabel, the transition-id string is [ilabel] when ilabel != 0.  This
@@ -101,6 +113,10 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat) {
       const int32_t il = (int32_t)std::atol(t[2].c_str());
       arc.ilabel = arc.olabel = (int32_t)std::atol(t[3].c_str());
       arc.string_len = il != 0 ? 1 : 0;
+      if (pool && il != 0) {
+        arc.string_off = (int32_t)pool->size();
+        pool->push_back(il);
+      }
       int32_t dummy;
       if (t.size() == 5 && !ParseCompactWeight(t[4], &arc.graph, &arc.acoustic, &dummy)) return false;
     } else {
@@ -113,9 +129,10 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat) {
 
 void WriteCompactLatticeText(std::ostream& os, const CompactLattice& clat) {
   os << '\n';
-  auto weight = [&](float g, float a, int32_t len) {
+  auto weight = [&](float g, float a, int32_t len, int32_t off) {
     os << g << ',' << a << ',';
-    for (int32_t i = 0; i < len; ++i) os << (i ? "_" : "") << 1;  // ids themselves are not kept
+    for (int32_t i = 0; i < len; ++i)  // the ids, or 1s when the reader did not keep them
+      os << (i ? "_" : "") << (off >= 0 ? clat.StringPool()[(size_t)(off + i)] : 1);
   };
   // OpenFst text order: start state first
   std::vector<int32_t> order;
@@ -126,12 +143,12 @@ void WriteCompactLatticeText(std::ostream& os, const CompactLattice& clat) {
     const CompactLatticeState& st = clat.State(s);
     for (const auto& arc : st.arcs) {
       os << s << '\t' << arc.nextstate << '\t' << arc.ilabel << '\t';
-      weight(arc.graph, arc.acoustic, arc.string_len);
+      weight(arc.graph, arc.acoustic, arc.string_len, arc.string_off);
       os << '\n';
     }
     if (st.IsFinal()) {
       os << s << '\t';
-      weight(st.final_graph, st.final_acoustic, st.final_string_len);
+      weight(st.final_graph, st.final_acoustic, st.final_string_len, st.final_string_off);
       os << '\n';
     }
   }
@@ -160,8 +177,9 @@ static void wr_string(std::ostream& os, const std::string& s) {
   os.write(s.data(), (std::streamsize)s.size());
 }
 
-bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat) {
+bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat, bool keep_strings) {
   clat->DeleteStates();
+  std::vector<int32_t>* pool = keep_strings ? &clat->StringPool() : nullptr;
   int32_t magic, version, flags;
   std::string fst_type, arc_type;
   uint64_t properties;
@@ -177,13 +195,19 @@ bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat) {
     KLAT_ERR("Unsupported arc type \"" << arc_type << "\" in lattice archive");
   if (flags & 3) KLAT_ERR("Lattice archives with embedded symbol tables are not supported");
   if (num_states < 0 || num_states > (int64_t)1 << 30) return false;
-  auto read_weight = [&](float* g, float* a, int32_t* len) -> bool {
+  auto read_weight = [&](float* g, float* a, int32_t* len, int32_t* off) -> bool {
     if (!rd(is, g) || !rd(is, a)) return false;
     *len = 0;
     if (compact) {
       int32_t n;
       if (!rd(is, &n) || n < 0) return false;
-      is.ignore((std::streamsize)n * 4);
+      if (pool && n > 0) {
+        *off = (int32_t)pool->size();
+        pool->resize(pool->size() + (size_t)n);
+        is.read(reinterpret_cast<char*>(pool->data() + *off), (std::streamsize)n * 4);
+      } else {
+        is.ignore((std::streamsize)n * 4);
+      }
       *len = n;
     }
     return (bool)is;
@@ -191,14 +215,14 @@ bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat) {
   for (int64_t s = 0; s < num_states; ++s) {
     clat->AddState();
     CompactLatticeState& st = clat->State((int32_t)s);
-    if (!read_weight(&st.final_graph, &st.final_acoustic, &st.final_string_len)) return false;
+    if (!read_weight(&st.final_graph, &st.final_acoustic, &st.final_string_len, &st.final_string_off)) return false;
     int64_t narcs;
     if (!rd(is, &narcs) || narcs < 0) return false;
     st.arcs.resize((size_t)narcs);
     for (auto& arc : st.arcs) {
       int32_t il, ol;
       if (!rd(is, &il) || !rd(is, &ol)) return false;
-      if (!read_weight(&arc.graph, &arc.acoustic, &arc.string_len)) return false;
+      if (!read_weight(&arc.graph, &arc.acoustic, &arc.string_len, &arc.string_off)) return false;
       if (!rd(is, &arc.nextstate)) return false;
       if (compact) {
         arc.ilabel = il;
@@ -206,6 +230,10 @@ bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat) {
       } else {  // Lattice: ilabel = transition id, olabel = word (arc-by-arc conversion, see text reader)
         arc.ilabel = arc.olabel = ol;
         arc.string_len = il != 0 ? 1 : 0;
+        if (pool && il != 0) {
+          arc.string_off = (int32_t)pool->size();
+          pool->push_back(il);
+        }
       }
     }
   }
@@ -223,27 +251,28 @@ void WriteCompactLatticeBinary(std::ostream& os, const CompactLattice& clat) {
   wr<int64_t>(os, clat.Start());
   wr<int64_t>(os, clat.NumStates());
   wr<int64_t>(os, clat.NumArcs());
-  auto write_weight = [&](float g, float a, int32_t len) {
+  auto write_weight = [&](float g, float a, int32_t len, int32_t off) {
     wr(os, g);
     wr(os, a);
     wr<int32_t>(os, len);
-    for (int32_t i = 0; i < len; ++i) wr<int32_t>(os, 1);
+    for (int32_t i = 0; i < len; ++i) wr<int32_t>(os, off >= 0 ? clat.StringPool()[(size_t)(off + i)] : 1);
   };
   for (int32_t s = 0; s < clat.NumStates(); ++s) {
     const CompactLatticeState& st = clat.State(s);
-    write_weight(st.final_graph, st.final_acoustic, st.final_string_len);
+    write_weight(st.final_graph, st.final_acoustic, st.final_string_len, st.final_string_off);
     wr<int64_t>(os, (int64_t)st.arcs.size());
     for (const auto& arc : st.arcs) {
       wr<int32_t>(os, arc.ilabel);
       wr<int32_t>(os, arc.olabel);
-      write_weight(arc.graph, arc.acoustic, arc.string_len);
+      write_weight(arc.graph, arc.acoustic, arc.string_len, arc.string_off);
       wr<int32_t>(os, arc.nextstate);
     }
   }
 }
 
 // ---- sequential archive reader ----
-SequentialCompactLatticeReader::SequentialCompactLatticeReader(const std::string& rspecifier) {
+SequentialCompactLatticeReader::SequentialCompactLatticeReader(const std::string& rspecifier, bool keep_strings)
+    : keep_strings_(keep_strings) {
   const Specifier sp = ParseSpecifier(rspecifier, false);
   input_.reset(new Input(sp.filename));
   Next();
@@ -265,11 +294,11 @@ void SequentialCompactLatticeReader::Next() {
   while ((c = is.peek()) == ' ' || c == '\t') is.get();
   bool ok;
   if (c == 0xD6) {
-    ok = ReadCompactLatticeBinary(is, &value_);
+    ok = ReadCompactLatticeBinary(is, &value_, keep_strings_);
   } else {
     if (c == '\r') is.get(), c = is.peek();
     if (c == '\n') is.get();
-    ok = ReadCompactLatticeText(is, &value_);
+    ok = ReadCompactLatticeText(is, &value_, keep_strings_);
   }
   if (!ok) KLAT_ERR("Failed reading lattice for key \"" << key_ << "\"");
 }

@@ -131,10 +131,12 @@ int32_t DisambiguateStateInputSequenceLength(const CompactLattice& ifst, Compact
     out.final_graph = in.final_graph;
     out.final_acoustic = in.final_acoustic;
     out.final_string_len = in.final_string_len;
+    out.final_string_off = -1;  // ids stay with the input lattice
     out.arcs.reserve(in.arcs.size());
     for (auto arc : in.arcs) {
       const int32_t nl = ((use_input ? arc.ilabel : arc.olabel) == 0) ? len : len + 1;
       arc.nextstate = state_map[Pair(nl, arc.nextstate)];
+      arc.string_off = -1;
       if (arc.nextstate <= u2) KLAT_ERR("DisambiguateStateInputSequenceLength: output would not be topologically sorted (cyclic input?)");
       out.arcs.push_back(arc);
     }
@@ -187,10 +189,9 @@ void AddSequenceLengthDisambiguationSymbol(CompactLattice* clat, std::vector<int
   }
 }
 
-namespace {
 // ConvertToCost of a weight after ScaleLattice / AddWordInsPen, with the reference's rounding:
 // products formed in double and stored as float, penalty added in float, sum in double.
-inline double ScaledCost(float g, float a, bool word, float gs, float as, float pen) {
+double ScaledCost(float g, float a, bool word, float gs, float as, float pen) {
   const float inf = std::numeric_limits<float>::infinity();
   if (as != 1.0f || gs != 1.0f) {
     if (g == inf) {
@@ -203,7 +204,6 @@ inline double ScaledCost(float g, float a, bool word, float gs, float as, float 
   if (pen != 0.0f && word) g = g + pen;
   return (double)g + (double)a;
 }
-}  // namespace
 
 bool PruneLattice(float beam, float gs, float as, float pen, CompactLattice* clat) {
   if (!(beam > 0.0f)) KLAT_ERR("PruneLattice: beam must be positive");
@@ -233,6 +233,7 @@ bool PruneLattice(float beam, float gs, float as, float pen, CompactLattice* cla
     if (bc + fc > cutoff && bc != inf) {
       st.final_graph = st.final_acoustic = std::numeric_limits<float>::infinity();
       st.final_string_len = 0;
+      st.final_string_off = -1;
     }
     keep[s].assign(st.arcs.size(), 1);
     for (size_t i = 0; i < st.arcs.size(); ++i) {
@@ -280,6 +281,7 @@ bool ConnectKeeping(const std::vector<std::vector<uint8_t>>& keep, CompactLattic
     dst.final_graph = src.final_graph;
     dst.final_acoustic = src.final_acoustic;
     dst.final_string_len = src.final_string_len;
+    dst.final_string_off = src.final_string_off;
     for (size_t i = 0; i < src.arcs.size(); ++i) {
       if (!keep[s][i] || newid[src.arcs[i].nextstate] < 0) continue;
       CompactLatticeArc arc = src.arcs[i];
@@ -318,6 +320,7 @@ void PruneLatticesOnDevice(Context& ctx, float beam, float gs, float as, float p
       if (st.IsFinal() && !keep_final[(size_t)(s0 + s)]) {
         st.final_graph = st.final_acoustic = std::numeric_limits<float>::infinity();
         st.final_string_len = 0;
+        st.final_string_off = -1;
       }
       keep[(size_t)s].assign(keep_arc.begin() + a, keep_arc.begin() + a + (int64_t)st.arcs.size());
       a += (int64_t)st.arcs.size();

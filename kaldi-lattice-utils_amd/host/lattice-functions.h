@@ -53,6 +53,9 @@ void AddSequenceLengthDisambiguationSymbol(CompactLattice* clat, std::vector<int
 bool PruneLattice(float beam, float graph_scale, float acoustic_scale, float insertion_penalty,
                   CompactLattice* clat);
 
+// ConvertToCost of a weight as the reference holds it after ScaleLattice / AddWordInsPenToCompactLattice.
+double ScaledCost(float graph, float acoustic, bool word, float graph_scale, float acoustic_scale, float insertion_penalty);
+
 // Connect() after pruning: keep[s][i] == 0 drops arc i of state s; states that are no longer
 // accessible and co-accessible go, ids stay in order.  Returns false (and empties the lattice) if
 // nothing survives.

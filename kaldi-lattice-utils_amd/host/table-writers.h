@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/klat.h"
+#include "compact-lattice.h"
 #include "kaldi-io.h"
 
 namespace klat {
@@ -63,6 +64,30 @@ class PosteriorWriter : public ArchiveWriter {
     }
     End();
   }
+};
+
+// CompactLatticeWriter (latbin/lattice-prune-dyn-beam.cc:158,190): "key " then the lattice, as text
+// (a newline, OpenFst text lines, an empty line) or as the binary VectorFst stream.
+class CompactLatticeWriter {
+ public:
+  explicit CompactLatticeWriter(const std::string& wspecifier) : spec_(ParseSpecifier(wspecifier, true)), out_(spec_.filename) {}
+  void Write(const std::string& key, const CompactLattice& clat) {
+    std::ostream& os = out_.Stream();
+    os << key << ' ';
+    if (spec_.text) {
+      os.precision(9);
+      WriteCompactLatticeText(os, clat);
+    } else {
+      WriteCompactLatticeBinary(os, clat);
+    }
+    if (spec_.text || spec_.filename == "-") os.flush();
+    if (!os.good()) KLAT_ERR("Write failure on " << spec_.filename);
+  }
+  void Close() { out_.Close(); }
+
+ private:
+  Specifier spec_;
+  Output out_;
 };
 
 // vector<int32> (Int32VectorWriter, latbin/lattice-best-path2.cc:75,199): BasicVectorHolder wire

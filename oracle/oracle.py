@@ -433,6 +433,25 @@ def prune_lattice(lat, beam):
     return res
 
 
+def prune_dyn_beam(lat, max_arcs, max_states, beam_ratio=0.9, min_beam=1e-3):
+    """The loop of latbin/lattice-prune-dyn-beam.cc:166-186 on a scaled, penalised, top-sorted
+    lattice, literally: ComputeLatticeBeam, then PruneLattice with the beam multiplied by
+    beam_ratio (a BaseFloat) until the lattice is small enough.  Returns (indices of the surviving
+    arcs and states in the input lattice, final beam); (None, beam) if nothing survives."""
+    beam, _, _ = lattice_beam(lat)
+    ratio, floor = float(np.float32(beam_ratio)), float(np.float32(min_beam))
+    cur = lat
+    arcs, states = np.arange(lat.A), np.arange(lat.S)
+    while beam > floor and (cur.A > max_arcs or cur.S > max_states):
+        beam = ratio * beam
+        nxt = prune_lattice(cur, float(np.float32(beam)))  # PruneLattice(BaseFloat beam, ...)
+        if nxt is None:
+            return None, None, beam
+        arcs, states = arcs[nxt.extra["arc_old"]], states[nxt.extra["state_old"]]
+        cur = nxt
+    return arcs, states, beam
+
+
 def batch_fb_post(state_off, arc_off, arc_begin_global, dst, ilabel, graph, acoustic, final_graph,
                   final_acoustic, graph_scale, acoustic_scale, insertion_penalty):
     """Timed CPU baseline body (bench.py cpu_baseline) and batch parity checker."""

@@ -341,6 +341,55 @@ def test_utterance_tool_matches_oracle(tmp_path, golden_dir, args, flt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("limits", [("--max-arcs=60",), ("--max-states=12",), ("--max-arcs=200", "--max-states=40"), ()])
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (0.7, 0.1, 0.5)])
+def test_prune_dyn_beam_tool_matches_oracle_loop(tmp_path, golden_dir, limits, scales):
+    """lattice-prune-dyn-beam (latbin/lattice-prune-dyn-beam.cc): the surviving arcs and states are
+    those of the reference's iterated PruneLattice loop (oracle: literally iterated), the lattice
+    comes back with its stored weights and transition ids, in text and in binary."""
+    gs, ac, pen = scales
+    ns = np.array([50, 30, 1, 80], np.int32)
+    fo = np.array([3, 2, 1, 4], np.int32)
+    arrays = klat_amd.synth(31337, ns, fo)
+    txt = str(tmp_path / "in.txt")
+    with open(txt, "w") as f:
+        f.write(open(os.path.join(golden_dir, "multi_final_lattice.ark.txt")).read().rstrip("\n") + "\n\n")
+        latfmt.write_synth_text(arrays, f, ["u%d" % i for i in range(len(ns))])
+    args = ["--graph-scale=%g" % gs, "--acoustic-scale=%g" % ac, "--insertion-penalty=%g" % pen] + list(limits)
+    out_txt, out_bin, back = str(tmp_path / "out.txt"), str(tmp_path / "out.ark"), str(tmp_path / "back.txt")
+    rc, _, err = run("lattice-prune-dyn-beam", *args, "ark:" + txt, "ark,t:" + out_txt)
+    assert rc == 0, err
+    rc, _, err2 = run("lattice-prune-dyn-beam", *args, "ark:" + txt, "ark:" + out_bin)
+    assert rc == 0, err2
+    rc, _, err3 = run("klat-lattice-copy", "ark:" + out_bin, "ark,t:" + back)
+    assert rc == 0, err3
+    max_arcs = max([int(l.split("=")[1]) for l in limits if l.startswith("--max-arcs")] + [0]) or 2 ** 31 - 1
+    max_states = max([int(l.split("=")[1]) for l in limits if l.startswith("--max-states")] + [0]) or 2 ** 31 - 1
+    ins = latfmt.read_text_archive(txt)
+    outs = latfmt.read_text_archive(out_txt)
+    assert [o.key for o in outs] == [i.key for i in ins]
+    pruned = 0
+    for lat, got in zip(ins, outs):
+        lat = latfmt.prepare(lat)
+        arcs, states, beam = orc.prune_dyn_beam(orc.scale_and_penalize(lat, gs, ac, pen), max_arcs, max_states)
+        assert arcs is not None
+        pruned += len(arcs) < lat.A
+        assert got.S == len(states) and got.A == len(arcs), (lat.key, got.S, got.A, len(states), len(arcs))
+        newid = -np.ones(lat.S, np.int64)
+        newid[states] = np.arange(len(states))
+        assert np.array_equal(got.dst, newid[lat.dst[arcs]]) and np.array_equal(got.ilabel, lat.ilabel[arcs])
+        assert np.allclose(got.graph, lat.graph[arcs], rtol=1e-6) and np.allclose(got.acoustic, lat.acoustic[arcs], rtol=1e-6)
+        assert np.array_equal(got.dur, lat.dur[arcs])
+        assert got.S <= max_states and got.A <= max_arcs or beam <= 1e-3
+    if limits:
+        assert pruned >= 2
+    # the binary output reads back as the same lattices; real transition ids survive (all 7 here)
+    assert "7_7" in open(out_txt).read()
+    for a, b in zip(outs, latfmt.read_text_archive(back)):
+        assert a.key == b.key and np.array_equal(a.dst, b.dst) and np.array_equal(a.dur, b.dur) and np.allclose(a.graph, b.graph, rtol=1e-6)
+
+
+@pytest.mark.gpu
 def test_tools_on_a_multi_lattice_archive(tmp_path):
     """Input order is kept, empty lattices still produce a record, batching does not change the
     output, binary input gives the same result as text input, scales reach the GPU."""
