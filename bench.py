@@ -189,7 +189,7 @@ def main():
                               "algorithmic_bytes_per_step": step_bytes},
             "kernel_ms": {"sweep": sweep_avg, "posterior": float(np.mean(post_ms)),
                           "convert": float(np.mean(conv_ms)), "device_total": float(np.mean(tot_ms))},
-            "pack_seconds_host": pack_s,
+            "batch_create_seconds": pack_s,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ns, fo, args.seed, scales)

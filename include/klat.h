@@ -191,8 +191,12 @@ int klat_utterance_scores(klat_batch* batch, const int64_t* word_off, const int3
 int klat_frame_post(klat_batch* batch, const int32_t* num_frames, int64_t* frame_off,
                     int32_t* labels, float* logps, int64_t capacity, int64_t* num_entries);
 
-/* Host-only view of the packed lockstep streams (no device needed): what klat_batch_create
- * uploads.  jobs: 24-byte records {int64 chunk_off; int32 nchunks, dir, lane_tab, pad};
+/* The streams of a batch as klat_batch_create built them on the device (for tests: they must equal
+ * klat_pack_host's, bit for bit).  Arrays of fwd_slots + bwd_slots entries each. */
+int klat_batch_get_streams(klat_batch* batch, int32_t* sw, float* sg, float* sa);
+
+/* Host-only view of the packed lockstep streams (no device needed): the host packer that defines
+ * the stream format klat_batch_create's device packer reproduces.  jobs: 24-byte records {int64 chunk_off; int32 nchunks, dir, lane_tab, pad};
  * lanes: 16-byte records {int64 state_base; int32 num_states, lattice};
  * items: 16-byte records {int64 arc_begin; int32 count, lattice}.  Stream slot of
  * (chunk c, lane l, round r) is ((chunk_off + c) * 64 + l) * 4 + r. */

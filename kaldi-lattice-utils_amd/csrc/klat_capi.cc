@@ -4,7 +4,9 @@
 // and fails loudly (KLAT_ERR_NO_DEVICE / KLAT_ERR_HIP) otherwise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <cstdio>
 #include <cstring>
@@ -14,6 +16,7 @@
 
 #include "../../include/klat.h"
 #include "klat_internal.h"
+#include "klat_pack_device.h"
 
 namespace klat {
 
@@ -114,31 +117,42 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   *out = nullptr;
   klat_pack_options o = {0, 0, 0};
   if (opt) o = *opt;
+  // The streams are built on the device from the CSR arrays (klat_pack_device.hip); the host
+  // packer (same streams, bit for bit) remains behind klat_pack_host and KLAT_HOST_PACK=1.
+  const bool host_pack = std::getenv("KLAT_HOST_PACK") != nullptr;
   PackedBatch P;
   std::string err;
-  int rc = pack_batch(*d, o, &P, &err);
-  if (rc != KLAT_OK) return set_error(rc, err);
+  int rc = KLAT_OK;
+  const int64_t U = d->num_lattices;
+  if (U < 0 || (U > 0 && (!d->state_off || !d->arc_off))) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc: null offsets");
+  const int64_t S_tot = U ? d->state_off[U] : 0, A_tot = U ? d->arc_off[U] : 0;
+  if (host_pack) {
+    rc = pack_batch(*d, o, &P, &err);
+    if (rc != KLAT_OK) return set_error(rc, err);
+  } else {
+    if (A_tot > 0 && (!d->src || !d->dst || !d->graph || !d->acoustic || !d->ilabel))
+      return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc: null arc arrays");
+    if (S_tot > 0 && (!d->final_graph || !d->final_acoustic))
+      return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc: null final-weight arrays");
+    if (S_tot + 2 * U >= (int64_t)1 << 31 || A_tot >= (int64_t)1 << 31)
+      return set_error(KLAT_ERR_INVALID_ARG, "batch too large for 32-bit stream positions: split it");
+    for (int64_t u = 0; u < U; ++u)
+      if (d->state_off[u + 1] - d->state_off[u] >= (int64_t)kRelMask)
+        return set_error(KLAT_ERR_INVALID_ARG, "lattice " + std::to_string(u) + ": too many states");
+    int G = o.lanes_per_lattice ? o.lanes_per_lattice : choose_lanes_per_lattice(U, S_tot, A_tot);
+    if (G < 1 || G > 64 || (G & (G - 1))) return set_error(KLAT_ERR_INVALID_ARG, "lanes_per_lattice must be a power of two in [1,64]");
+    if (o.ring_slots != 0 && (o.ring_slots < 8 || o.ring_slots > 1024 || (o.ring_slots & (o.ring_slots - 1))))
+      return set_error(KLAT_ERR_INVALID_ARG, "ring_slots must be a power of two in [8,1024]");
+    P.G = G;
+  }
 
   KLAT_HIP(hipSetDevice(c->device));
   klat_batch* b = new (std::nothrow) klat_batch();
   if (!b) return set_error(KLAT_ERR_OOM, "host allocation failed");
   b->ctx = c;
-  b->U = d->num_lattices;
-  b->S = b->U ? d->state_off[b->U] : 0;
-  b->A = b->U ? d->arc_off[b->U] : 0;
-  b->G = P.G;
-  b->W = P.W;
-  b->num_jobs = (int)P.jobs.size();
-  b->num_items = (int)P.items.size();
-  b->info.num_states = b->S;
-  b->info.num_arcs = b->A;
-  b->info.fwd_slots = P.fwd_slots;
-  b->info.bwd_slots = P.bwd_slots;
-  b->info.far_terms = P.far_terms;
-  b->info.lanes_per_lattice = P.G;
-  b->info.ring_slots = P.W;
-  b->info.num_jobs = b->num_jobs;
-  b->info.max_rounds = P.max_rounds;
+  b->U = U;
+  b->S = S_tot;
+  b->A = A_tot;
   b->h_state_off.assign(d->state_off, d->state_off + b->U + 1);
   b->h_arc_off.assign(d->arc_off, d->arc_off + b->U + 1);
 
@@ -158,6 +172,11 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       return rc;                                                     \
     }                                                                \
   } while (0)
+#define FAIL(code, msg)                                              \
+  do {                                                               \
+    klat_batch_destroy(b);                                           \
+    return set_error(code, msg);                                     \
+  } while (0)
   UP(state_off, d->state_off, b->U + 1);
   UP(arc_off, d->arc_off, b->U + 1);
   UP(src, d->src, b->A);
@@ -169,10 +188,110 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   if (d->state_time) UP(state_time, d->state_time, b->S);
   UP(final_graph, d->final_graph, b->S);
   UP(final_acoustic, d->final_acoustic, b->S);
-  UP(sw, P.sw.data(), P.sw.size());
-  UP(sg, P.sg.data(), P.sg.size());
-  UP(sa, P.sa.data(), P.sa.size());
-  UP(jobs, P.jobs.data(), P.jobs.size());
+  if (host_pack) {
+    UP(sw, P.sw.data(), P.sw.size());
+    UP(sg, P.sg.data(), P.sg.size());
+    UP(sa, P.sa.data(), P.sa.size());
+  } else {
+    // pass 1 on the device: validation, arcs by destination, rounds per state and per lattice
+    DevBuf<int32_t> cnt, r0f, r0b, frank, in_arc, rounds, status;
+    DevBuf<PackEntry> d_entries;
+    const int32_t status0[4] = {0, -1, 1, 0};
+    if ((rc = cnt.alloc((size_t)(S_tot + 2 * U))) || (rc = r0f.alloc((size_t)(S_tot + 2 * U))) ||
+        (rc = r0b.alloc((size_t)(S_tot + 2 * U))) || (rc = frank.alloc((size_t)S_tot)) || (rc = in_arc.alloc((size_t)A_tot)) ||
+        (rc = rounds.alloc((size_t)(2 * U))) || (rc = status.upload(status0, 4, c->stream))) {
+      klat_batch_destroy(b);
+      return rc;
+    }
+    PackDevArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.state_off = b->state_off.p;
+    pa.arc_off = b->arc_off.p;
+    pa.src = b->src.p;
+    pa.dst = b->dst.p;
+    pa.ilabel = b->ilabel.p;
+    pa.graph = b->graph.p;
+    pa.acoustic = b->acoustic.p;
+    pa.final_graph = b->final_graph.p;
+    pa.final_acoustic = b->final_acoustic.p;
+    pa.G = P.G;
+    pa.cnt = cnt.p;
+    pa.r0f = r0f.p;
+    pa.r0b = r0b.p;
+    pa.frank = frank.p;
+    pa.in_arc = in_arc.p;
+    pa.rounds = rounds.p;
+    pa.status = status.p;
+    std::vector<int32_t> h_rounds((size_t)(2 * U));
+    int32_t h_status[4] = {0, -1, 1, 0};
+    hipError_t he = launch_pack_count(pa, (int)U, c->stream);
+    if (he == hipSuccess && U > 0)
+      he = hipMemcpyAsync(h_rounds.data(), rounds.p, sizeof(int32_t) * h_rounds.size(), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he != hipSuccess) {
+      klat_batch_destroy(b);
+      return hip_fail(he, "stream packing (count pass)");
+    }
+    if (h_status[0] != 0)
+      FAIL(h_status[0] == 2 ? KLAT_ERR_BAD_TOPOLOGY : KLAT_ERR_INVALID_ARG,
+           "lattice " + std::to_string(h_status[1]) +
+               (h_status[0] == 2 ? ": arc with dst <= src or out of range (lattice is not topologically sorted)"
+                                 : ": malformed CSR (state ids out of range or arcs not grouped by source)"));
+    const int LPW = 64 / P.G;
+    const int W = o.ring_slots ? o.ring_slots : choose_ring_slots(P.G, h_status[2]);
+    if ((int64_t)W * LPW > kMaxRingCells) FAIL(KLAT_ERR_INVALID_ARG, "ring_slots * (64 / lanes_per_lattice) must not exceed 4032 ring cells per workgroup");
+    std::vector<int64_t> rf((size_t)U), rb((size_t)U);
+    for (int64_t u = 0; u < U; ++u) rf[(size_t)u] = h_rounds[(size_t)(2 * u)], rb[(size_t)u] = h_rounds[(size_t)(2 * u + 1)];
+    std::vector<std::vector<int64_t>> job_lats;
+    const int64_t chunk_total = slice_jobs(d->state_off, U, rf, rb, P.G, W, &P, &job_lats);
+    // pass 2: one workgroup per (job, slot)
+    std::vector<PackEntry> entries;
+    entries.reserve(job_lats.size() * (size_t)LPW);
+    for (size_t j = 0; j < job_lats.size(); ++j)
+      for (int k = 0; k < LPW; ++k)
+        entries.push_back(PackEntry{k < (int)job_lats[j].size() ? (int32_t)job_lats[j][(size_t)k] : -1, (int32_t)j, k, 0});
+    const size_t nslots = (size_t)chunk_total * 64 * kChunkRounds;
+    AL(sw, nslots);
+    AL(sg, nslots);
+    AL(sa, nslots);
+    UP(jobs, P.jobs.data(), P.jobs.size());
+    if ((rc = d_entries.upload(entries.data(), entries.size(), c->stream))) {
+      klat_batch_destroy(b);
+      return rc;
+    }
+    pa.W = W;
+    pa.entries = d_entries.p;
+    pa.jobs = b->jobs.p;
+    pa.sw = b->sw.p;
+    pa.sg = b->sg.p;
+    pa.sa = b->sa.p;
+    he = launch_pack_fill(pa, (int)entries.size(), c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);  // scratch and entries go out of scope below
+    if (he != hipSuccess) {
+      klat_batch_destroy(b);
+      return hip_fail(he, "stream packing (fill pass)");
+    }
+    P.far_terms = h_status[3];
+    for (int64_t u = 0; u < U; ++u)
+      for (int64_t a0 = d->arc_off[u]; a0 < d->arc_off[u + 1]; a0 += kPostItemArcs)
+        P.items.push_back(PostItem{a0, (int32_t)std::min<int64_t>(kPostItemArcs, d->arc_off[u + 1] - a0), (int32_t)u});
+  }
+  b->G = P.G;
+  b->W = P.W;
+  b->num_jobs = (int)P.jobs.size();
+  b->num_items = (int)P.items.size();
+  b->info.num_states = b->S;
+  b->info.num_arcs = b->A;
+  b->info.fwd_slots = P.fwd_slots;
+  b->info.bwd_slots = P.bwd_slots;
+  b->info.far_terms = P.far_terms;
+  b->info.lanes_per_lattice = P.G;
+  b->info.ring_slots = P.W;
+  b->info.num_jobs = b->num_jobs;
+  b->info.max_rounds = P.max_rounds;
+  if (host_pack) UP(jobs, P.jobs.data(), P.jobs.size());
   UP(lanes, P.lanes.data(), P.lanes.size());
   UP(items, P.items.data(), P.items.size());
   AL(job_flags, P.jobs.size());
@@ -185,6 +304,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   AL(logpost, b->A);
 #undef UP
 #undef AL
+#undef FAIL
   hipError_t e = hipStreamSynchronize(c->stream);  // uploads read pageable host memory of P
   if (e != hipSuccess) {
     klat_batch_destroy(b);
@@ -371,6 +491,18 @@ int klat_prune_mask(klat_batch* b, float beam, uint8_t* keep_arc, uint8_t* keep_
   if (lattice_beam && b->U > 0)
     KLAT_HIP(hipMemcpyAsync(lattice_beam, d_beam.p, sizeof(double) * (size_t)b->U, hipMemcpyDeviceToHost, c->stream));
   KLAT_HIP(hipStreamSynchronize(c->stream));
+  return KLAT_OK;
+}
+
+int klat_batch_get_streams(klat_batch* b, int32_t* sw, float* sg, float* sa) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  const size_t n = (size_t)(b->info.fwd_slots + b->info.bwd_slots);
+  if (n == 0) return KLAT_OK;
+  if (sw) KLAT_HIP(hipMemcpyAsync(sw, b->sw.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
+  if (sg) KLAT_HIP(hipMemcpyAsync(sg, b->sg.p, n * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
+  if (sa) KLAT_HIP(hipMemcpyAsync(sa, b->sa.p, n * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   return KLAT_OK;
 }
 

@@ -82,6 +82,65 @@ int choose_ring_slots(int G, int64_t max_rel) {
   return W;
 }
 
+int64_t slice_jobs(const int64_t* state_off, int64_t U, const std::vector<int64_t>& rf, const std::vector<int64_t>& rb,
+                   int G, int W, PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats) {
+  const int LPW = 64 / G;
+  const int D = kPrefetchChunks;
+  // ---- slicing: lattices of similar length share a wave ----
+  std::vector<int64_t> live;
+  for (int64_t u = 0; u < U; ++u)
+    if (state_off[u + 1] > state_off[u]) live.push_back(u);
+  struct ProtoJob {
+    int dir;
+    int64_t rounds;
+    std::vector<int64_t> lat;
+  };
+  std::vector<ProtoJob> proto;
+  for (int dir = 0; dir < 2; ++dir) {
+    const std::vector<int64_t>& r = dir ? rb : rf;
+    std::vector<int64_t> order(live);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r[a] > r[b]; });
+    for (size_t i = 0; i < order.size(); i += LPW) {
+      ProtoJob pj;
+      pj.dir = dir;
+      pj.rounds = r[order[i]];
+      for (size_t j = i; j < std::min(order.size(), i + (size_t)LPW); ++j) pj.lat.push_back(order[j]);
+      proto.push_back(std::move(pj));
+    }
+  }
+  std::stable_sort(proto.begin(), proto.end(),
+                   [](const ProtoJob& a, const ProtoJob& b) { return a.rounds > b.rounds; });
+
+  PackedBatch& P = *out;
+  P.G = G;
+  P.W = W;
+  P.jobs.resize(proto.size());
+  P.lanes.assign(proto.size() * LPW, LaneInfo{-1, 0, -1});
+  job_lats->resize(proto.size());
+  int64_t chunk_total = 0;
+  for (size_t j = 0; j < proto.size(); ++j) {
+    int64_t nch = ceil_div(proto[j].rounds, kChunkRounds);
+    nch = ceil_div(nch, D) * D;
+    P.jobs[j].chunk_off = chunk_total;
+    P.jobs[j].nchunks = (int32_t)nch;
+    P.jobs[j].dir = proto[j].dir;
+    P.jobs[j].lane_tab = (int32_t)(j * LPW);
+    P.jobs[j].pad = 0;
+    chunk_total += nch;
+    (proto[j].dir ? P.bwd_slots : P.fwd_slots) += nch * kChunkRounds * 64;
+    P.max_rounds = std::max<int32_t>(P.max_rounds, (int32_t)(nch * kChunkRounds));
+    for (size_t k = 0; k < proto[j].lat.size(); ++k) {
+      const int64_t u = proto[j].lat[k];
+      LaneInfo& li = P.lanes[j * LPW + k];
+      li.state_base = state_off[u];
+      li.num_states = (int32_t)(state_off[u + 1] - state_off[u]);
+      li.lattice = (int32_t)u;
+    }
+    (*job_lats)[j] = std::move(proto[j].lat);
+  }
+  return chunk_total;
+}
+
 int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBatch* out,
                std::string* err) {
   const int64_t U = d.num_lattices;
@@ -178,56 +237,9 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
     return KLAT_ERR_INVALID_ARG;
   }
 
-  // ---- slicing: lattices of similar length share a wave ----
-  std::vector<int64_t> live;
-  for (int64_t u = 0; u < U; ++u)
-    if (d.state_off[u + 1] > d.state_off[u]) live.push_back(u);
-  struct ProtoJob {
-    int dir;
-    int64_t rounds;
-    std::vector<int64_t> lat;
-  };
-  std::vector<ProtoJob> proto;
-  for (int dir = 0; dir < 2; ++dir) {
-    const std::vector<int64_t>& r = dir ? rb : rf;
-    std::vector<int64_t> order(live);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r[a] > r[b]; });
-    for (size_t i = 0; i < order.size(); i += LPW) {
-      ProtoJob pj;
-      pj.dir = dir;
-      pj.rounds = r[order[i]];
-      for (size_t j = i; j < std::min(order.size(), i + (size_t)LPW); ++j) pj.lat.push_back(order[j]);
-      proto.push_back(std::move(pj));
-    }
-  }
-  std::stable_sort(proto.begin(), proto.end(),
-                   [](const ProtoJob& a, const ProtoJob& b) { return a.rounds > b.rounds; });
-
   PackedBatch& P = *out;
-  P.G = G;
-  P.W = W;
-  P.jobs.resize(proto.size());
-  P.lanes.assign(proto.size() * LPW, LaneInfo{-1, 0, -1});
-  int64_t chunk_total = 0;
-  for (size_t j = 0; j < proto.size(); ++j) {
-    int64_t nch = ceil_div(proto[j].rounds, kChunkRounds);
-    nch = ceil_div(nch, D) * D;
-    P.jobs[j].chunk_off = chunk_total;
-    P.jobs[j].nchunks = (int32_t)nch;
-    P.jobs[j].dir = proto[j].dir;
-    P.jobs[j].lane_tab = (int32_t)(j * LPW);
-    P.jobs[j].pad = 0;
-    chunk_total += nch;
-    (proto[j].dir ? P.bwd_slots : P.fwd_slots) += nch * kChunkRounds * 64;
-    P.max_rounds = std::max<int32_t>(P.max_rounds, (int32_t)(nch * kChunkRounds));
-    for (size_t k = 0; k < proto[j].lat.size(); ++k) {
-      const int64_t u = proto[j].lat[k];
-      LaneInfo& li = P.lanes[j * LPW + k];
-      li.state_base = d.state_off[u];
-      li.num_states = (int32_t)(d.state_off[u + 1] - d.state_off[u]);
-      li.lattice = (int32_t)u;
-    }
-  }
+  std::vector<std::vector<int64_t>> job_lats;
+  const int64_t chunk_total = slice_jobs(d.state_off, U, rf, rb, G, W, &P, &job_lats);
   const size_t nslots = (size_t)chunk_total * 64 * kChunkRounds;
   if (!P.sw.resize(nslots) || !P.sg.resize(nslots) || !P.sa.resize(nslots)) {
     *err = "out of host memory for the arc streams";
@@ -236,7 +248,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
 
   // ---- pass 2: fill ----
   std::atomic<int64_t> far(0);
-  parallel_for((int64_t)proto.size(), threads, [&](int64_t j) {
+  parallel_for((int64_t)job_lats.size(), threads, [&](int64_t j) {
     const SweepJob& job = P.jobs[j];
     const size_t b0 = (size_t)job.chunk_off * 64 * kChunkRounds;
     const size_t n = (size_t)job.nchunks * 64 * kChunkRounds;
@@ -252,8 +264,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
     };
     std::vector<int64_t> in_begin;
     std::vector<int32_t> in_arc, out_ord;
-    for (size_t k = 0; k < proto[j].lat.size(); ++k) {
-      const int64_t u = proto[j].lat[k];
+    for (size_t k = 0; k < job_lats[j].size(); ++k) {
+      const int64_t u = job_lats[j][k];
       const int64_t s0 = d.state_off[u], a0 = d.arc_off[u];
       const int64_t S = d.state_off[u + 1] - s0, A = d.arc_off[u + 1] - a0;
       const int lane0 = (int)k * G;

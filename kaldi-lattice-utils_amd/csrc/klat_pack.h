@@ -55,6 +55,13 @@ struct PackedBatch {
 int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBatch* out,
                std::string* err);
 
+// Job slicing shared by the host and the device packer: lattices sorted by round count, 64/G per
+// job, jobs longest first; fills out->jobs / lanes / slot totals / max_rounds, returns the number
+// of chunks and, per job, its lattices in slot order.
+int64_t slice_jobs(const int64_t* state_off, int64_t num_lattices, const std::vector<int64_t>& rounds_fwd,
+                   const std::vector<int64_t>& rounds_bwd, int G, int W, PackedBatch* out,
+                   std::vector<std::vector<int64_t>>* job_lats);
+
 // Heuristics used when the options leave G / W at 0.
 int choose_lanes_per_lattice(int64_t num_lattices, int64_t num_states, int64_t num_arcs);
 int choose_ring_slots(int G, int64_t max_rel);

@@ -276,6 +276,14 @@ class Batch:
         _check(lib().klat_frame_post(self.h, _p(nf), _p(off), _p(labels), _p(logps), C.c_int64(len(labels)), C.byref(n)))
         return off, labels[:n.value], logps[:n.value]
 
+    def streams(self):
+        """(sw, sg, sa) as built on the device by klat_batch_create."""
+        i = self.info()
+        n = i["fwd_slots"] + i["bwd_slots"]
+        sw, sg, sa = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        _check(lib().klat_batch_get_streams(self.h, _p(sw), _p(sg), _p(sa)))
+        return sw, sg, sa
+
     def viterbi(self, graph_scale=1.0, acoustic_scale=1.0, insertion_penalty=0.0):
         s = Scales(graph_scale, acoustic_scale, insertion_penalty)
         _check(lib().klat_viterbi(self.h, C.byref(s)))

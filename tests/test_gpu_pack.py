@@ -1,0 +1,64 @@
+"""The device-side stream packer (csrc/klat_pack_device.hip, behind klat_batch_create) against the
+host packer that defines the stream format (klat_pack_host): same layout choice, same jobs, and
+the same term words and costs, bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
+import klat_amd  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = klat_amd.Ctx(0)
+    yield c
+    c.close()
+
+
+def _arrays(seed, long_spans, many_finals):
+    rng = np.random.RandomState(seed)
+    ns = np.concatenate([[1, 2, 3], rng.randint(2, 400, size=45), [1500]]).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4, 7], size=len(ns)).astype(np.int32)
+    a = klat_amd.synth(seed, ns, fo)
+    if long_spans:
+        lat = np.repeat(np.arange(len(ns)), np.diff(a["arc_off"]))
+        src, dst = a["src"], a["dst"].copy()
+        st = (rng.rand(len(dst)) < 0.3) & (dst != src + 1)
+        dst[st] = np.minimum(src[st] + rng.randint(2, 150, size=int(st.sum())), ns[lat][st] - 1)
+        a["dst"] = dst.astype(np.int32)
+    if many_finals:
+        fin = rng.rand(len(a["final_graph"])) < 0.15
+        a["final_graph"][fin] = (rng.rand(int(fin.sum())) * 3).astype(np.float32)
+        a["final_acoustic"][fin] = (rng.rand(int(fin.sum())) * 3).astype(np.float32)
+    # an empty lattice in the middle
+    return a
+
+
+@pytest.mark.parametrize("G,W", [(0, 0), (1, 16), (2, 8), (4, 32), (8, 64), (64, 16)])
+@pytest.mark.parametrize("long_spans,many_finals", [(False, False), (True, True)])
+def test_device_streams_equal_host_streams(ctx, G, W, long_spans, many_finals):
+    a = _arrays(17 + G, long_spans, many_finals)
+    host = klat_amd.pack_host(a, lanes_per_lattice=G, ring_slots=W)
+    b = klat_amd.Batch(ctx, a, lanes_per_lattice=G, ring_slots=W)
+    info = b.info()
+    sw, sg, sa = b.streams()
+    b.close()
+    for k in ("lanes_per_lattice", "ring_slots", "num_jobs", "max_rounds", "fwd_slots", "bwd_slots", "far_terms"):
+        assert info[k] == host["info"][k], (k, info[k], host["info"][k])
+    assert np.array_equal(sw, host["sw"])
+    assert np.array_equal(sg.view(np.uint32), host["sg"].view(np.uint32))
+    assert np.array_equal(sa.view(np.uint32), host["sa"].view(np.uint32))
+
+
+def test_device_packer_reports_bad_topology(ctx):
+    a = klat_amd.synth(2, np.array([6, 9], np.int32), np.array([2, 3], np.int32))
+    a["dst"][int(a["arc_off"][1]) + 3] = 0  # an arc of the second lattice goes backwards
+    with pytest.raises(klat_amd.KlatError) as e:
+        klat_amd.Batch(ctx, a)
+    assert e.value.code == klat_amd.ERR_BAD_TOPOLOGY and "lattice 1" in str(e.value)
