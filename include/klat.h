@@ -49,7 +49,10 @@ typedef struct klat_batch klat_batch;
  * Arcs of one lattice must be grouped by src in stored order (the order the reference's
  * ArcIterator visits them, needed by the first-maximum rule of
  * kwsbin2/lattice-word-index-position.cc:178).
- * final_graph/final_acoustic: +inf,+inf marks a non-final state (Weight::Zero()). */
+ * final_graph/final_acoustic: +inf,+inf marks a non-final state (Weight::Zero()).
+ * state_off / arc_off are read on the host; the arc and state arrays may be host OR device
+ * pointers (lattices produced on the GPU need no round trip): the stream packer runs on the
+ * device. */
 typedef struct {
   int32_t num_lattices;
   const int64_t* state_off;     /* [num_lattices+1] */

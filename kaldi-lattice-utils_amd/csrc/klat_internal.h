@@ -51,8 +51,10 @@ struct DevBuf {
     int rc = alloc(count);
     if (rc != KLAT_OK) return rc;
     if (count == 0) return KLAT_OK;
-    hipError_t e = hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(H2D)");
+    // hipMemcpyDefault: the source may be host or device memory (klat_batch_desc's arc and state
+    // arrays may already live on the GPU)
+    hipError_t e = hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyDefault, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
     return KLAT_OK;
   }
 };

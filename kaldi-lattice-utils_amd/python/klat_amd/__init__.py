@@ -125,6 +125,9 @@ def make_desc(arrays):
         if a is None:
             setattr(d, name, None)
             continue
+        if isinstance(a, int):  # a device pointer (the caller keeps the allocation alive)
+            setattr(d, name, a)
+            continue
         a = np.ascontiguousarray(a, dtype=dt)
         keep[name] = a
         setattr(d, name, a.ctypes.data)

@@ -62,3 +62,30 @@ def test_device_packer_reports_bad_topology(ctx):
     with pytest.raises(klat_amd.KlatError) as e:
         klat_amd.Batch(ctx, a)
     assert e.value.code == klat_amd.ERR_BAD_TOPOLOGY and "lattice 1" in str(e.value)
+
+
+def test_batch_from_device_resident_arrays(ctx):
+    """The arc and state arrays of klat_batch_desc may be device pointers (only the two offset
+    arrays are read on the host): same results as from host arrays."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")  # the runtime libklat.so itself is linked against
+    a = _arrays(5, True, True)
+    b = klat_amd.Batch(ctx, a)
+    b.forward_backward(1.0, 0.1, 0.0)
+    want = b.arc_logpost()
+    b.close()
+    dev, ptrs = dict(a), []
+    for name in ("src", "dst", "ilabel", "olabel", "graph", "acoustic", "final_graph", "final_acoustic", "state_time"):
+        h = np.ascontiguousarray(a[name])
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(max(h.nbytes, 4))) == 0
+        assert hip.hipMemcpy(p, C.c_void_p(h.ctypes.data), C.c_size_t(h.nbytes), C.c_int(1)) == 0  # hipMemcpyHostToDevice
+        ptrs.append(p)
+        dev[name] = int(p.value)
+    b = klat_amd.Batch(ctx, dev)
+    b.forward_backward(1.0, 0.1, 0.0)
+    got = b.arc_logpost()
+    b.close()
+    for p in ptrs:
+        hip.hipFree(p)
+    assert np.array_equal(got, want)
