@@ -238,7 +238,9 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
           // arc cost here as a float sum, so swap the double sum for the float one
           float g, ac;
           arc_cost_parts(a.graph[arc], a.acoustic[arc], true, sp, g, ac);
-          const double x = a.logpost[arc] + ((double)g + (double)ac) - (double)(g + ac);
+          // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
+          const double lpa = a.logpost[arc];
+          const double x = (lpa > -INFINITY) ? lpa + ((double)g + (double)ac) - (double)(g + ac) : lpa;
           acc = (j == i) ? x : fr_log_add(acc, x);
         }
         const float lp = (float)acc;  // BaseFloat narrowing of :126

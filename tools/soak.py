@@ -71,6 +71,25 @@ while time.time() < t_end:
             wd = dict(uw)
             for w, p in zip(words, lp):
                 assert abs(p - wd[int(w)]) < 1e-6 * max(1.0, abs(p)) or (np.isinf(p) and np.isinf(wd[int(w)])), (seed, u, w, p, wd[int(w)])
+    # frame posteriors and position index on a few small lattices
+    small = [u for u in range(U) if ok[u] and 0 < len(lats[u].dst) <= 400][:3]
+    if small:
+        nf = np.zeros(U, np.int32)
+        for u in small:
+            t = a["state_time"][a["state_off"][u]:a["state_off"][u + 1]]
+            nf[u] = int(t.max()) if len(t) else 0
+        foff, flab, flp = b.frame_post(nf)
+        base = np.concatenate([[0], np.cumsum(nf)])
+        for u in small:
+            sl = orc.scale_and_penalize(lats[u], *scales)
+            al, be, to, _, _ = orc.alphas_betas(sl)
+            t = a["state_time"][a["state_off"][u]:a["state_off"][u + 1]]
+            want, _ = orc.frame_post(sl, t, int(nf[u]), al, be, to)
+            for k in range(int(nf[u])):
+                g = sorted(zip(flab[foff[base[u] + k]:foff[base[u] + k + 1]].tolist(), flp[foff[base[u] + k]:foff[base[u] + k + 1]].tolist()))
+                w = sorted((l, float(p)) for l, p in want[k])
+                assert [x[0] for x in g] == [x[0] for x in w], (seed, u, k)
+                assert all(abs(x[1] - y[1]) < 1e-4 * max(1.0, abs(y[1])) or x[1] == y[1] for x, y in zip(g, w)), (seed, u, k, g, w)
     b.viterbi(*scales)
     fw, bw, best = b.viterbi_costs()
     for u in rng.choice(U, min(U, 6), replace=False):
