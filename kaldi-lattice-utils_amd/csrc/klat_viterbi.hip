@@ -107,7 +107,8 @@ __global__ __launch_bounds__(64) void viterbi_kernel(ViterbiArgs a) {
 // ComputeLatticeBeam and the PruneLattice decisions of one lattice per workgroup: arcs whose best
 // path costs more than best + beam are dropped (keep_arc = 0), so are such final weights;
 // lattice_beam = the largest (best path through an arc or final) - best, i.e. the beam at which
-// nothing would be pruned (latbin/lattice-prune-dyn-beam.cc:64-88).
+// nothing would be pruned (latbin/lattice-prune-dyn-beam.cc:64-88); as there, an arc that lies on no
+// complete path makes it +inf.
 __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
   __shared__ double red[256];
   const int u = blockIdx.x;
@@ -127,14 +128,14 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a) {
     const double c = arc_cost(a.graph[a0 + i], a.acoustic[a0 + i], a.ilabel[a0 + i] != 0, a.sp);
     const double through = fv[a.src[a0 + i]] + (c + bv[a.dst[a0 + i]]);
     if (a.keep_arc) a.keep_arc[a0 + i] = (through > cutoff) ? 0 : 1;
-    if (through > worst && through < INFINITY) worst = through;
+    if (through > worst) worst = through;
   }
   for (int s = threadIdx.x; s < S; s += 256) {
     const double fc = arc_cost(a.final_graph[s0 + s], a.final_acoustic[s0 + s], false, a.sp);
     const bool is_final = fc != INFINITY;
     const double through = fv[s] + fc;
     if (a.keep_final) a.keep_final[s0 + s] = (is_final && !(through > cutoff)) ? 1 : 0;
-    if (is_final && through > worst && through < INFINITY) worst = through;
+    if (is_final && through > worst) worst = through;
   }
   red[threadIdx.x] = worst;
   __syncthreads();

@@ -91,9 +91,9 @@ int main(int argc, char* argv[]) {
             std::fill(state_excess.begin(), state_excess.end(), inf);
             num_arcs = 0;
             for (int32_t s = 0; s < S; ++s) {
-              if (!(final_excess[(size_t)s] > cutoff)) state_excess[(size_t)s] = 0.0;
+              if (final_excess[(size_t)s] <= cutoff && final_excess[(size_t)s] < inf) state_excess[(size_t)s] = 0.0;
               for (size_t i = 0; i < excess[(size_t)s].size(); ++i)
-                if (!(excess[(size_t)s][i] > cutoff)) {
+                if (excess[(size_t)s][i] <= cutoff && excess[(size_t)s][i] < inf) {  // Connect drops dead arcs
                   ++num_arcs;
                   state_excess[(size_t)s] = 0.0;
                   state_excess[(size_t)clat.State(s).arcs[i].nextstate] = 0.0;
@@ -103,6 +103,11 @@ int main(int argc, char* argv[]) {
             for (int32_t s = 0; s < S; ++s) num_states += state_excess[(size_t)s] == 0.0;
           };
           for (size_t n_try = 1; beam > min_beam && (num_arcs > max_num_arcs || num_states > max_num_states); ++n_try) {
+            if (n_try > 1 && beam == inf) {  // the reference never leaves this loop (:168-172)
+              KLAT_LOG("WARNING: lattice " << keys[u] << " has arcs on no complete path (beam = inf) and is still over the limits "
+                       "once they are removed; written as is");
+              break;
+            }
             beam = beam_ratio * beam;
             cutoff = best[u] + (double)(float)beam;  // PruneLattice takes the beam as a BaseFloat
             const int64_t prev_arcs = num_arcs;
@@ -115,7 +120,7 @@ int main(int argc, char* argv[]) {
           for (int32_t s = 0; s < S; ++s) {
             CompactLatticeState& st = clat.State(s);
             keep[(size_t)s].resize(st.arcs.size());
-            for (size_t i = 0; i < st.arcs.size(); ++i) keep[(size_t)s][i] = !(excess[(size_t)s][i] > cutoff);
+            for (size_t i = 0; i < st.arcs.size(); ++i) keep[(size_t)s][i] = excess[(size_t)s][i] <= cutoff && excess[(size_t)s][i] < inf;
             if (st.IsFinal() && final_excess[(size_t)s] > cutoff) {
               st.final_graph = st.final_acoustic = std::numeric_limits<float>::infinity();
               st.final_string_len = 0;

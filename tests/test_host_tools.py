@@ -390,6 +390,29 @@ def test_prune_dyn_beam_tool_matches_oracle_loop(tmp_path, golden_dir, limits, s
 
 
 @pytest.mark.gpu
+def test_prune_dyn_beam_with_an_arc_on_no_complete_path(tmp_path):
+    """An arc into a dead end makes ComputeLatticeBeam +inf (latbin/lattice-prune-dyn-beam.cc:83-85);
+    the first PruneLattice pass then only trims the lattice, which is enough here.  Where it is not,
+    the reference never leaves its loop; this tool says so and writes the trimmed lattice."""
+    txt = str(tmp_path / "in.txt")
+    with open(txt, "w") as f:
+        f.write("dead\n0\t1\t5\t1,2,7\n0\t2\t6\t0.5,1,7\n1\t3\t8\t1,1,7_7\n3\n\n")
+    ins = latfmt.read_text_archive(txt)
+    lat = latfmt.prepare(ins[0])
+    assert orc.lattice_beam(lat)[0] == np.inf
+    for limit, hang in (("--max-arcs=2", False), ("--max-arcs=1", True)):
+        out = str(tmp_path / "out.txt")
+        rc, _, err = run("lattice-prune-dyn-beam", limit, "ark:" + txt, "ark,t:" + out)
+        assert rc == 0, err
+        got = latfmt.read_text_archive(out)[0]
+        assert got.S == 3 and got.A == 2 and sorted(got.ilabel.tolist()) == [5, 8]
+        assert ("no complete path" in err) == hang
+        if not hang:
+            arcs, states, beam = orc.prune_dyn_beam(lat, 2, 2 ** 31 - 1)
+            assert arcs.tolist() == [0, 2] and states.tolist() == [0, 1, 3] and beam == np.inf
+
+
+@pytest.mark.gpu
 def test_tools_on_a_multi_lattice_archive(tmp_path):
     """Input order is kept, empty lattices still produce a record, batching does not change the
     output, binary input gives the same result as text input, scales reach the GPU."""

@@ -98,6 +98,26 @@ while time.time() < t_end:
         s0, s1 = int(a["state_off"][u]), int(a["state_off"][u + 1])
         assert np.allclose(fw[s0:s1], wfw, rtol=1e-12, atol=1e-9, equal_nan=True), (seed, u)
         assert np.allclose(bw[s0:s1], wbw, rtol=1e-12, atol=1e-9, equal_nan=True), (seed, u)
+    # PruneLattice decisions on a few lattices
+    beam = float(rng.choice([0.5, 3.0, 12.0]))
+    ka, kf, lb = b.prune_mask(beam)
+    for u in rng.choice(U, min(U, 4), replace=False):
+        sl = orc.scale_and_penalize(lats[u], *scales)
+        if sl.S == 0:
+            continue
+        wbeam, wfw, wbw = orc.lattice_beam(sl)
+        if not np.isfinite(wbw[0]):
+            continue
+        pr = sl.copy()
+        oka = np.zeros(max(sl.A, 1), np.uint8); oks = np.zeros(max(sl.S, 1), np.uint8)
+        orc.lib().kor_prune_lattice(orc.C.c_int32(sl.S), orc._p(pr.arc_begin), orc._p(pr.dst), orc._p(pr.graph), orc._p(pr.acoustic),
+                                    orc._p(pr.final_graph), orc._p(pr.final_acoustic), orc.C.c_double(beam), orc._p(oka), orc._p(oks))
+        a0, a1 = int(a["arc_off"][u]), int(a["arc_off"][u + 1])
+        with np.errstate(invalid="ignore"):
+            through = wfw[sl.src()] + (sl.graph.astype(np.float64) + sl.acoustic.astype(np.float64)) + wbw[sl.dst]
+            sure = ~(np.abs(through - (wbw[0] + beam)) <= 1e-9)
+        assert np.array_equal(ka[a0:a1][sure], oka[:sl.A][sure]), (seed, u)
+        assert lb[u] == wbeam or abs(lb[u] - wbeam) < 1e-9 * max(1.0, abs(wbeam)), (seed, u, lb[u], wbeam)
     info = b.info()
     b.close()
     it += 1
