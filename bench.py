@@ -157,6 +157,22 @@ def main():
     total, tf, tb = batch.totals()
     assert os.environ.get("KLAT_EXPERIMENT") or np.all(np.isfinite(total)) and float(np.max(np.abs(tf - tb))) < 1e-6
 
+    def device_copy_gbs():
+        """Second roofline denominator: what a plain device-to-device copy of 1 GiB
+        reaches on this box, read + write bytes per second."""
+        x = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        y = torch.empty_like(x)
+        x.fill_(1.0)
+        for _ in range(3):
+            y.copy_(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        return 10 * 2.0 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * A * args.steps / elapsed
@@ -166,6 +182,7 @@ def main():
         achieved = sweep_bytes / (sweep_avg * 1e-3) / 1e9
         step_bytes = 56.0 * A + 48.0 * S  # fb + arc posterior: 72 B/arc at fanout 3
         traffic = measured_traffic(info["lanes_per_lattice"])
+        copy_gbs = device_copy_gbs()
         out = {
             "metric": "lattice-arcs/sec (whole node) on forward-backward + arc posteriors",
             "value": value, "unit": "lattice-arcs/s", "n_gpus": world, "steps": args.steps,
@@ -180,6 +197,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "klat::sweep_kernel (forward+backward lockstep sweep)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "device_copy_gbs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
                          "traffic": traffic["bytes"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
                          "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_avg},

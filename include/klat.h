@@ -77,7 +77,8 @@ typedef struct {
 
 /* Packing options (device layout of the lockstep arc streams, DESIGN.md "Data layout"). */
 typedef struct {
-  int32_t lanes_per_lattice; /* G in {1,2,4,8,16,32,64}; 0 = choose from the batch shape */
+  int32_t lanes_per_lattice; /* G in {1,2,4,8,16,32,64} for every lattice; 0 = chosen per lattice from its
+                                fanout and length (lattices of equal G form one layout class) */
   int32_t ring_slots;        /* W, power of two in [8,1024] with W * (64/G) <= 4032; 0 = choose from the batch */
   int32_t host_threads;      /* threads used by the host packer; 0 = hardware concurrency */
 } klat_pack_options;
@@ -86,9 +87,11 @@ typedef struct {
   int64_t num_states, num_arcs;       /* totals over the batch */
   int64_t fwd_slots, bwd_slots;       /* arc-stream slots incl. padding (12 B each) */
   int64_t far_terms;                  /* stream terms whose source fell outside the LDS ring */
-  int32_t lanes_per_lattice, ring_slots;
-  int32_t num_jobs;                   /* waves launched by the sweep kernel */
+  int32_t lanes_per_lattice, ring_slots; /* of the layout class that holds most of the stream */
+  int32_t num_jobs;                   /* workgroups launched by the sweep kernel */
   int32_t max_rounds;                 /* longest lockstep stream, in rounds */
+  int32_t num_layouts;                /* layout classes (distinct lanes_per_lattice) = sweep launches */
+  int32_t reserved;
 } klat_batch_info;
 
 /* Per-kernel device times of the last klat_forward_backward (HIP events on the ctx stream). */
@@ -199,7 +202,7 @@ int klat_frame_post(klat_batch* batch, const int32_t* num_frames, int64_t* frame
 int klat_batch_get_streams(klat_batch* batch, int32_t* sw, float* sg, float* sa);
 
 /* Host-only view of the packed lockstep streams (no device needed): the host packer that defines
- * the stream format klat_batch_create's device packer reproduces.  jobs: 24-byte records {int64 chunk_off; int32 nchunks, dir, lane_tab, pad};
+ * the stream format klat_batch_create's device packer reproduces.  jobs: 24-byte records {int64 chunk_off; int32 nchunks, dir, lane_tab, tag} (tag: bits 0-1 wave priority, 8-15 G, 16-27 W of the job's layout class);
  * lanes: 16-byte records {int64 state_base; int32 num_states, lattice};
  * items: 16-byte records {int64 arc_begin; int32 count, lattice}.  Stream slot of
  * (chunk c, lane l, round r) is ((chunk_off + c) * 64 + l) * 4 + r. */

@@ -36,6 +36,35 @@ int hip_fail(hipError_t e, const char* what) {
 
 using namespace klat;
 
+// Runs launch(layout class, stream) for every layout class of the batch: the first class (longest
+// chain) on the context's stream, the others on side streams that fork from it and join it again,
+// so that the few long workgroups of a skewed batch run beside the many short ones.
+template <class F>
+static int for_each_class(klat_batch* b, F launch) {
+  klat_ctx* c = b->ctx;
+  const size_t n = b->classes.size();
+  if (n <= 1) {
+    if (n == 1) KLAT_HIP(launch(b->classes[0], c->stream));
+    return KLAT_OK;
+  }
+  if (!c->fork_ev) {
+    KLAT_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < klat_ctx::kSideStreams; ++i) {
+      KLAT_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+      KLAT_HIP(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
+    }
+  }
+  KLAT_HIP(hipEventRecord(c->fork_ev, c->stream));
+  const int used = (int)std::min<size_t>(n - 1, klat_ctx::kSideStreams);
+  for (int i = 0; i < used; ++i) KLAT_HIP(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
+  for (size_t k = 0; k < n; ++k) KLAT_HIP(launch(b->classes[k], k == 0 ? c->stream : c->side[(k - 1) % klat_ctx::kSideStreams]));
+  for (int i = 0; i < used; ++i) {
+    KLAT_HIP(hipEventRecord(c->join_ev[i], c->side[i]));
+    KLAT_HIP(hipStreamWaitEvent(c->stream, c->join_ev[i], 0));
+  }
+  return KLAT_OK;
+}
+
 extern "C" {
 
 const char* klat_last_error(void) { return g_last_error.c_str(); }
@@ -98,6 +127,11 @@ void klat_ctx_destroy(klat_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < 5; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < klat_ctx::kSideStreams; ++i) {
+    if (c->side[i]) (void)hipStreamSynchronize(c->side[i]), (void)hipStreamDestroy(c->side[i]);
+    if (c->join_ev[i]) (void)hipEventDestroy(c->join_ev[i]);
+  }
+  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -139,11 +173,10 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     for (int64_t u = 0; u < U; ++u)
       if (d->state_off[u + 1] - d->state_off[u] >= (int64_t)kRelMask)
         return set_error(KLAT_ERR_INVALID_ARG, "lattice " + std::to_string(u) + ": too many states");
-    int G = o.lanes_per_lattice ? o.lanes_per_lattice : choose_lanes_per_lattice(U, S_tot, A_tot);
-    if (G < 1 || G > 64 || (G & (G - 1))) return set_error(KLAT_ERR_INVALID_ARG, "lanes_per_lattice must be a power of two in [1,64]");
+    if (o.lanes_per_lattice < 0 || o.lanes_per_lattice > 64 || (o.lanes_per_lattice & (o.lanes_per_lattice - 1)))
+      return set_error(KLAT_ERR_INVALID_ARG, "lanes_per_lattice must be a power of two in [1,64]");
     if (o.ring_slots != 0 && (o.ring_slots < 8 || o.ring_slots > 1024 || (o.ring_slots & (o.ring_slots - 1))))
       return set_error(KLAT_ERR_INVALID_ARG, "ring_slots must be a power of two in [8,1024]");
-    P.G = G;
   }
 
   KLAT_HIP(hipSetDevice(c->device));
@@ -193,13 +226,15 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     UP(sg, P.sg.data(), P.sg.size());
     UP(sa, P.sa.data(), P.sa.size());
   } else {
-    // pass 1 on the device: validation, arcs by destination, rounds per state and per lattice
-    DevBuf<int32_t> cnt, r0f, r0b, frank, in_arc, rounds, status;
+    // pass 1 on the device: validation, arcs by destination, rounds per lattice for every lane count
+    DevBuf<int32_t> cnt, r0f, r0b, frank, in_arc, status;
+    DevBuf<LatticeRounds> d_rounds;
+    DevBuf<int8_t> d_lat_g;
     DevBuf<PackEntry> d_entries;
     const int32_t status0[4] = {0, -1, 1, 0};
     if ((rc = cnt.alloc((size_t)(S_tot + 2 * U))) || (rc = r0f.alloc((size_t)(S_tot + 2 * U))) ||
         (rc = r0b.alloc((size_t)(S_tot + 2 * U))) || (rc = frank.alloc((size_t)S_tot)) || (rc = in_arc.alloc((size_t)A_tot)) ||
-        (rc = rounds.alloc((size_t)(2 * U))) || (rc = status.upload(status0, 4, c->stream))) {
+        (rc = d_rounds.alloc((size_t)U)) || (rc = status.upload(status0, 4, c->stream))) {
       klat_batch_destroy(b);
       return rc;
     }
@@ -214,19 +249,18 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pa.acoustic = b->acoustic.p;
     pa.final_graph = b->final_graph.p;
     pa.final_acoustic = b->final_acoustic.p;
-    pa.G = P.G;
     pa.cnt = cnt.p;
     pa.r0f = r0f.p;
     pa.r0b = r0b.p;
     pa.frank = frank.p;
     pa.in_arc = in_arc.p;
-    pa.rounds = rounds.p;
+    pa.lat_rounds = d_rounds.p;
     pa.status = status.p;
-    std::vector<int32_t> h_rounds((size_t)(2 * U));
+    std::vector<LatticeRounds> h_rounds((size_t)U);
     int32_t h_status[4] = {0, -1, 1, 0};
     hipError_t he = launch_pack_count(pa, (int)U, c->stream);
     if (he == hipSuccess && U > 0)
-      he = hipMemcpyAsync(h_rounds.data(), rounds.p, sizeof(int32_t) * h_rounds.size(), hipMemcpyDeviceToHost, c->stream);
+      he = hipMemcpyAsync(h_rounds.data(), d_rounds.p, sizeof(LatticeRounds) * h_rounds.size(), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) {
@@ -238,35 +272,37 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
            "lattice " + std::to_string(h_status[1]) +
                (h_status[0] == 2 ? ": arc with dst <= src or out of range (lattice is not topologically sorted)"
                                  : ": malformed CSR (state ids out of range or arcs not grouped by source)"));
-    const int LPW = 64 / P.G;
-    const int W = o.ring_slots ? o.ring_slots : choose_ring_slots(P.G, h_status[2]);
-    if ((int64_t)W * LPW > kMaxRingCells) FAIL(KLAT_ERR_INVALID_ARG, "ring_slots * (64 / lanes_per_lattice) must not exceed 4032 ring cells per workgroup");
-    std::vector<int64_t> rf((size_t)U), rb((size_t)U);
-    for (int64_t u = 0; u < U; ++u) rf[(size_t)u] = h_rounds[(size_t)(2 * u)], rb[(size_t)u] = h_rounds[(size_t)(2 * u + 1)];
+    // the plan: lanes per lattice, layout classes, jobs
+    std::vector<int8_t> lat_g;
+    plan_layout(U, d->state_off, d->arc_off, h_rounds.data(), o, &lat_g);
     std::vector<std::vector<int64_t>> job_lats;
-    const int64_t chunk_total = slice_jobs(d->state_off, U, rf, rb, P.G, W, &P, &job_lats);
-    // pass 2: one workgroup per (job, slot)
+    int64_t chunk_total = 0;
+    rc = build_jobs(U, d->state_off, h_rounds.data(), lat_g, o, &P, &job_lats, &chunk_total, &err);
+    if (rc != KLAT_OK) FAIL(rc, err);
+    // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, slot)
     std::vector<PackEntry> entries;
-    entries.reserve(job_lats.size() * (size_t)LPW);
-    for (size_t j = 0; j < job_lats.size(); ++j)
+    for (size_t j = 0; j < job_lats.size(); ++j) {
+      const int LPW = 64 / ((P.jobs[j].tag >> 8) & 0xFF);
       for (int k = 0; k < LPW; ++k)
         entries.push_back(PackEntry{k < (int)job_lats[j].size() ? (int32_t)job_lats[j][(size_t)k] : -1, (int32_t)j, k, 0});
+    }
     const size_t nslots = (size_t)chunk_total * 64 * kChunkRounds;
     AL(sw, nslots);
     AL(sg, nslots);
     AL(sa, nslots);
     UP(jobs, P.jobs.data(), P.jobs.size());
-    if ((rc = d_entries.upload(entries.data(), entries.size(), c->stream))) {
+    if ((rc = d_entries.upload(entries.data(), entries.size(), c->stream)) || (rc = d_lat_g.upload(lat_g.data(), lat_g.size(), c->stream))) {
       klat_batch_destroy(b);
       return rc;
     }
-    pa.W = W;
+    pa.lat_g = d_lat_g.p;
     pa.entries = d_entries.p;
     pa.jobs = b->jobs.p;
     pa.sw = b->sw.p;
     pa.sg = b->sg.p;
     pa.sa = b->sa.p;
-    he = launch_pack_fill(pa, (int)entries.size(), c->stream);
+    he = launch_pack_rounds(pa, (int)U, c->stream);
+    if (he == hipSuccess) he = launch_pack_fill(pa, (int)entries.size(), c->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);  // scratch and entries go out of scope below
     if (he != hipSuccess) {
@@ -280,6 +316,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   }
   b->G = P.G;
   b->W = P.W;
+  b->classes = P.classes;
   b->num_jobs = (int)P.jobs.size();
   b->num_items = (int)P.items.size();
   b->info.num_states = b->S;
@@ -291,6 +328,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   b->info.ring_slots = P.W;
   b->info.num_jobs = b->num_jobs;
   b->info.max_rounds = P.max_rounds;
+  b->info.num_layouts = (int32_t)P.classes.size();
   if (host_pack) UP(jobs, P.jobs.data(), P.jobs.size());
   UP(lanes, P.lanes.data(), P.lanes.size());
   UP(items, P.items.data(), P.items.size());
@@ -354,7 +392,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.ln_table = c->ln_table.p;
   sa.sp = sp;
   sa.sc = make_stream_cost(sp);
-  sa.ring_slots = b->W;
+  sa.ring_slots = 0;  // per layout class below
 
   TotalsArgs ta;
   ta.num_lattices = (int32_t)b->U;
@@ -380,7 +418,17 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   pa.sp = sp;
 
   KLAT_HIP(hipEventRecord(c->ev[0], c->stream));
-  KLAT_HIP(launch_sweep(sa, b->num_jobs, b->G, c->stream));
+  {
+    const int rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
+      SweepArgs ca = sa;
+      ca.jobs = sa.jobs + lc.job_begin;
+      ca.job_flags = sa.job_flags + lc.job_begin;
+      ca.sink = sa.sink + (size_t)lc.job_begin * 64;
+      ca.ring_slots = lc.W;
+      return launch_sweep(ca, lc.job_end - lc.job_begin, lc.G, stream);
+    });
+    if (rc != KLAT_OK) return rc;
+  }
   KLAT_HIP(hipEventRecord(c->ev[1], c->stream));
   KLAT_HIP(launch_totals(ta, c->stream));
   KLAT_HIP(hipEventRecord(c->ev[2], c->stream));
@@ -422,8 +470,14 @@ int klat_viterbi(klat_batch* b, const klat_scales* sc) {
   va.bwd_cost = b->bwd_cost.p;
   va.sp = make_scale_params(s);
   va.sc = make_stream_cost(va.sp);
-  va.ring_slots = b->W;
-  KLAT_HIP(launch_viterbi(va, b->num_jobs, b->G, c->stream));
+  va.ring_slots = 0;
+  rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
+    ViterbiArgs ca = va;
+    ca.jobs = va.jobs + lc.job_begin;
+    ca.ring_slots = lc.W;
+    return launch_viterbi(ca, lc.job_end - lc.job_begin, lc.G, stream);
+  });
+  if (rc != KLAT_OK) return rc;
   b->viterbi_done = true;
   return KLAT_OK;
 }
@@ -615,6 +669,7 @@ int klat_pack_host(const klat_batch_desc* d, const klat_pack_options* opt, klat_
   p->info.ring_slots = p->P.W;
   p->info.num_jobs = (int32_t)p->P.jobs.size();
   p->info.max_rounds = p->P.max_rounds;
+  p->info.num_layouts = (int32_t)p->P.classes.size();
   *out = p;
   return KLAT_OK;
 }

@@ -55,7 +55,18 @@ struct SweepJob {
   int32_t nchunks;    // multiple of kPrefetchChunks
   int32_t dir;        // 0 forward, 1 backward
   int32_t lane_tab;   // first LaneInfo of this job (64/G entries)
-  int32_t pad;
+  int32_t tag;        // bits 0-1: wave priority (long chains first); 8-15: G; 16-27: W of its layout
+};
+static const int kJobPrioMask = 3;
+inline int job_tag(int prio, int G, int W) { return prio | (G << 8) | (W << 16); }
+
+// What the count pass learns about one lattice: the rounds its forward and backward stream take
+// with G = 1, 2, 4 ... 64 lanes, and its longest arc span.  The layout planner (klat_pack.cc) picks
+// every lattice's G from these.
+static const int kNumLaneChoices = 7;
+struct LatticeRounds {
+  int32_t fwd[kNumLaneChoices], bwd[kNumLaneChoices];
+  int32_t max_rel, pad;
 };
 
 // One lattice inside a job.

@@ -65,6 +65,11 @@ struct klat_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // layout classes of one batch sweep side by side: class 0 on `stream`, the others on these,
+  // forked from and joined to `stream` by events (created on first use)
+  static const int kSideStreams = 3;
+  hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[kSideStreams] = {nullptr, nullptr, nullptr};
   klat::DevBuf<klat::LnTabEntry> ln_table;  // table behind the sweep's natural log
 };
 
@@ -92,7 +97,8 @@ struct klat_batch {
   klat_frame_state frame;
   klat_ctx* ctx = nullptr;
   int64_t U = 0, S = 0, A = 0;
-  int G = 1, W = 8, num_jobs = 0, num_items = 0;
+  int G = 1, W = 8, num_jobs = 0, num_items = 0;  // G, W: of the largest layout class (info only)
+  std::vector<klat::LayoutClass> classes;
   bool swept = false;
   klat_scales scales = {1.f, 1.f, 0.f};
   klat_batch_info info = {};

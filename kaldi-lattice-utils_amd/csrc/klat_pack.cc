@@ -56,20 +56,6 @@ inline bool is_final(const klat_batch_desc& d, int64_t gs) {
 
 }  // namespace
 
-int choose_lanes_per_lattice(int64_t U, int64_t S, int64_t A) {
-  if (U <= 0 || S <= 0) return 1;
-  // Spread each state's terms over G ~ fanout lanes: the dependency chain of a lattice is then one
-  // round per state.  Very large batches halve G (more lattices per wave, fewer padded lanes), but
-  // not below 2: with one lane per lattice the chain is one round per ARC and the sweep is slower
-  // even when the chip is full many times over (tools/layout_scan.py: 140 000 lattices x 150
-  // states, G = 1: 92 G arcs/s, G = 2: 112, G = 4: 110).
-  const double fan = (double)A / (double)S;
-  int G = 1;
-  while (G < fan && G < 64) G *= 2;
-  while (G > 2 && 2 * ceil_div(U, 64 / G) > 8192) G /= 2;
-  return G;
-}
-
 int choose_ring_slots(int G, int64_t max_rel) {
   const int LPW = 64 / G;
   int cap = 8;
@@ -82,14 +68,122 @@ int choose_ring_slots(int G, int64_t max_rel) {
   return W;
 }
 
-int64_t slice_jobs(const int64_t* state_off, int64_t U, const std::vector<int64_t>& rf, const std::vector<int64_t>& rb,
-                   int G, int W, PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats) {
+// ---- layout planner -------------------------------------------------------------------------
+//
+// Every lattice gets its own number of lanes G.  Its terms are dealt state by state, so a
+// lattice of S states with in-degree d takes sum ceil(d / G) >= S rounds, each of which depends
+// on the one before: G ~ fanout makes the chain one round per state, a larger G only pads.  The
+// starting point is therefore G = fanout rounded up to a power of two (at least 2 for a branching
+// lattice: with one lane the chain is one round per ARC and the sweep is slower even when the
+// chip is full many times over -- tools/layout_scan.py: 140 000 lattices x 150 states, G = 1:
+// 92 G arcs/s, G = 2: 112, G = 4: 110), halved while the batch would need more than 8192
+// workgroups.  A skewed batch is then bounded by its longest lattices, not by
+// the chip: the planner lowers the round budget R step by step, gives every lattice the smallest
+// G that meets R, and keeps the R with the smallest modelled time
+//   max( longest chain x t_lone(G),  job-rounds / resident workgroups x t_lone(G) x f(occupancy) )
+//   + launch overhead per layout class
+// with t_lone and f measured on MI355X (tools/occupancy_scan.py, tools/config_scan.py).
+namespace {
+
+const double kLoneCycles[kNumLaneChoices] = {300, 300, 308, 324, 359, 400, 450};  // cycles per round, one workgroup alone
+
+double occupancy_factor(double jobs) {  // slow-down of a round against workgroups per CU
+  static const double f[6] = {1.0, 1.0, 1.15, 1.47, 1.49, 1.78};
+  const double w = std::min(5.0, std::max(0.0, jobs / 256.0));
+  const int i = (int)w;
+  return i >= 5 ? f[5] : f[i] + (f[i + 1] - f[i]) * (w - i);
+}
+
+struct PlanCost {
+  double cycles, jobs;
+};
+
+PlanCost plan_cost(int64_t U, const LatticeRounds* lr, const std::vector<int8_t>& g) {
+  double chain = 0, work[kNumLaneChoices] = {0}, count[kNumLaneChoices] = {0};
+  for (int64_t u = 0; u < U; ++u) {
+    if (g[(size_t)u] < 0) continue;
+    const int k = g[(size_t)u];
+    chain = std::max(chain, (double)std::max(lr[u].fwd[k], lr[u].bwd[k]) * kLoneCycles[k]);
+    work[k] += ((double)lr[u].fwd[k] + (double)lr[u].bwd[k]) * (double)(1 << k) / 64.0 * kLoneCycles[k];
+    count[k] += 1;
+  }
+  double jobs = 0, cyc = 0, launches = 0;
+  for (int k = 0; k < kNumLaneChoices; ++k) {
+    jobs += 2.0 * std::ceil(count[k] * (double)(1 << k) / 64.0);
+    cyc += work[k];
+    launches += count[k] > 0 ? 1 : 0;
+  }
+  if (jobs <= 0) return PlanCost{0, 0};
+  const double kLaunchCycles = 30000;  // one more layout class = one more pair of launches
+  return PlanCost{std::max(chain, cyc / std::min(jobs, 1280.0) * occupancy_factor(jobs)) + kLaunchCycles * launches, jobs};
+}
+
+}  // namespace
+
+void plan_layout(int64_t U, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* lr,
+                 const klat_pack_options& opt, std::vector<int8_t>* lat_g) {
+  std::vector<int8_t>& g = *lat_g;
+  g.assign((size_t)U, -1);
+  if (opt.lanes_per_lattice != 0) {
+    int k = 0;
+    while ((1 << k) < opt.lanes_per_lattice) ++k;
+    for (int64_t u = 0; u < U; ++u)
+      if (state_off[u + 1] > state_off[u]) g[(size_t)u] = (int8_t)k;
+    return;
+  }
+  double jobs = 0;
+  for (int64_t u = 0; u < U; ++u) {
+    const int64_t S = state_off[u + 1] - state_off[u], A = arc_off[u + 1] - arc_off[u];
+    if (S <= 0) continue;
+    const double fan = (double)A / (double)S;
+    int k = 0;
+    while ((1 << k) < fan && k < kNumLaneChoices - 1) ++k;
+    g[(size_t)u] = (int8_t)k;
+    jobs += 2.0 * (double)(1 << k) / 64.0;
+  }
+  while (jobs > 8192) {
+    double nj = 0;
+    bool changed = false;
+    for (int64_t u = 0; u < U; ++u) {
+      if (g[(size_t)u] > 1) g[(size_t)u]--, changed = true;
+      if (g[(size_t)u] >= 0) nj += 2.0 * (double)(1 << g[(size_t)u]) / 64.0;
+    }
+    jobs = nj;
+    if (!changed) break;
+  }
+  // round budgets below the longest chain
+  const std::vector<int8_t> base(g);
+  std::vector<int8_t> best(g), cur(g);
+  PlanCost best_cost = plan_cost(U, lr, base);
+  const double base_cycles = best_cost.cycles;
+  int64_t longest = 0, floor_rounds = 0;
+  for (int64_t u = 0; u < U; ++u) {
+    if (base[(size_t)u] < 0) continue;
+    longest = std::max<int64_t>(longest, std::max(lr[u].fwd[base[(size_t)u]], lr[u].bwd[base[(size_t)u]]));
+    floor_rounds = std::max<int64_t>(floor_rounds, std::max(lr[u].fwd[kNumLaneChoices - 1], lr[u].bwd[kNumLaneChoices - 1]));
+  }
+  for (double R = 0.92 * (double)longest; R >= 0.999 * (double)floor_rounds && R > 0; R *= 0.92) {
+    for (int64_t u = 0; u < U; ++u) {
+      int k = base[(size_t)u];
+      if (k < 0) continue;
+      while (k < kNumLaneChoices - 1 && std::max(lr[u].fwd[k], lr[u].bwd[k]) > R &&
+             std::max(lr[u].fwd[k + 1], lr[u].bwd[k + 1]) < std::max(lr[u].fwd[k], lr[u].bwd[k]))
+        ++k;
+      cur[(size_t)u] = (int8_t)k;
+    }
+    const PlanCost c = plan_cost(U, lr, cur);
+    if (c.jobs > 8192) break;
+    if (c.cycles < best_cost.cycles) best_cost = c, best = cur;
+  }
+  if (best_cost.cycles < 0.95 * base_cycles) g = best;  // otherwise not worth the extra lanes
+}
+
+int64_t slice_jobs(const int64_t* state_off, const std::vector<int64_t>& members, const std::vector<int64_t>& rf,
+                   const std::vector<int64_t>& rb, int G, int W, int64_t chunk_base, PackedBatch* out,
+                   std::vector<std::vector<int64_t>>* job_lats) {
   const int LPW = 64 / G;
   const int D = kPrefetchChunks;
   // ---- slicing: lattices of similar length share a wave ----
-  std::vector<int64_t> live;
-  for (int64_t u = 0; u < U; ++u)
-    if (state_off[u + 1] > state_off[u]) live.push_back(u);
   struct ProtoJob {
     int dir;
     int64_t rounds;
@@ -98,7 +192,7 @@ int64_t slice_jobs(const int64_t* state_off, int64_t U, const std::vector<int64_
   std::vector<ProtoJob> proto;
   for (int dir = 0; dir < 2; ++dir) {
     const std::vector<int64_t>& r = dir ? rb : rf;
-    std::vector<int64_t> order(live);
+    std::vector<int64_t> order(members);
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r[a] > r[b]; });
     for (size_t i = 0; i < order.size(); i += LPW) {
       ProtoJob pj;
@@ -112,33 +206,86 @@ int64_t slice_jobs(const int64_t* state_off, int64_t U, const std::vector<int64_
                    [](const ProtoJob& a, const ProtoJob& b) { return a.rounds > b.rounds; });
 
   PackedBatch& P = *out;
-  P.G = G;
-  P.W = W;
-  P.jobs.resize(proto.size());
-  P.lanes.assign(proto.size() * LPW, LaneInfo{-1, 0, -1});
-  job_lats->resize(proto.size());
-  int64_t chunk_total = 0;
+  const size_t j0 = P.jobs.size();
+  const size_t l0 = P.lanes.size();
+  P.jobs.resize(j0 + proto.size());
+  P.lanes.resize(l0 + proto.size() * LPW, LaneInfo{-1, 0, -1});
+  job_lats->resize(j0 + proto.size());
+  int64_t chunk_total = chunk_base;
   for (size_t j = 0; j < proto.size(); ++j) {
     int64_t nch = ceil_div(proto[j].rounds, kChunkRounds);
     nch = ceil_div(nch, D) * D;
-    P.jobs[j].chunk_off = chunk_total;
-    P.jobs[j].nchunks = (int32_t)nch;
-    P.jobs[j].dir = proto[j].dir;
-    P.jobs[j].lane_tab = (int32_t)(j * LPW);
-    P.jobs[j].pad = 0;
+    SweepJob& job = P.jobs[j0 + j];
+    job.chunk_off = chunk_total;
+    job.nchunks = (int32_t)nch;
+    job.dir = proto[j].dir;
+    job.lane_tab = (int32_t)(l0 + j * LPW);
+    job.tag = job_tag(0, G, W);
     chunk_total += nch;
     (proto[j].dir ? P.bwd_slots : P.fwd_slots) += nch * kChunkRounds * 64;
     P.max_rounds = std::max<int32_t>(P.max_rounds, (int32_t)(nch * kChunkRounds));
     for (size_t k = 0; k < proto[j].lat.size(); ++k) {
       const int64_t u = proto[j].lat[k];
-      LaneInfo& li = P.lanes[j * LPW + k];
+      LaneInfo& li = P.lanes[l0 + j * LPW + k];
       li.state_base = state_off[u];
       li.num_states = (int32_t)(state_off[u + 1] - state_off[u]);
       li.lattice = (int32_t)u;
     }
-    (*job_lats)[j] = std::move(proto[j].lat);
+    (*job_lats)[j0 + j] = std::move(proto[j].lat);
   }
+  P.classes.push_back(LayoutClass{G, W, (int32_t)j0, (int32_t)(j0 + proto.size())});
   return chunk_total;
+}
+
+int build_jobs(int64_t U, const int64_t* state_off, const LatticeRounds* lr, const std::vector<int8_t>& lat_g,
+               const klat_pack_options& opt, PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats,
+               int64_t* chunk_total, std::string* err) {
+  PackedBatch& P = *out;
+  struct Proto {
+    int k;
+    int64_t longest, max_rel, slots;
+    std::vector<int64_t> members;
+  };
+  std::vector<Proto> cls;
+  for (int k = 0; k < kNumLaneChoices; ++k) {
+    Proto c{k, 0, 1, 0, {}};
+    for (int64_t u = 0; u < U; ++u)
+      if (lat_g[(size_t)u] == k) {
+        c.members.push_back(u);
+        c.longest = std::max<int64_t>(c.longest, std::max(lr[u].fwd[k], lr[u].bwd[k]));
+        c.max_rel = std::max<int64_t>(c.max_rel, lr[u].max_rel);
+        c.slots += ((int64_t)lr[u].fwd[k] + lr[u].bwd[k]) << k;
+      }
+    if (!c.members.empty()) cls.push_back(std::move(c));
+  }
+  // launch order: the class with the longest chain first
+  std::stable_sort(cls.begin(), cls.end(), [](const Proto& a, const Proto& b) { return a.longest > b.longest; });
+  std::vector<int64_t> rf((size_t)U, 0), rb((size_t)U, 0);
+  int64_t chunks = 0, most_slots = -1;
+  for (const Proto& c : cls) {
+    const int G = 1 << c.k, LPW = 64 / G;
+    // The ring only has to cover arcs; final terms (rel = S - s) may be far without harm, so the
+    // automatic W follows the arcs' span, which the count pass folded into max_rel with the finals.
+    const int W = opt.ring_slots ? opt.ring_slots : choose_ring_slots(G, c.max_rel);
+    if ((int64_t)W * LPW > kMaxRingCells) {
+      *err = "ring_slots * (64 / lanes_per_lattice) must not exceed 4032 ring cells per workgroup";
+      return KLAT_ERR_INVALID_ARG;
+    }
+    for (int64_t u : c.members) rf[(size_t)u] = lr[u].fwd[c.k], rb[(size_t)u] = lr[u].bwd[c.k];
+    chunks = slice_jobs(state_off, c.members, rf, rb, G, W, chunks, &P, job_lats);
+    if (c.slots > most_slots) most_slots = c.slots, P.G = G, P.W = W;  // what klat_batch_info reports
+  }
+  if (cls.empty()) {
+    P.G = opt.lanes_per_lattice ? opt.lanes_per_lattice : 1;
+    P.W = opt.ring_slots ? opt.ring_slots : choose_ring_slots(P.G, 1);
+  }
+  // wave priorities: in a skewed batch the long chains outrank the waves they share a SIMD with
+  int64_t sum_rounds = 0, longest = 0;
+  for (const SweepJob& j : P.jobs) sum_rounds += j.nchunks, longest = std::max<int64_t>(longest, j.nchunks);
+  if (!P.jobs.empty() && longest * (int64_t)P.jobs.size() > 2 * sum_rounds)
+    for (SweepJob& j : P.jobs) j.tag |= (int32_t)std::min<int64_t>(3, 4 * (int64_t)j.nchunks / (longest + 1));
+  *chunk_total = chunks;
+  return KLAT_OK;
 }
 
 int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBatch* out,
@@ -160,9 +307,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   int threads = opt.host_threads > 0 ? opt.host_threads : (int)std::thread::hardware_concurrency();
   if (threads < 1) threads = 1;
 
-  int G = opt.lanes_per_lattice;
-  if (G == 0) G = choose_lanes_per_lattice(U, S_tot, A_tot);
-  if (G < 1 || G > 64 || (G & (G - 1))) {
+  const int G_opt = opt.lanes_per_lattice;
+  if (G_opt < 0 || G_opt > 64 || (G_opt & (G_opt - 1))) {
     *err = "lanes_per_lattice must be a power of two in [1,64]";
     return KLAT_ERR_INVALID_ARG;
   }
@@ -171,17 +317,15 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
     *err = "ring_slots must be a power of two in [8,1024]";
     return KLAT_ERR_INVALID_ARG;
   }
-  const int LPW = 64 / G;
-  const int D = kPrefetchChunks;
 
-  // ---- pass 1: validate, count rounds per lattice and direction ----
-  std::vector<int64_t> rf(U, 0), rb(U, 0);
-  std::atomic<int64_t> max_rel(1);
+  // ---- pass 1: validate, count the rounds of every lattice and direction for every G ----
+  std::vector<LatticeRounds> lr((size_t)U);
   std::atomic<int> bad(0);
   std::atomic<int64_t> bad_lat(-1);
   parallel_for(U, threads, [&](int64_t u) {
     const int64_t s0 = d.state_off[u], a0 = d.arc_off[u];
     const int64_t S = d.state_off[u + 1] - s0, A = d.arc_off[u + 1] - a0;
+    std::memset(&lr[(size_t)u], 0, sizeof(LatticeRounds));
     if (S < 0 || A < 0 || S >= (int64_t)kRelMask || (S == 0 && A > 0)) {
       bad = KLAT_ERR_INVALID_ARG;
       bad_lat = u;
@@ -203,7 +347,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
       out_cnt[s]++;
       mr = std::max<int64_t>(mr, t - s);
     }
-    int64_t nfinal = 0, f = 0, b = 0;
+    int64_t nfinal = 0, f[kNumLaneChoices] = {0}, b[kNumLaneChoices] = {0};
     for (int64_t s = 0; s < S; ++s) {
       const bool fin = is_final(d, s0 + s);
       if (fin) {
@@ -212,15 +356,16 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
       }
       const int64_t nf = (s == 0) ? in_cnt[0] + 1 : std::max<int64_t>(in_cnt[s], 1);
       const int64_t nb = std::max<int64_t>(out_cnt[s] + (fin ? 1 : 0), 1);
-      f += ceil_div(nf, G);
-      b += ceil_div(nb, G);
+      for (int k = 0; k < kNumLaneChoices; ++k) {
+        f[k] += ceil_div(nf, (int64_t)1 << k);
+        b[k] += ceil_div(nb, (int64_t)1 << k);
+      }
     }
-    f += ceil_div(std::max<int64_t>(nfinal, 1), G);
-    rf[u] = f;
-    rb[u] = b;
-    int64_t cur = max_rel.load();
-    while (mr > cur && !max_rel.compare_exchange_weak(cur, mr)) {
+    for (int k = 0; k < kNumLaneChoices; ++k) {
+      lr[(size_t)u].fwd[k] = (int32_t)(f[k] + ceil_div(std::max<int64_t>(nfinal, 1), (int64_t)1 << k));
+      lr[(size_t)u].bwd[k] = (int32_t)b[k];
     }
+    lr[(size_t)u].max_rel = (int32_t)mr;
   });
   if (bad.load() != 0) {
     *err = "lattice " + std::to_string(bad_lat.load()) +
@@ -229,17 +374,14 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
                 : ": malformed CSR (state ids out of range or arcs not grouped by source)");
     return bad.load();
   }
-  // The ring only has to cover arcs; final terms (rel = S - s) may be far without harm, so the
-  // automatic W follows the arcs' span, which pass 1 folded into max_rel together with finals.
-  int W = opt.ring_slots ? opt.ring_slots : choose_ring_slots(G, max_rel.load());
-  if ((int64_t)W * LPW > kMaxRingCells) {
-    *err = "ring_slots * (64 / lanes_per_lattice) must not exceed 4032 ring cells per workgroup";
-    return KLAT_ERR_INVALID_ARG;
-  }
 
   PackedBatch& P = *out;
+  std::vector<int8_t> lat_g;
+  plan_layout(U, d.state_off, d.arc_off, lr.data(), opt, &lat_g);
   std::vector<std::vector<int64_t>> job_lats;
-  const int64_t chunk_total = slice_jobs(d.state_off, U, rf, rb, G, W, &P, &job_lats);
+  int64_t chunk_total = 0;
+  const int rc = build_jobs(U, d.state_off, lr.data(), lat_g, opt, &P, &job_lats, &chunk_total, err);
+  if (rc != KLAT_OK) return rc;
   const size_t nslots = (size_t)chunk_total * 64 * kChunkRounds;
   if (!P.sw.resize(nslots) || !P.sg.resize(nslots) || !P.sa.resize(nslots)) {
     *err = "out of host memory for the arc streams";
@@ -250,6 +392,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   std::atomic<int64_t> far(0);
   parallel_for((int64_t)job_lats.size(), threads, [&](int64_t j) {
     const SweepJob& job = P.jobs[j];
+    const int G = (job.tag >> 8) & 0xFF, W = (job.tag >> 16) & 0xFFF, LPW = 64 / G;
     const size_t b0 = (size_t)job.chunk_off * 64 * kChunkRounds;
     const size_t n = (size_t)job.nchunks * 64 * kChunkRounds;
     // padding: zero-weight terms that read cell 0 and park their (unused) result in the lane's

@@ -39,8 +39,15 @@ class HostBuf {
   size_t n_ = 0;
 };
 
+// Jobs [job_begin, job_end) share one layout: G lanes per lattice, W ring slots.  One sweep launch
+// per class, the class with the longest chain first.
+struct LayoutClass {
+  int32_t G, W, job_begin, job_end;
+};
+
 struct PackedBatch {
-  int G = 0, W = 0;
+  int G = 0, W = 0;  // of the class that holds most of the stream (klat_batch_info)
+  std::vector<LayoutClass> classes;
   HostBuf<int32_t> sw;  // [chunks][64][4]
   HostBuf<float> sg, sa;
   std::vector<SweepJob> jobs;    // sorted longest first
@@ -55,15 +62,18 @@ struct PackedBatch {
 int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBatch* out,
                std::string* err);
 
-// Job slicing shared by the host and the device packer: lattices sorted by round count, 64/G per
-// job, jobs longest first; fills out->jobs / lanes / slot totals / max_rounds, returns the number
-// of chunks and, per job, its lattices in slot order.
-int64_t slice_jobs(const int64_t* state_off, int64_t num_lattices, const std::vector<int64_t>& rounds_fwd,
-                   const std::vector<int64_t>& rounds_bwd, int G, int W, PackedBatch* out,
-                   std::vector<std::vector<int64_t>>* job_lats);
+// Layout planning and job slicing, shared by the host and the device packer.  plan_layout picks
+// log2(lanes) of every lattice (-1: no states) from the round counts of the count pass; build_jobs
+// groups the lattices by lanes into layout classes, slices every class into jobs (lattices sorted
+// by round count, 64/G per job, longest first), fills out->classes / jobs / lanes / slot totals /
+// max_rounds and returns the number of chunks and, per job, its lattices in slot order.
+void plan_layout(int64_t num_lattices, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* rounds,
+                 const klat_pack_options& opt, std::vector<int8_t>* lat_g);
+int build_jobs(int64_t num_lattices, const int64_t* state_off, const LatticeRounds* rounds, const std::vector<int8_t>& lat_g,
+               const klat_pack_options& opt, PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats,
+               int64_t* chunk_total, std::string* err);
 
-// Heuristics used when the options leave G / W at 0.
-int choose_lanes_per_lattice(int64_t num_lattices, int64_t num_states, int64_t num_arcs);
+// Ring slots when the options leave W at 0.
 int choose_ring_slots(int G, int64_t max_rel);
 
 }  // namespace klat

@@ -4,9 +4,12 @@
 //
 //   pack_count_kernel  one workgroup per lattice: validates the topology, counts in-degrees,
 //                      sorts the arcs by destination (counting sort; sources ascending inside a
-//                      destination), and prefix-sums the rounds every state will take in the
-//                      forward and in the backward stream.  The per-lattice round counts go back
-//                      to the host, which slices the lattices into jobs (slice_jobs).
+//                      destination), and counts the rounds its forward and its backward stream
+//                      would take with 1, 2 ... 64 lanes.  These counts go back to the host, which
+//                      picks every lattice's lanes and slices the lattices into jobs
+//                      (plan_layout, build_jobs in klat_pack.cc).
+//   pack_rounds_kernel one workgroup per lattice: prefix sums of the rounds every state takes in
+//                      the forward and in the backward stream with the lanes the plan gave it.
 //   pack_fill_kernel   one workgroup per (job, lattice slot): every state writes the term words
 //                      and costs of its rounds -- ring cells, BYPASS / ONE / FAR / WORD, FIRST /
 //                      LAST / COMMIT -- and the padding of its unused lanes; the rounds behind the
@@ -63,12 +66,13 @@ __device__ __forceinline__ int lower_bound_src(const int32_t* src, int n, int s)
 __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   __shared__ int sh[kT / 64];
   __shared__ int sh_bad, sh_nfinal, sh_mr;
+  __shared__ int sh_rounds[2 * kNumLaneChoices];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
   const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
+  if (tid < (int)(sizeof(LatticeRounds) / sizeof(int32_t))) reinterpret_cast<int32_t*>(&a.lat_rounds[u])[tid] = 0;
   if (S <= 0) {
     if (tid == 0) {
-      a.rounds[2 * u] = a.rounds[2 * u + 1] = 0;
       if (S < 0 || A != 0) {
         if (atomicCAS(&a.status[0], 0, 1 /* KLAT_ERR_INVALID_ARG */) == 0) a.status[1] = u;
       }
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   const int32_t* src = a.src + a0;
   const int32_t* dst = a.dst + a0;
   if (tid == 0) sh_bad = 0, sh_nfinal = 0, sh_mr = 1;
+  if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
   for (int s = tid; s < S + 2; s += kT) cnt[s] = 0;
   __syncthreads();
   // in-degrees + validation (the host packer's checks: ids in range, arcs grouped by source,
@@ -108,7 +113,6 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   if (sh_bad) {
     if (tid == 0) {
       if (atomicCAS(&a.status[0], 0, sh_bad == 2 ? 1 /* INVALID_ARG */ : 2 /* BAD_TOPOLOGY */) == 0) a.status[1] = u;
-      a.rounds[2 * u] = a.rounds[2 * u + 1] = 0;
     }
     return;
   }
@@ -124,25 +128,21 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
     carry += tot;
   }
   const int nfinal = carry;
-  // forward: rounds per position p = 0..S (S = the virtual super-final state), prefix -> r0f;
-  // in-degrees -> exclusive prefix in place (cnt[p] = first in-arc of p, cnt[S] = A)
-  int carry_r = 0, carry_c = 0;
+  // forward: rounds of every position p = 0..S (S = the virtual super-final state) for every
+  // number of lanes; in-degrees -> exclusive prefix in place (cnt[p] = first in-arc of p, cnt[S] = A)
+  int fsum[kNumLaneChoices] = {0}, bsum[kNumLaneChoices] = {0};
+  int carry_c = 0;
   for (int base = 0; base <= S; base += kT) {
     const int p = base + tid;
     const int c = (p < S) ? cnt[p] : 0;
     const int nterm = (p < S) ? c + (p == 0 ? 1 : 0) : nfinal;
-    const int nr = (p <= S) ? (max(nterm, 1) + a.G - 1) / a.G : 0;
-    int tot_r, tot_c;
-    const int ex_r = block_scan(nr, &tot_r, sh);
+    if (p <= S)
+      for (int k = 0; k < kNumLaneChoices; ++k) fsum[k] += (max(nterm, 1) + (1 << k) - 1) >> k;
+    int tot_c;
     const int ex_c = block_scan(c, &tot_c, sh);
-    if (p <= S) {
-      r0f[p] = carry_r + ex_r;
-      cnt[p] = carry_c + ex_c;
-    }
-    carry_r += tot_r;
+    if (p <= S) cnt[p] = carry_c + ex_c;
     carry_c += tot_c;
   }
-  if (tid == 0) r0f[S + 1] = carry_r;
   __syncthreads();
   // stable counting sort of the arcs by destination: scatter, then order every bucket by arc index
   for (int s = tid; s < S; s += kT) r0b[s] = cnt[s];  // cursors (r0b is free until the backward scan)
@@ -163,6 +163,46 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   }
   __syncthreads();
   // backward: position p = S-1-s holds the out-arcs of s (+ its final weight)
+  for (int s = tid; s < S; s += kT) {
+    const int nb = lower_bound_src(src, A, s + 1) - lower_bound_src(src, A, s) + (dev_is_final(a, s0 + s) ? 1 : 0);
+    for (int k = 0; k < kNumLaneChoices; ++k) bsum[k] += (max(nb, 1) + (1 << k) - 1) >> k;
+  }
+  for (int k = 0; k < kNumLaneChoices; ++k) {
+    if (fsum[k]) atomicAdd(&sh_rounds[k], fsum[k]);
+    if (bsum[k]) atomicAdd(&sh_rounds[kNumLaneChoices + k], bsum[k]);
+  }
+  __syncthreads();
+  if (tid < kNumLaneChoices) {
+    a.lat_rounds[u].fwd[tid] = sh_rounds[tid];
+    a.lat_rounds[u].bwd[tid] = sh_rounds[kNumLaneChoices + tid];
+  }
+  if (tid == 0) a.lat_rounds[u].max_rel = sh_mr;
+}
+
+__global__ __launch_bounds__(kT) void pack_rounds_kernel(PackDevArgs a) {
+  __shared__ int sh[kT / 64];
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
+  const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
+  if (S <= 0 || a.lat_g[u] < 0) return;
+  const int k = a.lat_g[u];
+  const int64_t sb = s0 + 2 * (int64_t)u;
+  const int32_t* cnt = a.cnt + sb;
+  int32_t* r0f = a.r0f + sb;
+  int32_t* r0b = a.r0b + sb;
+  const int32_t* src = a.src + a0;
+  const int nfinal = a.frank[s0 + S - 1] + (dev_is_final(a, s0 + S - 1) ? 1 : 0);
+  int carry_r = 0;
+  for (int base = 0; base <= S; base += kT) {
+    const int p = base + tid;
+    const int nterm = (p < S) ? cnt[p + 1] - cnt[p] + (p == 0 ? 1 : 0) : nfinal;
+    const int nr = (p <= S) ? (max(nterm, 1) + (1 << k) - 1) >> k : 0;
+    int tot_r;
+    const int ex_r = block_scan(nr, &tot_r, sh);
+    if (p <= S) r0f[p] = carry_r + ex_r;
+    carry_r += tot_r;
+  }
+  if (tid == 0) r0f[S + 1] = carry_r;
   int carry_b = 0;
   for (int base = 0; base < S; base += kT) {
     const int p = base + tid;
@@ -170,25 +210,21 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
     if (p < S) {
       const int s = S - 1 - p;
       const int nb = lower_bound_src(src, A, s + 1) - lower_bound_src(src, A, s) + (dev_is_final(a, s0 + s) ? 1 : 0);
-      nr = (max(nb, 1) + a.G - 1) / a.G;
+      nr = (max(nb, 1) + (1 << k) - 1) >> k;
     }
     int tot;
     const int ex = block_scan(nr, &tot, sh);
     if (p < S) r0b[p] = carry_b + ex;
     carry_b += tot;
   }
-  if (tid == 0) {
-    r0b[S] = carry_b;
-    a.rounds[2 * u] = carry_r;
-    a.rounds[2 * u + 1] = carry_b;
-  }
+  if (tid == 0) r0b[S] = carry_b;
 }
 
 __global__ __launch_bounds__(kT) void pack_fill_kernel(PackDevArgs a) {
   __shared__ int sh_far;
   const PackEntry e = a.entries[blockIdx.x];
   const SweepJob job = a.jobs[e.job];
-  const int G = a.G, W = a.W, LPW = 64 / G;
+  const int G = (job.tag >> 8) & 0xFF, W = (job.tag >> 16) & 0xFFF, LPW = 64 / G;
   const int tid = threadIdx.x;
   const int lane0 = e.slot * G;
   const int total_rounds = job.nchunks * kChunkRounds;
@@ -330,6 +366,12 @@ __global__ __launch_bounds__(kT) void pack_fill_kernel(PackDevArgs a) {
 hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
   hipLaunchKernelGGL(pack_count_kernel, dim3(num_lattices), dim3(kT), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_rounds(const PackDevArgs& a, int num_lattices, hipStream_t stream) {
+  if (num_lattices <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_rounds_kernel, dim3(num_lattices), dim3(kT), 0, stream, a);
   return hipGetLastError();
 }
 

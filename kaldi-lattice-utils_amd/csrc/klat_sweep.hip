@@ -167,6 +167,13 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   const bool producer = threadIdx.x < 64;  // wave 0
   const SweepJob job = args.jobs[blockIdx.x];
   const int nchunks = job.nchunks;
+  // long chains first: a job on the batch's critical path outranks the waves it shares a SIMD with
+  switch (job.tag & kJobPrioMask) {
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: break;
+  }
   const LaneInfo li = args.lanes[job.lane_tab + slot];
   const int S = li.num_states;
   const bool bwd = job.dir != 0;

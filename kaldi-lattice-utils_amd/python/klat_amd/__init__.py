@@ -47,7 +47,8 @@ class BatchInfo(C.Structure):
     _fields_ = [("num_states", C.c_int64), ("num_arcs", C.c_int64), ("fwd_slots", C.c_int64),
                 ("bwd_slots", C.c_int64), ("far_terms", C.c_int64),
                 ("lanes_per_lattice", C.c_int32), ("ring_slots", C.c_int32),
-                ("num_jobs", C.c_int32), ("max_rounds", C.c_int32)]
+                ("num_jobs", C.c_int32), ("max_rounds", C.c_int32), ("num_layouts", C.c_int32),
+                ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -68,7 +69,7 @@ class LabelFilter(C.Structure):
 
 SEGMENT_DTYPE = np.dtype([("label", "<i4"), ("t0", "<i4"), ("t1", "<i4"), ("pad", "<i4"), ("logp", "<f8")])
 POSITION_DTYPE = np.dtype([("label", "<i4"), ("pos", "<i4"), ("t0", "<i4"), ("t1", "<i4"), ("logp", "<f8")])
-JOB_DTYPE = np.dtype([("chunk_off", "<i8"), ("nchunks", "<i4"), ("dir", "<i4"), ("lane_tab", "<i4"), ("pad", "<i4")])
+JOB_DTYPE = np.dtype([("chunk_off", "<i8"), ("nchunks", "<i4"), ("dir", "<i4"), ("lane_tab", "<i4"), ("tag", "<i4")])
 LANE_DTYPE = np.dtype([("state_base", "<i8"), ("num_states", "<i4"), ("lattice", "<i4")])
 ITEM_DTYPE = np.dtype([("arc_begin", "<i8"), ("count", "<i4"), ("lattice", "<i4")])
 

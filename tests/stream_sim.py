@@ -42,10 +42,6 @@ def _ln(m, e):
 
 def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalty=0.0):
     """Returns alpha, beta (natural log, per state), tot_fwd, tot_bwd per lattice."""
-    info = packed["info"]
-    G, W = info["lanes_per_lattice"], info["ring_slots"]
-    LPW = 64 // G
-    assert W * LPW + 64 <= CELL_MASK + 1
     sw = packed["sw"].view(np.uint32)
     sg, sa = packed["sg"], packed["sa"]
     S_tot = int(state_off[-1])
@@ -56,6 +52,9 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
     totf = np.full(U, np.nan)
     for job in packed["jobs"]:
         d = int(job["dir"])
+        G, W = (int(job["tag"]) >> 8) & 0xFF, (int(job["tag"]) >> 16) & 0xFFF  # the job's layout class
+        LPW = 64 // G
+        assert W * LPW + 64 <= CELL_MASK + 1
         ring = {}  # cell index -> (m, e); shared by the job's lattices like the LDS ring
         for slot in range(LPW):
             li = packed["lanes"][int(job["lane_tab"]) + slot]

@@ -49,8 +49,9 @@ def test_device_streams_equal_host_streams(ctx, G, W, long_spans, many_finals):
     info = b.info()
     sw, sg, sa = b.streams()
     b.close()
-    for k in ("lanes_per_lattice", "ring_slots", "num_jobs", "max_rounds", "fwd_slots", "bwd_slots", "far_terms"):
+    for k in ("lanes_per_lattice", "ring_slots", "num_jobs", "max_rounds", "fwd_slots", "bwd_slots", "far_terms", "num_layouts"):
         assert info[k] == host["info"][k], (k, info[k], host["info"][k])
+    assert (info["num_layouts"] > 2) if G == 0 else (info["num_layouts"] == 1)  # automatic: lanes per lattice
     assert np.array_equal(sw, host["sw"])
     assert np.array_equal(sg.view(np.uint32), host["sg"].view(np.uint32))
     assert np.array_equal(sa.view(np.uint32), host["sa"].view(np.uint32))

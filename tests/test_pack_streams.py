@@ -70,6 +70,48 @@ def test_synthetic_lattices_through_streams(G, W):
     _close(0.5 * (tf + tb), wt, 1e-8)
 
 
+def _job_layouts(packed):
+    return sorted({((int(t) >> 8) & 0xFF, (int(t) >> 16) & 0xFFF) for t in packed["jobs"]["tag"]})
+
+
+def test_automatic_layout_gives_every_lattice_its_own_lanes():
+    """With lanes_per_lattice = 0 every lattice gets lanes ~ its fanout, lattices of equal lanes
+    form a layout class (one sweep launch each, longest chain first), and in a skewed batch the
+    longest lattices get more lanes and their jobs a higher wave priority."""
+    ns = np.array([40, 40, 57, 64, 9, 33, 900, 12, 30, 30, 30, 30], np.int32)
+    fo = np.array([2, 3, 4, 6, 1, 3, 6, 3, 2, 3, 2, 3], np.int32)
+    arrays = klat_amd.synth(20260005, ns, fo)
+    packed = klat_amd.pack_host(arrays)
+    info = packed["info"]
+    layouts = _job_layouts(packed)
+    assert info["num_layouts"] == len(layouts) >= 3 and {g for g, _ in layouts} >= {1, 2, 4}
+    jobs, lanes = packed["jobs"], packed["lanes"]
+    lat_g = {}
+    for j in jobs:
+        g = (int(j["tag"]) >> 8) & 0xFF
+        for li in lanes[int(j["lane_tab"]):int(j["lane_tab"]) + 64 // g]:
+            if li["state_base"] >= 0:
+                assert lat_g.setdefault(int(li["lattice"]), g) == g  # same lanes in both directions
+    assert sorted(lat_g) == list(range(len(ns)))
+    assert lat_g[4] == 1 and lat_g[0] == 2 and lat_g[1] == 4 and lat_g[6] >= 8
+    # the 900-state lattice is the critical path: highest priority, and its class is launched first
+    prio = jobs["tag"] & 3
+    longest = int(np.argmax(jobs["nchunks"]))
+    assert prio[longest] == 3 and prio.min() == 0 and longest == 0
+    a, b, tf, tb = stream_sim.run(packed, arrays["state_off"], 1.0, 0.1, 0.0)
+    ab = np.concatenate([[0], np.cumsum(np.bincount(arrays["src"] + np.repeat(arrays["state_off"][:-1], np.diff(arrays["arc_off"])),
+                                                 minlength=int(arrays["state_off"][-1])))]).astype(np.int64)
+    wa, wb, wt, _ = orc.batch_fb_post(arrays["state_off"], arrays["arc_off"], ab, arrays["dst"], arrays["ilabel"],
+                                      arrays["graph"], arrays["acoustic"], arrays["final_graph"],
+                                      arrays["final_acoustic"], 1.0, 0.1, 0.0)
+    _close(a, wa, 1e-8), _close(b, wb, 1e-8)
+    _close(0.5 * (tf + tb), wt, 1e-8)
+    # a uniform batch stays one class with lanes ~ fanout and no priorities
+    uni = klat_amd.pack_host(klat_amd.synth(7, np.full(300, 50, np.int32), np.full(300, 3, np.int32)))
+    assert uni["info"]["num_layouts"] == 1 and uni["info"]["lanes_per_lattice"] == 4
+    assert not np.any(uni["jobs"]["tag"] & 3)
+
+
 def test_packer_rejects_bad_topology():
     arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
     bad = dict(arrays)
