@@ -197,14 +197,100 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
   __syncthreads();   // ... and skey / sarc are dead: the storage is the sort's again
 
   // ---- 3. order by descending logp (stable: ties keep the key order) ----
-  Sort().sort(keys2, vals2, storage, 0, 64);
+  // The order-preserving images of one lattice's values share their upper bits, and 64 bits of
+  // radix passes are 8 passes.  Instead: subtract the smallest image (the rest needs `hb` bits),
+  // run the passes over the upper 23 of those bits plus one bit that sends the padding to the end
+  // (3 passes), and let the first thread of every run of records that agree in the sorted bits
+  // (relative difference ~1e-6: a handful per lattice) order it on all bits with a stable
+  // insertion sort in LDS.  A long unsorted run (> kLongRun records) takes the remaining passes
+  // instead: lower bits, then the upper bits again -- stable passes over the current arrangement
+  // give the same final order.
+  constexpr int kLongRun = 128;
+  constexpr int kUpperBits = 24;
+  __shared__ unsigned long long sh_min, sh_max;
+  if (tid == 0) sh_min = ~0ull, sh_max = 0ull, sh[kThreads / 64] = 0;
+  __syncthreads();
+  {
+    unsigned long long lo = ~0ull, hi = 0ull;
+#pragma unroll
+    for (int j = 0; j < kItems; ++j)
+      if (head_mask & (1u << j)) lo = min(lo, (unsigned long long)keys2[j]), hi = max(hi, (unsigned long long)keys2[j]);
+    for (int d = 32; d > 0; d >>= 1) {
+      lo = min(lo, (unsigned long long)__shfl_xor(lo, d, 64));
+      hi = max(hi, (unsigned long long)__shfl_xor(hi, d, 64));
+    }
+    if ((tid & 63) == 0 && lo <= hi) atomicMin(&sh_min, lo), atomicMax(&sh_max, hi);
+  }
+  __syncthreads();
+  const uint64_t kmin = m > 0 ? sh_min : 0ull;
+  const uint64_t range = m > 0 ? sh_max - sh_min : 0ull;
+  const int hb = range ? 64 - __clzll((long long)range) : 0;  // bits of the largest (image - kmin)
+  const bool narrow = hb <= 62;  // else: values of both signs; sort the raw images' upper half
+  const int sort_end = narrow ? hb + 1 : 64;
+  const int sort_begin = narrow ? max(0, sort_end - kUpperBits) : 32;
+  if (narrow) {
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) keys2[j] = (head_mask & (1u << j)) ? keys2[j] - kmin : (1ull << hb);
+  }
+  Sort().sort(keys2, vals2, storage, sort_begin, sort_end);
+  __syncthreads();  // the sort's storage becomes skey / sarc again
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    skey[tid * kItems + j] = keys2[j];
+    sarc[tid * kItems + j] = (uint16_t)vals2[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    const int p = tid * kItems + j;
+    const uint64_t hi = keys2[j] >> sort_begin;
+    // the sorted bits do not move during the fix-up (a run permutes records that agree in them)
+    if (p + 1 < m && (skey[p + 1] >> sort_begin) == hi && (p == 0 || (skey[p - 1] >> sort_begin) != hi)) {
+      int q = p + 1;
+      bool sorted = true;
+      while (q < m && (skey[q] >> sort_begin) == hi) {
+        sorted = sorted && skey[q - 1] <= skey[q];
+        ++q;
+      }
+      if (sorted) continue;
+      if (q - p > kLongRun) {
+        sh[kThreads / 64] = 1;
+        continue;
+      }
+      for (int i = p + 1; i < q; ++i) {
+        const uint64_t k = skey[i];
+        const uint16_t v = sarc[i];
+        int t = i - 1;
+        while (t >= p && skey[t] > k) {
+          skey[t + 1] = skey[t];
+          sarc[t + 1] = sarc[t];
+          --t;
+        }
+        skey[t + 1] = k;
+        sarc[t + 1] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const bool long_run = sh[kThreads / 64] != 0;  // workgroup-uniform
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    keys2[j] = skey[tid * kItems + j];
+    vals2[j] = sarc[tid * kItems + j];
+  }
+  if (long_run) {
+    __syncthreads();  // skey / sarc are read: the storage is the sort's again
+    Sort().sort(keys2, vals2, storage, 0, sort_begin);
+    __syncthreads();
+    Sort().sort(keys2, vals2, storage, sort_begin, sort_end);
+  }
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
     const int p = tid * kItems + j;
     if (p < m) {
       const Payload q = payload[vals2[j]];
       Rec r;
-      r.k0 = keys2[j];
+      r.k0 = narrow ? keys2[j] + kmin : keys2[j];
       r.k1 = q.k1;
       r.k2 = q.k2;
       recs[p] = r;

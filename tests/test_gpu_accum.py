@@ -135,6 +135,43 @@ def test_segment_index_synthetic(ctx, G, flt, largest):
 
 
 @pytest.mark.parametrize("kernel", ["radix", "general"])
+def test_segment_index_orders_near_ties_exactly(ctx, kernel, monkeypatch):
+    """Records whose log-posteriors agree to 1e-6 and better: the radix kernel sorts on the upper
+    half of the double and repairs runs of equal upper halves afterwards (short runs: insertion
+    sort; long unsorted runs: the remaining radix passes).  The output must be ordered on ALL bits
+    of its own logp, ties by (label, t0, t1) -- kwsbin2/lattice-word-index-segment.cc:98-126."""
+    if kernel == "general":
+        monkeypatch.setenv("KLAT_INDEX_BITONIC", "1")
+    rng = np.random.RandomState(3)
+    lats, times = [], []
+    for n in (3000, 100, 7):
+        ab = np.array([0, n, n + 1, n + 1], np.int64)
+        dst = np.concatenate([np.ones(n, np.int32), [2]]).astype(np.int32)
+        lab = np.concatenate([rng.permutation(n) + 1, [5000]]).astype(np.int32)
+        graph = np.ones(n + 1, np.float32)
+        ac = np.concatenate([rng.permutation(n) * 1e-9, [0.5]]).astype(np.float32)
+        ac[:n][rng.rand(n) < 0.2] = np.float32(1e-7)  # exact ties as well
+        fg, fa = np.full(3, np.inf, np.float32), np.full(3, np.inf, np.float32)
+        fg[2] = fa[2] = 0.0
+        lats.append(orc.Lat(ab, dst, lab, lab.copy(), graph, ac, np.zeros(n + 1, np.int32), fg, fa, np.zeros(3, np.int32)))
+        times.append(np.array([0, 1, 2], np.int32))
+    arrays = klat_amd.concat_lattices(lats, times)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 1.0, 0.0)
+    off, rec = b.segment_index()
+    b.close()
+    for u, lat in enumerate(lats):
+        alpha, beta, total, _, _ = orc.alphas_betas(lat)
+        want = orc.segment_index(lat, times[u], alpha, beta, total)
+        r = rec[off[u]:off[u + 1]]
+        got = [(int(x["label"]), int(x["t0"]), int(x["t1"]), float(x["logp"])) for x in r]
+        _check_sorted_records(got, want, 3)
+        keys = [(-g[3],) + g[:3] for g in got]
+        assert keys == sorted(keys), "lattice %d: not ordered on all bits of logp" % u
+        assert len({g[3] for g in got}) > 0.7 * len(got)  # mostly distinct values, 1e-9 apart
+
+
+@pytest.mark.parametrize("kernel", ["radix", "general"])
 def test_position_index_synthetic(ctx, kernel, monkeypatch):
     """Both index kernels: the radix-sort one these small lattices qualify for, and the general
     (bitonic) one, forced through the library's test hook."""
