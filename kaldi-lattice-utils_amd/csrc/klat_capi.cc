@@ -393,6 +393,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.sp = sp;
   sa.sc = make_stream_cost(sp);
   sa.ring_slots = 0;  // per layout class below
+  sa.far_prefetch = 0;
 
   TotalsArgs ta;
   ta.num_lattices = (int32_t)b->U;
@@ -425,6 +426,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
       ca.job_flags = sa.job_flags + lc.job_begin;
       ca.sink = sa.sink + (size_t)lc.job_begin * 64;
       ca.ring_slots = lc.W;
+      ca.far_prefetch = lc.far;
       return launch_sweep(ca, lc.job_end - lc.job_begin, lc.G, stream);
     });
     if (rc != KLAT_OK) return rc;

@@ -59,6 +59,7 @@ struct SweepArgs {
   ScaleParams sp;
   StreamCost sc;  // = make_stream_cost(sp)
   int32_t ring_slots;
+  int32_t far_prefetch;  // the jobs hold sources older than the ring: prefetch their values (W >= 32)
 };
 
 struct TotalsArgs {

@@ -58,13 +58,14 @@ inline bool is_final(const klat_batch_desc& d, int64_t gs) {
 
 int choose_ring_slots(int G, int64_t max_rel) {
   const int LPW = 64 / G;
-  int cap = 8;
-  while (cap * 2 * LPW <= kMaxRingCells && cap < 1024) cap *= 2;  // ring + dummy cells fit 12-bit cell numbers (48 KiB)
-  // 32 slots where they fit: the sweep then stages two chunks per barrier and never has to wait
-  // for its own stores (klat_sweep.hip); 16 otherwise
-  int W = cap < 32 ? cap : 32;
-  if (W < 16) W = 16;
-  while (W <= max_rel && W < cap) W *= 2;
+  // 32 slots: the sweep then stages two chunks per barrier and never has to wait for its own
+  // stores (klat_sweep.hip).  The ring grows with the longest arc span only while the workgroup
+  // stays within the LDS that lets five of them share a CU (1024 ring cells: W = 64 at G = 4):
+  // longer arcs are FAR terms, whose sources the producer prefetches one period ahead, and that
+  // costs less than a CU that holds three workgroups instead of five (tools/span_scan.py: 30 % of
+  // the arcs stretched up to 1000 states, W = 32 / 64 / 128: 0.84 / 0.83 / 1.26 ms).
+  int W = 32;
+  while (W <= max_rel && 2 * W * LPW <= 1024) W *= 2;
   return W;
 }
 
@@ -233,7 +234,7 @@ int64_t slice_jobs(const int64_t* state_off, const std::vector<int64_t>& members
     }
     (*job_lats)[j0 + j] = std::move(proto[j].lat);
   }
-  P.classes.push_back(LayoutClass{G, W, (int32_t)j0, (int32_t)(j0 + proto.size())});
+  P.classes.push_back(LayoutClass{G, W, (int32_t)j0, (int32_t)(j0 + proto.size()), 0});
   return chunk_total;
 }
 
@@ -273,6 +274,7 @@ int build_jobs(int64_t U, const int64_t* state_off, const LatticeRounds* lr, con
     }
     for (int64_t u : c.members) rf[(size_t)u] = lr[u].fwd[c.k], rb[(size_t)u] = lr[u].bwd[c.k];
     chunks = slice_jobs(state_off, c.members, rf, rb, G, W, chunks, &P, job_lats);
+    P.classes.back().far = c.max_rel >= W ? 1 : 0;
     if (c.slots > most_slots) most_slots = c.slots, P.G = G, P.W = W;  // what klat_batch_info reports
   }
   if (cls.empty()) {

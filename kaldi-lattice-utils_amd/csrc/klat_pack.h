@@ -43,6 +43,7 @@ class HostBuf {
 // per class, the class with the longest chain first.
 struct LayoutClass {
   int32_t G, W, job_begin, job_end;
+  int32_t far;  // some lattice of the class has arcs (or final states) W or more positions long
 };
 
 struct PackedBatch {

@@ -146,7 +146,9 @@ static constexpr uint32_t kCtlOne = kOne;
 //          (arc costs hundreds of nats apart inside one state) sets the job's flag.
 //   !FAST  exact for any input: every lane carries its own (mantissa, exponent) accumulator and
 //          re-references on demand.  It runs afterwards and only for flagged jobs.
-template <int G, bool FAST, int CPB>  // CPB = stream chunks (of 4 rounds) staged per barrier: 2 when W >= 32, else 1
+// CPB = stream chunks (of 4 rounds) staged per barrier: 2 when W >= 32, else 1.  FARP (CPB = 2 only):
+// the values of sources older than the ring are prefetched one period ahead (see put_far).
+template <int G, bool FAST, int CPB, bool FARP>
 __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   extern __shared__ double smem[];
   constexpr int LPW = 64 / G;
@@ -229,14 +231,13 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       // program order before this load -- so the term becomes a constant-one source with the
       // cost c - v: exp(-(c - v)) = exp(v) * exp(-c), formed off the chain with the same routine
       // as every other weight.  The consumer never sees FAR.
-      auto put_far = [&](StagedTerm* dst, uint32_t w, float g, float a) {
+      // v = the source's value when the term is FAR (ignored otherwise)
+      auto put_far_v = [&](StagedTerm* dst, uint32_t w, float g, float a, double v) {
         StagedTerm t;
         double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : stream_cost(w, g, a, sc);
         const bool last = (w & kLast) != 0;
         uint32_t ctl = w;
         if (w & kFar) {
-          const int q = p - (int)(w & kRelMask);
-          const double v = __hip_atomic_load(&vals[q_off + q_step * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           c = (v == -INFINITY) ? INFINITY : c - v;  // a log-zero source kills the term
           ctl = (w & ~(kRelMask | kFar)) | kOne;     // RD cell 0: ignored for a constant-one source
           if (last && sub == 0)
@@ -249,6 +250,41 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         t.ctl = ctl;
         store_staged(dst, t);
         p += last ? 1 : 0;
+      };
+      // the value read when the term is staged (L1 bypassed: the line may have been cached before
+      // this wave stored the value) ...
+      auto put_far = [&](StagedTerm* dst, uint32_t w, float g, float a) {
+        double v = 0.0;
+        if (w & kFar) {
+          const int q = p - (int)(w & kRelMask);
+          v = __hip_atomic_load(&vals[q_off + q_step * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        put_far_v(dst, w, g, a, v);
+      };
+      // ... or, FARP, one period ahead: right after the copy-out stores of the iteration that
+      // stages period n, the values the FAR terms of period n+1 name are loaded into fv.  Such a
+      // source lies >= W >= 32 positions behind its term, i.e. it was finished in period n-2 or
+      // earlier, and the stores of those periods precede these loads in this wave's program order.
+      // Always 4*CPB loads per period (the barrier's vmcnt counts on it): rounds without a FAR
+      // term, and the periods behind the job's end, read the lane's slot of the sink row.
+      double fv[FARP ? CPB : 1][4] = {};
+      double* const sink_row = args.sink + (size_t)blockIdx.x * 64 + lane;
+      auto far_loads = [&](int c_next, const int4& wn0, const int4& wn1) {
+        int pp = p;
+#pragma unroll
+        for (int i = 0; i < CPB; ++i) {
+          const bool inside = c_next + i < nchunks;  // wave-uniform
+          const int4& wn = i == 0 ? wn0 : wn1;
+          const uint32_t w4[4] = {(uint32_t)wn.x, (uint32_t)wn.y, (uint32_t)wn.z, (uint32_t)wn.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t w = w4[r];
+            const int q = pp - (int)(w & kRelMask);
+            const double* srcp = (inside && (w & kFar) != 0) ? &vals[q_off + q_step * q] : sink_row;
+            fv[i][r] = __hip_atomic_load(srcp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pp += (int)((w / kLast) & 1u);
+          }
+        }
       };
       // Copy-out: turns the states the consumer finished during the previous period into natural
       // log (the only log of the sweep, off the chain, spread over the lattice's G lanes) and
@@ -285,11 +321,17 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           *dst = v;
         }
       };
-      auto stage_chunk = [&](int cj, const int4& w4, const float4& g4, const float4& a4) {
+      auto stage_chunk = [&](int cj, const int4& w4, const float4& g4, const float4& a4, const double (&v)[4]) {
         // stage buffer: [barrier period parity][chunk within the period][round][lane]
         const int sidx = (((cj / CPB) & 1) * CPB + (cj % CPB)) * 256 + lane;
         StagedTerm* st = stage + sidx;
-        if (__any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0)) {  // rare
+        const bool any_far = __any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0);
+        if (FARP && any_far) {
+          put_far_v(st, (uint32_t)w4.x, g4.x, a4.x, v[0]);
+          put_far_v(st + 64, (uint32_t)w4.y, g4.y, a4.y, v[1]);
+          put_far_v(st + 128, (uint32_t)w4.z, g4.z, a4.z, v[2]);
+          put_far_v(st + 192, (uint32_t)w4.w, g4.w, a4.w, v[3]);
+        } else if (any_far) {  // rare
           put_far(st, (uint32_t)w4.x, g4.x, a4.x);
           put_far(st + 64, (uint32_t)w4.y, g4.y, a4.y);
           put_far(st + 128, (uint32_t)w4.z, g4.z, a4.z);
@@ -322,10 +364,11 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
             copy_table();
             copy_store();
           }
-          stage_chunk(c + j0, wb[j0], gb[j0], ab[j0]);
+          stage_chunk(c + j0, wb[j0], gb[j0], ab[j0], fv[0]);
           if (!early_copy) copy_table();
-          if (CPB == 2) stage_chunk(c + j0 + 1, wb[j0 + 1], gb[j0 + 1], ab[j0 + 1]);
+          if (CPB == 2) stage_chunk(c + j0 + 1, wb[j0 + 1], gb[j0 + 1], ab[j0 + 1], fv[FARP ? 1 : 0]);
           if (!early_copy) copy_store();
+          if (FARP) far_loads(c + j0 + CPB, wb[(j0 + CPB) % D], wb[(j0 + CPB + 1) % D]);
 #pragma unroll
           for (int i = 0; i < CPB; ++i) {
             const int64_t cn = min(c + j0 + i + D, nchunks - 1);
@@ -334,7 +377,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
             ab[j0 + i] = sa[cn * 64];
           }
           // this period is staged; the consumer has finished the previous one,
-          producer_barrier<2 * (3 * CPB + kIters)>();
+          producer_barrier<2 * (3 * CPB + kIters + (FARP ? 4 * CPB : 0))>();
           out_p0 = pend_p0;             // whose states are now stable in the ring (W >= 2 periods of states)
           out_n = pend_n;
           pend_p0 = period_p0;
@@ -516,12 +559,15 @@ static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, dim3(num_jobs), dim3(128), lds, stream, args);
   };
-  if (cpb == 2) {
-    launch(&sweep_kernel<G, true, 2>);
-    launch(&sweep_kernel<G, false, 2>);
+  if (cpb == 2 && args.far_prefetch) {
+    launch(&sweep_kernel<G, true, 2, true>);
+    launch(&sweep_kernel<G, false, 2, true>);
+  } else if (cpb == 2) {
+    launch(&sweep_kernel<G, true, 2, false>);
+    launch(&sweep_kernel<G, false, 2, false>);
   } else {
-    launch(&sweep_kernel<G, true, 1>);
-    launch(&sweep_kernel<G, false, 1>);
+    launch(&sweep_kernel<G, true, 1, false>);
+    launch(&sweep_kernel<G, false, 1, false>);
   }
 }
 
