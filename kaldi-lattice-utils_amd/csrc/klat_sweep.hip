@@ -169,13 +169,10 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   const bool producer = threadIdx.x < 64;  // wave 0
   const SweepJob job = args.jobs[blockIdx.x];
   const int nchunks = job.nchunks;
-  // long chains first: a job on the batch's critical path outranks the waves it shares a SIMD with
-  switch (job.tag & kJobPrioMask) {
-    case 3: __builtin_amdgcn_s_setprio(3); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    default: break;
-  }
+  // long chains first: both waves of a job on the batch's critical path (priority tag 3, skewed
+  // batches only) outrank the waves they share a SIMD with
+  const bool critical = (job.tag & kJobPrioMask) == kJobPrioMask;
+  if (critical) __builtin_amdgcn_s_setprio(3);
   const LaneInfo li = args.lanes[job.lane_tab + slot];
   const int S = li.num_states;
   const bool bwd = job.dir != 0;
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   // -------------------------------------------------------------------- wave 1: the chain
   // the chain wave is the critical path of its job: let it win issue arbitration against the
   // producer waves (of other jobs) that share its SIMD -- those spend part of their time at barriers
-  __builtin_amdgcn_s_setprio(2);
+  if (!critical) __builtin_amdgcn_s_setprio(2);
 
   // every ring cell starts as log-zero so that padding terms read something well-defined
   for (int i = lane; i < W * LPW; i += 64) {

@@ -269,3 +269,14 @@ def test_c5_skewed_mix_properties(ctx):
     _run_and_check(ctx, arrays, 2)
     _run_and_check(ctx, arrays, 2, lanes_per_lattice=1)
     _run_and_check(ctx, arrays, 2, lanes_per_lattice=8, ring_slots=16)
+
+
+def test_one_very_long_lattice_among_short_ones(ctx):
+    """A 300 000-state lattice (0.9 M arcs, a chain of 300 000 dependent rounds) in a batch of short
+    ones: the planner gives it its own layout class and the highest wave priority; flow properties
+    over everything, oracle parity on the long lattice (it comes first)."""
+    ns = np.concatenate([[300000], np.full(400, 120)]).astype(np.int32)
+    fo = np.concatenate([[3], np.full(400, 2)]).astype(np.int32)
+    arrays = klat_amd.synth(77, ns, fo)
+    info, exact = _run_and_check(ctx, arrays, 1)
+    assert info["num_layouts"] >= 2 and info["max_rounds"] >= 300000
