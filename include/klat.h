@@ -96,8 +96,9 @@ typedef struct {
 
 /* Per-kernel device times of the last klat_forward_backward (HIP events on the ctx stream). */
 typedef struct {
-  float sweep_ms;      /* forward+backward lockstep sweep kernel */
-  float totals_ms;     /* per-lattice total kernel */
+  float sweep_ms;      /* forward+backward lockstep sweep: the fast sweep kernel alone for a batch of one
+                          layout class, all classes' launches (fast + exact) otherwise */
+  float totals_ms;     /* exact sweep (its workgroups exit at once unless a job was flagged) + per-lattice totals */
   float posterior_ms;  /* arc posterior kernel */
   float convert_ms;    /* always 0: the sweep writes natural-log alpha/beta itself (kept for ABI stability) */
   float total_ms;      /* first event to last event */

@@ -418,7 +418,11 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   pa.logpost = b->logpost.p;
   pa.sp = sp;
 
-  KLAT_HIP(hipEventRecord(c->ev[0], c->stream));
+  // sweep_ms of a one-class batch is the fast sweep kernel alone (what rocprofv3 lists under its
+  // name): the events sit right around its launch.  The exact sweep's launch after it (all of its
+  // workgroups exit at once unless the fast sweep flagged a job) falls to totals_ms.
+  const bool one_class = b->classes.size() == 1;
+  if (!one_class) KLAT_HIP(hipEventRecord(c->ev[0], c->stream));
   {
     const int rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
       SweepArgs ca = sa;
@@ -427,11 +431,12 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
       ca.sink = sa.sink + (size_t)lc.job_begin * 64;
       ca.ring_slots = lc.W;
       ca.far_prefetch = lc.far;
-      return launch_sweep(ca, lc.job_end - lc.job_begin, lc.G, stream);
+      return launch_sweep(ca, lc.job_end - lc.job_begin, lc.G, stream, one_class ? c->ev[0] : nullptr,
+                          one_class ? c->ev[1] : nullptr);
     });
     if (rc != KLAT_OK) return rc;
   }
-  KLAT_HIP(hipEventRecord(c->ev[1], c->stream));
+  if (!one_class) KLAT_HIP(hipEventRecord(c->ev[1], c->stream));
   KLAT_HIP(launch_totals(ta, c->stream));
   KLAT_HIP(hipEventRecord(c->ev[2], c->stream));
   KLAT_HIP(launch_posterior(pa, b->num_items, c->stream));

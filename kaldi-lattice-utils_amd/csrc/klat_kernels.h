@@ -114,7 +114,9 @@ struct PruneArgs {
 hipError_t launch_viterbi(const ViterbiArgs& a, int num_jobs, int G, hipStream_t stream);
 hipError_t launch_prune(const PruneArgs& a, int num_lattices, hipStream_t stream);
 
-hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream);
+// fast_begin / fast_end (may be null): events recorded right before and after the fast kernel
+hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream, hipEvent_t fast_begin = nullptr,
+                        hipEvent_t fast_end = nullptr);
 hipError_t launch_totals(const TotalsArgs& a, hipStream_t stream);
 hipError_t launch_unpad(const UnpadArgs& a, hipStream_t stream);
 void fill_ln_table(LnTabEntry* host_table);  // kLnTabSize entries

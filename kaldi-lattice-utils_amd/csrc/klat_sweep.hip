@@ -545,7 +545,7 @@ static size_t sweep_lds_bytes(int ring_slots, int LPW, int cpb) {
 }
 
 template <int G>
-static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream) {
+static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream, hipEvent_t fast_begin, hipEvent_t fast_end) {
   const int LPW = 64 / G;
   // the producer copies a period's states out one period later: the ring must hold two periods
   const int cpb = args.ring_slots >= 32 ? 2 : 1;
@@ -556,34 +556,40 @@ static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, dim3(num_jobs), dim3(128), lds, stream, args);
   };
+  auto launch_fast = [&](auto kernel) {
+    if (fast_begin) (void)hipEventRecord(fast_begin, stream);
+    launch(kernel);
+    if (fast_end) (void)hipEventRecord(fast_end, stream);
+  };
   if (cpb == 2 && args.far_prefetch) {
-    launch(&sweep_kernel<G, true, 2, true>);
+    launch_fast(&sweep_kernel<G, true, 2, true>);
     launch(&sweep_kernel<G, false, 2, true>);
   } else if (cpb == 2) {
-    launch(&sweep_kernel<G, true, 2, false>);
+    launch_fast(&sweep_kernel<G, true, 2, false>);
     launch(&sweep_kernel<G, false, 2, false>);
   } else {
-    launch(&sweep_kernel<G, true, 1, false>);
+    launch_fast(&sweep_kernel<G, true, 1, false>);
     launch(&sweep_kernel<G, false, 1, false>);
   }
 }
 
 // Clears the job flags, runs the fast sweep over every job and the exact sweep over the jobs the
 // fast one flagged (normally none: those workgroups exit at once).
-hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream) {
+hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream, hipEvent_t fast_begin,
+                        hipEvent_t fast_end) {
   if (num_jobs <= 0) return hipSuccess;
   const int LPW = 64 / G;
   if ((size_t)args.ring_slots * LPW + 64 > kCellMask + 1) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(args.job_flags, 0, sizeof(int32_t) * (size_t)num_jobs, stream);
   if (e != hipSuccess) return e;
   switch (G) {
-    case 1: launch_pair<1>(args, num_jobs, stream); break;
-    case 2: launch_pair<2>(args, num_jobs, stream); break;
-    case 4: launch_pair<4>(args, num_jobs, stream); break;
-    case 8: launch_pair<8>(args, num_jobs, stream); break;
-    case 16: launch_pair<16>(args, num_jobs, stream); break;
-    case 32: launch_pair<32>(args, num_jobs, stream); break;
-    case 64: launch_pair<64>(args, num_jobs, stream); break;
+    case 1: launch_pair<1>(args, num_jobs, stream, fast_begin, fast_end); break;
+    case 2: launch_pair<2>(args, num_jobs, stream, fast_begin, fast_end); break;
+    case 4: launch_pair<4>(args, num_jobs, stream, fast_begin, fast_end); break;
+    case 8: launch_pair<8>(args, num_jobs, stream, fast_begin, fast_end); break;
+    case 16: launch_pair<16>(args, num_jobs, stream, fast_begin, fast_end); break;
+    case 32: launch_pair<32>(args, num_jobs, stream, fast_begin, fast_end); break;
+    case 64: launch_pair<64>(args, num_jobs, stream, fast_begin, fast_end); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
