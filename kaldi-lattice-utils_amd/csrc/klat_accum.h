@@ -78,10 +78,25 @@ struct UttArgs {
 };
 hipError_t launch_utterance(const UttArgs& a, int num_workgroups, hipStream_t stream);
 
+struct FrameArc {  // 16 B
+  int32_t k0, k1;  // frames [k0, k1) the arc covers, clipped to the utterance; empty for epsilon arcs
+  double x;        // its log-posterior with the arc cost formed the reference's way
+};
+
+// Frame buckets above kFrSerialMax entries are sorted by the whole workgroup in scratch rows behind
+// the lattice's records; a bucket holds at most one entry per arc.
+static constexpr int kFrSerialMax = 256;
+__host__ __device__ inline int64_t frame_sort_slots(int64_t num_arcs) {
+  if (num_arcs <= kFrSerialMax) return 0;
+  int64_t p = 1;
+  while (p < num_arcs) p <<= 1;
+  return p;
+}
+
 struct FrameArgs {
   const int64_t* state_off;
   const int64_t* arc_off;
-  const int64_t* scratch_off;  // [U+1], per-lattice capacity = next_pow2(expansions)
+  const int64_t* scratch_off;  // [U+1], per-lattice capacity = next_pow2(expansions) + frame_sort_slots(arcs)
   const int32_t* src;
   const int32_t* dst;
   const int32_t* ilabel;
@@ -89,6 +104,7 @@ struct FrameArgs {
   const float* acoustic;
   const int32_t* state_time;
   const int32_t* num_frames;  // [U]
+  FrameArc* arc_info;         // [A] scratch: clipped span and x of every arc
   const double* logpost;
   const double* total;
   void* key_scratch;  // 16 B per slot

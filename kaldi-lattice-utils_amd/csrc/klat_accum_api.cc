@@ -274,6 +274,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       st.frame_base[u + 1] = st.frame_base[u] + num_frames[u];
     }
     if ((rc = st.num_frames.upload(num_frames, (size_t)b->U, c->stream))) return rc;
+    if ((rc = st.arc_scratch.alloc((size_t)b->A * sizeof(FrameArc)))) return rc;
     if ((rc = st.num_expansions.alloc((size_t)b->U))) return rc;
     if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
     a.num_frames = st.num_frames.p;
@@ -288,7 +289,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     std::vector<int64_t> off((size_t)b->U + 1, 0);
     for (int64_t u = 0; u < b->U; ++u) {
       if (nexp[u] > (int64_t)1 << 30) return set_error(KLAT_ERR_OOM, "lattice has more than 2^30 (frame,word) expansions");
-      off[u + 1] = off[u] + next_pow2(nexp[u]);
+      off[u + 1] = off[u] + next_pow2(nexp[u]) + frame_sort_slots(b->h_arc_off[(size_t)u + 1] - b->h_arc_off[(size_t)u]);
     }
     if ((rc = st.scratch_off.upload(off.data(), off.size(), c->stream))) return rc;
     if ((rc = st.key_scratch.alloc((size_t)off[b->U] * 16))) return rc;
@@ -296,6 +297,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     a.scratch_off = st.scratch_off.p;
     a.key_scratch = st.key_scratch.p;
     a.rec_scratch = st.rec_scratch.p;
+    a.arc_info = reinterpret_cast<FrameArc*>(st.arc_scratch.p);
     KLAT_HIP(launch_frame(a, (int)b->U, c->stream));
     std::vector<int32_t> counts((size_t)b->U);
     if (b->U > 0)

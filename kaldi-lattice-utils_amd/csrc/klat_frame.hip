@@ -5,10 +5,19 @@
 //   x = fw[src] + bw[dst] - (float)(Value1 + Value2)          (a FLOAT sum, :102-104)
 // then :121-135: logp = acc - total narrowed to float, per-frame sort by (logp desc, label asc).
 //
-// One workgroup owns one lattice: arcs are expanded into (frame,label | arc) keys, the keys are
-// bitonic-sorted, runs of equal (frame,label) are folded in arc order with the reference's
-// LogAdd, and the folded entries are sorted by (frame, float logp desc, label).  The gather
-// kernel lays them out densely with per-frame offsets.
+// One workgroup owns one lattice.  A frame holds only the few words whose arcs cross it, so the
+// (frame, word) expansions are bucketed by frame instead of sorted as a whole:
+//   0. every arc forms its clipped span and its x once (16 B per arc in scratch);
+//   per tile of kFrTileFrames frames, with the per-frame counters in LDS:
+//   1. entries per frame from a difference array over the spans (two LDS atomics per arc),
+//      prefix sums -> bucket offsets;
+//   2. every arc drops (label | arc, x) into the buckets of its frames (LDS cursors);
+//   3. one thread per frame, 256 frames at a time: bucket into the thread's LDS slab (<= 16
+//      entries; in place in L2 up to 256), insertion sort by (label, arc), runs of one label folded
+//      in arc order with the reference's LogAdd, narrowed to float, insertion sort by (float logp
+//      desc, label asc); a block scan places the frame's records, frames ascending.  Buckets above
+//      256 entries are sorted by the whole workgroup first (bitonic network through an LDS tile).
+// The gather kernel lays the records out densely with per-frame offsets.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -18,8 +27,11 @@
 
 namespace klat {
 
-static constexpr int kFrThreads = 512;
-static constexpr int kFrTile = 2048;  // 16-byte keys per LDS tile (32 KiB)
+static constexpr int kFrThreads = 256;
+static constexpr int kFrTile = 2048;    // 16-byte keys per LDS tile of the cooperative sort (32 KiB)
+static constexpr int kFrSlab = 16;      // bucket entries a frame's thread sorts in its LDS slab (64 KiB in all)
+static constexpr int kFrBigList = 64;
+static constexpr int kFrTileFrames = 1920;  // frames whose counters live in LDS at a time (15 KiB; two workgroups per CU)
 
 __device__ __forceinline__ double fr_log_add(double x, double y) {
   double diff;
@@ -48,8 +60,8 @@ __device__ __forceinline__ float fr_desc_unkey(uint32_t k) {
 }
 
 struct FKey {
-  uint64_t a;  // pass 1: frame|label      pass 2: frame|desc(float logp)
-  uint64_t b;  // pass 1: arc              pass 2: label
+  uint64_t a;  // bucket entry: label|arc   folded: desc(float logp)|label   record: frame|desc(float logp)
+  uint64_t b;  // bucket entry: x (double)  folded: 0                        record: label
 };
 struct FKeyLess {
   __device__ bool operator()(const FKey& x, const FKey& y) const { return x.a < y.a || (x.a == y.a && x.b < y.b); }
@@ -173,9 +185,51 @@ __global__ __launch_bounds__(256) void frame_count_kernel(FrameArgs a) {
   if (threadIdx.x == 0) a.num_expansions[u] = (int64_t)s_sum;
 }
 
+// Sorts a bucket of w entries by (label, arc), folds the runs of one label in arc order, sorts the
+// folded keys (desc(float logp) | label); returns their number.  E(j) is the j-th entry.
+template <class Entry>
+__device__ __forceinline__ int fr_fold_bucket(int w, Entry E) {
+  for (int i = 1; i < w; ++i) {
+    const FKey v = E(i);
+    int t = i - 1;
+    while (t >= 0 && E(t).a > v.a) {
+      E(t + 1) = E(t);
+      --t;
+    }
+    E(t + 1) = v;
+  }
+  int m = 0;
+  for (int j = 0; j < w;) {
+    const FKey e = E(j);
+    const uint32_t lab = (uint32_t)(e.a >> 32);
+    double acc = __longlong_as_double((long long)e.b);
+    for (++j; j < w && (uint32_t)(E(j).a >> 32) == lab; ++j) acc = fr_log_add(acc, __longlong_as_double((long long)E(j).b));
+    const float lp = (float)acc;  // BaseFloat narrowing of :126
+    FKey out;
+    out.a = ((uint64_t)fr_desc_key(lp) << 32) | lab;
+    out.b = 0;
+    E(m++) = out;  // m <= the entries already read
+  }
+  for (int i = 1; i < m; ++i) {
+    const FKey v = E(i);
+    int t = i - 1;
+    while (t >= 0 && E(t).a > v.a) {
+      E(t + 1) = E(t);
+      --t;
+    }
+    E(t + 1) = v;
+  }
+  return m;
+}
+
 __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
-  __shared__ __attribute__((aligned(16))) FKey tile[kFrTile];
+  extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
+  FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrSlab][kFrThreads]; the cooperative sort's tile
+  __shared__ int lboff[kFrTileFrames + 1];  // first expansion of every frame of the tile (tile-local)
+  __shared__ int lcur[kFrTileFrames];       // scatter cursors; then -(folded entries) - 1 for a bucket the workgroup folded
   __shared__ int sh[kFrThreads / 64];
+  __shared__ int big_list[kFrBigList];
+  __shared__ int big_n;
   const int u = blockIdx.x;
   const int tid = threadIdx.x;
   const int64_t a0 = a.arc_off[u];
@@ -184,97 +238,185 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   const int T = a.num_frames[u];
   FKey* keys = reinterpret_cast<FKey*>(a.key_scratch) + a.scratch_off[u];
   FKey* recs = reinterpret_cast<FKey*>(a.rec_scratch) + a.scratch_off[u];
+  FrameArc* ai = a.arc_info + a0;
   const ScaleParams sp = a.sp;
+  // the last frame_sort_slots(nA) record rows of the lattice are the cooperative sort's scratch
+  FKey* tmp = recs + ((a.scratch_off[u + 1] - a.scratch_off[u]) - frame_sort_slots(nA));
 
-  // ---- 1. expand arcs into (frame,label | arc) keys ----
-  int n = 0;
-  for (int base = 0; base < nA; base += kFrThreads) {
-    const int i = base + tid;
-    int k0 = 0, k1 = 0;
-    if (i < nA) fr_span(a, a0, s0, T, i, k0, k1);
-    int tot;
-    const int off = fr_block_scan(k1 - k0, &tot, sh);
-    if (k1 > k0) {
-      const uint32_t lab = fr_bias(a.ilabel[a0 + i]);
-      for (int k = k0; k < k1; ++k) {
-        FKey key;
-        key.a = ((uint64_t)(uint32_t)k << 32) | lab;
-        key.b = (uint32_t)i;
-        keys[n + off + (k - k0)] = key;
-      }
+  // ---- 0. clipped span and x of every arc ----
+  for (int i = tid; i < nA; i += kFrThreads) {
+    FrameArc r;
+    fr_span(a, a0, s0, T, i, r.k0, r.k1);
+    r.x = 0.0;
+    if (r.k1 > r.k0) {
+      // logpost holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
+      // cost here as a float sum, so swap the double sum for the float one
+      float g, ac;
+      arc_cost_parts(a.graph[a0 + i], a.acoustic[a0 + i], true, sp, g, ac);
+      // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
+      const double lpa = a.logpost[a0 + i];
+      r.x = (lpa > -INFINITY) ? lpa + ((double)g + (double)ac) - (double)(g + ac) : lpa;
     }
-    n += tot;
-  }
-  int np = 1;
-  while (np < n) np <<= 1;
-  if (n == 0) np = 0;
-  for (int i = n + tid; i < np; i += kFrThreads) {
-    FKey pad;
-    pad.a = pad.b = ~0ull;
-    keys[i] = pad;
+    ai[i] = r;
   }
   __syncthreads();
-  if (np > 1) fr_bitonic_sort(keys, np, tile, FKeyLess());
 
-  // ---- 2. fold runs of equal (frame,label) in arc order ----
-  const double tot_u = a.total[u];
-  (void)tot_u;
-  int m = 0;
-  for (int base = 0; base < n; base += kFrThreads) {
-    const int i = base + tid;
-    bool head = false;
-    FKey rec;
-    rec.a = rec.b = 0;
-    if (i < n) {
-      const FKey ki = keys[i];
-      head = (i == 0) || (keys[i - 1].a != ki.a);
-      if (head) {
-        double acc = 0.0;
-        for (int j = i; j < n; ++j) {
-          const FKey kj = keys[j];
-          if (kj.a != ki.a) break;
-          const int64_t arc = a0 + (int64_t)(uint32_t)kj.b;
-          // logpost holds alpha - (double)g - (double)a + beta - total; the reference forms the
-          // arc cost here as a float sum, so swap the double sum for the float one
-          float g, ac;
-          arc_cost_parts(a.graph[arc], a.acoustic[arc], true, sp, g, ac);
-          // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
-          const double lpa = a.logpost[arc];
-          const double x = (lpa > -INFINITY) ? lpa + ((double)g + (double)ac) - (double)(g + ac) : lpa;
-          acc = (j == i) ? x : fr_log_add(acc, x);
+  int nbase = 0;  // expansions of the tiles before this one
+  int mbase = 0;  // records written so far
+  for (int f0 = 0; f0 < T; f0 += kFrTileFrames) {
+    const int tf = min(kFrTileFrames, T - f0);
+    // ---- 1. entries per frame: difference array over the spans, prefix sums ----
+    for (int k = tid; k <= tf; k += kFrThreads) lboff[k] = 0;
+    if (tid == 0) big_n = 0;
+    __syncthreads();
+    for (int i = tid; i < nA; i += kFrThreads) {
+      const int lo = max(ai[i].k0, f0) - f0, hi = min(ai[i].k1, f0 + tf) - f0;
+      if (hi > lo) {
+        atomicAdd(&lboff[lo], 1);
+        atomicAdd(&lboff[hi], -1);
+      }
+    }
+    __syncthreads();
+    int carry_c = 0, n = 0;
+    for (int base = 0; base <= tf; base += kFrThreads) {
+      const int k = base + tid;
+      const int d = (k <= tf) ? lboff[k] : 0;
+      int tot_d, tot_c;
+      const int ex = fr_block_scan(d, &tot_d, sh);
+      const int c = (k < tf) ? carry_c + ex + d : 0;  // entries of frame k
+      const int o = n + fr_block_scan(c, &tot_c, sh);
+      if (k <= tf) lboff[k] = o;
+      if (k < tf) lcur[k] = o;
+      carry_c += tot_d;
+      n += tot_c;
+    }
+    __syncthreads();
+
+    // ---- 2. every arc drops (label | arc, x) into the buckets of its frames ----
+    for (int i = tid; i < nA; i += kFrThreads) {
+      const FrameArc r = ai[i];
+      const int lo = max(r.k0, f0) - f0, hi = min(r.k1, f0 + tf) - f0;
+      if (hi <= lo) continue;
+      FKey e;
+      e.a = ((uint64_t)fr_bias(a.ilabel[a0 + i]) << 32) | (uint32_t)i;
+      e.b = (uint64_t)__double_as_longlong(r.x);
+      for (int k = lo; k < hi; ++k) keys[nbase + atomicAdd(&lcur[k], 1)] = e;
+    }
+    __syncthreads();
+
+    // ---- 3a. buckets above kFrSerialMax entries, kFrBigList at a time: sorted through the LDS
+    // tile (which overlays the slabs), folded by the heads of the runs, sorted again; the folded
+    // keys stay at the bucket's start ----
+    for (;;) {
+      for (int k = tid; k < tf; k += kFrThreads)
+        if (lboff[k + 1] - lboff[k] > kFrSerialMax && lcur[k] >= 0) {
+          const int slot = atomicAdd(&big_n, 1);
+          if (slot < kFrBigList) big_list[slot] = k;
         }
-        const float lp = (float)acc;  // BaseFloat narrowing of :126
-        rec.a = (ki.a & 0xFFFFFFFF00000000ull) | fr_desc_key(lp);
-        rec.b = (uint32_t)ki.a;  // biased label
+      __syncthreads();
+      const int nbig = min(big_n, kFrBigList);
+      if (nbig == 0) break;
+      for (int bi = 0; bi < nbig; ++bi) {
+        const int k = big_list[bi];
+        const int o = nbase + lboff[k], w = lboff[k + 1] - lboff[k];
+        int np = 1;
+        while (np < w) np <<= 1;
+        for (int i = tid; i < np; i += kFrThreads) {
+          FKey e;
+          e.a = e.b = ~0ull;
+          if (i < w) e = keys[o + i];
+          tmp[i] = e;
+        }
+        __syncthreads();
+        fr_bitonic_sort(tmp, np, slab, FKeyLess());
+        int m = 0;
+        for (int base = 0; base < w; base += kFrThreads) {
+          const int i = base + tid;
+          bool head = false;
+          FKey out;
+          out.a = out.b = 0;
+          if (i < w) {
+            const uint32_t lab = (uint32_t)(tmp[i].a >> 32);
+            head = (i == 0) || ((uint32_t)(tmp[i - 1].a >> 32) != lab);
+            if (head) {
+              double acc = __longlong_as_double((long long)tmp[i].b);
+              for (int j = i + 1; j < w && (uint32_t)(tmp[j].a >> 32) == lab; ++j)
+                acc = fr_log_add(acc, __longlong_as_double((long long)tmp[j].b));
+              out.a = ((uint64_t)fr_desc_key((float)acc) << 32) | lab;
+            }
+          }
+          int tot;
+          const int off = fr_block_scan(head ? 1 : 0, &tot, sh);
+          if (head) keys[o + m + off] = out;
+          m += tot;
+        }
+        __syncthreads();
+        int mp = 1;
+        while (mp < m) mp <<= 1;
+        for (int i = tid; i < mp; i += kFrThreads) {
+          FKey e;
+          e.a = e.b = ~0ull;
+          if (i < m) e = keys[o + i];
+          tmp[i] = e;
+        }
+        __syncthreads();
+        fr_bitonic_sort(tmp, mp, slab, FKeyLess());
+        for (int i = tid; i < m; i += kFrThreads) keys[o + i] = tmp[i];
+        if (tid == 0) lcur[k] = -m - 1;
+        __syncthreads();
       }
+      if (tid == 0) big_n = 0;
+      __syncthreads();
     }
-    // compact heads
-    const uint64_t ballot = __ballot(head);
-    const int lane = tid & 63, wave = tid >> 6;
-    const int within = __popcll(ballot & ((1ull << lane) - 1ull));
-    if (lane == 0) sh[wave] = __popcll(ballot);
-    __syncthreads();
-    int off = 0, tot = 0;
-    for (int w = 0; w < kFrThreads / 64; ++w) {
-      if (w < wave) off += sh[w];
-      tot += sh[w];
+
+    // ---- 3b. one thread per frame, kFrThreads frames at a time: sort, fold, sort, place ----
+    for (int r0 = 0; r0 < tf; r0 += kFrThreads) {
+      const int k = r0 + tid;
+      int o = 0, w = 0, mk = 0;
+      bool in_slab = false;
+      if (k < tf) {
+        o = nbase + lboff[k];
+        w = lboff[k + 1] - lboff[k];
+        if (lcur[k] < 0) {
+          mk = -lcur[k] - 1;  // folded by the workgroup
+        } else if (w > kFrSlab) {
+          mk = fr_fold_bucket(w, [&](int j) -> FKey& { return keys[o + j]; });
+        } else if (w > 0) {
+          in_slab = true;
+#pragma unroll
+          for (int j = 0; j < kFrSlab; ++j)
+            if (j < w) slab[j * kFrThreads + tid] = keys[o + j];
+          mk = fr_fold_bucket(w, [&](int j) -> FKey& { return slab[j * kFrThreads + tid]; });
+        }
+      }
+      int tot;
+      const int dst = mbase + fr_block_scan(mk, &tot, sh);
+      const uint64_t frame_hi = (uint64_t)(uint32_t)(f0 + k) << 32;
+      if (in_slab) {
+#pragma unroll
+        for (int j = 0; j < kFrSlab; ++j)
+          if (j < mk) {
+            const uint64_t key = slab[j * kFrThreads + tid].a;
+            FKey r;
+            r.a = frame_hi | (key >> 32);
+            r.b = (uint32_t)key;  // biased label
+            recs[dst + j] = r;
+          }
+      } else {
+        for (int j = 0; j < mk; ++j) {
+          const uint64_t key = keys[o + j].a;
+          FKey r;
+          r.a = frame_hi | (key >> 32);
+          r.b = (uint32_t)key;
+          recs[dst + j] = r;
+        }
+      }
+      mbase += tot;
     }
+    nbase += n;
     __syncthreads();
-    if (head) recs[m + off + within] = rec;
-    m += tot;
   }
-  int mp = 1;
-  while (mp < m) mp <<= 1;
-  if (m == 0) mp = 0;
-  for (int i = m + tid; i < mp; i += kFrThreads) {
-    FKey pad;
-    pad.a = pad.b = ~0ull;
-    recs[i] = pad;
-  }
-  __syncthreads();
-  // ---- 3. per-frame order: float logp descending, then label ascending ----
-  if (mp > 1) fr_bitonic_sort(recs, mp, tile, FKeyLess());
-  if (tid == 0) a.num_records[u] = m;
+  if (tid == 0) a.num_records[u] = mbase;
 }
 
 // Dense output: entries of lattice u at entry_off[u].., frame offsets at frame_base[u]...
@@ -308,7 +450,10 @@ hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t 
 }
 hipError_t launch_frame(const FrameArgs& a, int num_lattices, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
-  hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), 0, stream, a);
+  const size_t lds = sizeof(FKey) * kFrSlab * kFrThreads;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a);
   return hipGetLastError();
 }
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,

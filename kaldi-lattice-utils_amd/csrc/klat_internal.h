@@ -26,7 +26,8 @@ int hip_fail(hipError_t e, const char* what);
 template <class T>
 struct DevBuf {
   T* p = nullptr;
-  size_t n = 0;
+  size_t n = 0;    // elements in use
+  size_t cap = 0;  // elements allocated
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -34,17 +35,24 @@ struct DevBuf {
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
-    n = 0;
+    n = cap = 0;
   }
+  // contents unspecified; an allocation that is large enough is kept (hipFree + hipMalloc of the
+  // gigabyte-sized scratch of the accumulate stage costs tens of milliseconds)
   int alloc(size_t count) {
+    if (p && count <= cap) {
+      n = count;
+      return KLAT_OK;
+    }
     release();
-    n = count;
-    if (count == 0) count = 1;  // keep pointers non-null for empty batches
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    const size_t want = count == 0 ? 1 : count;  // keep pointers non-null for empty batches
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
     if (e != hipSuccess) {
       p = nullptr;
       return hip_fail(e, "hipMalloc");
     }
+    n = count;
+    cap = want;
     return KLAT_OK;
   }
   int upload(const T* host, size_t count, hipStream_t s) {
@@ -89,7 +97,7 @@ struct klat_frame_state {
   std::vector<int64_t> frame_base, entry_off;
   klat::DevBuf<int64_t> scratch_off, num_expansions;
   klat::DevBuf<int32_t> num_frames, num_records;
-  klat::DevBuf<unsigned char> key_scratch, rec_scratch;
+  klat::DevBuf<unsigned char> key_scratch, rec_scratch, arc_scratch;
 };
 
 struct klat_batch {

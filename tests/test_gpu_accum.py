@@ -281,3 +281,41 @@ def test_frame_post_synthetic(ctx, scales):
         _check_frames(off, labels, logps, fb, want)
         fb += nframes[u]
     assert off[-1] == len(labels)
+
+
+@pytest.mark.parametrize("width", [40, 200, 700, 5000])
+def test_frame_post_wide_frames(ctx, width):
+    """Frames crossed by many arcs: up to 16 entries a frame's thread sorts in LDS, up to 256 in
+    place, above that the whole workgroup sorts the frame's bucket (700: through the LDS tile;
+    5000: beyond it).  Labels repeat inside a frame, so runs get folded; some arcs are dead."""
+    rng = np.random.RandomState(width)
+    lats, times, nframes = [], [], []
+    for n, dur in ((width, 3), (width // 3 + 1, 2), (5, 4)):
+        ab = np.array([0, n, n + 1, n + 1], np.int64)
+        dst = np.concatenate([np.ones(n, np.int32), [2]]).astype(np.int32)
+        lab = np.concatenate([rng.randint(1, max(2, n // 2), size=n), [7]]).astype(np.int32)
+        lab[rng.rand(n + 1) < 0.05] = 0  # epsilon arcs are skipped
+        graph = np.concatenate([rng.rand(n) * 6, [0.25]]).astype(np.float32)
+        ac = np.concatenate([rng.rand(n) * 3, [0.5]]).astype(np.float32)
+        dead = rng.rand(n + 1) < 0.03
+        dead[0] = dead[n] = False
+        graph[dead] = np.inf
+        ac[dead] = np.inf
+        fg, fa = np.full(3, np.inf, np.float32), np.full(3, np.inf, np.float32)
+        fg[2] = fa[2] = 0.0
+        lats.append(orc.Lat(ab, dst, lab, lab.copy(), graph, ac, np.zeros(n + 1, np.int32), fg, fa, np.zeros(3, np.int32)))
+        times.append(np.array([0, dur, dur + 2], np.int32))
+        nframes.append(dur + 2)
+    arrays = klat_amd.concat_lattices(lats, times)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.5, 0.25)
+    off, labels, logps = b.frame_post(nframes)
+    b.close()
+    fb = 0
+    for u, lat in enumerate(lats):
+        sl = orc.scale_and_penalize(lat, 1.0, 0.5, 0.25)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        want, mis = orc.frame_post(sl, times[u], nframes[u], alpha, beta, total)
+        _check_frames(off, labels, logps, fb, want)
+        fb += nframes[u]
+    assert off[-1] == len(labels)

@@ -21,6 +21,13 @@ rec = np.zeros(n.value, klat_amd.SEGMENT_DTYPE)
 t0 = time.perf_counter()
 klat_amd._check(klat_amd.lib().klat_segment_index(b.h, C.byref(f), klat_amd._p(off), klat_amd._p(rec), C.c_int64(len(rec)), C.byref(n)))
 print("gather + D2H of %.1f MB: %.2f ms" % (rec.nbytes / 1e6, 1e3 * (time.perf_counter() - t0)))
-if U <= 2000:
+if U <= 4000:
     nf = a["state_time"][a["state_off"][1:] - 1].astype(np.int32)
-    t0 = time.perf_counter(); o, l, p = b.frame_post(nf); print("frame post total %.1f ms, %d entries" % (1e3 * (time.perf_counter() - t0), len(l)))
+    foff = np.zeros(int(nf.sum()) + 1, np.int64)
+    for it in range(3):
+        ne = C.c_int64(0)
+        t0 = time.perf_counter()
+        klat_amd._check(klat_amd.lib().klat_frame_post(b.h, klat_amd._p(nf), klat_amd._p(foff), None, None, C.c_int64(0), C.byref(ne)))
+        t1 = time.perf_counter()
+        print("frame post compute (count + bucket/fold/sort kernels + scratch allocation): %.2f ms, %d entries, %.2f G arcs/s" % (1e3 * (t1 - t0), ne.value, b.A / (t1 - t0) / 1e9))
+    t0 = time.perf_counter(); o, l, p = b.frame_post(nf); print("frame post total incl. gather + D2H of %.0f MB: %.1f ms" % ((l.nbytes + p.nbytes + o.nbytes) / 1e6, 1e3 * (time.perf_counter() - t0)))
