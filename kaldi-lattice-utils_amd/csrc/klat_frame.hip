@@ -12,11 +12,12 @@
 //   1. entries per frame from a difference array over the spans (two LDS atomics per arc),
 //      prefix sums -> bucket offsets;
 //   2. every arc drops (label | arc, x) into the buckets of its frames (LDS cursors);
-//   3. one thread per frame, 256 frames at a time: bucket into the thread's LDS slab (<= 16
-//      entries; in place in L2 up to 256), insertion sort by (label, arc), runs of one label folded
-//      in arc order with the reference's LogAdd, narrowed to float, insertion sort by (float logp
-//      desc, label asc); a block scan places the frame's records, frames ascending.  Buckets above
-//      256 entries are sorted by the whole workgroup first (bitonic network through an LDS tile).
+//   3. one thread per frame, 256 frames at a time: a bucket of <= 16 entries is sorted by (label,
+//      arc) in registers (bitonic network, 8 or 16 wide), runs of one label are folded in arc
+//      order with the reference's LogAdd and narrowed to float, the folded keys (float logp desc,
+//      label asc) sorted by the same network; a block scan places the frame's records, frames
+//      ascending.  Buckets of up to 256 entries take insertion sorts in place (L2), larger ones
+//      are sorted by the whole workgroup first (bitonic network through an LDS tile).
 // The gather kernel lays the records out densely with per-frame offsets.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -29,7 +30,7 @@ namespace klat {
 
 static constexpr int kFrThreads = 256;
 static constexpr int kFrTile = 2048;    // 16-byte keys per LDS tile of the cooperative sort (32 KiB)
-static constexpr int kFrSlab = 16;      // bucket entries a frame's thread sorts in its LDS slab (64 KiB in all)
+static constexpr int kFrRegs = 16;      // bucket entries a frame's thread sorts in registers
 static constexpr int kFrBigList = 64;
 static constexpr int kFrTileFrames = 1920;  // frames whose counters live in LDS at a time (15 KiB; two workgroups per CU)
 
@@ -185,6 +186,43 @@ __global__ __launch_bounds__(256) void frame_count_kernel(FrameArgs a) {
   if (threadIdx.x == 0) a.num_expansions[u] = (int64_t)s_sum;
 }
 
+// Bitonic network over the first N of 16 register-resident keys (ascending), payload alongside.
+// Sizes and strides are template parameters so that every index is a constant and the arrays
+// stay in registers.
+template <int N, int SIZE, int STRIDE, bool WITH_VAL>
+__device__ __forceinline__ void fr_sort_stage(uint64_t (&k)[kFrRegs], double (&v)[kFrRegs]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int l = i ^ STRIDE;
+    if (l > i) {
+      const bool up = (i & SIZE) == 0;
+      // (values first, selects on the values: a select between k[i] and k[l] themselves becomes a
+      // select of the index, and the arrays leave the registers)
+      const uint64_t ki = k[i], kl = k[l];
+      const double vi = v[i], vl = v[l];
+      // VOP3 selects with the lane mask in a scalar pair (klat_math.h: runs of the VOP2 / VCC
+      // form cost ~16 cycles each once several waves share a CU)
+      const uint64_t sw = lane_mask(up ? (ki > kl) : (ki < kl));
+      k[i] = (uint64_t)__double_as_longlong(select64(sw, __longlong_as_double((long long)kl), __longlong_as_double((long long)ki)));
+      k[l] = (uint64_t)__double_as_longlong(select64(sw, __longlong_as_double((long long)ki), __longlong_as_double((long long)kl)));
+      if (WITH_VAL) {
+        v[i] = select64(sw, vl, vi);
+        v[l] = select64(sw, vi, vl);
+      }
+    }
+  }
+  if constexpr (STRIDE > 1) fr_sort_stage<N, SIZE, STRIDE / 2, WITH_VAL>(k, v);
+}
+template <int N, int SIZE, bool WITH_VAL>
+__device__ __forceinline__ void fr_sort_sizes(uint64_t (&k)[kFrRegs], double (&v)[kFrRegs]) {
+  fr_sort_stage<N, SIZE, SIZE / 2, WITH_VAL>(k, v);
+  if constexpr (SIZE < N) fr_sort_sizes<N, SIZE * 2, WITH_VAL>(k, v);
+}
+template <int N, bool WITH_VAL>
+__device__ __forceinline__ void fr_sort_regs(uint64_t (&k)[kFrRegs], double (&v)[kFrRegs]) {
+  fr_sort_sizes<N, 2, WITH_VAL>(k, v);
+}
+
 // Sorts a bucket of w entries by (label, arc), folds the runs of one label in arc order, sorts the
 // folded keys (desc(float logp) | label); returns their number.  E(j) is the j-th entry.
 template <class Entry>
@@ -224,7 +262,7 @@ __device__ __forceinline__ int fr_fold_bucket(int w, Entry E) {
 
 __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
-  FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrSlab][kFrThreads]; the cooperative sort's tile
+  FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrTile]: the cooperative sort's tile
   __shared__ int lboff[kFrTileFrames + 1];  // first expansion of every frame of the tile (tile-local)
   __shared__ int lcur[kFrTileFrames];       // scatter cursors; then -(folded entries) - 1 for a bucket the workgroup folded
   __shared__ int sh[kFrThreads / 64];
@@ -373,33 +411,64 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
     for (int r0 = 0; r0 < tf; r0 += kFrThreads) {
       const int k = r0 + tid;
       int o = 0, w = 0, mk = 0;
-      bool in_slab = false;
+      bool in_regs = false;
       if (k < tf) {
         o = nbase + lboff[k];
         w = lboff[k + 1] - lboff[k];
-        if (lcur[k] < 0) {
+        if (lcur[k] < 0)
           mk = -lcur[k] - 1;  // folded by the workgroup
-        } else if (w > kFrSlab) {
+        else if (w > kFrRegs)
           mk = fr_fold_bucket(w, [&](int j) -> FKey& { return keys[o + j]; });
-        } else if (w > 0) {
-          in_slab = true;
+        else
+          in_regs = w > 0;
+      }
+      uint64_t ek[kFrRegs];
+      double ex[kFrRegs];
 #pragma unroll
-          for (int j = 0; j < kFrSlab; ++j)
-            if (j < w) slab[j * kFrThreads + tid] = keys[o + j];
-          mk = fr_fold_bucket(w, [&](int j) -> FKey& { return slab[j * kFrThreads + tid]; });
+      for (int j = 0; j < kFrRegs; ++j) {
+        ek[j] = ~0ull;
+        ex[j] = 0.0;
+        if (in_regs && j < w) {
+          const FKey e = keys[o + j];
+          ek[j] = e.a;
+          ex[j] = __longlong_as_double((long long)e.b);
         }
       }
+      const bool narrow = __all(!in_regs || w <= 8);  // wave-uniform: the 8-wide network is enough
+      if (narrow)
+        fr_sort_regs<8, true>(ek, ex);
+      else
+        fr_sort_regs<kFrRegs, true>(ek, ex);
+      // fold: the key of a run is emitted at its last entry, the other entries turn into padding
+      double acc = ex[0];
+#pragma unroll
+      for (int j = 1; j <= kFrRegs; ++j) {
+        const uint32_t lab = (uint32_t)(ek[j - 1] >> 32);
+        const bool cont = j < kFrRegs && j < w && (uint32_t)(ek[j < kFrRegs ? j : 0] >> 32) == lab;
+        const bool emit = in_regs && !cont && j - 1 < w;
+        ek[j - 1] = emit ? (((uint64_t)fr_desc_key((float)acc) << 32) | lab) : ~0ull;  // BaseFloat narrowing of :126
+        mk += emit ? 1 : 0;
+        if (j < kFrRegs) {
+          if (cont)
+            acc = fr_log_add(acc, ex[j]);
+          else
+            acc = ex[j];
+        }
+      }
+      if (narrow)
+        fr_sort_regs<8, false>(ek, ex);
+      else
+        fr_sort_regs<kFrRegs, false>(ek, ex);
       int tot;
       const int dst = mbase + fr_block_scan(mk, &tot, sh);
       const uint64_t frame_hi = (uint64_t)(uint32_t)(f0 + k) << 32;
-      if (in_slab) {
+      if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < kFrSlab; ++j)
+        for (int j = 0; j < kFrRegs; ++j)
           if (j < mk) {
-            const uint64_t key = slab[j * kFrThreads + tid].a;
             FKey r;
-            r.a = frame_hi | (key >> 32);
-            r.b = (uint32_t)key;  // biased label
+            r.a = frame_hi | (ek[j] >> 32);
+            r.b = (uint32_t)ek[j];  // biased label
             recs[dst + j] = r;
           }
       } else {
@@ -450,7 +519,7 @@ hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t 
 }
 hipError_t launch_frame(const FrameArgs& a, int num_lattices, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
-  const size_t lds = sizeof(FKey) * kFrSlab * kFrThreads;
+  const size_t lds = sizeof(FKey) * kFrTile;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a);
