@@ -27,6 +27,8 @@ struct AccumArgs {
   void* rec_scratch;  // 24 B per slot
   int32_t* num_records;  // [U]
   int32_t tile_bytes;    // dynamic LDS per workgroup (sort tile), <= 128 KiB
+  uint32_t* arc_order;   // 4 B per slot: the radix kernel's sorted values
+  int32_t min_arcs, max_arcs;  // a launch takes the lattices with min_arcs < arcs <= max_arcs
 };
 
 struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)
@@ -39,7 +41,7 @@ hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hip
 // Radix path (klat_accum_radix.hip): lattices of at most kRadixMaxArcs arcs whose index keys pack
 // into total_bits <= 62 bits -- (label - label_min) in label_bits, times / positions in time_bits
 // each.  The ranges come from range_kernel over the batch.
-static const int kRadixMaxArcs = 8192;
+static const int kRadixMaxArcs = 16384;  // 8 items per thread up to 8192 arcs, 16 above
 struct RadixPack {
   int32_t label_min;
   int32_t label_bits, time_bits, total_bits;
@@ -52,7 +54,7 @@ struct RangeArgs {
   int32_t* out;              // [4]: label min, label max, time max, length max
 };
 hipError_t launch_range(const RangeArgs& a, hipStream_t stream);
-hipError_t launch_index_radix(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position,
+hipError_t launch_index_radix(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int items,
                               hipStream_t stream);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
                                OutRecord* out, hipStream_t stream);

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
   const int64_t a0 = a.arc_off[u], a1 = a.arc_off[u + 1];
   const int64_t s0 = a.state_off[u];
   const int nA = (int)(a1 - a0);
+  if (nA <= a.min_arcs || nA > a.max_arcs) return;  // the radix kernel's lattice (workgroup-uniform)
   Key* keys = reinterpret_cast<Key*>(a.key_scratch) + a.scratch_off[u];
   Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + a.scratch_off[u];
   const int cap = (int)(a.scratch_off[u + 1] - a.scratch_off[u]);  // power of two >= nA (or 0)

@@ -38,6 +38,7 @@ int ensure_index_scratch(klat_batch* b) {
   if ((rc = st.scratch_off.upload(off.data(), off.size(), b->ctx->stream))) return rc;
   if ((rc = st.key_scratch.alloc((size_t)st.scratch_slots * 16))) return rc;
   if ((rc = st.rec_scratch.alloc((size_t)st.scratch_slots * 24))) return rc;
+  if ((rc = st.arc_order.alloc((size_t)st.scratch_slots))) return rc;
   if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   st.scratch_ready = true;
@@ -71,6 +72,9 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
   a.logpost = b->logpost.p;
   a.key_scratch = st.key_scratch.p;
   a.rec_scratch = st.rec_scratch.p;
+  a.arc_order = st.arc_order.p;
+  a.min_arcs = -1;
+  a.max_arcs = 0x7FFFFFFF;
   a.num_records = st.num_records.p;
   {
     // sort tile: big enough for the largest lattice's keys if that fits 128 KiB of LDS
@@ -97,14 +101,16 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     a.exclude = st.exclude.p;
     a.num_exclude = (int32_t)exc.size();
     a.state_len = st.state_len.p;
-    // lattices of up to 8192 arcs whose keys pack into 62 bits take the radix-sort kernel
+    // lattices of up to 16384 arcs take the radix-sort kernel if the batch's keys pack into 62
+    // bits (8 items per thread up to 8192 arcs, 16 above), the others the general kernel
     bool radix = std::getenv("KLAT_INDEX_BITONIC") == nullptr;  // (test hook: force the general kernel)
     RadixPack pk = {0, 0, 0, 0};
-    {
-      int64_t max_arcs = 0;
-      for (int64_t u = 0; u < b->U; ++u) max_arcs = std::max(max_arcs, b->h_arc_off[u + 1] - b->h_arc_off[u]);
-      radix = radix && max_arcs <= kRadixMaxArcs && b->A > 0;
+    int64_t n_small = 0, n_medium = 0, n_large = 0;
+    for (int64_t u = 0; u < b->U; ++u) {
+      const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
+      (arcs <= kRadixMaxArcs / 2 ? n_small : arcs <= kRadixMaxArcs ? n_medium : n_large)++;
     }
+    radix = radix && n_small + n_medium > 0 && b->A > 0;
     if (radix) {
       const int32_t init[4] = {0x7FFFFFFF, (int32_t)0x80000000, 0, 0};
       int32_t range[4];
@@ -125,10 +131,23 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       pk.total_bits = pk.label_bits + (position ? 1 : 2) * pk.time_bits;
       radix = pk.total_bits <= 62;
     }
-    if (radix)
-      KLAT_HIP(launch_index_radix(a, pk, (int)b->U, position, c->stream));
-    else
+    if (radix) {
+      if (n_small > 0) {
+        a.min_arcs = -1, a.max_arcs = kRadixMaxArcs / 2;
+        KLAT_HIP(launch_index_radix(a, pk, (int)b->U, position, 8, c->stream));
+      }
+      if (n_medium > 0) {
+        a.min_arcs = kRadixMaxArcs / 2, a.max_arcs = kRadixMaxArcs;
+        KLAT_HIP(launch_index_radix(a, pk, (int)b->U, position, 16, c->stream));
+      }
+      if (n_large > 0) {
+        a.min_arcs = kRadixMaxArcs, a.max_arcs = 0x7FFFFFFF;
+        KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
+      }
+      a.min_arcs = -1, a.max_arcs = 0x7FFFFFFF;
+    } else {
       KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
+    }
     std::vector<int32_t> counts((size_t)b->U);
     if (b->U > 0)
       KLAT_HIP(hipMemcpyAsync(counts.data(), st.num_records.p, sizeof(int32_t) * (size_t)b->U,

@@ -11,10 +11,16 @@
 //      second stable radix sort on all 64 bits of the order-preserving image of the double: ties
 //      keep the (label, t0, t1) / (label, pos) order, which is the reference's comparator
 //      (kwsbin2/lattice-word-index-segment.cc:98-126, -position.cc:102-127).
-// One workgroup of 1024 threads per lattice, 80 KiB of LDS (two workgroups per CU).
+// One workgroup of 1024 threads per lattice; 8 items per thread (lattices of up to 8192 arcs, 64 KiB
+// of LDS, two workgroups per CU) or 16 (up to 16384 arcs, 132 KiB, one workgroup per CU).  A launch
+// takes the lattices whose arc count lies in (min_arcs, max_arcs]; the others belong to another
+// instantiation or to the general kernel (klat_accum.hip).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+
+#include <algorithm>
+#include <type_traits>
 
 #include <rocprim/block/block_radix_sort.hpp>
 
@@ -25,8 +31,8 @@ namespace klat {
 namespace {
 
 constexpr int kThreads = 1024;
-constexpr int kItems = 8;
-using Sort = rocprim::block_radix_sort<uint64_t, kThreads, kItems, uint32_t>;
+template <int ITEMS>
+using SortT = rocprim::block_radix_sort<uint64_t, kThreads, ITEMS, uint32_t>;
 
 __device__ __forceinline__ double radix_log_add(double x, double y) {
   double diff;
@@ -85,18 +91,25 @@ __device__ int block_exclusive_sum(int v, int* total, int* sh /* [kThreads/64 + 
   return off + incl - v;
 }
 
-template <bool POSITION>
+template <bool POSITION, int kItems>
 __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, RadixPack pk) {
+  using Sort = SortT<kItems>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int sh[kThreads / 64 + 1];
   typename Sort::storage_type& storage = *reinterpret_cast<typename Sort::storage_type*>(smem);
-  uint64_t* skey = reinterpret_cast<uint64_t*>(smem);                                   // [8192], after sort 1
-  uint16_t* sarc = reinterpret_cast<uint16_t*>(smem + sizeof(uint64_t) * kThreads * kItems);  // [8192]
+  uint64_t* skey = reinterpret_cast<uint64_t*>(smem);  // [kThreads * kItems], after a sort
   const int u = blockIdx.x;
   const int tid = threadIdx.x;
   const int64_t a0 = a.arc_off[u], a1 = a.arc_off[u + 1];
   const int64_t s0 = a.state_off[u];
   const int nA = (int)(a1 - a0);
+  if (nA <= a.min_arcs || nA > a.max_arcs) return;  // another launch's lattice (workgroup-uniform)
+  // the sorted values beside skey: in LDS behind the keys with 8 items per thread, in the lattice's
+  // `cap` slots of arc_order (L2) with 16, where LDS has no room for them
+  using ArcT = std::conditional_t<kItems == 8, uint16_t, uint32_t>;
+  ArcT* sarc = kItems == 8 ? reinterpret_cast<ArcT*>(smem + sizeof(uint64_t) * kThreads * kItems)
+                           : reinterpret_cast<ArcT*>(a.arc_order + a.scratch_off[u]);
+  const int cap = kItems == 8 ? kThreads * kItems : (int)(a.scratch_off[u + 1] - a.scratch_off[u]);
   Payload* payload = reinterpret_cast<Payload*>(a.key_scratch) + a.scratch_off[u];
   Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + a.scratch_off[u];
   const uint64_t invalid = 1ull << pk.total_bits;
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
     skey[tid * kItems + j] = keys[j];
-    sarc[tid * kItems + j] = (uint16_t)vals[j];
+    if (tid * kItems + j < cap) sarc[tid * kItems + j] = (ArcT)vals[j];
   }
   __syncthreads();
 
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
     const int i = tid * kItems + j;
-    if (i < n && (i == 0 || skey[i - 1] != keys[j])) head_mask |= 1u << j;
+    if (i < n && (i == 0 || skey[i - 1] != skey[i])) head_mask |= 1u << j;
   }
   int m;
   int id = block_exclusive_sum(__popc(head_mask), &m, sh);  // record ids follow the key order
@@ -157,11 +170,14 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
     keys2[j] = ~0ull;
     vals2[j] = 0xFFFFFFFFu;
     if (head_mask & (1u << j)) {
-      int arc = (int)vals[j];
+      // (key and arc from skey / sarc, not from the sort's registers: those are dead by now, which
+      // the 16-item instantiation needs to stay within its 128 registers)
+      const uint64_t kj = skey[i];
+      int arc = (int)sarc[i];
       double acc = a.logpost[a0 + arc];
       double best = acc;
       int best_arc = arc;
-      for (int k = i + 1; k < n && skey[k] == keys[j]; ++k) {
+      for (int k = i + 1; k < n && skey[k] == kj; ++k) {
         arc = (int)sarc[k];
         const double x = a.logpost[a0 + arc];
         acc = radix_log_add(acc, x);
@@ -172,16 +188,16 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
       }
       Payload q;
       if (POSITION) {
-        const int32_t label = (int32_t)(uint32_t)(keys[j] >> pk.time_bits) + pk.label_min;
-        const int32_t pos = (int32_t)(uint32_t)(keys[j] & tmask) + 1;  // 1-based on output
+        const int32_t label = (int32_t)(uint32_t)(kj >> pk.time_bits) + pk.label_min;
+        const int32_t pos = (int32_t)(uint32_t)(kj & tmask) + 1;  // 1-based on output
         q.k1 = ((uint64_t)rbias(label) << 32) | rbias(pos);
         const int32_t t0 = a.state_time[s0 + a.src[a0 + best_arc]];
         const int32_t t1 = a.state_time[s0 + a.dst[a0 + best_arc]];
         q.k2 = ((uint64_t)(uint32_t)t0 << 32) | (uint32_t)t1;
       } else {
-        const int32_t label = (int32_t)(uint32_t)(keys[j] >> (2 * pk.time_bits)) + pk.label_min;
-        const int32_t t0 = (int32_t)(uint32_t)((keys[j] >> pk.time_bits) & tmask);
-        const int32_t t1 = (int32_t)(uint32_t)(keys[j] & tmask);
+        const int32_t label = (int32_t)(uint32_t)(kj >> (2 * pk.time_bits)) + pk.label_min;
+        const int32_t t0 = (int32_t)(uint32_t)((kj >> pk.time_bits) & tmask);
+        const int32_t t1 = (int32_t)(uint32_t)(kj & tmask);
         q.k1 = ((uint64_t)rbias(label) << 32) | rbias(t0);
         q.k2 = (uint64_t)rbias(t1) << 32;
       }
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
     skey[tid * kItems + j] = keys2[j];
-    sarc[tid * kItems + j] = (uint16_t)vals2[j];
+    if (tid * kItems + j < cap) sarc[tid * kItems + j] = (ArcT)vals2[j];
   }
   __syncthreads();
 #pragma unroll
@@ -259,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
       }
       for (int i = p + 1; i < q; ++i) {
         const uint64_t k = skey[i];
-        const uint16_t v = sarc[i];
+        const ArcT v = sarc[i];
         int t = i - 1;
         while (t >= p && skey[t] > k) {
           skey[t + 1] = skey[t];
@@ -276,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
     keys2[j] = skey[tid * kItems + j];
-    vals2[j] = sarc[tid * kItems + j];
+    vals2[j] = (tid * kItems + j < cap) ? sarc[tid * kItems + j] : 0xFFFFFFFFu;
   }
   if (long_run) {
     __syncthreads();  // skey / sarc are read: the storage is the sort's again
@@ -299,30 +315,25 @@ __global__ __launch_bounds__(kThreads) void index_radix_kernel(AccumArgs a, Radi
   if (tid == 0) a.num_records[u] = m;
 }
 
-}  // namespace
-
-size_t index_radix_lds_bytes() {
-  const size_t arrays = (sizeof(uint64_t) + sizeof(uint16_t)) * kThreads * kItems;
-  return sizeof(Sort::storage_type) > arrays ? sizeof(Sort::storage_type) : arrays;
+template <bool POSITION, int ITEMS>
+static hipError_t launch_one(const AccumArgs& a, const RadixPack& pk, int num_lattices, hipStream_t stream) {
+  const size_t arrays = (sizeof(uint64_t) + (ITEMS == 8 ? sizeof(uint16_t) : 0)) * kThreads * ITEMS;  // skey (+ sarc)
+  const size_t lds = std::max(sizeof(typename SortT<ITEMS>::storage_type), arrays);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_radix_kernel<POSITION, ITEMS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((index_radix_kernel<POSITION, ITEMS>), dim3(num_lattices), dim3(kThreads), lds, stream, a, pk);
+  return hipGetLastError();
 }
 
-hipError_t launch_index_radix(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position,
+}  // namespace
+
+hipError_t launch_index_radix(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int items,
                               hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
-  const size_t lds = index_radix_lds_bytes();
-  hipError_t e;
-  if (position) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_radix_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(index_radix_kernel<true>, dim3(num_lattices), dim3(kThreads), lds, stream, a, pk);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_radix_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(index_radix_kernel<false>, dim3(num_lattices), dim3(kThreads), lds, stream, a, pk);
-  }
-  return hipGetLastError();
+  if (items == 8) return position ? launch_one<true, 8>(a, pk, num_lattices, stream) : launch_one<false, 8>(a, pk, num_lattices, stream);
+  if (items == 16) return position ? launch_one<true, 16>(a, pk, num_lattices, stream) : launch_one<false, 16>(a, pk, num_lattices, stream);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace klat

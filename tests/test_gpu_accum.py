@@ -109,10 +109,12 @@ def test_position_index_readme_vector(ctx, golden_dir):
 
 @pytest.mark.parametrize("G", [1, 4])
 @pytest.mark.parametrize("flt", [{}, {"exclude": [3, 7, 500]}, {"include": list(range(1, 200))}])
-@pytest.mark.parametrize("largest", [2700, 5000])
+@pytest.mark.parametrize("largest", [2700, 5000, 6000])
 def test_segment_index_synthetic(ctx, G, flt, largest):
-    """largest = 2700 states (8 097 arcs): every lattice fits the radix-sort kernel (<= 8 192 arcs);
-    5000 states (14 997 arcs): the batch takes the general kernel, whose sort leaves the LDS tile."""
+    """Every lattice goes to the kernel its arc count asks for.  largest = 2700 states (8 097
+    arcs): all take the radix-sort kernel with 8 items per thread (<= 8 192 arcs); 5000 states
+    (14 997 arcs): that one takes the 16-item instantiation; 6000 states (17 997 arcs): the general
+    kernel, whose sort leaves the LDS tile."""
     rng = np.random.RandomState(11)
     ns = np.concatenate([[1, 2], rng.randint(3, 400, size=60), [largest]]).astype(np.int32)
     fo = rng.choice([1, 2, 3, 4], size=len(ns)).astype(np.int32)

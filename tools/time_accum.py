@@ -5,7 +5,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
 import klat_amd, ctypes as C
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-ns = np.full(U, 2000, np.int32); fo = np.full(U, 3, np.int32)
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+ns = np.full(U, S, np.int32); fo = np.full(U, 3, np.int32)
 a = klat_amd.synth(20260001, ns, fo)
 ctx = klat_amd.Ctx(0)
 b = klat_amd.Batch(ctx, a)
