@@ -75,10 +75,7 @@ inline void WritePosteriors(Context& ctx, const LatticeBatch& batch, const klat_
         "klat_frame_post");
   int64_t fb = 0;
   for (size_t u = 0; u < keys.size(); ++u) {
-    PosteriorWriter::T post((size_t)num_frames[u]);
-    for (int32_t k = 0; k < num_frames[u]; ++k)
-      for (int64_t i = frame_off[fb + k]; i < frame_off[fb + k + 1]; ++i) post[k].emplace_back(labels[i], logps[i]);
-    writer->Write(keys[u], post);
+    writer->WriteFlat(keys[u], num_frames[u], frame_off.data() + fb, labels.data(), logps.data());
     fb += num_frames[u];
   }
 }

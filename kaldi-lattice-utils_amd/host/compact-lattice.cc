@@ -156,17 +156,22 @@ void WriteCompactLatticeText(std::ostream& os, const CompactLattice& clat) {
 }
 
 // ---- binary: OpenFst VectorFst stream (Appendix B.4) ----
+// (straight from the stream buffer: istream::read builds a sentry per call, and a lattice is read
+// field by field -- seven reads per arc)
+static bool rd_bytes(std::istream& is, void* p, std::streamsize n) {
+  if (is.rdbuf()->sgetn(static_cast<char*>(p), n) == n) return true;
+  is.setstate(std::ios::failbit | std::ios::eofbit);
+  return false;
+}
 template <class T>
 static bool rd(std::istream& is, T* v) {
-  is.read(reinterpret_cast<char*>(v), sizeof(T));
-  return (bool)is;
+  return rd_bytes(is, v, (std::streamsize)sizeof(T));
 }
 static bool rd_string(std::istream& is, std::string* s) {
   int32_t n;
   if (!rd(is, &n) || n < 0 || n > 1024) return false;
   s->resize((size_t)n);
-  is.read(&(*s)[0], n);
-  return (bool)is;
+  return n == 0 || rd_bytes(is, &(*s)[0], n);
 }
 template <class T>
 static void wr(std::ostream& os, T v) {
@@ -204,9 +209,11 @@ bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat, bool keep_
       if (pool && n > 0) {
         *off = (int32_t)pool->size();
         pool->resize(pool->size() + (size_t)n);
-        is.read(reinterpret_cast<char*>(pool->data() + *off), (std::streamsize)n * 4);
+        if (!rd_bytes(is, pool->data() + *off, (std::streamsize)n * 4)) return false;
       } else {
-        is.ignore((std::streamsize)n * 4);
+        int32_t skip[64];
+        for (int32_t left = n; left > 0; left -= 64)
+          if (!rd_bytes(is, skip, (std::streamsize)std::min(left, 64) * 4)) return false;
       }
       *len = n;
     }

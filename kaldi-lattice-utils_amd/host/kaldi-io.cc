@@ -52,7 +52,10 @@ Input::Input(const std::string& filename) {
     owned_.reset(new std::istream(buf_.get()));
     is_ = owned_.get();
   } else {
-    std::unique_ptr<std::ifstream> f(new std::ifstream(filename, std::ios_base::in | std::ios_base::binary));
+    std::unique_ptr<std::ifstream> f(new std::ifstream());
+    iobuf_.resize((size_t)1 << 20);
+    f->rdbuf()->pubsetbuf(iobuf_.data(), (std::streamsize)iobuf_.size());
+    f->open(filename, std::ios_base::in | std::ios_base::binary);
     if (!f->is_open()) KLAT_ERR("Error opening input stream " << filename);
     owned_ = std::move(f);
     is_ = owned_.get();
@@ -75,7 +78,10 @@ Output::Output(const std::string& filename) {
     owned_.reset(new std::ostream(buf_.get()));
     os_ = owned_.get();
   } else {
-    std::unique_ptr<std::ofstream> f(new std::ofstream(filename, std::ios_base::out | std::ios_base::binary));
+    std::unique_ptr<std::ofstream> f(new std::ofstream());
+    iobuf_.resize((size_t)1 << 20);
+    f->rdbuf()->pubsetbuf(iobuf_.data(), (std::streamsize)iobuf_.size());
+    f->open(filename, std::ios_base::out | std::ios_base::binary);
     if (!f->is_open()) KLAT_ERR("Error opening output stream " << filename);
     owned_ = std::move(f);
     os_ = owned_.get();

@@ -69,6 +69,7 @@ class Input {
   std::istream* is_ = nullptr;
   FILE* pipe_ = nullptr;
   std::unique_ptr<std::streambuf> buf_;
+  std::vector<char> iobuf_;  // 1 MiB stream buffer of a file (set before it is opened)
 };
 class Output {
  public:
@@ -82,6 +83,7 @@ class Output {
   std::ostream* os_ = nullptr;
   FILE* pipe_ = nullptr;
   std::unique_ptr<std::streambuf> buf_;
+  std::vector<char> iobuf_;
 };
 
 // ---- basic types (Kaldi WriteBasicType: binary = 1-byte size tag + little-endian value;

@@ -30,6 +30,14 @@ class ArchiveWriter {
     return os;
   }
   bool binary() const { return !spec_.text; }
+  // Binary records are assembled in one buffer and written with one call: a value is Kaldi's
+  // 1-byte size tag + the little-endian bytes (WriteBasicType), and a stream call per value is what
+  // the tools' time went into.
+  template <class V>
+  static void Put(std::string* buf, V v) {
+    buf->push_back((char)sizeof(V));
+    buf->append(reinterpret_cast<const char*>(&v), sizeof(V));
+  }
   void End() {
     if (spec_.text || spec_.filename == "-") out_.Stream().flush();
     if (!out_.Stream().good()) KLAT_ERR("Write failure on " << spec_.filename);
@@ -43,6 +51,33 @@ class PosteriorWriter : public ArchiveWriter {
  public:
   typedef std::vector<std::vector<std::pair<int32_t, float>>> T;
   using ArchiveWriter::ArchiveWriter;
+  // the same record straight from klat_frame_post's flat arrays: frames [0, num_frames) of one
+  // utterance, entries of frame k at [frame_off[k], frame_off[k + 1])
+  void WriteFlat(const std::string& key, int32_t num_frames, const int64_t* frame_off, const int32_t* labels,
+                 const float* logps) {
+    std::ostream& os = Begin(key);
+    if (binary()) {
+      buf_.clear();
+      buf_.reserve((size_t)(frame_off[num_frames] - frame_off[0]) * 10 + (size_t)num_frames * 5 + 16);
+      Put(&buf_, num_frames);
+      for (int32_t k = 0; k < num_frames; ++k) {
+        Put(&buf_, (int32_t)(frame_off[k + 1] - frame_off[k]));
+        for (int64_t i = frame_off[k]; i < frame_off[k + 1]; ++i) {
+          Put(&buf_, labels[i]);
+          Put(&buf_, logps[i]);
+        }
+      }
+      os.write(buf_.data(), (std::streamsize)buf_.size());
+    } else {
+      for (int32_t k = 0; k < num_frames; ++k) {
+        os << "[ ";
+        for (int64_t i = frame_off[k]; i < frame_off[k + 1]; ++i) os << labels[i] << ' ' << logps[i] << ' ';
+        os << "] ";
+      }
+      os << '\n';
+    }
+    End();
+  }
   void Write(const std::string& key, const T& post) {
     std::ostream& os = Begin(key);
     if (binary()) {
@@ -64,6 +99,9 @@ class PosteriorWriter : public ArchiveWriter {
     }
     End();
   }
+
+ private:
+  std::string buf_;
 };
 
 // CompactLatticeWriter (latbin/lattice-prune-dyn-beam.cc:158,190): "key " then the lattice, as text
@@ -127,17 +165,28 @@ class SegmentScoreWriter : public ArchiveWriter {
   using ArchiveWriter::ArchiveWriter;
   void Write(const std::string& key, const klat_segment_record* rec, int64_t n) {
     std::ostream& os = Begin(key);
-    if (binary()) WriteBasicType(os, true, (int32_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-      WriteBasicType(os, binary(), rec[i].label);
-      WriteBasicType(os, binary(), rec[i].t0);
-      WriteBasicType(os, binary(), rec[i].t1);
-      WriteBasicType(os, binary(), rec[i].logp);
-      if (!binary() && i + 1 < n) os << "; ";
+    if (binary()) {
+      buf_.clear();
+      buf_.reserve((size_t)n * 24 + 8);
+      Put(&buf_, (int32_t)n);
+      for (int64_t i = 0; i < n; ++i) Put(&buf_, rec[i].label), Put(&buf_, rec[i].t0), Put(&buf_, rec[i].t1), Put(&buf_, rec[i].logp);
+      os.write(buf_.data(), (std::streamsize)buf_.size());
+      End();
+      return;
     }
-    if (!binary()) os << '\n';
+    for (int64_t i = 0; i < n; ++i) {
+      WriteBasicType(os, false, rec[i].label);
+      WriteBasicType(os, false, rec[i].t0);
+      WriteBasicType(os, false, rec[i].t1);
+      WriteBasicType(os, false, rec[i].logp);
+      if (i + 1 < n) os << "; ";
+    }
+    os << '\n';
     End();
   }
+
+ private:
+  std::string buf_;
 };
 
 // vector<tuple<int32,int32,int32,int32,double>> (position index: label,pos,t0,t1,logp).
@@ -146,18 +195,30 @@ class PositionScoreWriter : public ArchiveWriter {
   using ArchiveWriter::ArchiveWriter;
   void Write(const std::string& key, const klat_position_record* rec, int64_t n) {
     std::ostream& os = Begin(key);
-    if (binary()) WriteBasicType(os, true, (int32_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-      WriteBasicType(os, binary(), rec[i].label);
-      WriteBasicType(os, binary(), rec[i].pos);
-      WriteBasicType(os, binary(), rec[i].t0);
-      WriteBasicType(os, binary(), rec[i].t1);
-      WriteBasicType(os, binary(), rec[i].logp);
-      if (!binary() && i + 1 < n) os << "; ";
+    if (binary()) {
+      buf_.clear();
+      buf_.reserve((size_t)n * 29 + 8);
+      Put(&buf_, (int32_t)n);
+      for (int64_t i = 0; i < n; ++i)
+        Put(&buf_, rec[i].label), Put(&buf_, rec[i].pos), Put(&buf_, rec[i].t0), Put(&buf_, rec[i].t1), Put(&buf_, rec[i].logp);
+      os.write(buf_.data(), (std::streamsize)buf_.size());
+      End();
+      return;
     }
-    if (!binary()) os << '\n';
+    for (int64_t i = 0; i < n; ++i) {
+      WriteBasicType(os, false, rec[i].label);
+      WriteBasicType(os, false, rec[i].pos);
+      WriteBasicType(os, false, rec[i].t0);
+      WriteBasicType(os, false, rec[i].t1);
+      WriteBasicType(os, false, rec[i].logp);
+      if (i + 1 < n) os << "; ";
+    }
+    os << '\n';
     End();
   }
+
+ private:
+  std::string buf_;
 };
 
 }  // namespace klat
