@@ -81,8 +81,7 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   }
   const int64_t sb = s0 + 2 * (int64_t)u;
   int32_t* cnt = a.cnt + sb;
-  int32_t* r0f = a.r0f + sb;
-  int32_t* r0b = a.r0b + sb;
+  int32_t* r0b = a.r0b + sb;  // (scratch for the counting sort's cursors here)
   int32_t* frank = a.frank + s0;
   int32_t* in_arc = a.in_arc + a0;
   const int32_t* src = a.src + a0;

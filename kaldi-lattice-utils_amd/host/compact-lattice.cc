@@ -70,7 +70,6 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat, bool keep_st
   clat->DeleteStates();
   std::vector<int32_t>* pool = keep_strings ? &clat->StringPool() : nullptr;
   std::string line;
-  bool any = false;
   auto need_state = [&](int32_t s) {
     while (s >= clat->NumStates()) clat->AddState();
   };
@@ -82,7 +81,6 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat, bool keep_st
       while (ls >> w) t.push_back(w);
     }
     if (t.empty()) break;  // blank line terminates the entry (right after the key: empty lattice)
-    any = true;
     if (!IsInt(t[0])) return false;
     const int32_t s = (int32_t)std::atol(t[0].c_str());
     if (s < 0) return false;
