@@ -153,6 +153,14 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # D2H of the step's results, outside the timed region and reported on its own
+    t0 = time.perf_counter()
+    post = batch.arc_logpost()
+    alpha, beta = batch.alpha_beta()
+    d2h_s = time.perf_counter() - t0
+    d2h_bytes = post.nbytes + alpha.nbytes + beta.nbytes
+    del post, alpha, beta
+
     # light end-of-run sanity: forward and backward totals agree
     total, tf, tb = batch.totals()
     assert os.environ.get("KLAT_EXPERIMENT") or np.all(np.isfinite(total)) and float(np.max(np.abs(tf - tb))) < 1e-6
@@ -208,6 +216,7 @@ def main():
             "kernel_ms": {"sweep": sweep_avg, "posterior": float(np.mean(post_ms)),
                           "convert": float(np.mean(conv_ms)), "device_total": float(np.mean(tot_ms))},
             "batch_create_seconds": pack_s,
+            "results_d2h": {"seconds": d2h_s, "bytes": d2h_bytes, "what": "arc log-posteriors + alpha + beta to pageable host memory"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ns, fo, args.seed, scales)
