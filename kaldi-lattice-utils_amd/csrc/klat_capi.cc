@@ -467,22 +467,29 @@ int klat_viterbi(klat_batch* b, const klat_scales* sc) {
     if ((rc = b->bwd_cost.alloc((size_t)(b->S + b->U)))) return rc;
   }
   b->viterbi_scales = s;
-  ViterbiArgs va;
+  SweepArgs va;
   va.jobs = b->jobs.p;
   va.lanes = b->lanes.p;
   va.sw = b->sw.p;
   va.sg = b->sg.p;
   va.sa = b->sa.p;
-  va.fwd_cost = b->fwd_cost.p;
-  va.bwd_cost = b->bwd_cost.p;
+  va.alpha = b->fwd_cost.p;
+  va.beta = b->bwd_cost.p;
+  va.job_flags = b->job_flags.p;  // not used by the tropical sweep
+  va.sink = b->sink.p;
+  va.ln_table = c->ln_table.p;    // not used
   va.sp = make_scale_params(s);
   va.sc = make_stream_cost(va.sp);
   va.ring_slots = 0;
+  va.far_prefetch = 0;
   rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
-    ViterbiArgs ca = va;
+    SweepArgs ca = va;
     ca.jobs = va.jobs + lc.job_begin;
+    ca.job_flags = va.job_flags + lc.job_begin;
+    ca.sink = va.sink + (size_t)lc.job_begin * 64;
     ca.ring_slots = lc.W;
-    return launch_viterbi(ca, lc.job_end - lc.job_begin, lc.G, stream);
+    ca.far_prefetch = lc.far;
+    return launch_sweep_tropical(ca, lc.job_end - lc.job_begin, lc.G, stream);
   });
   if (rc != KLAT_OK) return rc;
   b->viterbi_done = true;

@@ -89,17 +89,9 @@ struct PosteriorArgs {
   ScaleParams sp;
 };
 
-// Tropical twin (klat_viterbi.hip): Viterbi costs over the same streams, then the beam decisions.
-struct ViterbiArgs {
-  const SweepJob* jobs;
-  const LaneInfo* lanes;
-  const int32_t* sw; const float* sg; const float* sa;
-  double* fwd_cost;  // [S+U] padded: best cost from the start; slot S = best complete path
-  double* bwd_cost;  // [S+U] padded: best cost to a final state (final weight included)
-  ScaleParams sp;
-  StreamCost sc;
-  int32_t ring_slots;
-};
+// Tropical twin: the Viterbi costs come from the sweep kernel's TROPICAL instantiation
+// (launch_sweep_tropical: SweepArgs with alpha / beta = the padded forward / backward cost rows,
+// slot S of a forward row = the best complete path); klat_viterbi.hip takes the beam decisions.
 struct PruneArgs {
   const int64_t* state_off; const int64_t* arc_off;
   const int32_t* src; const int32_t* dst; const int32_t* ilabel;
@@ -111,7 +103,7 @@ struct PruneArgs {
   double* lattice_beam;  // [U]
   ScaleParams sp;
 };
-hipError_t launch_viterbi(const ViterbiArgs& a, int num_jobs, int G, hipStream_t stream);
+hipError_t launch_sweep_tropical(const SweepArgs& args, int num_jobs, int G, hipStream_t stream);
 hipError_t launch_prune(const PruneArgs& a, int num_lattices, hipStream_t stream);
 
 // fast_begin / fast_end (may be null): events recorded right before and after the fast kernel

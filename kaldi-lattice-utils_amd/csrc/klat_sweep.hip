@@ -53,6 +53,17 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+template <int G>
+__device__ __forceinline__ double group_min(double v) {
+  if (G >= 2) v = fmin(v, dpp_double<kDppXor1>(v));
+  if (G >= 4) v = fmin(v, dpp_double<kDppXor2>(v));
+  if (G >= 8) v = fmin(v, dpp_double<kDppHalfMirror>(v));
+  if (G >= 16) v = fmin(v, dpp_double<kDppMirror>(v));
+  if (G >= 32) v = fmin(v, __shfl_xor(v, 16, 64));
+  if (G >= 64) v = fmin(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
 // Workgroup barriers of the producer/consumer pair.  __syncthreads() would drain vmcnt(0): the
 // producer would then wait at every barrier for the stream loads it has just prefetched (a full
 // HBM latency per period).  Only LDS has to be ordered here, so the producer keeps its newest
@@ -148,7 +159,11 @@ static constexpr uint32_t kCtlOne = kOne;
 //          re-references on demand.  It runs afterwards and only for flagged jobs.
 // CPB = stream chunks (of 4 rounds) staged per barrier: 2 when W >= 32, else 1.  FARP (CPB = 2 only):
 // the values of sources older than the ring are prefetched one period ahead (see put_far).
-template <int G, bool FAST, int CPB, bool FARP>
+// TROPICAL: the (min,+) twin over the same streams and the same machinery -- the staged term is
+// the arc cost itself, a state is the cheapest cost of reaching it (no exponents, no logarithm,
+// nothing to flag), alpha / beta receive the Viterbi forward / backward costs
+// (ComputeLatticeBeam / PruneLattice, latbin/lattice-prune-dyn-beam.cc:27-90).
+template <int G, bool FAST, int CPB, bool FARP, bool TROPICAL = false>
 __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   extern __shared__ double smem[];
   constexpr int LPW = 64 / G;
@@ -185,7 +200,8 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 
   if (producer) {
     // ------------------------------------------------------------------ wave 0
-    for (int i = lane; i < kLnTabSize; i += 64) lntab[i] = args.ln_table[i];
+    if (!TROPICAL)
+      for (int i = lane; i < kLnTabSize; i += 64) lntab[i] = args.ln_table[i];
     const bool live = li.state_base >= 0;
     const bool early_copy = W < 12 * CPB;  // see the period schedule below
 
@@ -213,8 +229,13 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 
       auto weigh = [&](StagedTerm& t, uint32_t w, float g, float a) {
         const double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : stream_cost(w, g, a, sc);
-        bool dead;
-        arc_weight(c, t.wm, t.k, dead);
+        if (TROPICAL) {
+          t.wm = (c < 1.0e30) ? c : INFINITY;  // Zero weights, NaN, padding
+          t.k = 0;
+        } else {
+          bool dead;
+          arc_weight(c, t.wm, t.k, dead);
+        }
       };
       auto put = [&](StagedTerm* dst, uint32_t w, float g, float a) {
         StagedTerm t;
@@ -235,15 +256,23 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         const bool last = (w & kLast) != 0;
         uint32_t ctl = w;
         if (w & kFar) {
-          c = (v == -INFINITY) ? INFINITY : c - v;  // a log-zero source kills the term
+          if (TROPICAL)
+            c = c + v;  // the cost of the path through the source; a constant-zero source below
+          else
+            c = (v == -INFINITY) ? INFINITY : c - v;  // a log-zero source kills the term
           ctl = (w & ~(kRelMask | kFar)) | kOne;     // RD cell 0: ignored for a constant-one source
           if (last && sub == 0)
             ctl |= kCommit | ((uint32_t)((p & (W - 1)) * LPW + slot) << kWrShift);
           else
             ctl |= (uint32_t)(W * LPW + lane) << kWrShift;  // the lane's dummy cell
         }
-        bool dead;
-        arc_weight(c, t.wm, t.k, dead);
+        if (TROPICAL) {
+          t.wm = (c < 1.0e30) ? c : INFINITY;
+          t.k = 0;
+        } else {
+          bool dead;
+          arc_weight(c, t.wm, t.k, dead);
+        }
         t.ctl = ctl;
         store_staged(dst, t);
         p += last ? 1 : 0;
@@ -304,7 +333,8 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       };
       auto copy_table = [&]() {
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) ct[it] = lntab[ln_table_index(cm[it])];
+        for (int it = 0; it < kIters; ++it)
+          if (!TROPICAL) ct[it] = lntab[ln_table_index(cm[it])];
       };
       // exactly kIters store instructions per period (the barrier's vmcnt counts on it): lanes
       // without a state park their value in the job's sink row
@@ -313,7 +343,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
           const int j = sub + it * G;
-          const double v = table_ln(cm[it], ce[it], ct[it]);
+          const double v = TROPICAL ? cm[it] : table_ln(cm[it], ce[it], ct[it]);
           double* dst = (live && j < out_n) ? vals + (q_off + q_step * (out_p0 + j)) : sink;
           *dst = v;
         }
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 
   // every ring cell starts as log-zero so that padding terms read something well-defined
   for (int i = lane; i < W * LPW; i += 64) {
-    ringM[i] = 0.0;
+    ringM[i] = TROPICAL ? INFINITY : 0.0;
     ringE[i] = kExpMin;
   }
 
@@ -413,7 +443,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   int accE = kExpMin;
   int refE = 0;        // FAST: exponent of the lattice's previous non-zero state
   bool sticky = false; // FAST: some term left the safe exponent window
-  double lastM = 0.0;  // value of the state finished by the previous round (register bypass)
+  double lastM = TROPICAL ? INFINITY : 0.0;  // value of the state finished by the previous round (register bypass)
   int lastE = kExpMin;
   double preM = 0.0;   // ring read for the upcoming round, software-pipelined one round ahead
   int preE = kExpMin;
@@ -424,6 +454,21 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     const uint32_t ctl = t.ctl;
     const bool last = (ctl & kCtlLast) != 0;
     const bool first = (ctl & kCtlFirst) != 0;
+    if constexpr (TROPICAL) {
+      // source cost (ring, register bypass or the constant 0) + arc cost -> min over the state's
+      // terms -> min over the lattice's G lanes -> ring cell and next round's bypass
+      double from = preM;
+      if (decltype(do_pre)::value) preM = ringM[(int)(ctl_next & kCellMask)];
+      from = select64(lane_mask((ctl & kCtlBypass) != 0), lastM, from);
+      if (decltype(special)::value) from = (ctl & kCtlOne) ? 0.0 : from;
+      const double tc = from + t.wm;
+      accM = select64(lane_mask(first), tc, fmin(accM, tc));
+      const double best = G > 1 ? group_min<G>(accM) : accM;
+      lastM = best;
+      ringM[(int)((ctl >> kWrShift) & kCellMask)] = best;
+      (void)last;
+      return;
+    }
     double sm = preM;
     int se = preE;
     // issue next round's ring read now, ahead of this round's ring write
@@ -534,7 +579,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     }
   }
   __syncthreads();  // lets the producer copy out the last period's states
-  if (FAST) {
+  if (FAST && !TROPICAL) {
     if (__any(sticky) && lane == 0) args.job_flags[blockIdx.x] = 1;
   }
 }
@@ -571,6 +616,43 @@ static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream,
     launch_fast(&sweep_kernel<G, true, 1, false>);
     launch(&sweep_kernel<G, false, 1, false>);
   }
+}
+
+template <int G>
+static void launch_tropical(const SweepArgs& args, int num_jobs, hipStream_t stream) {
+  const int LPW = 64 / G;
+  const int cpb = args.ring_slots >= 32 ? 2 : 1;
+  const size_t lds = sweep_lds_bytes(args.ring_slots, LPW, cpb);
+  auto launch = [&](auto kernel) {
+    if (lds > 60 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(num_jobs), dim3(128), lds, stream, args);
+  };
+  if (cpb == 2 && args.far_prefetch)
+    launch(&sweep_kernel<G, true, 2, true, true>);
+  else if (cpb == 2)
+    launch(&sweep_kernel<G, true, 2, false, true>);
+  else
+    launch(&sweep_kernel<G, true, 1, false, true>);
+}
+
+// The (min,+) twin: args.alpha / args.beta receive the Viterbi forward / backward costs (padded rows
+// like alpha / beta); job_flags and ln_table are not used.
+hipError_t launch_sweep_tropical(const SweepArgs& args, int num_jobs, int G, hipStream_t stream) {
+  if (num_jobs <= 0) return hipSuccess;
+  const int LPW = 64 / G;
+  if ((size_t)args.ring_slots * LPW + 64 > kCellMask + 1) return hipErrorInvalidValue;
+  switch (G) {
+    case 1: launch_tropical<1>(args, num_jobs, stream); break;
+    case 2: launch_tropical<2>(args, num_jobs, stream); break;
+    case 4: launch_tropical<4>(args, num_jobs, stream); break;
+    case 8: launch_tropical<8>(args, num_jobs, stream); break;
+    case 16: launch_tropical<16>(args, num_jobs, stream); break;
+    case 32: launch_tropical<32>(args, num_jobs, stream); break;
+    case 64: launch_tropical<64>(args, num_jobs, stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 // Clears the job flags, runs the fast sweep over every job and the exact sweep over the jobs the
