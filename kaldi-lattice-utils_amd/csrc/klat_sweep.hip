@@ -146,9 +146,10 @@ static constexpr uint32_t kCtlOne = kOne;
 // The values of the last W visited states of each lattice live in an LDS ring of 16-byte cells
 // ([slot][lattice]).  The ring read of round r+1 is issued before round r's result is written and
 // is patched from registers when it names the state round r just finished (BYPASS), so the LDS
-// write->read latency is off the chain.  Chunks in which some lane has a constant-one source or
-// a source older than W states (FAR: re-read from the alpha/beta values already stored) take a
-// slower instantiation of the same round.
+// write->read latency is off the chain.  Chunks in which some lane has a constant-one source take
+// an instantiation of the round with one more select.  A source older than W states (FAR) never
+// reaches the consumer: the producer reads its stored natural-log value back from alpha / beta
+// and stages the term as a constant-one source with the cost c - v (see put_far).
 //
 // Two instantiations share this body:
 //   FAST   every term of a state is aligned to ONE reference exponent -- that of the lattice's
