@@ -214,6 +214,44 @@ def test_position_index_synthetic(ctx, kernel, monkeypatch):
             assert x[4] >= y[4] - TOL
 
 
+@pytest.mark.parametrize("width", [3000, 6500, 9000])
+def test_position_index_wide_lattices(ctx, width):
+    """Position index on lattices of 2 * width arcs (two bundles of parallel arcs, so the length
+    disambiguation leaves them as they are): 6 000 arcs take the radix kernel with 8 items per
+    thread, 13 000 the 16-item instantiation, 18 000 the general kernel; a small lattice rides along."""
+    rng = np.random.RandomState(width)
+    lats, sls, tms = [], [], []
+    for n in (width, 40):
+        ab = np.array([0, n, 2 * n, 2 * n], np.int64)
+        dst = np.concatenate([np.ones(n, np.int32), np.full(n, 2, np.int32)]).astype(np.int32)
+        lab = rng.randint(1, max(3, n // 3), size=2 * n).astype(np.int32)
+        graph = (rng.rand(2 * n) * 8).astype(np.float32)
+        ac = (rng.rand(2 * n) * 4).astype(np.float32)
+        fg, fa = np.full(3, np.inf, np.float32), np.full(3, np.inf, np.float32)
+        fg[2] = fa[2] = 0.0
+        lats.append(orc.Lat(ab, dst, lab, lab.copy(), graph, ac, np.ones(2 * n, np.int32), fg, fa, np.zeros(3, np.int32)))
+        sls.append(np.array([0, 1, 2], np.int32))  # words before each state
+        tms.append(np.array([0, 1, 2], np.int32))
+    arrays = klat_amd.concat_lattices(lats, tms)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.5, 0.0)
+    off, rec = b.position_index(np.concatenate(sls))
+    b.close()
+    for u, lat in enumerate(lats):
+        sl = orc.scale_and_penalize(lat, 1.0, 0.5, 0.0)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        want = orc.position_index(sl, tms[u], sls[u], alpha, beta, total)
+        got = [(int(r["label"]), int(r["pos"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in rec[off[u]:off[u + 1]]]
+        assert len(got) == len(want)
+        gk = {g[:2]: g for g in got}
+        assert len(gk) == len(got)
+        for w in want:
+            g = gk[w[:2]]
+            assert abs(g[4] - w[4]) <= TOL and g[2:4] == w[2:4]
+        for x, y in zip(got[:-1], got[1:]):
+            assert x[4] > y[4] or (x[4] == y[4] and x[:2] < y[:2])
+
+
 def test_index_needs_state_time(ctx):
     arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
     del arrays["state_time"]
