@@ -137,17 +137,19 @@ def main():
     for _ in range(args.warmup):
         batch.forward_backward(*scales)
     barrier()
-    sweep_ms, post_ms, conv_ms, tot_ms = [], [], [], []
+    # The K steps are enqueued without waiting in between (the library records HIP events around
+    # its kernels on the ctx stream into a ring); their per-kernel durations are read after the
+    # timed region.
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.forward_backward(*scales)
-        # per-kernel durations from HIP events recorded on the ctx stream inside the library
-        # (klat_get_timings waits for the step's last event; steps are serial on one stream)
-        t = batch.timings()
-        sweep_ms.append(t["sweep_ms"]), post_ms.append(t["posterior_ms"])
-        conv_ms.append(t["convert_ms"]), tot_ms.append(t["total_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
+    hist = ctx.timing_history(min(args.steps, 512))
+    sweep_ms = [t["sweep_ms"] for t in hist]
+    post_ms = [t["posterior_ms"] for t in hist]
+    conv_ms = [t["convert_ms"] for t in hist]
+    tot_ms = [t["total_ms"] for t in hist]
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)

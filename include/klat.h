@@ -129,6 +129,10 @@ int klat_batch_get_info(const klat_batch* batch, klat_batch_info* info);
  * ctx stream; results stay on the device until fetched. */
 int klat_forward_backward(klat_batch* batch, const klat_scales* scales);
 int klat_get_timings(const klat_batch* batch, klat_timings* t);
+/* Kernel times of the last `count` (<= 512) calls of klat_forward_backward on this context, oldest
+ * first: a caller may enqueue many steps without waiting and read their times afterwards (waits for
+ * the newest).  bench.py times its steps this way. */
+int klat_ctx_timing_history(klat_ctx* ctx, int32_t count, klat_timings* out);
 /* Number of sweep jobs (waves) of the last klat_forward_backward that left the fast sweep's
  * exponent window and were recomputed by the exact sweep (0 for ordinary lattices; non-zero when
  * the terms entering one state are hundreds of nats apart).  Results are exact either way. */

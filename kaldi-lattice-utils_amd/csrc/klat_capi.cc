@@ -65,6 +65,18 @@ static int for_each_class(klat_batch* b, F launch) {
   return KLAT_OK;
 }
 
+// kernel times of step `step` of the context (its events are in the ring)
+static int read_timings(klat_ctx* c, int64_t step, klat_timings* t) {
+  hipEvent_t* ev = c->evring[step % klat_ctx::kTimingSlots];
+  KLAT_HIP(hipEventSynchronize(ev[3]));
+  KLAT_HIP(hipEventElapsedTime(&t->sweep_ms, ev[0], ev[1]));
+  KLAT_HIP(hipEventElapsedTime(&t->totals_ms, ev[1], ev[2]));
+  KLAT_HIP(hipEventElapsedTime(&t->posterior_ms, ev[2], ev[3]));
+  t->convert_ms = 0.0f;  // the sweep's producer wave writes natural-log alpha/beta itself
+  KLAT_HIP(hipEventElapsedTime(&t->total_ms, ev[0], ev[3]));
+  return KLAT_OK;
+}
+
 extern "C" {
 
 const char* klat_last_error(void) { return g_last_error.c_str(); }
@@ -100,10 +112,10 @@ int klat_ctx_create(int device, klat_ctx** out) {
     delete c;
     return hip_fail(e, "hipStreamCreate");
   }
-  for (int i = 0; i < 5; ++i) {
-    e = hipEventCreate(&c->ev[i]);
+  for (int i = 0; i < klat_ctx::kTimingSlots * 4; ++i) {
+    e = hipEventCreate(&c->evring[i / 4][i % 4]);
     if (e != hipSuccess) {
-      delete c;
+      klat_ctx_destroy(c);
       return hip_fail(e, "hipEventCreate");
     }
   }
@@ -125,8 +137,8 @@ void klat_ctx_destroy(klat_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (int i = 0; i < 5; ++i)
-    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < klat_ctx::kTimingSlots * 4; ++i)
+    if (c->evring[i / 4][i % 4]) (void)hipEventDestroy(c->evring[i / 4][i % 4]);
   for (int i = 0; i < klat_ctx::kSideStreams; ++i) {
     if (c->side[i]) (void)hipStreamSynchronize(c->side[i]), (void)hipStreamDestroy(c->side[i]);
     if (c->join_ev[i]) (void)hipEventDestroy(c->join_ev[i]);
@@ -422,7 +434,8 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   // name): the events sit right around its launch.  The exact sweep's launch after it (all of its
   // workgroups exit at once unless the fast sweep flagged a job) falls to totals_ms.
   const bool one_class = b->classes.size() == 1;
-  if (!one_class) KLAT_HIP(hipEventRecord(c->ev[0], c->stream));
+  hipEvent_t* ev = c->evring[c->steps % klat_ctx::kTimingSlots];
+  if (!one_class) KLAT_HIP(hipEventRecord(ev[0], c->stream));
   {
     const int rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
       SweepArgs ca = sa;
@@ -431,16 +444,17 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
       ca.sink = sa.sink + (size_t)lc.job_begin * 64;
       ca.ring_slots = lc.W;
       ca.far_prefetch = lc.far;
-      return launch_sweep(ca, lc.job_end - lc.job_begin, lc.G, stream, one_class ? c->ev[0] : nullptr,
-                          one_class ? c->ev[1] : nullptr);
+      return launch_sweep(ca, lc.job_end - lc.job_begin, lc.G, stream, one_class ? ev[0] : nullptr,
+                          one_class ? ev[1] : nullptr);
     });
     if (rc != KLAT_OK) return rc;
   }
-  if (!one_class) KLAT_HIP(hipEventRecord(c->ev[1], c->stream));
+  if (!one_class) KLAT_HIP(hipEventRecord(ev[1], c->stream));
   KLAT_HIP(launch_totals(ta, c->stream));
-  KLAT_HIP(hipEventRecord(c->ev[2], c->stream));
+  KLAT_HIP(hipEventRecord(ev[2], c->stream));
   KLAT_HIP(launch_posterior(pa, b->num_items, c->stream));
-  KLAT_HIP(hipEventRecord(c->ev[3], c->stream));
+  KLAT_HIP(hipEventRecord(ev[3], c->stream));
+  b->timing_step = c->steps++;
   b->swept = true;
   return KLAT_OK;
 }
@@ -579,12 +593,20 @@ int klat_get_timings(const klat_batch* b, klat_timings* t) {
   if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
-  KLAT_HIP(hipEventSynchronize(c->ev[3]));
-  KLAT_HIP(hipEventElapsedTime(&t->sweep_ms, c->ev[0], c->ev[1]));
-  KLAT_HIP(hipEventElapsedTime(&t->totals_ms, c->ev[1], c->ev[2]));
-  KLAT_HIP(hipEventElapsedTime(&t->posterior_ms, c->ev[2], c->ev[3]));
-  t->convert_ms = 0.0f;  // the sweep's producer wave writes natural-log alpha/beta itself
-  KLAT_HIP(hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[3]));
+  if (c->steps - b->timing_step > klat_ctx::kTimingSlots)
+    return set_error(KLAT_ERR_STATE, "the timing events of this step have been reused by later steps");
+  return read_timings(c, b->timing_step, t);
+}
+
+int klat_ctx_timing_history(klat_ctx* c, int32_t count, klat_timings* out) {
+  if (!c || !out || count < 0) return set_error(KLAT_ERR_INVALID_ARG, "bad argument");
+  if (count > klat_ctx::kTimingSlots || count > c->steps)
+    return set_error(KLAT_ERR_INVALID_ARG, "klat_ctx_timing_history: more steps than were run or than the ring holds (512)");
+  KLAT_HIP(hipSetDevice(c->device));
+  for (int32_t i = 0; i < count; ++i) {
+    const int rc = read_timings(c, c->steps - count + i, &out[i]);
+    if (rc != KLAT_OK) return rc;
+  }
   return KLAT_OK;
 }
 

@@ -72,7 +72,11 @@ struct DevBuf {
 struct klat_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // timing events of the last kTimingSlots calls of klat_forward_backward on this context (a ring:
+  // a caller that enqueues many steps without waiting can read all their kernel times afterwards)
+  static const int kTimingSlots = 512;
+  hipEvent_t evring[kTimingSlots][4] = {};
+  int64_t steps = 0;  // calls of klat_forward_backward so far
   // layout classes of one batch sweep side by side: class 0 on `stream`, the others on these,
   // forked from and joined to `stream` by events (created on first use)
   static const int kSideStreams = 3;
@@ -109,6 +113,7 @@ struct klat_batch {
   int G = 1, W = 8, num_jobs = 0, num_items = 0;  // G, W: of the largest layout class (info only)
   std::vector<klat::LayoutClass> classes;
   bool swept = false;
+  int64_t timing_step = -1;  // the context's step counter at this batch's last klat_forward_backward
   klat_scales scales = {1.f, 1.f, 0.f};
   klat_batch_info info = {};
   std::vector<int64_t> h_state_off, h_arc_off;

@@ -175,6 +175,12 @@ class Ctx:
         _check(lib().klat_ctx_create(C.c_int(device), C.byref(self.h)))
         _live.add(self)
 
+    def timing_history(self, count):
+        """Kernel times (dicts) of the last `count` forward_backward calls on this context."""
+        arr = (Timings * count)()
+        _check(lib().klat_ctx_timing_history(self.h, C.c_int32(count), arr))
+        return [t.as_dict() for t in arr]
+
     def sync(self):
         _check(lib().klat_ctx_sync(self.h))
 
