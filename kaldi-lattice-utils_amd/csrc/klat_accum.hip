@@ -345,7 +345,19 @@ __global__ __launch_bounds__(256) void range_kernel(RangeArgs a) {
     tmax = max(tmax, __shfl_xor(tmax, d, 64));
     nmax = max(nmax, __shfl_xor(nmax, d, 64));
   }
-  if ((threadIdx.x & 63) == 0) {
+  // one set of atomics per workgroup: thousands of them on the same four words are what this
+  // kernel's time went into
+  __shared__ int32_t part[4][4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) part[wave][0] = lmin, part[wave][1] = lmax, part[wave][2] = tmax, part[wave][3] = nmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      lmin = min(lmin, part[w][0]);
+      lmax = max(lmax, part[w][1]);
+      tmax = max(tmax, part[w][2]);
+      nmax = max(nmax, part[w][3]);
+    }
     atomicMin(&a.out[0], lmin);
     atomicMax(&a.out[1], lmax);
     atomicMax(&a.out[2], tmax);
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(256) void range_kernel(RangeArgs a) {
 }
 
 hipError_t launch_range(const RangeArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(range_kernel, dim3(1024), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(range_kernel, dim3(512), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
