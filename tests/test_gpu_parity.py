@@ -280,3 +280,21 @@ def test_one_very_long_lattice_among_short_ones(ctx):
     arrays = klat_amd.synth(77, ns, fo)
     info, exact = _run_and_check(ctx, arrays, 1)
     assert info["num_layouts"] >= 2 and info["max_rounds"] >= 300000
+
+
+def test_timing_history_of_a_context():
+    """klat_ctx_timing_history: kernel times of the last calls of klat_forward_backward on a
+    context, read after enqueueing them all (bench.py times its steps this way)."""
+    c = klat_amd.Ctx(0)
+    arrays = klat_amd.synth(3, np.full(200, 300, np.int32), np.full(200, 3, np.int32))
+    b = klat_amd.Batch(c, arrays)
+    for _ in range(5):
+        b.forward_backward(1.0, 0.1, 0.0)
+    hist = c.timing_history(5)
+    assert len(hist) == 5 and all(t["sweep_ms"] > 0 and t["total_ms"] >= t["sweep_ms"] for t in hist)
+    last = b.timings()
+    assert abs(last["sweep_ms"] - hist[-1]["sweep_ms"]) < 1e-6
+    with pytest.raises(klat_amd.KlatError):
+        c.timing_history(6)  # only five steps were run
+    b.close()
+    c.close()
