@@ -1,16 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- lattice-arcs/second of the forward-backward + arc-posterior path on MI355X.
 
-One "step" = one pass of the hot path (klat_forward_backward: forward+backward lockstep
-sweep, per-lattice totals, arc log-posteriors, alpha/beta in natural log) over one batch of
-synthetic lattices already resident in HBM.  Workload at every N: BASELINE.json configs[1]
-per GPU (10k lattices x 2k states x fanout 3, SURVEY.md Appendix D generator, scales
---acoustic-scale=0.1 --graph-scale=1), i.e. weak scaling with utterances sharded across
-ranks and no data-path collective.  Prints ONE JSON line on rank 0.
-"""
+One "step" = one pass of the hot path (klat_forward_backward: forward+backward lockstep sweep,
+per-lattice totals, arc log-posteriors, alpha/beta in natural log) over one batch of synthetic
+lattices already resident in HBM.  Workload at every N: BASELINE.json configs[1] per GPU (10k
+lattices x 2k states x fanout 3, SURVEY.md Appendix D generator, --acoustic-scale=0.1
+--graph-scale=1), i.e. weak scaling with utterances sharded across ranks and no data-path
+collective.  Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself
+(python -m torch.distributed.run, one rank per GPU) BEFORE touching the GPU, and exits with their
+code.  Under torchrun (WORLD_SIZE set) --gpus must agree with it.
+
+Beside the headline the line carries:
+  shapes       sweep / step time and roofline fractions on the shard one GPU of an 8-GPU node would
+               hold of BASELINE configs[3] (C4/8: 12 500 x 5 000 states) and configs[4] (C5/8: the
+               skewed mix), and on a wide shape whose topological depth is far below its states;
+  accumulate   device time of the segment-index and frame-posterior kernels on the C2 batch;
+  index_gather (N > 1) klat_segment_index on every rank's shard + the gather of the 24-byte
+               records to rank 0 over RCCL from device buffers (include/klat_dist.h), timed.
+KLAT_BENCH_DRYRUN=1: no GPU work at all -- the ranks rendezvous over gloo and run the launch,
+sharding and gather plumbing on the host transport (the CPU test of the N > 1 path)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -22,12 +37,24 @@ sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_hbm_traffic.json")  # PMC passes of this round's kernels
+SCALES = (1.0, 0.1, 0.0)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(ns, fo, seed, scales, target_seconds=12.0):
-    """The oracle (CPU restatement of the reference algorithm, kind "port") timed on this
-    box's host cores on a bounded sample of the same workload, one lattice per task over
-    `cores` threads (TaskSequencer's model, kwsbin2/lattice-word-index-segment.cc:260-275)."""
+    """The oracle (CPU restatement of the reference algorithm, kind "port") timed on this box's host
+    cores on a bounded sample of the same workload, one lattice per task over `cores` threads
+    (TaskSequencer's model, kwsbin2/lattice-word-index-segment.cc:260-275)."""
     import klat_amd
     from oracle import oracle as orc
 
@@ -62,28 +89,164 @@ def cpu_baseline(ns, fo, seed, scales, target_seconds=12.0):
     for t in threads:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": arcs / dt, "unit": "lattice-arcs/s", "cores": cores, "kind": "port",
+    return {"value": arcs / dt, "unit": "lattice-arcs/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "one_thread_value": one_thread,
-            "sample": "%d threads x %d lattices x %d states x fanout %d, %d passes each (%d arcs), "
-                      "fb + arc posteriors, one lattice per task, %.1f s"
-                      % (cores, per_thread, int(ns[0]), int(fo[0]), reps, arcs, dt)}
+            "sample": "%d threads x %d lattices x %d states x fanout %d, %d passes each (%d arcs), fb + arc "
+                      "posteriors, one lattice per task, %.1f s; each thread's %d lattices (%.1f MB) stay "
+                      "cache-resident across its passes, which flatters the CPU"
+                      % (cores, per_thread, int(ns[0]), int(fo[0]), reps, arcs, dt, per_thread,
+                         int(probe["arc_off"][-1]) * 24 / 1e6)}
 
 
-def measured_traffic(G):
-    """HBM bytes per sweep launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+def measured_traffic(kernel_substr):
+    """HBM bytes per sweep launch from this round's PMC passes (FETCH_SIZE / WRITE_SIZE collected in
     separate rocprofv3 runs of this same command, corrected as MI355X_MICROARCH.md prescribes;
-    condensed by tools/prof_summarize.py into profiles/*_hbm_traffic.json).  None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)
-    for f in reversed(files):
-        try:
-            t = json.load(open(f))
-        except Exception:
-            continue
-        for k, v in t.items():
-            if "sweep_kernel<%d, true" % G in k or "sweep_kernel<%d>" % G in k:  # the fast sweep
-                return {"bytes": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT)}
+    condensed by tools/prof_summarize.py into the one file named above).  None if absent."""
+    f = os.path.join(ROOT, TRAFFIC_PROFILE)
+    try:
+        t = json.load(open(f))
+    except Exception:
+        return None
+    for k, v in t.items():
+        if kernel_substr in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+            return {"bytes": v["hbm_bytes_per_launch"], "source": TRAFFIC_PROFILE, "kernel": k}
     return None
+
+
+def c5_sizes(U):
+    """BASELINE configs[4] skewed mix: sizes log-uniform in [200, 20 000] states,
+    fanout uniform in {2,3,4,6}."""
+    rng = np.random.RandomState(20260004)
+    ns = np.exp(rng.uniform(np.log(200), np.log(20000), U)).astype(np.int32)
+    fo = rng.choice([2, 3, 4, 6], U).astype(np.int32)
+    return ns, fo
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """The parent of a `--gpus N` run: starts the ranks as child processes and returns their exit
+    code.  Nothing here touches the GPU (no torch.cuda, no klat_amd call)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def median(xs):
+    return float(np.median(np.asarray(xs, dtype=np.float64))) if len(xs) else 0.0
+
+
+def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=10, wide=0):
+    """sweep / step time of one more batch shape on this GPU (medians over `steps` steps)."""
+    arrays = klat_amd.synth(seed, ns, fo, host_threads=host_threads, wide=wide)
+    b = klat_amd.Batch(ctx, arrays, host_threads=host_threads)
+    info = b.info()
+    for _ in range(warm):
+        b.forward_backward(*SCALES)
+    for _ in range(steps):
+        b.forward_backward(*SCALES)
+    hist = ctx.timing_history(steps)
+    total, tf, tb = b.totals()
+    ok = bool(np.all(np.isfinite(total)) and float(np.max(np.abs(tf - tb))) < 1e-6)
+    A, S = info["num_arcs"], info["num_states"]
+    sweep, step = median([t["sweep_ms"] for t in hist]), median([t["total_ms"] for t in hist])
+    out = {"workload": name, "lattices": int(len(ns)), "arcs": A, "states": S,
+           "topological_depth": int(info.get("max_depth", 0)) or None,
+           "lanes_per_lattice": info["lanes_per_lattice"], "layout_classes": info["num_layouts"],
+           "sweep_waves": info["num_jobs"], "max_rounds": info["max_rounds"],
+           "sweep_ms": sweep, "step_ms": step, "arcs_per_s": A / (step * 1e-3),
+           "sweep_frac": (32.0 * A + 32.0 * S) / (sweep * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "step_frac": (56.0 * A + 48.0 * S) / (step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "fwd_bwd_totals_agree": ok}
+    b.close()
+    return out
+
+
+def accumulate_leg(klat_amd, batch, arrays, A):
+    """Device time of the accumulate kernels (a9-a12) on the resident C2 batch: segment index
+    (kwsbin2/lattice-word-index-segment.cc:143-174,98-126) and frame posteriors
+    (latbin/lattice-to-word-frame-post.cc:93-135), medians of 3 runs each."""
+    import ctypes as C
+    L = klat_amd.lib()
+    U = batch.U
+    f, keep = klat_amd.Batch._filter(None, None)
+    off = np.zeros(U + 1, np.int64)
+    n = C.c_int64(0)
+    seg, fr = [], []
+    ims, fms = C.c_float(0), C.c_float(0)
+    for _ in range(3):
+        klat_amd._check(L.klat_segment_index(batch.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
+        klat_amd._check(L.klat_get_accum_timings(batch.h, C.byref(ims), None))
+        seg.append(ims.value)
+    records = n.value
+    nf = arrays["state_time"][arrays["state_off"][1:] - 1].astype(np.int32)
+    foff = np.zeros(int(nf.sum()) + 1, np.int64)
+    ne = C.c_int64(0)
+    for _ in range(3):
+        klat_amd._check(L.klat_frame_post(batch.h, klat_amd._p(nf), klat_amd._p(foff), None, None, C.c_int64(0), C.byref(ne)))
+        klat_amd._check(L.klat_get_accum_timings(batch.h, None, C.byref(fms)))
+        fr.append(fms.value)
+    seg_ms, fr_ms = median(seg), median(fr)
+    # algorithmic bytes: src,dst,olabel (12) + logpost (8) per arc + state_time 4 B/state in, 24 B/record out;
+    # frames: src,dst,ilabel,graph,acoustic (20) + logpost (8) per arc in, 8 B per (frame, word) entry out
+    S = int(arrays["state_off"][-1])
+    seg_bytes = 20.0 * A + 4.0 * S + 24.0 * records
+    fr_bytes = 28.0 * A + 4.0 * S + 8.0 * ne.value + 8.0 * int(nf.sum())
+    return {"workload": "the C2 batch of this run", "segment_ms": seg_ms, "segment_records": records,
+            "segment_frac": seg_bytes / (seg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if seg_ms > 0 else None,
+            "segment_algorithmic_bytes": seg_bytes,
+            "frame_ms": fr_ms, "frame_entries": ne.value,
+            "frame_frac": fr_bytes / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fr_ms > 0 else None,
+            "frame_algorithmic_bytes": fr_bytes,
+            "frac": min(x for x in (seg_bytes / (seg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if seg_ms > 0 else 1e9,
+                                    fr_bytes / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fr_ms > 0 else 1e9))}
+
+
+def dry_run(args, rank, world):
+    """CPU rehearsal of the N-rank plumbing (launch, rendezvous, sharding, C++ gather over the host
+    transport).  No kernel runs and nothing is measured: `value` is null."""
+    import torch.distributed as dist
+
+    import klat_amd
+    from klat_amd import dist as kdist
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    U = 64
+    ns = np.full(U, 40, np.int32)
+    fo = np.full(U, 3, np.int32)
+    arrays = klat_amd.synth(args.seed, ns, fo)  # every rank sees the same utterance list
+    bounds = kdist.partition_by_arcs(np.diff(arrays["arc_off"]), world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    # stand-in records: one per arc of the rank's utterances, tagged with the global arc number
+    a0, a1 = int(arrays["arc_off"][lo]), int(arrays["arc_off"][hi])
+    rec = np.zeros(a1 - a0, klat_amd.SEGMENT_DTYPE)
+    rec["label"] = np.arange(a0, a1)
+    off = (arrays["arc_off"][lo:hi + 1] - a0).astype(np.int64)
+    gathered = None
+    if world > 1:
+        comm = kdist.Comm.over_group()
+        all_rec, all_off = comm.gather_records(rec, off, root=0)
+        nranks = comm.info()["transport_ranks"]
+        comm.close()
+        if rank == 0:
+            assert all_off.tolist() == arrays["arc_off"].tolist() and all_rec["label"].tolist() == list(range(len(all_rec)))
+            gathered = {"ranks": nranks, "records": int(len(all_rec)), "order_restored": True}
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "lattice-arcs/sec (whole node) on forward-backward + arc posteriors", "value": None,
+                          "unit": "lattice-arcs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "index_gather": gathered}))
 
 
 def main():
@@ -97,12 +260,23 @@ def main():
     ap.add_argument("--seed", type=int, default=20260001)
     ap.add_argument("--lanes-per-lattice", type=int, default=0)
     ap.add_argument("--ring-slots", type=int, default=0)
+    ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed steps before the counted warm-up (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shapes", action="store_true")
+    ap.add_argument("--no-accumulate", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))  # parent: no GPU call before or after this point
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or let --gpus spawn them)" % (args.gpus, world))
+    if os.environ.get("KLAT_BENCH_DRYRUN"):
+        return dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
@@ -111,6 +285,8 @@ def main():
 
     if not torch.cuda.is_available() or klat_amd.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d GPUs visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -118,7 +294,6 @@ def main():
     U = args.lattices
     ns = np.full(U, args.states, np.int32)
     fo = np.full(U, args.fanout, np.int32)
-    scales = (1.0, 0.1, 0.0)
     host_threads = max(1, (os.cpu_count() or 1) // max(1, world))  # ranks share the host cores
     arrays = klat_amd.synth(args.seed, ns, fo, first_utt=rank * U, host_threads=host_threads)
     ctx = klat_amd.Ctx(local_rank)
@@ -134,21 +309,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the GPU's clock ramps for the first ~50 ms of load: a fixed duration of untimed steps first,
+    # then the counted warm-up
+    t_end = time.perf_counter() + args.settle_seconds
+    while time.perf_counter() < t_end:
+        for _ in range(16):
+            batch.forward_backward(*SCALES)
+        ctx.sync()
     for _ in range(args.warmup):
-        batch.forward_backward(*scales)
+        batch.forward_backward(*SCALES)
     barrier()
     # The K steps are enqueued without waiting in between (the library records HIP events around
     # its kernels on the ctx stream into a ring); their per-kernel durations are read after the
     # timed region.
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.forward_backward(*scales)
+        batch.forward_backward(*SCALES)
     barrier()
     elapsed = time.perf_counter() - t0
     hist = ctx.timing_history(min(args.steps, 512))
     sweep_ms = [t["sweep_ms"] for t in hist]
     post_ms = [t["posterior_ms"] for t in hist]
-    conv_ms = [t["convert_ms"] for t in hist]
     tot_ms = [t["total_ms"] for t in hist]
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -183,15 +364,16 @@ def main():
         torch.cuda.synchronize()
         return 10 * 2.0 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
+    out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * A * args.steps / elapsed
-        sweep_avg = float(np.mean(sweep_ms))
+        sweep_med = median(sweep_ms)
         # algorithmic bytes of the sweep launch (SURVEY.md 8d "fb-only"): 32 B/arc + 32 B/state
         sweep_bytes = 32.0 * A + 32.0 * S
-        achieved = sweep_bytes / (sweep_avg * 1e-3) / 1e9
+        achieved = sweep_bytes / (sweep_med * 1e-3) / 1e9
         step_bytes = 56.0 * A + 48.0 * S  # fb + arc posterior: 72 B/arc at fanout 3
-        traffic = measured_traffic(info["lanes_per_lattice"])
+        traffic = measured_traffic("sweep_kernel<%d, true" % info["lanes_per_lattice"])
         copy_gbs = device_copy_gbs()
         out = {
             "metric": "lattice-arcs/sec (whole node) on forward-backward + arc posteriors",
@@ -210,18 +392,80 @@ def main():
                          "device_copy_gbs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
                          "traffic": traffic["bytes"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
-                         "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_avg},
+                         "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": float(np.mean(sweep_ms)),
+                         "median_launch_ms": sweep_med},
             "roofline_step": {"bound": "hbm", "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_step": step_bytes},
-            "kernel_ms": {"sweep": sweep_avg, "posterior": float(np.mean(post_ms)),
-                          "convert": float(np.mean(conv_ms)), "device_total": float(np.mean(tot_ms))},
+            "kernel_ms": {"sweep": sweep_med, "posterior": median(post_ms), "device_total": median(tot_ms),
+                          "statistic": "median over the timed steps (HIP events on the ctx stream)"},
             "batch_create_seconds": pack_s,
             "results_d2h": {"seconds": d2h_s, "bytes": d2h_bytes, "what": "arc log-posteriors + alpha + beta to pageable host memory"},
         }
+
+    # ---- accumulate stage on the resident C2 batch (all ranks: the gather leg needs every shard's index)
+    if not args.no_accumulate:
+        acc = accumulate_leg(klat_amd, batch, arrays, A) if (rank == 0 or world > 1) else None
+        if rank == 0:
+            out["accumulate"] = acc
+
+    # ---- N > 1: segment index of every shard gathered to rank 0 over RCCL, from device buffers
+    if world > 1:
+        from klat_amd import dist as kdist
+        uid = [kdist.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = kdist.Comm.rccl(ctx, rank, world, uid[0])
+        nranks = comm.info()["transport_ranks"]
+        assert nranks == world, "RCCL communicator has %d ranks, expected %d" % (nranks, world)
+        import ctypes as C
+        f, keep = klat_amd.Batch._filter(None, None)
+        off = np.zeros(batch.U + 1, np.int64)
+        n = C.c_int64(0)
+        klat_amd._check(klat_amd.lib().klat_segment_index(batch.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
+        comm.gather_index(batch, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)  # warm-up: buffers, RCCL channels
+        times = []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            tu, tr = comm.gather_index(batch, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)
+            barrier()
+            times.append(time.perf_counter() - t0)
+        if rank == 0:
+            st = comm.stats()
+            sec = median(times)
+            assert tu == world * batch.U, (tu, world, batch.U)
+            rec, roff = comm._fetch(klat_amd.SEGMENT_DTYPE, 0, tu, tr)  # order check on the host, outside the timing
+            assert roff[-1] == tr and np.array_equal(roff[:batch.U + 1], off), "rank 0's own records must come first, unchanged"
+            out["index_gather"] = {"ranks": nranks, "transport": "RCCL send/recv from device buffers, all-gather of sizes",
+                                   "utterances": int(tu), "records": int(tr), "payload_bytes_into_rank0": st["payload_bytes"],
+                                   "seconds": sec, "GB_per_s_into_rank0": st["payload_bytes"] / sec / 1e9 if sec > 0 else None,
+                                   "order": "rank order = input order (checked)"}
+            del rec, roff
+        comm.close()
+
+    # ---- other BASELINE shapes, on rank 0 (the others wait at the barrier below)
+    if rank == 0 and not args.no_shapes:
+        batch.close()
+        shapes = []
+        c5n, c5f = c5_sizes(2500)
+        for name, seed, sn, sf, wide in (
+                ("C4/8 shard (configs[3]): 12500 lattices x 5000 states x fanout 3", 20260003,
+                 np.full(12500, 5000, np.int32), np.full(12500, 3, np.int32), 0),
+                ("C5/8 shard (configs[4] mix): 2500 lattices, 200..20000 states log-uniform, fanout {2,3,4,6}", 20260004, c5n, c5f, 0),
+                ("wide: 10000 lattices x 2000 states x fanout 3 in levels of 32 states (depth ~63)", 20260005,
+                 np.full(10000, 2000, np.int32), np.full(10000, 3, np.int32), 32)):
+            try:
+                shapes.append(time_shape(ctx, klat_amd, name, seed, sn, sf, host_threads, wide=wide))
+            except Exception as e:  # a shape that fails must not take the headline with it
+                shapes.append({"workload": name, "error": str(e)[:300]})
+        out["shapes"] = shapes
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ns, fo, args.seed, scales)
+            out["cpu_baseline"] = cpu_baseline(ns, fo, args.seed, SCALES)
         print(json.dumps(out))
     batch.close()
     ctx.close()

@@ -187,6 +187,19 @@ int klat_position_index(klat_batch* batch, const int32_t* state_len,
                         const klat_label_filter* filter, int64_t* record_off,
                         klat_position_record* records, int64_t capacity, int64_t* num_records);
 
+/* The records of the last sizing call (records == NULL) of klat_segment_index / klat_position_index,
+ * gathered utterance-major into one device array owned by the batch (24 B each, record_off as that
+ * call returned it; *record_off points at a host array of num_lattices+1 entries owned by the batch).
+ * This is what the multi-GPU gather of klat_dist.h sends from: the records need not visit the host
+ * on the ranks that do not write them (the serial writer of
+ * kwsbin2/lattice-word-index-segment.cc:96-128 runs on rank 0 only). */
+int klat_index_device_records(klat_batch* batch, const void** dev_records, const int64_t** record_off,
+                              int64_t* num_lattices, int64_t* num_records);
+
+/* Device time (HIP events on the ctx stream) of the index kernels / the frame-posterior kernels of
+ * the last sizing call on this batch; 0 if none ran.  Either pointer may be NULL. */
+int klat_get_accum_timings(klat_batch* batch, float* index_ms, float* frame_ms);
+
 /* Utterance index (kwsbin2/lattice-word-index-utterance.cc:143-196; known answer
  * kwsbin2/README.md:25): for lattice u and each of its query words words[word_off[u] ..
  * word_off[u+1]) the log-probability that the word occurs at least once on the path,
@@ -228,6 +241,19 @@ int klat_synth_generate(uint64_t seed, int64_t first_utt_index, int32_t num_latt
                         int64_t* arc_off, int32_t* src, int32_t* dst, int32_t* ilabel,
                         int32_t* olabel, float* graph, float* acoustic, float* final_graph,
                         float* final_acoustic, int32_t* state_time, int32_t host_threads);
+
+/* A second synthetic shape, for lattices whose topological depth is far below their number of
+ * states (real word lattices): levels of `width` states after the start state, every arc leads into
+ * the next level, the last level is final; depth = 1 + ceil((S - 1) / width).  See klat_synth.cc for
+ * the draw order (tests/test_synth.py restates both generators in Python). */
+int klat_synth_wide_sizes(int32_t num_lattices, const int32_t* num_states, const int32_t* fanout, int32_t width,
+                          int64_t* total_states, int64_t* total_arcs);
+int klat_synth_wide_generate(uint64_t seed, int64_t first_utt_index, int32_t num_lattices,
+                             const int32_t* num_states, const int32_t* fanout, int32_t width,
+                             int64_t* state_off, int64_t* arc_off, int32_t* src, int32_t* dst,
+                             int32_t* ilabel, int32_t* olabel, float* graph, float* acoustic,
+                             float* final_graph, float* final_acoustic, int32_t* state_time,
+                             int32_t host_threads);
 
 #ifdef __cplusplus
 }

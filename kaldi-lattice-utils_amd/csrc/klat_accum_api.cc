@@ -45,6 +45,22 @@ int ensure_index_scratch(klat_batch* b) {
   return KLAT_OK;
 }
 
+// The cached per-lattice records gathered into one dense device array (utterance-major): what the
+// fetch call copies to the host and what the multi-GPU gather sends from (klat_dist.h).
+int gather_dense(klat_batch* b, const AccumArgs& a, bool position) {
+  klat_accum_state& st = b->accum;
+  if (st.dense_mode == st.cached_mode) return KLAT_OK;
+  klat_ctx* c = b->ctx;
+  const int64_t total = st.record_off[b->U];
+  int rc;
+  if ((rc = st.d_record_off.upload(st.record_off.data(), st.record_off.size(), c->stream))) return rc;
+  if ((rc = st.dense.alloc((size_t)total))) return rc;
+  KLAT_HIP(launch_index_gather(a, (int)b->U, position, st.d_record_off.p, st.dense.p, c->stream));
+  KLAT_HIP(hipStreamSynchronize(c->stream));  // record_off was read from pageable host memory
+  st.dense_mode = st.cached_mode;
+  return KLAT_OK;
+}
+
 int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat_label_filter* f,
               int64_t* record_off, void* records, int64_t capacity, int64_t* num_records) {
   if (!b || !num_records || !record_off) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
@@ -111,6 +127,12 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       (arcs <= kRadixMaxArcs / 2 ? n_small : arcs <= kRadixMaxArcs ? n_medium : n_large)++;
     }
     radix = radix && n_small + n_medium > 0 && b->A > 0;
+    st.cached_mode = st.dense_mode = 0;
+    if (!st.ev[0]) {
+      KLAT_HIP(hipEventCreate(&st.ev[0]));
+      KLAT_HIP(hipEventCreate(&st.ev[1]));
+    }
+    KLAT_HIP(hipEventRecord(st.ev[0], c->stream));
     if (radix) {
       const int32_t init[4] = {0x7FFFFFFF, (int32_t)0x80000000, 0, 0};
       int32_t range[4];
@@ -148,6 +170,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     } else {
       KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
     }
+    KLAT_HIP(hipEventRecord(st.ev[1], c->stream));
     std::vector<int32_t> counts((size_t)b->U);
     if (b->U > 0)
       KLAT_HIP(hipMemcpyAsync(counts.data(), st.num_records.p, sizeof(int32_t) * (size_t)b->U,
@@ -169,13 +192,9 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     return set_error(KLAT_ERR_STATE, "call with records == NULL first: it computes and sizes the index");
   const int64_t total = st.record_off[b->U];
   if (capacity < total) return set_error(KLAT_ERR_INVALID_ARG, "records capacity too small");
-  DevBuf<int64_t> d_off;
-  DevBuf<OutRecord> d_out;
-  if ((rc = d_off.upload(st.record_off.data(), st.record_off.size(), c->stream))) return rc;
-  if ((rc = d_out.alloc((size_t)total))) return rc;
-  KLAT_HIP(launch_index_gather(a, (int)b->U, position, d_off.p, d_out.p, c->stream));
+  if ((rc = gather_dense(b, a, position))) return rc;
   if (total > 0)
-    KLAT_HIP(hipMemcpyAsync(records, d_out.p, sizeof(OutRecord) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    KLAT_HIP(hipMemcpyAsync(records, st.dense.p, sizeof(OutRecord) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
   KLAT_HIP(hipStreamSynchronize(c->stream));
   std::memcpy(record_off, st.record_off.data(), sizeof(int64_t) * ((size_t)b->U + 1));
   *num_records = total;
@@ -299,6 +318,11 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     a.num_frames = st.num_frames.p;
     a.num_expansions = st.num_expansions.p;
     a.num_records = st.num_records.p;
+    if (!st.ev[0]) {
+      KLAT_HIP(hipEventCreate(&st.ev[0]));
+      KLAT_HIP(hipEventCreate(&st.ev[1]));
+    }
+    KLAT_HIP(hipEventRecord(st.ev[0], c->stream));
     KLAT_HIP(launch_frame_count(a, (int)b->U, c->stream));
     std::vector<int64_t> nexp((size_t)b->U);
     if (b->U > 0)
@@ -318,6 +342,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     a.rec_scratch = st.rec_scratch.p;
     a.arc_info = reinterpret_cast<FrameArc*>(st.arc_scratch.p);
     KLAT_HIP(launch_frame(a, (int)b->U, c->stream));
+    KLAT_HIP(hipEventRecord(st.ev[1], c->stream));
     std::vector<int32_t> counts((size_t)b->U);
     if (b->U > 0)
       KLAT_HIP(hipMemcpyAsync(counts.data(), st.num_records.p, sizeof(int32_t) * (size_t)b->U,
@@ -353,6 +378,47 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
   KLAT_HIP(hipStreamSynchronize(c->stream));
   frame_off[T] = total;
   *num_entries = total;
+  return KLAT_OK;
+}
+
+int klat_index_device_records(klat_batch* b, const void** dev_records, const int64_t** record_off,
+                              int64_t* num_lattices, int64_t* num_records) {
+  if (!b || !dev_records || !num_records) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  klat_accum_state& st = b->accum;
+  if (st.cached_mode == 0)
+    return set_error(KLAT_ERR_STATE, "no index on this batch: call klat_segment_index / klat_position_index with records == NULL first");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  AccumArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.scratch_off = st.scratch_off.p;
+  a.rec_scratch = st.rec_scratch.p;
+  a.num_records = st.num_records.p;
+  int rc = gather_dense(b, a, st.cached_mode == 2);
+  if (rc != KLAT_OK) return rc;
+  *dev_records = st.dense.p;
+  if (record_off) *record_off = st.record_off.data();
+  if (num_lattices) *num_lattices = b->U;
+  *num_records = st.record_off[b->U];
+  return KLAT_OK;
+}
+
+int klat_get_accum_timings(klat_batch* b, float* index_ms, float* frame_ms) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  if (index_ms) {
+    *index_ms = 0.0f;
+    if (b->accum.ev[1]) {
+      KLAT_HIP(hipEventSynchronize(b->accum.ev[1]));
+      KLAT_HIP(hipEventElapsedTime(index_ms, b->accum.ev[0], b->accum.ev[1]));
+    }
+  }
+  if (frame_ms) {
+    *frame_ms = 0.0f;
+    if (b->frame.ev[1]) {
+      KLAT_HIP(hipEventSynchronize(b->frame.ev[1]));
+      KLAT_HIP(hipEventElapsedTime(frame_ms, b->frame.ev[0], b->frame.ev[1]));
+    }
+  }
   return KLAT_OK;
 }
 

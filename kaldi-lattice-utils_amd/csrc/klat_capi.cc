@@ -112,13 +112,7 @@ int klat_ctx_create(int device, klat_ctx** out) {
     delete c;
     return hip_fail(e, "hipStreamCreate");
   }
-  for (int i = 0; i < klat_ctx::kTimingSlots * 4; ++i) {
-    e = hipEventCreate(&c->evring[i / 4][i % 4]);
-    if (e != hipSuccess) {
-      klat_ctx_destroy(c);
-      return hip_fail(e, "hipEventCreate");
-    }
-  }
+  // (the timing events of the ring are created when a step first uses their slot)
   {
     std::vector<LnTabEntry> tab((size_t)kLnTabSize);
     fill_ln_table(tab.data());
@@ -171,8 +165,21 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   int rc = KLAT_OK;
   const int64_t U = d->num_lattices;
   if (U < 0 || (U > 0 && (!d->state_off || !d->arc_off))) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc: null offsets");
+  if (U > 0 && (d->state_off[0] != 0 || d->arc_off[0] != 0))
+    return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc: state_off[0] and arc_off[0] must be 0");
+  for (int64_t u = 0; u < U; ++u)
+    if (d->state_off[u + 1] < d->state_off[u] || d->arc_off[u + 1] < d->arc_off[u])
+      return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc: offsets of lattice " + std::to_string(u) + " decrease");
   const int64_t S_tot = U ? d->state_off[U] : 0, A_tot = U ? d->arc_off[U] : 0;
   if (host_pack) {
+    // the host packer reads the arc and state arrays on the host
+    for (const void* ptr : {(const void*)d->src, (const void*)d->dst, (const void*)d->ilabel, (const void*)d->graph,
+                            (const void*)d->acoustic, (const void*)d->final_graph, (const void*)d->final_acoustic}) {
+      hipPointerAttribute_t attr;
+      if (ptr && hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type == hipMemoryTypeDevice)
+        return set_error(KLAT_ERR_INVALID_ARG, "KLAT_HOST_PACK=1 needs host arrays in klat_batch_desc (got a device pointer)");
+    }
+    (void)hipGetLastError();  // hipPointerGetAttributes on plain host memory reports an error: not ours
     rc = pack_batch(*d, o, &P, &err);
     if (rc != KLAT_OK) return set_error(rc, err);
   } else {
@@ -368,6 +375,8 @@ void klat_batch_destroy(klat_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
   (void)hipStreamSynchronize(b->ctx->stream);
+  for (hipEvent_t e : {b->accum.ev[0], b->accum.ev[1], b->frame.ev[0], b->frame.ev[1]})
+    if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -435,6 +444,11 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   // workgroups exit at once unless the fast sweep flagged a job) falls to totals_ms.
   const bool one_class = b->classes.size() == 1;
   hipEvent_t* ev = c->evring[c->steps % klat_ctx::kTimingSlots];
+  for (int i = 0; i < 4; ++i)
+    if (!ev[i]) KLAT_HIP(hipEventCreate(&ev[i]));
+  // results derived from the previous posteriors are stale from here on
+  b->accum.cached_mode = b->accum.dense_mode = 0;
+  b->frame.ready = false;
   if (!one_class) KLAT_HIP(hipEventRecord(ev[0], c->stream));
   {
     const int rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {

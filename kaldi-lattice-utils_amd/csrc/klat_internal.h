@@ -9,6 +9,7 @@
 
 #include "../../include/klat.h"
 #include "klat_device.h"
+#include "klat_accum.h"
 #include "klat_kernels.h"
 #include "klat_pack.h"
 
@@ -90,6 +91,10 @@ struct klat_accum_state {
   bool scratch_ready = false;
   int64_t scratch_slots = 0;
   int cached_mode = 0;  // 0 none, 1 segment, 2 position
+  int dense_mode = 0;   // the mode `dense` was gathered for (0: stale)
+  klat::DevBuf<klat::OutRecord> dense;  // the cached records, gathered utterance-major
+  klat::DevBuf<int64_t> d_record_off;
+  hipEvent_t ev[2] = {nullptr, nullptr};  // around the index kernels of the last sizing call
   std::vector<int64_t> record_off;
   klat::DevBuf<int64_t> scratch_off;
   klat::DevBuf<unsigned char> key_scratch, rec_scratch;
@@ -99,6 +104,7 @@ struct klat_accum_state {
 
 struct klat_frame_state {
   bool ready = false;
+  hipEvent_t ev[2] = {nullptr, nullptr};  // around the frame kernels of the last sizing call
   std::vector<int64_t> frame_base, entry_off;
   klat::DevBuf<int64_t> scratch_off, num_expansions;
   klat::DevBuf<int32_t> num_frames, num_records;

@@ -660,7 +660,11 @@ hipError_t launch_sweep_tropical(const SweepArgs& args, int num_jobs, int G, hip
 // fast one flagged (normally none: those workgroups exit at once).
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream, hipEvent_t fast_begin,
                         hipEvent_t fast_end) {
-  if (num_jobs <= 0) return hipSuccess;
+  if (num_jobs <= 0) {  // nothing to sweep: the timing events must still be recorded
+    hipError_t e = fast_begin ? hipEventRecord(fast_begin, stream) : hipSuccess;
+    if (e == hipSuccess && fast_end) e = hipEventRecord(fast_end, stream);
+    return e;
+  }
   const int LPW = 64 / G;
   if ((size_t)args.ring_slots * LPW + 64 > kCellMask + 1) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(args.job_flags, 0, sizeof(int32_t) * (size_t)num_jobs, stream);

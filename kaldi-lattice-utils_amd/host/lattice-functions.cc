@@ -1,6 +1,8 @@
 // lattice-functions.cc -- see lattice-functions.h.
 #include "lattice-functions.h"
 
+#include <mutex>
+
 #include <algorithm>
 #include <map>
 #include <queue>
@@ -390,11 +392,55 @@ void DeviceBatch::ForwardBackward(float graph_scale, float acoustic_scale, float
   Check(klat_forward_backward(b_, &s), "klat_forward_backward");
 }
 
+namespace {
+// The GPU contexts behind ComputeLatticeAlphasAndBetas: every calling thread leases one for its
+// lifetime (one HIP stream per thread: the B2 contract of kwsbin2/lattice-word-index-segment.cc:
+// 181,264-272, where each TaskSequencer worker owns its lattice) and hands it back when the thread
+// ends, so a pool of short-lived workers creates as many contexts as run at once, not one per
+// thread.  The pool itself is never destroyed: a context must not be torn down from a static or
+// thread_local destructor at process exit, when the HIP runtime may already be gone.
+struct ContextPool {
+  std::mutex mu;
+  std::vector<Context*> idle;
+  int device = 0;
+  Context* Acquire() {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!idle.empty()) {
+        Context* c = idle.back();
+        idle.pop_back();
+        return c;
+      }
+    }
+    return new Context(device);
+  }
+  void Release(Context* c) {
+    std::lock_guard<std::mutex> lock(mu);
+    idle.push_back(c);
+  }
+};
+ContextPool& Pool() {
+  static ContextPool* pool = new ContextPool();  // intentionally leaked, see above
+  return *pool;
+}
+struct ContextLease {
+  Context* ctx;
+  ContextLease() : ctx(Pool().Acquire()) {}
+  ~ContextLease() { Pool().Release(ctx); }
+};
+}  // namespace
+
+void SetDefaultDevice(int device) {
+  std::lock_guard<std::mutex> lock(Pool().mu);
+  Pool().device = device;
+}
+
 double ComputeLatticeAlphasAndBetas(const CompactLattice& clat, bool viterbi, std::vector<double>* alpha,
                                     std::vector<double>* beta) {
   if (viterbi) KLAT_ERR("ComputeLatticeAlphasAndBetas: viterbi=true is not on the accelerated path");
   if (clat.NumStates() == 0 || clat.Start() != 0) KLAT_ERR("ComputeLatticeAlphasAndBetas: lattice must be top-sorted with start state 0");
-  static thread_local Context ctx(0);  // one HIP stream per calling thread (re-entrant, B2 contract)
+  static thread_local ContextLease lease;  // one HIP stream per calling thread (re-entrant, B2 contract)
+  Context& ctx = *lease.ctx;
   LatticeBatch lb;
   lb.Add(clat, nullptr);
   DeviceBatch db(ctx, lb);

@@ -116,6 +116,9 @@ void PruneLatticesOnDevice(Context& ctx, float beam, float graph_scale, float ac
 // context; batch callers should use LatticeBatch/DeviceBatch directly.
 double ComputeLatticeAlphasAndBetas(const CompactLattice& clat, bool viterbi, std::vector<double>* alpha,
                                     std::vector<double>* beta);
+// The GPU the contexts behind ComputeLatticeAlphasAndBetas are created on (default 0); call before
+// the first use.
+void SetDefaultDevice(int device);
 
 }  // namespace klat
 #endif

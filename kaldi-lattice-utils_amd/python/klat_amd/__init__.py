@@ -350,20 +350,27 @@ def pack_host(arrays, lanes_per_lattice=0, ring_slots=0, host_threads=0):
     return {"info": info.as_dict(), "sw": sw, "sg": sg, "sa": sa, "jobs": jobs, "lanes": lanes, "items": items}
 
 
-def synth(seed, num_states, fanout, first_utt=0, host_threads=0):
-    """SURVEY.md Appendix D generator (C++ implementation in the library)."""
+def synth(seed, num_states, fanout, first_utt=0, host_threads=0, wide=0):
+    """SURVEY.md Appendix D generator (C++ implementation in the library); wide > 0 selects the
+    levelled shape of klat_synth_wide_generate with that level width."""
     ns = np.ascontiguousarray(num_states, np.int32)
     fo = np.ascontiguousarray(fanout, np.int32)
     n = len(ns)
     St, At = C.c_int64(0), C.c_int64(0)
-    _check(lib().klat_synth_sizes(C.c_int32(n), _p(ns), _p(fo), C.byref(St), C.byref(At)))
+    if wide:
+        _check(lib().klat_synth_wide_sizes(C.c_int32(n), _p(ns), _p(fo), C.c_int32(wide), C.byref(St), C.byref(At)))
+    else:
+        _check(lib().klat_synth_sizes(C.c_int32(n), _p(ns), _p(fo), C.byref(St), C.byref(At)))
     out = {"state_off": np.zeros(n + 1, np.int64), "arc_off": np.zeros(n + 1, np.int64)}
     for name, dt in FIELDS[2:]:
         size = At.value if name in ("src", "dst", "ilabel", "olabel", "graph", "acoustic") else St.value
         out[name] = np.zeros(size, dt)
-    _check(lib().klat_synth_generate(C.c_uint64(seed), C.c_int64(first_utt), C.c_int32(n), _p(ns), _p(fo),
-                                     _p(out["state_off"]), _p(out["arc_off"]), _p(out["src"]), _p(out["dst"]),
-                                     _p(out["ilabel"]), _p(out["olabel"]), _p(out["graph"]), _p(out["acoustic"]),
-                                     _p(out["final_graph"]), _p(out["final_acoustic"]), _p(out["state_time"]),
-                                     C.c_int32(host_threads)))
+    tail = (_p(out["state_off"]), _p(out["arc_off"]), _p(out["src"]), _p(out["dst"]),
+            _p(out["ilabel"]), _p(out["olabel"]), _p(out["graph"]), _p(out["acoustic"]),
+            _p(out["final_graph"]), _p(out["final_acoustic"]), _p(out["state_time"]), C.c_int32(host_threads))
+    if wide:
+        _check(lib().klat_synth_wide_generate(C.c_uint64(seed), C.c_int64(first_utt), C.c_int32(n), _p(ns), _p(fo),
+                                              C.c_int32(wide), *tail))
+    else:
+        _check(lib().klat_synth_generate(C.c_uint64(seed), C.c_int64(first_utt), C.c_int32(n), _p(ns), _p(fo), *tail))
     return out

@@ -1,0 +1,152 @@
+"""Re-entrancy and teardown of the C ABI (interface B2): the reference calls
+ComputeLatticeAlphasAndBetas concurrently from TaskSequencer workers, each on its own lattice
+(kwsbin2/lattice-word-index-segment.cc:181,260-275).  Here: one klat_ctx per host thread, used
+at the same time; contexts created and destroyed repeatedly; processes that exit with handles
+still open; and the C++ mirror of B2 driven from threads through a tool."""
+import os
+import subprocess
+import sys
+import textwrap
+import threading
+
+import numpy as np
+import pytest
+
+import latfmt
+from oracle import oracle as orc
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
+import klat_amd  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "kaldi-lattice-utils_amd", "bin")
+
+
+def _workload(i, n=48):
+    rng = np.random.RandomState(100 + i)
+    ns = rng.randint(2, 400, size=n).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4, 6], size=n).astype(np.int32)
+    return klat_amd.synth(4242, ns, fo, first_utt=1000 * i)
+
+
+def _run(ctx, arrays, steps=1):
+    b = klat_amd.Batch(ctx, arrays)
+    for _ in range(steps):
+        b.forward_backward(1.0, 0.1, 0.5)
+    out = b.alpha_beta() + b.totals() + (b.arc_logpost(),)
+    off, rec = b.segment_index()
+    b.close()
+    return out + (off, rec)
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y) if x.dtype.fields is None else x.tobytes() == y.tobytes() for x, y in zip(a, b))
+
+
+def test_four_threads_four_contexts_bit_equal_to_single_thread():
+    assert klat_amd.device_count() >= 1
+    work = [_workload(i) for i in range(4)]
+    ctx = klat_amd.Ctx(0)
+    want = [_run(ctx, w) for w in work]  # single thread, one context, one after the other
+    ctx.close()
+    got, errors = [None] * 4, []
+
+    def worker(i):
+        try:
+            c = klat_amd.Ctx(0)  # its own context = its own HIP stream
+            for rep in range(6):  # several batches per thread so that the threads really overlap
+                r = _run(c, work[i], steps=3)
+                if got[i] is None:
+                    got[i] = r
+                elif not _same(got[i], r):
+                    errors.append("thread %d: run %d differs from its first run" % (i, rep))
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (i, e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        assert _same(got[i], want[i]), "thread %d: results differ from the single-thread run" % i
+
+
+def test_one_context_is_reusable_from_another_thread():
+    """A context is not tied to the thread that created it (the library sets the device per call)."""
+    ctx = klat_amd.Ctx(0)
+    w = _workload(7)
+    want = _run(ctx, w)
+    res = []
+    t = threading.Thread(target=lambda: res.append(_run(ctx, w)))
+    t.start()
+    t.join()
+    ctx.close()
+    assert res and _same(res[0], want)
+
+
+PROBE = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(%(root)r, "kaldi-lattice-utils_amd", "python"))
+    import klat_amd
+    mode = sys.argv[1]
+    ns = np.full(256, 300, np.int32); fo = np.full(256, 3, np.int32)
+    for round in range(3 if mode == "cycle" else 1):
+        ctxs = [klat_amd.Ctx(0) for _ in range(3)]
+        batches = [klat_amd.Batch(ctxs[i], klat_amd.synth(1, ns, fo, first_utt=i * 256)) for i in range(3)]
+        for s in range(240):                      # steps enqueued on three streams without waiting
+            batches[s %% 3].forward_backward(1.0, 0.1, 0.0)
+        for c in ctxs:
+            c.sync()
+        t = [b.totals()[0] for b in batches]
+        assert all(np.all(np.isfinite(x)) for x in t)
+        print(ctxs[0].timing_history(16)[0]["sweep_ms"] > 0, flush=True)
+        if mode == "cycle":                       # explicit teardown, three times over
+            for b in batches: b.close()
+            for c in ctxs: c.close()
+    print("PROBE_DONE", mode, flush=True)         # mode == "leak": handles stay open at exit
+""")
+
+
+@pytest.mark.parametrize("mode", ["cycle", "leak"])
+def test_contexts_tear_down_cleanly(tmp_path, mode):
+    """Three contexts created and destroyed three times over, and a process that exits with three
+    contexts and their batches still open: both must end with exit code 0 (round 1 saw
+    `terminate called after throwing std::bad_variant_access` at exit with two contexts)."""
+    script = tmp_path / "probe.py"
+    script.write_text(PROBE % {"root": ROOT})
+    for attempt in range(2):
+        p = subprocess.run([sys.executable, str(script), mode], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "PROBE_DONE" in p.stdout and "terminate" not in p.stderr, (p.returncode, p.stdout[-500:], p.stderr[-2000:])
+
+
+def test_b2_mirror_from_worker_threads(tmp_path, golden_dir):
+    """ComputeLatticeAlphasAndBetas (the C++ mirror of B2) from 4 short-lived worker threads at a
+    time, every lattice on its own thread: totals must match the oracle and the single-thread run
+    exactly, and the process must exit cleanly (its contexts are leased from a pool that outlives
+    the threads)."""
+    rng = np.random.RandomState(5)
+    ns = rng.randint(2, 120, size=24).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4], size=24).astype(np.int32)
+    arrays = klat_amd.synth(31337, ns, fo)
+    ark = tmp_path / "lats.ark.txt"
+    from test_host_tools import _write_text_archive
+    _write_text_archive(str(ark), arrays, ns)
+    outs = []
+    for nt in (1, 4):
+        p = subprocess.run([os.path.join(BIN, "klat-alphas-betas"), "--num-threads=%d" % nt, "ark:%s" % ark],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == len(ns)
+    from test_gpu_parity import _oracle_batch
+    wa, wb, wt, _ = _oracle_batch(arrays, 1.0, 1.0, 0.0)
+    for u, line in enumerate(outs[0].splitlines()):
+        f = line.split()
+        assert f[0] == "utt%07d" % u
+        assert abs(float(f[1]) - wt[u]) <= 1e-8 * max(1.0, abs(wt[u]))
+        assert abs(float(f[3]) - wb[arrays["state_off"][u]]) <= 1e-8 * max(1.0, abs(wt[u]))

@@ -34,6 +34,14 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, "declared in include/klat.h but not exported: %s" % missing
     assert b"gfx950" in lib.klat_version()
+    # the multi-GPU library (include/klat_dist.h)
+    from klat_amd import dist as kdist
+    hdr = open(os.path.join(ROOT, "include", "klat_dist.h")).read()
+    names = sorted(set(re.findall(r"^(?:int|void)\s+(klat_[a-z_0-9]+)\s*\(", hdr, re.M)))
+    assert len(names) >= 10, names
+    dlib = kdist.dlib()
+    missing = [n for n in names if not hasattr(dlib, n)]
+    assert not missing, "declared in include/klat_dist.h but not exported: %s" % missing
 
 
 @pytest.mark.parametrize("tool", TOOLS)
