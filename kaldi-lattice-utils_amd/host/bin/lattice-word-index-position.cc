@@ -6,6 +6,7 @@
 
 #include "../lattice-functions.h"
 #include "../table-writers.h"
+#include "sharded-index.h"
 #include "tool-common.h"
 
 int main(int argc, char* argv[]) {
@@ -23,58 +24,15 @@ int main(int argc, char* argv[]) {
     IndexOptions io;
     co.Register(&po);
     io.Register(&po);
+    ShardOptions so;
+    so.Register(&po);
     po.Read(argc, argv);
     if (po.NumArgs() != 2) {
       po.PrintUsage();
       exit(1);
     }
     io.Check();
-    const std::vector<int32_t> include = ParseIntList(io.include_str, "--include-words");
-    const std::vector<int32_t> exclude = ParseIntList(io.exclude_str, "--exclude-words");
-    const klat_label_filter filter = {include.data(), (int32_t)include.size(), exclude.data(), (int32_t)exclude.size()};
-
-    PositionScoreWriter score_writer(po.GetArg(2));
-    Context ctx(co.device);
-    klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
-
-    std::vector<std::string> keys;
-    std::vector<int32_t> state_len_all;
-    LatticeBatch batch;
-    auto flush = [&]() {
-      if (keys.empty()) return;
-      DeviceBatch db(ctx, batch, &popt);
-      db.ForwardBackward(co.graph_scale, co.acoustic_scale, co.insertion_penalty);
-      std::vector<int64_t> off(keys.size() + 1, 0);
-      int64_t n = 0;
-      Check(klat_position_index(db.get(), state_len_all.data(), &filter, off.data(), nullptr, 0, &n), "klat_position_index");
-      std::vector<klat_position_record> rec((size_t)std::max<int64_t>(n, 1));
-      Check(klat_position_index(db.get(), state_len_all.data(), &filter, off.data(), rec.data(), (int64_t)rec.size(), &n),
-            "klat_position_index");
-      for (size_t u = 0; u < keys.size(); ++u) score_writer.Write(keys[u], rec.data() + off[u], off[u + 1] - off[u]);
-      keys.clear();
-      state_len_all.clear();
-      batch.Clear();
-    };
-
-    for (PrunedLatticeReader reader(po.GetArg(1), ctx, co, io); !reader.Done(); reader.Next()) {
-      CompactLattice& clat = reader.Value();
-      CompactLattice dlat;
-      std::vector<int32_t> times, state_len;
-      if (clat.Start() != CompactLattice::kNoStateId) {
-        TopSortCompactLatticeIfNeeded(&clat);
-        DisambiguateStateInputSequenceLength(clat, &dlat, &state_len, false);
-        CompactLatticeStateTimes(dlat, &times);
-      }
-      KLAT_VLOG(1, "Lattice " << reader.Key() << ": #states " << clat.NumStates() << " -> " << dlat.NumStates());
-      keys.push_back(reader.Key());
-      batch.Add(dlat, &times);
-      state_len_all.insert(state_len_all.end(), state_len.begin(), state_len.end());
-      reader.FreeCurrent();
-      if ((int32_t)keys.size() >= co.batch_size || batch.NumArcs() >= co.max_batch_arcs) flush();
-    }
-    flush();
-    score_writer.Close();
-    return 0;
+    return RunIndexTool<true, PositionScoreWriter, klat_position_record>(co, io, so, po.GetArg(1), po.GetArg(2));
   } catch (const std::exception& e) {
     std::cerr << e.what();
     return -1;

@@ -1,0 +1,116 @@
+"""The multi-GPU part of the path on the one GPU a test box has: the RCCL transport with a single
+rank (communicator, all-gather of sizes, device-side assembly, fetch), and the tools' --devices
+mode as several real processes sharing GPU 0 with the host transport (--gather=host) -- fork before
+HIP, partition by arcs, per-rank batches, gather, ordered emission on rank 0
+(kwsbin2/lattice-word-index-segment.cc:96-128,260-275).  The 8-GPU RCCL run itself belongs to
+the driver (bench.py --gpus 8, `index_gather`)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
+import klat_amd  # noqa: E402
+from klat_amd import dist as kdist  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "kaldi-lattice-utils_amd", "bin")
+
+
+def _batch(ctx, n=40, seed=11):
+    rng = np.random.RandomState(seed)
+    ns = rng.randint(1, 300, size=n).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4], size=n).astype(np.int32)
+    arrays = klat_amd.synth(555, ns, fo)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.1, 0.0)
+    return b, arrays, ns
+
+
+def test_rccl_transport_single_rank_gathers_the_batch_index():
+    ctx = klat_amd.Ctx(0)
+    b, arrays, ns = _batch(ctx)
+    off, rec = b.segment_index()          # sizing call + host fetch: the expected answer
+    comm = kdist.Comm.rccl(ctx, 0, 1, kdist.rccl_unique_id())
+    assert comm.info() == {"rank": 0, "world": 1, "transport_ranks": 1}
+    for _ in range(2):
+        got, goff = comm.gather_index(b, klat_amd.SEGMENT_DTYPE, root=0)
+        assert goff.tolist() == off.tolist() and got.tobytes() == rec.tobytes()
+    assert comm.stats()["payload_bytes"] == 0
+    # a later sweep invalidates the cached index: the gather must refuse stale records
+    b.forward_backward(1.0, 0.2, 0.0)
+    with pytest.raises(klat_amd.KlatError):
+        comm.gather_index(b, klat_amd.SEGMENT_DTYPE, root=0)
+    comm.close()
+    b.close()
+    ctx.close()
+
+
+def test_device_records_match_host_fetch_for_position_index():
+    import ctypes as C
+    ctx = klat_amd.Ctx(0)
+    b, arrays, ns = _batch(ctx, n=12, seed=3)
+    state_len = np.zeros(int(arrays["state_off"][-1]), np.int32)  # any labelling will do for this plumbing check
+    for u in range(len(ns)):
+        s0, s1 = arrays["state_off"][u], arrays["state_off"][u + 1]
+        state_len[s0:s1] = np.arange(s1 - s0) % 7
+    off, rec = b.position_index(state_len)
+    dev, poff, nl, nr = C.c_void_p(), C.POINTER(C.c_int64)(), C.c_int64(), C.c_int64()
+    klat_amd._check(klat_amd.lib().klat_index_device_records(b.h, C.byref(dev), C.byref(poff), C.byref(nl), C.byref(nr)))
+    assert nl.value == len(ns) and nr.value == len(rec) and [poff[i] for i in range(len(ns) + 1)] == off.tolist()
+    assert dev.value  # a device pointer; its contents come back through the gather below
+    comm = kdist.Comm.rccl(ctx, 0, 1, kdist.rccl_unique_id())
+    got, goff = comm.gather_index(b, klat_amd.POSITION_DTYPE, root=0)
+    assert got.tobytes() == rec.tobytes() and goff.tolist() == off.tolist()
+    comm.close(), b.close(), ctx.close()
+
+
+@pytest.mark.parametrize("tool,extra", [("lattice-word-index-segment", []), ("lattice-word-index-position", []),
+                                        ("lattice-word-index-segment", ["--beam=4", "--acoustic-scale=0.1"])])
+def test_tool_devices_mode_three_processes_equals_one(tmp_path, tool, extra):
+    rng = np.random.RandomState(8)
+    ns = rng.randint(1, 150, size=37).astype(np.int32)
+    ns[5] = 1  # a lattice without arcs: still one (empty) record line, kwsbin2/lattice-word-index-segment.cc:64-69
+    fo = rng.choice([1, 2, 3], size=37).astype(np.int32)
+    arrays = klat_amd.synth(2024, ns, fo)
+    ark = tmp_path / "lats.ark.txt"
+    from test_host_tools import _write_text_archive
+    _write_text_archive(str(ark), arrays, ns)
+    outs = []
+    for dev in (["--device=0"], ["--devices=0,0,0", "--gather=host", "--batch-size=5"], ["--devices=0,0", "--gather=host", "--batch-size=64"]):
+        p = subprocess.run([os.path.join(BIN, tool)] + extra + dev + ["ark:%s" % ark, "ark,t:-"], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        outs.append(p.stdout)
+    assert len(outs[0].splitlines()) == len(ns)
+    # A lattice's lanes-per-lattice layout depends on the batch it shares (plan_layout), so sums may
+    # differ in the last bits between the runs: compare as SURVEY.md C.3 prescribes -- keys in input
+    # order, integer fields bit-exact as sets, values within tolerance, order valid up to ties.
+    import latfmt
+    nint = 4 if tool.endswith("position") else 3
+    want = [latfmt.parse_tuple_line(l, nint) for l in outs[0].splitlines()]
+    for other in outs[1:]:
+        got = [latfmt.parse_tuple_line(l, nint) for l in other.splitlines()]
+        assert [k for k, _ in got] == [k for k, _ in want] == ["utt%07d" % u for u in range(len(ns))]
+        for (_, g), (_, w) in zip(got, want):
+            wk = {r[:nint]: r[nint] for r in w}
+            assert sorted(r[:nint] for r in g) == sorted(wk)
+            assert all(abs(r[nint] - wk[r[:nint]]) <= 1e-6 * max(1.0, abs(r[nint])) for r in g)
+            lp = [r[nint] for r in g]
+            assert all(lp[i] >= lp[i + 1] - 1e-6 * max(1.0, abs(lp[i])) for i in range(len(lp) - 1))
+
+
+def test_tool_devices_mode_reports_a_failing_rank(tmp_path):
+    """A rank that cannot do its share (device index out of range) must end the whole run with a
+    non-zero exit code instead of leaving the writer waiting."""
+    ns = np.array([30, 20, 10, 25], np.int32)
+    arrays = klat_amd.synth(1, ns, np.full(4, 2, np.int32))
+    ark = tmp_path / "lats.ark.txt"
+    from test_host_tools import _write_text_archive
+    _write_text_archive(str(ark), arrays, ns)
+    p = subprocess.run([os.path.join(BIN, "lattice-word-index-segment"), "--devices=0,99", "--gather=host", "ark:%s" % ark, "ark,t:-"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "device index out of range" in p.stderr or "worker rank failed" in p.stderr
