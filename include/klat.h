@@ -215,6 +215,20 @@ int klat_utterance_scores(klat_batch* batch, const int64_t* word_off, const int3
 int klat_frame_post(klat_batch* batch, const int32_t* num_frames, int64_t* frame_off,
                     int32_t* labels, float* logps, int64_t capacity, int64_t* num_entries);
 
+/* ---- n-best over the batch's graphs in the tropical semiring ----
+ * The k lowest-cost complete paths of every lattice over the caller's arc costs: the n-best
+ * extension of ShortestPath(new_fst, &nbest_fst, 1) at latbin/lattice-best-path2.cc:185, where the
+ * costs are 1 - P(label, position) (:171-173).  Costs are float32 >= 0 (+inf removes an arc) and
+ * add left to right along a path (StdArc); final states add nothing (:157-160); paths are distinct
+ * arc sequences, ascending by cost (equal costs: by the kernel's back-pointer order).
+ * num_paths[u] <= k paths exist for lattice u; path n of lattice u has cost path_cost[u*k+n] and
+ * path_len[u*k+n] non-zero output labels at path_labels[(u*k+n)*max_labels ..].  arc_cost may be a
+ * host or a device pointer.  Does not need klat_forward_backward. */
+#define KLAT_NBEST_MAX 128
+int klat_nbest(klat_batch* batch, const float* arc_cost /* [A] */, int32_t k, int32_t max_labels,
+               int32_t* num_paths /* [U] */, float* path_cost /* [U*k] */, int32_t* path_len /* [U*k] */,
+               int32_t* path_labels /* [U*k*max_labels] */);
+
 /* The streams of a batch as klat_batch_create built them on the device (for tests: they must equal
  * klat_pack_host's, bit for bit).  Arrays of fwd_slots + bwd_slots entries each. */
 int klat_batch_get_streams(klat_batch* batch, int32_t* sw, float* sg, float* sa);

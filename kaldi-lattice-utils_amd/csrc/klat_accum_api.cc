@@ -13,6 +13,7 @@
 #include "../../include/klat.h"
 #include "klat_accum.h"
 #include "klat_internal.h"
+#include "klat_nbest.h"
 
 using namespace klat;
 
@@ -419,6 +420,71 @@ int klat_get_accum_timings(klat_batch* b, float* index_ms, float* frame_ms) {
       KLAT_HIP(hipEventElapsedTime(frame_ms, b->frame.ev[0], b->frame.ev[1]));
     }
   }
+  return KLAT_OK;
+}
+
+int klat_nbest(klat_batch* b, const float* arc_cost, int32_t k, int32_t max_labels, int32_t* num_paths,
+               float* path_cost, int32_t* path_len, int32_t* path_labels) {
+  if (!b || !num_paths || !path_cost || !path_len || !path_labels) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (k < 1 || k > KLAT_NBEST_MAX) return set_error(KLAT_ERR_INVALID_ARG, "klat_nbest: k must be in [1, KLAT_NBEST_MAX]");
+  if (max_labels < 1) return set_error(KLAT_ERR_INVALID_ARG, "klat_nbest: max_labels must be positive");
+  if (b->A > 0 && !arc_cost) return set_error(KLAT_ERR_INVALID_ARG, "klat_nbest: arc_cost is null");
+  if (b->A > 0 && b->olabel.n == 0) return set_error(KLAT_ERR_INVALID_ARG, "the batch was created without olabel");
+  if (b->U == 0) return KLAT_OK;
+  klat_ctx* c = b->ctx;
+  KLAT_HIP(hipSetDevice(c->device));
+  int64_t max_states = 1;
+  for (int64_t u = 0; u < b->U; ++u) {
+    max_states = std::max(max_states, b->h_state_off[u + 1] - b->h_state_off[u]);
+    if (b->h_arc_off[u + 1] - b->h_arc_off[u] >= (int64_t)1 << 25 || b->h_state_off[u + 1] - b->h_state_off[u] >= (int64_t)1 << 25)
+      return set_error(KLAT_ERR_INVALID_ARG, "klat_nbest: lattice too large for the 25-bit back pointers");
+  }
+  // persistent one-wave workgroups, each with [max_states][128] keys of scratch; at most 8 GiB of it
+  int64_t wgs = std::min<int64_t>(b->U, 256 * 8);
+  wgs = std::max<int64_t>(1, std::min<int64_t>(wgs, (8ll << 30) / (max_states * kNbestWidth * 8)));
+  const size_t paths = (size_t)b->U * (size_t)k;
+  DevBuf<float> d_cost, d_pcost;
+  DevBuf<int32_t> d_next, d_np, d_plen, d_plab, d_status;
+  DevBuf<uint64_t> d_scratch;
+  int rc;
+  const int32_t zero = 0;
+  if ((rc = d_cost.upload(arc_cost, (size_t)b->A, c->stream))) return rc;
+  if ((rc = d_next.upload(&zero, 1, c->stream))) return rc;
+  if ((rc = d_status.upload(&zero, 1, c->stream))) return rc;
+  if ((rc = d_np.alloc((size_t)b->U)) || (rc = d_pcost.alloc(paths)) || (rc = d_plen.alloc(paths)) ||
+      (rc = d_plab.alloc(paths * (size_t)max_labels)) || (rc = d_scratch.alloc((size_t)(wgs * max_states * kNbestWidth))))
+    return rc;
+  NbestArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.num_lattices = (int32_t)b->U;
+  a.next_lattice = d_next.p;
+  a.state_off = b->state_off.p;
+  a.arc_off = b->arc_off.p;
+  a.src = b->src.p;
+  a.dst = b->dst.p;
+  a.olabel = b->olabel.p;
+  a.final_graph = b->final_graph.p;
+  a.final_acoustic = b->final_acoustic.p;
+  a.arc_cost = d_cost.p;
+  a.k = k;
+  a.max_labels = max_labels;
+  a.scratch = d_scratch.p;
+  a.scratch_states = max_states;
+  a.num_paths = d_np.p;
+  a.path_cost = d_pcost.p;
+  a.path_len = d_plen.p;
+  a.path_labels = d_plab.p;
+  a.status = d_status.p;
+  KLAT_HIP(launch_nbest(a, (int)wgs, c->stream));
+  int32_t status = 0;
+  KLAT_HIP(hipMemcpyAsync(&status, d_status.p, sizeof(status), hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipMemcpyAsync(num_paths, d_np.p, sizeof(int32_t) * (size_t)b->U, hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipMemcpyAsync(path_cost, d_pcost.p, sizeof(float) * paths, hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipMemcpyAsync(path_len, d_plen.p, sizeof(int32_t) * paths, hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipMemcpyAsync(path_labels, d_plab.p, sizeof(int32_t) * paths * (size_t)max_labels, hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipStreamSynchronize(c->stream));
+  if (status > 0) return set_error(KLAT_ERR_INVALID_ARG, "klat_nbest: lattice " + std::to_string(status - 1) + " has a negative or NaN arc cost");
+  if (status < 0) return set_error(KLAT_ERR_INVALID_ARG, "klat_nbest: a path of lattice " + std::to_string(-status - 1) + " has more labels than max_labels");
   return KLAT_OK;
 }
 

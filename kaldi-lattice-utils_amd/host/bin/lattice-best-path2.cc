@@ -3,13 +3,19 @@
 //   sum_k (1 - P(y_k = w | x))   over the length-disambiguated, length-padded lattice.
 // Same command line (:55-70), Int32Vector output (:75,199), log lines and exit codes.
 //
-// GPU: forward-backward of the padded lattices and the (label, position) accumulation -- the
-// position-index kernels with an empty filter compute the reference's word_pos_acc (:121-139).
+// GPU: forward-backward of the padded lattices, the (label, position) accumulation -- the
+// position-index kernels with an empty filter compute the reference's word_pos_acc (:121-139) --
+// and the tropical shortest paths over arc costs 1 - P (:149-188; klat_nbest, one wave per lattice).
 // Host: graph surgery before (ArcSort, DisambiguateStateInputSequenceLength,
-// AddSequenceLengthDismabiguationSymbol :103-110) and, after, the tropical shortest path over arc
-// costs 1 - P (:149-188), a single pass over the topologically sorted states.  Among paths of
-// equal cost the first one found in (state, arc) order is kept; OpenFst's ShortestPath may break
-// such ties differently (its queue discipline is not part of the reference's contract).
+// AddSequenceLengthDismabiguationSymbol :103-110) and the mapping of the accumulated posteriors
+// back to the arcs.  Among paths of equal cost the kernel's back-pointer order decides; OpenFst's
+// ShortestPath may break such ties differently (its queue discipline is not part of the
+// reference's contract).
+//
+// --nbest=N (N <= 128; the reference stops at ShortestPath(.., 1), :185; BASELINE configs[2] asks
+// for 100): the N best paths per utterance under keys "<utt>-<n>", n = 1..N as Kaldi's
+// lattice-to-nbest names them, and their costs to an optional third table.  --nbest=1 (default) is
+// the reference's output.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -28,17 +34,23 @@ int main(int argc, char* argv[]) {
         "bound on the expected Levenshtein distance given p(y|x).\n"
         "\n"
         "Usage: lattice-best-path2 [options] lat-rspecifier [transcriptions-wspecifier]\n"
+        "       lattice-best-path2 --nbest=N [options] lat-rspecifier [transcriptions-wspecifier [costs-wspecifier]]\n"
         " e.g.: lattice-best-path2 --acoustic-scale=0.1 ark:1.lats ark,t:1.tra\n";
     ParseOptions po(usage);
     CommonOptions co;
     co.Register(&po);
+    int32_t nbest = 1;
+    po.Register("nbest", &nbest, "Number of best paths per utterance (1 = the reference's output; up to 128).");
     po.Read(argc, argv);
-    if (po.NumArgs() < 1 || po.NumArgs() > 2) {
+    if (po.NumArgs() < 1 || po.NumArgs() > 3) {
       po.PrintUsage();
       exit(1);
     }
+    if (nbest < 1 || nbest > KLAT_NBEST_MAX) KLAT_ERR("--nbest must be in [1, " << KLAT_NBEST_MAX << "]");
     std::unique_ptr<Int32VectorWriter> transcriptions_writer;
+    std::unique_ptr<BaseFloatWriter> costs_writer;
     if (po.NumArgs() > 1) transcriptions_writer.reset(new Int32VectorWriter(po.GetArg(2)));
+    if (po.NumArgs() > 2) costs_writer.reset(new BaseFloatWriter(po.GetArg(3)));
     Context ctx(co.device);
     klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
 
@@ -68,57 +80,55 @@ int main(int argc, char* argv[]) {
       std::vector<double> total(U), tot_bwd(U);
       Check(klat_get_totals(db.get(), total.data(), nullptr, tot_bwd.data()), "klat_get_totals");
 
+      // arc costs 1 - P(label, position) = exp(LogSub(0, log P)) stored as float (:171-173); log P
+      // normalised by bw[Start()] and clipped at 0 (:143-146); epsilon arcs cost nothing (:166-168)
+      std::vector<float> arc_cost((size_t)std::max<int64_t>(batch.NumArcs(), 1), 0.0f);
+      int32_t max_labels = 1;
       for (size_t u = 0; u < U; ++u) {
         const CompactLattice& clat = lats[u];
         const std::vector<int32_t>& len = lens[u];
-        std::vector<int32_t> transcript;
-        float transcript_cost = 0.0f;
-        if (clat.NumStates() > 0) {
-          // log P(w | x, k), normalised by bw[Start()] and clipped at 0 (:143-146)
-          std::map<std::pair<int32_t, int32_t>, double> post;
-          for (int64_t i = record_off[u]; i < record_off[u + 1]; ++i)
-            post[std::make_pair(rec[i].label, rec[i].pos)] = std::min(0.0, rec[i].logp + total[u] - tot_bwd[u]);
-          // tropical shortest path, arc cost 1 - P = exp(LogSub(0, log P)) stored as float (:171-173)
-          const int32_t S = clat.NumStates();
-          const float inf = std::numeric_limits<float>::infinity();
-          std::vector<float> dist((size_t)S, inf);
-          std::vector<int32_t> parent((size_t)S, -1), parent_label((size_t)S, 0);
-          dist[0] = 0.0f;
-          int32_t best_final = -1;
-          float best_cost = inf;
-          for (int32_t s = 0; s < S; ++s) {
-            if (dist[(size_t)s] == inf) continue;
-            const CompactLatticeState& st = clat.State(s);
-            if (st.IsFinal() && dist[(size_t)s] < best_cost) {
-              best_cost = dist[(size_t)s];
-              best_final = s;
+        std::map<std::pair<int32_t, int32_t>, double> post;
+        for (int64_t i = record_off[u]; i < record_off[u + 1]; ++i)
+          post[std::make_pair(rec[i].label, rec[i].pos)] = std::min(0.0, rec[i].logp + total[u] - tot_bwd[u]);
+        int64_t a = batch.ArcOff()[u];
+        for (int32_t s = 0; s < clat.NumStates(); ++s) {
+          max_labels = std::max(max_labels, len[(size_t)s] + 2);
+          for (const auto& arc : clat.State(s).arcs) {
+            if (arc.olabel != 0) {
+              const auto it = post.find(std::make_pair(arc.olabel, len[(size_t)arc.nextstate]));
+              const double p = it == post.end() ? -std::numeric_limits<double>::infinity() : it->second;
+              arc_cost[(size_t)a] = (float)std::exp(p >= 0.0 ? -std::numeric_limits<double>::infinity() : std::log1p(-std::exp(p)));
             }
-            for (const auto& arc : st.arcs) {
-              float w = 0.0f;
-              if (arc.olabel != 0) {
-                const auto it = post.find(std::make_pair(arc.olabel, len[(size_t)arc.nextstate]));
-                const double p = it == post.end() ? -std::numeric_limits<double>::infinity() : it->second;
-                w = (float)std::exp(p >= 0.0 ? -std::numeric_limits<double>::infinity() : std::log1p(-std::exp(p)));
-              }
-              const float nd = dist[(size_t)s] + w;
-              if (nd < dist[(size_t)arc.nextstate]) {
-                dist[(size_t)arc.nextstate] = nd;
-                parent[(size_t)arc.nextstate] = s;
-                parent_label[(size_t)arc.nextstate] = arc.olabel;
-              }
-            }
-          }
-          if (best_final >= 0) {
-            transcript_cost = best_cost;
-            for (int32_t s = best_final; parent[(size_t)s] >= 0; s = parent[(size_t)s])
-              if (parent_label[(size_t)s] != 0 && parent_label[(size_t)s] != -1) transcript.push_back(parent_label[(size_t)s]);
-            std::reverse(transcript.begin(), transcript.end());
+            ++a;
           }
         }
-        if (transcriptions_writer) transcriptions_writer->Write(keys[u], transcript);
-        total_cost += transcript_cost;
+      }
+      std::vector<int32_t> num_paths(U), path_len(U * (size_t)nbest), path_labels(U * (size_t)nbest * (size_t)max_labels);
+      std::vector<float> path_cost(U * (size_t)nbest);
+      Check(klat_nbest(db.get(), arc_cost.data(), nbest, max_labels, num_paths.data(), path_cost.data(), path_len.data(),
+                       path_labels.data()),
+            "klat_nbest");
+
+      for (size_t u = 0; u < U; ++u) {
+        float best_cost = 0.0f;
+        for (int32_t n = 0; n < std::max(1, num_paths[u]); ++n) {
+          std::vector<int32_t> transcript;
+          float cost = 0.0f;
+          if (n < num_paths[u]) {
+            const size_t slot = u * (size_t)nbest + (size_t)n;
+            cost = path_cost[slot];
+            // Filter out epsilons and special disambiguation symbols (:191-196).
+            for (int32_t k = 0; k < path_len[slot]; ++k)
+              if (path_labels[slot * (size_t)max_labels + (size_t)k] != -1) transcript.push_back(path_labels[slot * (size_t)max_labels + (size_t)k]);
+          }
+          if (n == 0) best_cost = cost;
+          const std::string key = nbest == 1 ? keys[u] : keys[u] + "-" + std::to_string(n + 1);
+          if (transcriptions_writer) transcriptions_writer->Write(key, transcript);
+          if (costs_writer) costs_writer->Write(key, cost);
+        }
+        total_cost += best_cost;
         total_frames += frames[u];
-        KLAT_LOG("For utterance " << keys[u] << ", best cost is " << transcript_cost << " over " << frames[u] << " frames.");
+        KLAT_LOG("For utterance " << keys[u] << ", best cost is " << best_cost << " over " << frames[u] << " frames.");
       }
       keys.clear();
       frames.clear();
@@ -158,6 +168,7 @@ int main(int argc, char* argv[]) {
     }
     flush();
     if (transcriptions_writer) transcriptions_writer->Close();
+    if (costs_writer) costs_writer->Close();
     KLAT_LOG("Overall cost per frame is " << (total_frames ? total_cost / total_frames : 0.0) << " over " << total_frames
                                           << " frames.");
     return 0;

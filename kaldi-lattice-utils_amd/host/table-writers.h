@@ -142,6 +142,18 @@ class Int32VectorWriter : public ArchiveWriter {
   }
 };
 
+// one BaseFloat per key (Kaldi's BaseFloatWriter): the cost table of lattice-best-path2 --nbest
+class BaseFloatWriter : public ArchiveWriter {
+ public:
+  using ArchiveWriter::ArchiveWriter;
+  void Write(const std::string& key, float v) {
+    std::ostream& os = Begin(key);
+    WriteBasicType(os, binary(), v);
+    if (!binary()) os << '\n';
+    End();
+  }
+};
+
 // vector<tuple<int32,double>> (utterance index, kwsbin2/lattice-word-index-utterance.cc:267-268).
 class UtteranceScoreWriter : public ArchiveWriter {
  public:

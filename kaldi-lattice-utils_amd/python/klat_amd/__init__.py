@@ -308,6 +308,16 @@ class Batch:
         _check(lib().klat_prune_mask(self.h, C.c_float(beam), _p(ka), _p(kf), _p(lb)))
         return ka[:self.A], kf[:self.S], lb[:self.U]
 
+    def nbest(self, arc_cost, k, max_labels):
+        """klat_nbest: returns (num_paths[U], path_cost[U,k], path_len[U,k], path_labels[U,k,max_labels])."""
+        ac = np.ascontiguousarray(arc_cost, np.float32)
+        npaths = np.zeros(max(self.U, 1), np.int32)
+        cost = np.full((max(self.U, 1), k), np.inf, np.float32)
+        plen = np.zeros((max(self.U, 1), k), np.int32)
+        labels = np.zeros((max(self.U, 1), k, max_labels), np.int32)
+        _check(lib().klat_nbest(self.h, _p(ac), C.c_int32(k), C.c_int32(max_labels), _p(npaths), _p(cost), _p(plen), _p(labels)))
+        return npaths[:self.U], cost[:self.U], plen[:self.U], labels[:self.U]
+
     def utterance_scores(self, word_off, words):
         """log P(word occurs on the path) for the query words of every lattice (klat_utterance_scores)."""
         wo = np.ascontiguousarray(word_off, np.int64)

@@ -401,6 +401,103 @@ def best_path2(lat):
     return out[::-1], best, min(best_ways, 2)
 
 
+
+def best_path2_arc_costs(plat, plen):
+    """The tropical arc costs of latbin/lattice-best-path2.cc:121-179 on the padded lattice `plat`
+    (state lengths `plen`): 0 for epsilon arcs, exp(LogSub(0, log P(label, position))) = 1 - P as
+    float32 for the others, with P accumulated by LogAdd in (state, arc) order and normalised by
+    bw[Start()], clipped at 0 (:143-146)."""
+    alpha, beta, total, _, _ = alphas_betas(plat)
+    src = plat.src()
+    acc = {}
+    for i in range(plat.A):
+        label = int(plat.olabel[i])
+        if label == 0:
+            continue
+        key = (label, int(plen[plat.dst[i]]))
+        w = alpha[src[i]] + beta[plat.dst[i]] - (float(plat.graph[i]) + float(plat.acoustic[i]))
+        acc[key] = w if key not in acc else log_add(acc[key], w)
+    cost = np.zeros(plat.A, np.float32)
+    for i in range(plat.A):
+        label = int(plat.olabel[i])
+        if label != 0:
+            p = min(0.0, acc[(label, int(plen[plat.dst[i]]))] - beta[0])
+            cost[i] = np.float32(0.0 if p >= 0.0 else np.exp(np.log1p(-np.exp(p))))
+    return cost
+
+
+def enumerate_paths(lat, arc_cost, limit=200000):
+    """Every complete path (start state 0 to a final state) of a small top-sorted DAG, the
+    reference's own test idiom (fstext/expand-subpaths-test-utils.h:10-52: ShortestPath with
+    n = INT_MAX, then compare multisets).  Returns [(float32 cost, [arc ids])]; the cost is the
+    left-to-right float32 sum (TropicalWeight Times on StdArc), final states add nothing
+    (latbin/lattice-best-path2.cc:157-160)."""
+    out = []
+    final = ~(np.isinf(lat.final_graph) & np.isinf(lat.final_acoustic))
+
+    def walk(s, cost, arcs):
+        if len(out) > limit:
+            raise RuntimeError("too many paths to enumerate")
+        if final[s]:
+            out.append((cost, list(arcs)))
+        for i in range(int(lat.arc_begin[s]), int(lat.arc_begin[s + 1])):
+            arcs.append(i)
+            walk(int(lat.dst[i]), np.float32(cost + arc_cost[i]), arcs)
+            arcs.pop()
+
+    if lat.S:
+        walk(0, np.float32(0.0), [])
+    return out
+
+
+def kbest_paths(lat, arc_cost, k):
+    """The k lowest-cost complete paths by dynamic programming over the top-sorted states (the
+    algorithm the GPU kernel follows: per state the k best partial paths, pushed along the arcs;
+    latbin/lattice-best-path2.cc:185 asks ShortestPath for n = 1, this is the n-best extension).
+    Returns [(float32 cost, [arc ids])] ascending by cost; equal costs in an unspecified order.
+    numpy per state: fine up to a few thousand states."""
+    S = lat.S
+    if S == 0:
+        return []
+    cands = [[] for _ in range(S)]  # per state: list of (cost array, arc id, k ranks of the source)
+    lists = [None] * S
+    final = ~(np.isinf(lat.final_graph) & np.isinf(lat.final_acoustic))
+    fin = []
+    for s in range(S):
+        if s == 0:
+            cost, back = np.zeros(1, np.float32), np.full((1, 2), -1, np.int64)
+        elif not cands[s]:
+            lists[s] = (np.zeros(0, np.float32), np.zeros((0, 2), np.int64))
+            continue
+        else:
+            allc = np.concatenate([c for c, _, _ in cands[s]])
+            allb = np.concatenate([np.stack([np.full(len(c), a, np.int64), np.arange(len(c), dtype=np.int64)], 1) for c, a, _ in cands[s]])
+            order = np.argsort(allc, kind="stable")[:k]
+            cost, back = allc[order], allb[order]
+        lists[s] = (cost, back)
+        cands[s] = None
+        if final[s]:
+            fin.append(s)
+        for i in range(int(lat.arc_begin[s]), int(lat.arc_begin[s + 1])):
+            cands[int(lat.dst[i])].append(((cost + np.float32(arc_cost[i])).astype(np.float32), i, None))
+    if not fin:
+        return []
+    allc = np.concatenate([lists[f][0] for f in fin])
+    alls = np.concatenate([np.stack([np.full(len(lists[f][0]), f, np.int64), np.arange(len(lists[f][0]), dtype=np.int64)], 1) for f in fin])
+    order = np.argsort(allc, kind="stable")[:k]
+    src = lat.src()
+    out = []
+    for c, (f, r) in zip(allc[order], alls[order]):
+        arcs, s, r = [], int(f), int(r)
+        while True:
+            a, pr = lists[s][1][r]
+            if a < 0:
+                break
+            arcs.append(int(a))
+            s, r = int(src[a]), int(pr)
+        out.append((np.float32(c), arcs[::-1]))
+    return out
+
 def lattice_beam(lat):
     """ComputeLatticeBeam (latbin/lattice-prune-dyn-beam.cc:27-90): (beam, fwd costs, bwd costs)."""
     fw, bw = np.zeros(max(lat.S, 1)), np.zeros(max(lat.S, 1))

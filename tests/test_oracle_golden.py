@@ -206,3 +206,32 @@ def test_sweep_equals_path_enumeration(golden_dir, name):
             assert through[i] == -math.inf
         else:
             assert abs(through[i] - want) < 1e-9
+
+
+def test_kbest_oracle_against_enumeration_of_all_paths():
+    """The oracle's k-best dynamic programme (the checker of klat_nbest) against the reference's
+    own test idiom: every path of small random DAGs (fstext/expand-subpaths-test-utils.h:10-52)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kaldi-lattice-utils_amd", "python"))
+    import klat_amd
+    rng = np.random.RandomState(0)
+    for trial in range(80):
+        S, fan = int(rng.randint(2, 14)), int(rng.randint(1, 4))
+        a = klat_amd.synth(trial, [S], [fan])
+        ab = np.concatenate([[0], np.cumsum(np.bincount(a["src"], minlength=S))]).astype(np.int64)
+        lat = orc.Lat(ab, a["dst"], a["ilabel"], a["olabel"], a["graph"], a["acoustic"], np.ones(len(a["dst"]), np.int32),
+                      a["final_graph"], a["final_acoustic"], np.zeros(S, np.int32))
+        if trial % 2:
+            lat.final_graph[rng.randint(0, S)] = 0
+            lat.final_acoustic[:] = lat.final_graph
+        cost = (rng.choice([0.0, 0.25, 0.5, 1.0, 0.3, 0.7], size=lat.A) if trial % 3 else rng.rand(lat.A)).astype(np.float32)
+        allp = sorted(orc.enumerate_paths(lat, cost), key=lambda x: x[0])
+        for k in (1, 3, 100):
+            got = orc.kbest_paths(lat, cost, k)
+            assert [float(c) for c, _ in got] == [float(c) for c, _ in allp[:k]]
+            assert len(set(tuple(p) for _, p in got)) == len(got)
+            for c, p in got:
+                cc = np.float32(0)
+                for i in p:
+                    cc = np.float32(cc + cost[i])
+                assert cc == c
