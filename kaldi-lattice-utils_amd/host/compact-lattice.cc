@@ -59,6 +59,91 @@ static bool ParseCompactWeight(const std::string& tok, float* g, float* a, int32
   return true;
 }
 
+// ---- Lattice (non-compact) entries fed to a CompactLattice reader ----
+// The reference does this (kwsbin2/README.md:176 runs lattice-char-index-segment on
+// egs/lattice.char.ark.txt, a Lattice-format file); Kaldi's holder then converts with
+// ConvertLattice(lat, &clat) [upstream, fstext/lattice-utils-inl.h], i.e. Factor() [upstream,
+// fstext/factor-inl.h] followed by a per-arc rewrite.  Restated:
+//   * a state is REMOVED if it is neither initial nor final, has exactly one arc in and exactly one
+//     arc out, and that outgoing arc carries no output label: it lies inside a linear chain whose
+//     word (if any) sits on the chain's first arc;
+//   * every arc leaving a kept state absorbs the chain behind it: the weights multiply
+//     (LatticeWeight Times = the float sums of the two components, left to right), the non-zero
+//     input labels (transition ids) concatenate;
+//   * the compact arc is (olabel, olabel, weight, ids); final weights carry an empty string; kept
+//     states are renumbered in their original order (ConvertLattice top-sorts afterwards, which the
+//     tools do anyway: no output holds a state id).
+struct RawArc {
+  int32_t ilabel, olabel, nextstate;
+  float graph, acoustic;
+};
+struct RawLattice {
+  int32_t start = CompactLattice::kNoStateId;
+  std::vector<std::vector<RawArc>> arcs;
+  std::vector<float> final_graph, final_acoustic;
+  void Need(int32_t s) {
+    while (s >= (int32_t)arcs.size()) {
+      arcs.emplace_back();
+      final_graph.push_back(kInf);
+      final_acoustic.push_back(kInf);
+    }
+  }
+};
+
+static bool ConvertLattice(const RawLattice& in, CompactLattice* clat, std::vector<int32_t>* pool) {
+  clat->DeleteStates();
+  const int32_t S = (int32_t)in.arcs.size();
+  if (S == 0 || in.start == CompactLattice::kNoStateId) return true;
+  std::vector<int32_t> arcs_in((size_t)S, 0);
+  for (int32_t s = 0; s < S; ++s)
+    for (const RawArc& a : in.arcs[(size_t)s]) {
+      if (a.nextstate < 0 || a.nextstate >= S) return false;
+      ++arcs_in[(size_t)a.nextstate];
+    }
+  std::vector<char> remove((size_t)S, 0);
+  for (int32_t s = 0; s < S; ++s) {
+    const bool is_final = !(in.final_graph[(size_t)s] == kInf && in.final_acoustic[(size_t)s] == kInf);
+    remove[(size_t)s] = s != in.start && !is_final && arcs_in[(size_t)s] == 1 && in.arcs[(size_t)s].size() == 1 &&
+                        in.arcs[(size_t)s][0].olabel == 0;
+  }
+  std::vector<int32_t> map((size_t)S, -1);
+  for (int32_t s = 0; s < S; ++s)
+    if (!remove[(size_t)s]) map[(size_t)s] = clat->AddState();
+  clat->SetStart(map[(size_t)in.start]);
+  std::vector<int32_t> ids;
+  for (int32_t s = 0; s < S; ++s) {
+    if (remove[(size_t)s]) continue;
+    CompactLatticeState& st = clat->State(map[(size_t)s]);
+    st.final_graph = in.final_graph[(size_t)s];
+    st.final_acoustic = in.final_acoustic[(size_t)s];
+    for (const RawArc& first : in.arcs[(size_t)s]) {
+      CompactLatticeArc arc;
+      arc.ilabel = arc.olabel = first.olabel;
+      arc.graph = first.graph;
+      arc.acoustic = first.acoustic;
+      ids.clear();
+      if (first.ilabel != 0) ids.push_back(first.ilabel);
+      int32_t next = first.nextstate;
+      for (int32_t steps = 0; remove[(size_t)next]; ++steps) {
+        if (steps > S) return false;  // a cycle of chain states: not a lattice
+        const RawArc& a2 = in.arcs[(size_t)next][0];
+        arc.graph = arc.graph + a2.graph;  // Times(weight, arc2.weight), float as LatticeWeightTpl<float>
+        arc.acoustic = arc.acoustic + a2.acoustic;
+        if (a2.ilabel != 0) ids.push_back(a2.ilabel);
+        next = a2.nextstate;
+      }
+      arc.nextstate = map[(size_t)next];
+      arc.string_len = (int32_t)ids.size();
+      if (pool && !ids.empty()) {
+        arc.string_off = (int32_t)pool->size();
+        pool->insert(pool->end(), ids.begin(), ids.end());
+      }
+      st.arcs.push_back(arc);
+    }
+  }
+  return true;
+}
+
 static bool IsInt(const std::string& s) {
   if (s.empty()) return false;
   char* end = nullptr;
@@ -70,8 +155,11 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat, bool keep_st
   clat->DeleteStates();
   std::vector<int32_t>* pool = keep_strings ? &clat->StringPool() : nullptr;
   std::string line;
+  RawLattice raw;               // filled instead of clat if the entry turns out to be in Lattice format
+  int format = 0;               // 0 unknown, 1 CompactLattice lines seen, 2 Lattice lines seen
   auto need_state = [&](int32_t s) {
     while (s >= clat->NumStates()) clat->AddState();
+    raw.Need(s);
   };
   while (std::getline(is, line)) {
     std::vector<std::string> t;
@@ -85,13 +173,15 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat, bool keep_st
     const int32_t s = (int32_t)std::atol(t[0].c_str());
     if (s < 0) return false;
     need_state(s);
-    if (clat->Start() == CompactLattice::kNoStateId) clat->SetStart(s);
+    if (clat->Start() == CompactLattice::kNoStateId) clat->SetStart(s), raw.start = s;
     if (t.size() <= 2) {  // final state line: "<state> [weight]"
       CompactLatticeState& st = clat->State(s);
       st.final_graph = 0.f;
       st.final_acoustic = 0.f;
       st.final_string_len = 0;
       if (t.size() == 2 && !ParseCompactWeight(t[1], &st.final_graph, &st.final_acoustic, &st.final_string_len, pool, &st.final_string_off)) return false;
+      raw.final_graph[(size_t)s] = st.final_graph;
+      raw.final_acoustic[(size_t)s] = st.final_acoustic;
       continue;
     }
     if (!IsInt(t[1]) || !IsInt(t[2])) return false;
@@ -104,24 +194,28 @@ bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat, bool keep_st
       arc.ilabel = arc.olabel = (int32_t)std::atol(t[2].c_str());
       if (t.size() == 4 && !ParseCompactWeight(t[3], &arc.graph, &arc.acoustic, &arc.string_len, pool, &arc.string_off)) return false;
     } else if (t.size() == 4 || t.size() == 5) {
-      // Lattice format: src dst ilabel(transition-id) olabel(word) [g,a].  Converted arc by arc:
-      // the word is the olabel, the transition-id string is [ilabel] when ilabel != 0.  This
-      // equals ConvertLattice whenever no chain can be merged (every arc carries an olabel).
+      // Lattice format: src dst ilabel(transition-id) olabel(word) [g,a]; converted once the whole
+      // entry is read (ConvertLattice above)
       if (!IsInt(t[3])) return false;
-      const int32_t il = (int32_t)std::atol(t[2].c_str());
-      arc.ilabel = arc.olabel = (int32_t)std::atol(t[3].c_str());
-      arc.string_len = il != 0 ? 1 : 0;
-      if (pool && il != 0) {
-        arc.string_off = (int32_t)pool->size();
-        pool->push_back(il);
-      }
+      if (format == 1) return false;  // an entry is in one format or the other
+      format = 2;
+      RawArc ra;
+      ra.ilabel = (int32_t)std::atol(t[2].c_str());
+      ra.olabel = (int32_t)std::atol(t[3].c_str());
+      ra.nextstate = arc.nextstate;
+      ra.graph = ra.acoustic = 0.f;
       int32_t dummy;
-      if (t.size() == 5 && !ParseCompactWeight(t[4], &arc.graph, &arc.acoustic, &dummy)) return false;
+      if (t.size() == 5 && !ParseCompactWeight(t[4], &ra.graph, &ra.acoustic, &dummy)) return false;
+      raw.arcs[(size_t)s].push_back(ra);
+      continue;
     } else {
       return false;
     }
+    if (format == 2) return false;
+    format = 1;
     clat->State(s).arcs.push_back(arc);
   }
+  if (format == 2) return ConvertLattice(raw, clat, pool);
   return true;
 }
 
@@ -217,6 +311,24 @@ bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat, bool keep_
     }
     return (bool)is;
   };
+  if (!compact) {  // a Lattice: read it raw, then ConvertLattice (chains merge; see above)
+    RawLattice raw;
+    if (num_states > 0) raw.Need((int32_t)num_states - 1);
+    for (int64_t s = 0; s < num_states; ++s) {
+      int32_t len, off;
+      if (!read_weight(&raw.final_graph[(size_t)s], &raw.final_acoustic[(size_t)s], &len, &off)) return false;
+      int64_t narcs;
+      if (!rd(is, &narcs) || narcs < 0) return false;
+      raw.arcs[(size_t)s].resize((size_t)narcs);
+      for (RawArc& ra : raw.arcs[(size_t)s]) {
+        if (!rd(is, &ra.ilabel) || !rd(is, &ra.olabel)) return false;
+        if (!read_weight(&ra.graph, &ra.acoustic, &len, &off)) return false;
+        if (!rd(is, &ra.nextstate)) return false;
+      }
+    }
+    raw.start = num_states > 0 ? (int32_t)start : CompactLattice::kNoStateId;
+    return ConvertLattice(raw, clat, pool);
+  }
   for (int64_t s = 0; s < num_states; ++s) {
     clat->AddState();
     CompactLatticeState& st = clat->State((int32_t)s);
@@ -229,17 +341,8 @@ bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat, bool keep_
       if (!rd(is, &il) || !rd(is, &ol)) return false;
       if (!read_weight(&arc.graph, &arc.acoustic, &arc.string_len, &arc.string_off)) return false;
       if (!rd(is, &arc.nextstate)) return false;
-      if (compact) {
-        arc.ilabel = il;
-        arc.olabel = ol;
-      } else {  // Lattice: ilabel = transition id, olabel = word (arc-by-arc conversion, see text reader)
-        arc.ilabel = arc.olabel = ol;
-        arc.string_len = il != 0 ? 1 : 0;
-        if (pool && il != 0) {
-          arc.string_off = (int32_t)pool->size();
-          pool->push_back(il);
-        }
-      }
+      arc.ilabel = il;
+      arc.olabel = ol;
     }
   }
   clat->SetStart(num_states > 0 ? (int32_t)start : CompactLattice::kNoStateId);

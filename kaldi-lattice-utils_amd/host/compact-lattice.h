@@ -70,7 +70,7 @@ class CompactLattice {
   std::vector<int32_t> string_pool_;
 };
 
-// Text (Appendix B.2; Lattice-format B.3 entries are converted arc by arc) and binary
+// Text (Appendix B.2; Lattice-format B.3 entries go through ConvertLattice: linear chains merge) and binary
 // (Appendix B.4, OpenFst VectorFst stream) readers for ONE lattice positioned after "key ".
 bool ReadCompactLatticeText(std::istream& is, CompactLattice* clat, bool keep_strings = false);
 bool ReadCompactLatticeBinary(std::istream& is, CompactLattice* clat, bool keep_strings = false);

@@ -22,9 +22,8 @@ def _parse_weight(tok):
 
 def read_text_archive(path):
     """Yields orc.Lat per entry.  Accepts CompactLattice text (B.2: 'src dst label
-    g,a,tids') and Lattice text (B.3: 'src dst ilabel olabel [g,a]'); the latter is turned
-    into a compact lattice one arc per arc (string = [ilabel] if ilabel != 0), which is
-    what ConvertLattice gives when no chain can be merged (every arc carries an olabel)."""
+    g,a,tids') and Lattice text (B.3: 'src dst ilabel olabel [g,a]'); the latter goes through
+    convert_lattice() below, the test-side restatement of Kaldi's ConvertLattice / Factor."""
     with open(path) as f:
         lines = f.read().split("\n")
     i = 0
@@ -36,6 +35,7 @@ def read_text_archive(path):
         key = lines[i].strip()
         i += 1
         arcs, finals, ids = [], {}, {}
+        raw = []  # Lattice-format arcs (s, d, ilabel, olabel, g, a)
         start = None
 
         def sid(x):
@@ -65,15 +65,55 @@ def read_text_archive(path):
                 # Lattice format: ilabel olabel [weight]
                 il, ol = int(rest[0]), int(rest[1])
                 g, a, _ = _parse_weight(rest[2]) if len(rest) > 2 else (0.0, 0.0, 0)
-                arcs.append((s, d, ol, ol, g, a, 1 if il != 0 else 0))
+                raw.append((s, d, il, ol, g, a))
             else:
                 lab = int(rest[0])
                 g, a, dur = _parse_weight(rest[1]) if len(rest) > 1 else (0.0, 0.0, 0)
                 arcs.append((s, d, lab, lab, g, a, dur))
         S = (max(ids) + 1) if ids else 0
+        if raw:
+            assert not arcs, "an entry is in one format or the other"
+            S, arcs, finals, start = convert_lattice(S, raw, finals, start)
         lat = orc.lat_from_arcs(S, arcs, finals, key=key, start=start if start is not None else -1)
         out.append(lat)
     return out
+
+
+def convert_lattice(S, raw, finals, start):
+    """ConvertLattice(lat, &clat) [upstream Kaldi, fstext/lattice-utils-inl.h] = Factor
+    [fstext/factor-inl.h] + per-arc rewrite, as a CompactLattice reader applies it to a Lattice
+    entry (kwsbin2/README.md:176).  A state inside a linear chain -- not initial, not final, one
+    arc in, one arc out, no output label on the arc out -- disappears; the arc entering the chain
+    takes the float32 sums of the weights (left to right) and the concatenated non-zero input labels
+    as its string; the word is the first arc's olabel.  Kept states are renumbered in order."""
+    import numpy as np
+    out_arcs = [[] for _ in range(S)]
+    nin = [0] * S
+    for (s, d, il, ol, g, a) in raw:
+        out_arcs[s].append((d, il, ol, g, a))
+        nin[d] += 1
+    remove = [s != start and s not in finals and nin[s] == 1 and len(out_arcs[s]) == 1 and out_arcs[s][0][2] == 0
+              for s in range(S)]
+    new_id, n = {}, 0
+    for s in range(S):
+        if not remove[s]:
+            new_id[s] = n
+            n += 1
+    arcs = []
+    for s in range(S):
+        if remove[s]:
+            continue
+        for (d, il, ol, g, a) in out_arcs[s]:
+            g, a = np.float32(g), np.float32(a)
+            dur = 1 if il != 0 else 0
+            while remove[d]:
+                d2, il2, _, g2, a2 = out_arcs[d][0]
+                g, a = np.float32(g + np.float32(g2)), np.float32(a + np.float32(a2))
+                dur += 1 if il2 != 0 else 0
+                d = d2
+            arcs.append((new_id[s], new_id[d], ol, ol, float(g), float(a), dur))
+    new_finals = {new_id[s]: w for s, w in finals.items()}
+    return n, arcs, new_finals, (new_id[start] if start is not None else None)
 
 
 def _isint(s):

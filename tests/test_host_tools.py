@@ -59,6 +59,55 @@ def test_bad_beam_is_refused_loudly(tmp_path):
     assert rc == 255 and "--beam must be positive" in err
 
 
+LATTICE_FORMAT_WITH_CHAINS = """chains
+0 1 11 5 1.5,2.25
+1 2 12 0 0.25,0.5
+2 3 13 0 0.125,1
+3 4 0 0
+0 5 21 6 3,1
+5 4 22 7 0.5,0.5
+4 6 31 8
+6 7 32 0 1,1
+4 7 33 9 2,2
+7 0.5,0.25
+
+allwords
+0 1 1 1 0.5,0.5
+1 2 2 2 0.5,0.5
+2
+
+"""
+
+
+def test_lattice_format_entries_merge_linear_chains(tmp_path):
+    """A Lattice-format entry read as CompactLattice (kwsbin2/README.md:176) goes through
+    ConvertLattice: states 1, 2, 3 (one arc in, one arc out without word, not final) fold into
+    the arc 0 -> 4 carrying word 5, weight sums and three transition ids; state 5 stays (its arc
+    out carries word 7), state 6 goes.  Checked against the test-side restatement in latfmt.py
+    through klat-lattice-copy, text and binary."""
+    src = tmp_path / "in.txt"
+    src.write_text(LATTICE_FORMAT_WITH_CHAINS)
+    want = latfmt.read_text_archive(str(src))
+    assert [l.S for l in want] == [4, 3]  # kept: 0, 4, 5, 7
+    w0 = want[0]
+    assert (int(w0.dst[0]), int(w0.olabel[0]), int(w0.dur[0])) == (1, 5, 3)  # 0 -> (old 4 = new 1), word 5, ids 11_12_13
+    assert abs(float(w0.graph[0]) - 1.875) < 1e-7 and abs(float(w0.acoustic[0]) - 3.75) < 1e-7
+    for mode in ("ark,t:", "ark:"):
+        mid = str(tmp_path / ("copy" + ("t" if "t" in mode else "b")))
+        rc, out, err = run("klat-lattice-copy", "ark:" + str(src), mode + mid)
+        assert rc == 0, err
+        rc, out, err = run("klat-lattice-copy", "ark:" + mid, "ark,t:-")
+        assert rc == 0, err
+        got_path = tmp_path / "got.txt"
+        got_path.write_bytes(out)
+        got = latfmt.read_text_archive(str(got_path))
+        assert [g.key for g in got] == ["chains", "allwords"]
+        for g, w in zip(got, want):
+            assert g.S == w.S and g.A == w.A
+            for f in ("arc_begin", "dst", "ilabel", "olabel", "graph", "acoustic", "dur", "final_graph", "final_acoustic"):
+                assert np.array_equal(getattr(g, f), getattr(w, f)), (g.key, f)
+
+
 def _write_text_archive(path, arrays, ns):
     with open(path, "w") as f:
         for u in range(len(ns)):
