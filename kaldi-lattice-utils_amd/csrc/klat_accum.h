@@ -27,8 +27,9 @@ struct AccumArgs {
   void* rec_scratch;  // 24 B per slot
   int32_t* num_records;  // [U]
   int32_t tile_bytes;    // dynamic LDS per workgroup (sort tile), <= 128 KiB
-  uint32_t* arc_order;   // 4 B per slot: the radix kernel's sorted values
+  double* val_scratch;   // 8 B per slot: the hash kernel's record values, by record id
   int32_t min_arcs, max_arcs;  // a launch takes the lattices with min_arcs < arcs <= max_arcs
+  long long* phase_clock;      // [U][8] or null: s_memtime stamps of the hash kernel's phases (KLAT_ACCUM_PROFILE)
 };
 
 struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)
@@ -38,10 +39,10 @@ struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)
 
 hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hipStream_t stream);
 
-// Radix path (klat_accum_radix.hip): lattices of at most kRadixMaxArcs arcs whose index keys pack
+// Hash path (klat_accum_hash.hip): lattices of at most kHashMaxArcs arcs whose index keys pack
 // into total_bits <= 62 bits -- (label - label_min) in label_bits, times / positions in time_bits
 // each.  The ranges come from range_kernel over the batch.
-static const int kRadixMaxArcs = 16384;  // 8 items per thread up to 8192 arcs, 16 above
+static const int kHashMaxArcs = 16384;  // 2^14 table slots up to 8192 arcs, 2^15 above
 struct RadixPack {
   int32_t label_min;
   int32_t label_bits, time_bits, total_bits;
@@ -54,8 +55,8 @@ struct RangeArgs {
   int32_t* out;              // [4]: label min, label max, time max, length max
 };
 hipError_t launch_range(const RangeArgs& a, hipStream_t stream);
-hipError_t launch_index_radix(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int items,
-                              hipStream_t stream);
+hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots,
+                             hipStream_t stream);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
                                OutRecord* out, hipStream_t stream);
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -39,7 +40,7 @@ int ensure_index_scratch(klat_batch* b) {
   if ((rc = st.scratch_off.upload(off.data(), off.size(), b->ctx->stream))) return rc;
   if ((rc = st.key_scratch.alloc((size_t)st.scratch_slots * 16))) return rc;
   if ((rc = st.rec_scratch.alloc((size_t)st.scratch_slots * 24))) return rc;
-  if ((rc = st.arc_order.alloc((size_t)st.scratch_slots))) return rc;
+  if ((rc = st.val_scratch.alloc((size_t)st.scratch_slots))) return rc;
   if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   st.scratch_ready = true;
@@ -89,7 +90,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
   a.logpost = b->logpost.p;
   a.key_scratch = st.key_scratch.p;
   a.rec_scratch = st.rec_scratch.p;
-  a.arc_order = st.arc_order.p;
+  a.val_scratch = st.val_scratch.p;
   a.min_arcs = -1;
   a.max_arcs = 0x7FFFFFFF;
   a.num_records = st.num_records.p;
@@ -118,14 +119,14 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     a.exclude = st.exclude.p;
     a.num_exclude = (int32_t)exc.size();
     a.state_len = st.state_len.p;
-    // lattices of up to 16384 arcs take the radix-sort kernel if the batch's keys pack into 62
-    // bits (8 items per thread up to 8192 arcs, 16 above), the others the general kernel
+    // lattices of up to 16384 arcs take the hash kernel if the batch's keys pack into 62 bits (a
+    // table of 2^14 slots up to 8192 arcs, 2^15 above), the others the general kernel
     bool radix = std::getenv("KLAT_INDEX_BITONIC") == nullptr;  // (test hook: force the general kernel)
     RadixPack pk = {0, 0, 0, 0};
     int64_t n_small = 0, n_medium = 0, n_large = 0;
     for (int64_t u = 0; u < b->U; ++u) {
       const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
-      (arcs <= kRadixMaxArcs / 2 ? n_small : arcs <= kRadixMaxArcs ? n_medium : n_large)++;
+      (arcs <= kHashMaxArcs / 2 ? n_small : arcs <= kHashMaxArcs ? n_medium : n_large)++;
     }
     radix = radix && n_small + n_medium > 0 && b->A > 0;
     st.cached_mode = st.dense_mode = 0;
@@ -154,17 +155,23 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       pk.total_bits = pk.label_bits + (position ? 1 : 2) * pk.time_bits;
       radix = pk.total_bits <= 62;
     }
+    DevBuf<long long> d_clock;
+    if (radix && std::getenv("KLAT_ACCUM_PROFILE")) {  // diagnostic: where a workgroup of the hash kernel spends its cycles
+      if ((rc = d_clock.alloc((size_t)b->U * 8))) return rc;
+      KLAT_HIP(hipMemsetAsync(d_clock.p, 0, sizeof(long long) * (size_t)b->U * 8, c->stream));
+      a.phase_clock = d_clock.p;
+    }
     if (radix) {
       if (n_small > 0) {
-        a.min_arcs = -1, a.max_arcs = kRadixMaxArcs / 2;
-        KLAT_HIP(launch_index_radix(a, pk, (int)b->U, position, 8, c->stream));
+        a.min_arcs = -1, a.max_arcs = kHashMaxArcs / 2;
+        KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 14, c->stream));
       }
       if (n_medium > 0) {
-        a.min_arcs = kRadixMaxArcs / 2, a.max_arcs = kRadixMaxArcs;
-        KLAT_HIP(launch_index_radix(a, pk, (int)b->U, position, 16, c->stream));
+        a.min_arcs = kHashMaxArcs / 2, a.max_arcs = kHashMaxArcs;
+        KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 15, c->stream));
       }
       if (n_large > 0) {
-        a.min_arcs = kRadixMaxArcs, a.max_arcs = 0x7FFFFFFF;
+        a.min_arcs = kHashMaxArcs, a.max_arcs = 0x7FFFFFFF;
         KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
       }
       a.min_arcs = -1, a.max_arcs = 0x7FFFFFFF;
@@ -172,6 +179,21 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
     }
     KLAT_HIP(hipEventRecord(st.ev[1], c->stream));
+    if (a.phase_clock) {
+      std::vector<long long> clk((size_t)b->U * 8);
+      KLAT_HIP(hipMemcpyAsync(clk.data(), d_clock.p, sizeof(long long) * clk.size(), hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipStreamSynchronize(c->stream));
+      double sum[8] = {0};
+      int64_t cnt = 0;
+      for (int64_t u = 0; u < b->U; ++u)
+        if (clk[(size_t)u * 8 + 7] > clk[(size_t)u * 8]) {
+          ++cnt;
+          for (int k = 1; k < 8; ++k) sum[k] += (double)(clk[(size_t)u * 8 + k] - clk[(size_t)u * 8 + k - 1]);
+        }
+      std::fprintf(stderr, "index_hash_kernel phases (mean s_memtime ticks (100 MHz) per workgroup over %lld): load %.0f  hash %.0f  classify %.0f  singles %.0f  dups %.0f  bucket %.0f  order %.0f  write %.0f\n",
+                   (long long)cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[7] / cnt, 0.0);
+      a.phase_clock = nullptr;
+    }
     std::vector<int32_t> counts((size_t)b->U);
     if (b->U > 0)
       KLAT_HIP(hipMemcpyAsync(counts.data(), st.num_records.p, sizeof(int32_t) * (size_t)b->U,

@@ -98,7 +98,7 @@ struct klat_accum_state {
   std::vector<int64_t> record_off;
   klat::DevBuf<int64_t> scratch_off;
   klat::DevBuf<unsigned char> key_scratch, rec_scratch;
-  klat::DevBuf<uint32_t> arc_order;
+  klat::DevBuf<double> val_scratch;
   klat::DevBuf<int32_t> num_records, include, exclude, state_len;
 };
 
