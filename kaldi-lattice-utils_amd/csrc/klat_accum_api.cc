@@ -135,7 +135,10 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       KLAT_HIP(hipEventCreate(&st.ev[1]));
     }
     KLAT_HIP(hipEventRecord(st.ev[0], c->stream));
-    if (radix) {
+    if (radix && !position && st.pack_mode == 1) {
+      pk = st.pack;  // the segment keys' ranges are the batch's own: computed once
+      radix = pk.total_bits <= 62;
+    } else if (radix) {
       const int32_t init[4] = {0x7FFFFFFF, (int32_t)0x80000000, 0, 0};
       int32_t range[4];
       DevBuf<int32_t> d_range;
@@ -153,6 +156,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       pk.label_bits = bits((uint64_t)((int64_t)range[1] - (int64_t)range[0]));
       pk.time_bits = bits((uint64_t)(uint32_t)(position ? range[3] : range[2]));
       pk.total_bits = pk.label_bits + (position ? 1 : 2) * pk.time_bits;
+      if (!position) st.pack = pk, st.pack_mode = 1;  // (the position keys depend on the caller's state_len)
       radix = pk.total_bits <= 62;
     }
     DevBuf<long long> d_clock;
@@ -190,8 +194,10 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
           ++cnt;
           for (int k = 1; k < 8; ++k) sum[k] += (double)(clk[(size_t)u * 8 + k] - clk[(size_t)u * 8 + k - 1]);
         }
-      std::fprintf(stderr, "index_hash_kernel phases (mean s_memtime ticks (100 MHz) per workgroup over %lld): load %.0f  hash %.0f  classify %.0f  singles %.0f  dups %.0f  bucket %.0f  order %.0f  write %.0f\n",
-                   (long long)cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[7] / cnt, 0.0);
+      std::fprintf(stderr,
+                   "index_hash_kernel: mean shader cycles per workgroup over %lld lattices: keys %.0f  hash %.0f  classify %.0f  fold %.0f  "
+                   "bucket+scatter %.0f  order %.0f  write %.0f\n",
+                   (long long)cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[7] / cnt);
       a.phase_clock = nullptr;
     }
     std::vector<int32_t> counts((size_t)b->U);

@@ -92,6 +92,8 @@ struct klat_accum_state {
   int64_t scratch_slots = 0;
   int cached_mode = 0;  // 0 none, 1 segment, 2 position
   int dense_mode = 0;   // the mode `dense` was gathered for (0: stale)
+  int pack_mode = 0;    // the mode `pack` was computed for (label / time ranges of the batch: they do not change)
+  klat::RadixPack pack = {0, 0, 0, 0};
   klat::DevBuf<klat::OutRecord> dense;  // the cached records, gathered utterance-major
   klat::DevBuf<int64_t> d_record_off;
   hipEvent_t ev[2] = {nullptr, nullptr};  // around the index kernels of the last sizing call
