@@ -11,7 +11,11 @@
 //   per tile of kFrTileFrames frames, with the per-frame counters in LDS:
 //   1. entries per frame from a difference array over the spans (two LDS atomics per arc),
 //      prefix sums -> bucket offsets;
-//   2. every arc drops (label | arc, x) into the buckets of its frames (LDS cursors);
+//   2. every arc drops its number into the buckets of its frames (LDS cursors).  The buckets of a
+//      tile live in LDS as 16-bit arc numbers -- 2 bytes per (frame, word) expansion instead of a
+//      16-byte entry written to and read back from HBM -- unless the tile holds more than
+//      kFrLdsEntries expansions, a frame more than kFrSerialMax, or the lattice more than 65 535
+//      arcs: then they go through the lattice's scratch rows as (label | arc, x) entries;
 //   3. one thread per frame, 256 frames at a time: a bucket of <= 16 entries is sorted by (label,
 //      arc) in registers (bitonic network, 8 or 16 wide), runs of one label are folded in arc
 //      order with the reference's LogAdd and narrowed to float, the folded keys (float logp desc,
@@ -33,6 +37,7 @@ static constexpr int kFrTile = 2048;    // 16-byte keys per LDS tile of the coop
 static constexpr int kFrRegs = 16;      // bucket entries a frame's thread sorts in registers
 static constexpr int kFrBigList = 64;
 static constexpr int kFrTileFrames = 1920;  // frames whose counters live in LDS at a time (15 KiB; two workgroups per CU)
+static constexpr int kFrLdsEntries = 20480; // bucket entries of a tile kept in LDS as 16-bit arc numbers (40 KiB, over the sort tile)
 
 __device__ __forceinline__ double fr_log_add(double x, double y) {
   double diff;
@@ -263,6 +268,8 @@ __device__ __forceinline__ int fr_fold_bucket(int w, Entry E) {
 __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
   FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrTile]: the cooperative sort's tile
+  uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kFrLdsEntries]: a tile's buckets as arc numbers (same memory)
+  __shared__ int tile_max;
   __shared__ int lboff[kFrTileFrames + 1];  // first expansion of every frame of the tile (tile-local)
   __shared__ int lcur[kFrTileFrames];       // scatter cursors; then -(folded entries) - 1 for a bucket the workgroup folded
   __shared__ int sh[kFrThreads / 64];
@@ -315,37 +322,51 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
       }
     }
     __syncthreads();
-    int carry_c = 0, n = 0;
+    int carry_c = 0, n = 0, cmax = 0;
     for (int base = 0; base <= tf; base += kFrThreads) {
       const int k = base + tid;
       const int d = (k <= tf) ? lboff[k] : 0;
       int tot_d, tot_c;
       const int ex = fr_block_scan(d, &tot_d, sh);
       const int c = (k < tf) ? carry_c + ex + d : 0;  // entries of frame k
+      cmax = max(cmax, c);
       const int o = n + fr_block_scan(c, &tot_c, sh);
       if (k <= tf) lboff[k] = o;
       if (k < tf) lcur[k] = o;
       carry_c += tot_d;
       n += tot_c;
     }
+    if (tid == 0) tile_max = 0;
     __syncthreads();
+    for (int d = 32; d > 0; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d, 64));
+    if ((tid & 63) == 0) atomicMax(&tile_max, cmax);
+    __syncthreads();
+    const bool in_lds = nA <= 65535 && n <= kFrLdsEntries && tile_max <= kFrSerialMax;  // workgroup-uniform
 
-    // ---- 2. every arc drops (label | arc, x) into the buckets of its frames ----
-    for (int i = tid; i < nA; i += kFrThreads) {
-      const FrameArc r = ai[i];
-      const int lo = max(r.k0, f0) - f0, hi = min(r.k1, f0 + tf) - f0;
-      if (hi <= lo) continue;
-      FKey e;
-      e.a = ((uint64_t)fr_bias(a.ilabel[a0 + i]) << 32) | (uint32_t)i;
-      e.b = (uint64_t)__double_as_longlong(r.x);
-      for (int k = lo; k < hi; ++k) keys[nbase + atomicAdd(&lcur[k], 1)] = e;
+    // ---- 2. every arc drops itself into the buckets of its frames ----
+    if (in_lds) {
+      for (int i = tid; i < nA; i += kFrThreads) {
+        const FrameArc r = ai[i];
+        const int lo = max(r.k0, f0) - f0, hi = min(r.k1, f0 + tf) - f0;
+        for (int k = lo; k < hi; ++k) lbucket[atomicAdd(&lcur[k], 1)] = (uint16_t)i;
+      }
+    } else {
+      for (int i = tid; i < nA; i += kFrThreads) {
+        const FrameArc r = ai[i];
+        const int lo = max(r.k0, f0) - f0, hi = min(r.k1, f0 + tf) - f0;
+        if (hi <= lo) continue;
+        FKey e;
+        e.a = ((uint64_t)fr_bias(a.ilabel[a0 + i]) << 32) | (uint32_t)i;
+        e.b = (uint64_t)__double_as_longlong(r.x);
+        for (int k = lo; k < hi; ++k) keys[nbase + atomicAdd(&lcur[k], 1)] = e;
+      }
     }
     __syncthreads();
 
     // ---- 3a. buckets above kFrSerialMax entries, kFrBigList at a time: sorted through the LDS
     // tile (which overlays the slabs), folded by the heads of the runs, sorted again; the folded
     // keys stay at the bucket's start ----
-    for (;;) {
+    for (; !in_lds;) {  // (a tile whose buckets sit in LDS has no such frame)
       for (int k = tid; k < tf; k += kFrThreads)
         if (lboff[k + 1] - lboff[k] > kFrSerialMax && lcur[k] >= 0) {
           const int slot = atomicAdd(&big_n, 1);
@@ -415,23 +436,48 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
       if (k < tf) {
         o = nbase + lboff[k];
         w = lboff[k + 1] - lboff[k];
-        if (lcur[k] < 0)
+        if (lcur[k] < 0) {
           mk = -lcur[k] - 1;  // folded by the workgroup
-        else if (w > kFrRegs)
+        } else if (w > kFrRegs) {
+          if (in_lds)  // a mid-sized bucket: its entries take their scratch rows after all
+            for (int j = 0; j < w; ++j) {
+              const int i = (int)lbucket[lboff[k] + j];
+              FKey e;
+              e.a = ((uint64_t)fr_bias(a.ilabel[a0 + i]) << 32) | (uint32_t)i;
+              e.b = (uint64_t)__double_as_longlong(ai[i].x);
+              keys[o + j] = e;
+            }
           mk = fr_fold_bucket(w, [&](int j) -> FKey& { return keys[o + j]; });
-        else
+        } else {
           in_regs = w > 0;
+        }
       }
       uint64_t ek[kFrRegs];
       double ex[kFrRegs];
+      if (in_lds) {
+        int arc[kFrRegs];
+        const int lo = (k < tf) ? lboff[k] : 0;
 #pragma unroll
-      for (int j = 0; j < kFrRegs; ++j) {
-        ek[j] = ~0ull;
-        ex[j] = 0.0;
-        if (in_regs && j < w) {
-          const FKey e = keys[o + j];
-          ek[j] = e.a;
-          ex[j] = __longlong_as_double((long long)e.b);
+        for (int j = 0; j < kFrRegs; ++j) arc[j] = (in_regs && j < w) ? (int)lbucket[lo + j] : -1;
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) {  // (label, x) of the arcs: gathers served by L2, all in flight together
+          ek[j] = ~0ull;
+          ex[j] = 0.0;
+          if (arc[j] >= 0) {
+            ek[j] = ((uint64_t)fr_bias(a.ilabel[a0 + arc[j]]) << 32) | (uint32_t)arc[j];
+            ex[j] = ai[arc[j]].x;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) {
+          ek[j] = ~0ull;
+          ex[j] = 0.0;
+          if (in_regs && j < w) {
+            const FKey e = keys[o + j];
+            ek[j] = e.a;
+            ex[j] = __longlong_as_double((long long)e.b);
+          }
         }
       }
       const bool narrow = __all(!in_regs || w <= 8);  // wave-uniform: the 8-wide network is enough
@@ -519,7 +565,7 @@ hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t 
 }
 hipError_t launch_frame(const FrameArgs& a, int num_lattices, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
-  const size_t lds = sizeof(FKey) * kFrTile;
+  const size_t lds = sizeof(FKey) * kFrTile > sizeof(uint16_t) * kFrLdsEntries ? sizeof(FKey) * kFrTile : sizeof(uint16_t) * kFrLdsEntries;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a);
