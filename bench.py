@@ -404,6 +404,27 @@ def main():
             "results_d2h": {"seconds": d2h_s, "bytes": d2h_bytes, "what": "arc log-posteriors + alpha + beta to pageable host memory"},
         }
 
+    # ---- the boundary when the caller holds HOST lattices and wants HOST results: create (H2D of the CSR
+    # arrays + stream packing) -> sweep -> fetch, serial on this context; never `value`
+    if rank == 0:
+        post = np.empty(A, np.float64)
+        ab = (np.empty(S, np.float64), np.empty(S, np.float64))
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            b2 = klat_amd.Batch(ctx, arrays, host_threads=host_threads)
+            b2.forward_backward(*SCALES)
+            b2.arc_logpost(out=post)
+            b2.alpha_beta(out=ab)
+            times.append(time.perf_counter() - t0)
+            b2.close()
+        sec = median(times[1:])
+        out["boundary"] = {"what": "host CSR arrays in, host alpha/beta/arc posteriors out, one batch after the other "
+                                   "(H2D + packing + sweep + D2H; PCIe-bound)", "seconds_per_batch": sec,
+                           "arcs_per_s": A / sec, "h2d_bytes": int(sum(v.nbytes for v in arrays.values())),
+                           "d2h_bytes": int(post.nbytes + ab[0].nbytes + ab[1].nbytes)}
+        del post, ab
+
     # ---- accumulate stage on the resident C2 batch (all ranks: the gather leg needs every shard's index)
     if not args.no_accumulate:
         acc = accumulate_leg(klat_amd, batch, arrays, A) if (rank == 0 or world > 1) else None

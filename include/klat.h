@@ -114,6 +114,15 @@ int klat_ctx_sync(klat_ctx* ctx);
 /* the ctx's hipStream_t, for callers that enqueue their own work or events behind it */
 void* klat_ctx_stream(klat_ctx* ctx);
 
+/* Page-locked host memory for the arrays of klat_batch_desc and for the result buffers of the
+ * fetch calls: copies from / to it run at the full PCIe rate and asynchronously to the host
+ * (pageable memory is staged by the runtime: results came back at 17 GB/s instead of ~50).  A
+ * caller that keeps two contexts on two host threads -- one creating batch k+1 while the other
+ * sweeps batch k and fetches batch k-1 -- overlaps the three (the contexts are re-entrant).
+ * Optional: every entry point accepts ordinary memory as well. */
+int klat_host_alloc(void** ptr, size_t bytes);
+void klat_host_free(void* ptr);
+
 /* Validates (KLAT_ERR_BAD_TOPOLOGY on a non-top-sorted lattice), builds the forward and
  * backward lockstep arc streams on the host and uploads everything the sweeps need.
  * The timed region of the reference starts after this point, too ("Timer does not include

@@ -74,6 +74,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
   if (position && b->S > 0 && !state_len) return set_error(KLAT_ERR_INVALID_ARG, "state_len is null");
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   klat_accum_state& st = b->accum;
   int rc = ensure_index_scratch(b);
   if (rc != KLAT_OK) return rc;
@@ -243,6 +244,7 @@ int klat_utterance_scores(klat_batch* b, const int64_t* word_off, const int32_t*
   if (b->olabel.n == 0) return set_error(KLAT_ERR_INVALID_ARG, "the batch was created without olabel");
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   std::vector<UttItem> items;
   int64_t max_states = 1;
   for (int64_t u = 0; u < b->U; ++u) {
@@ -312,6 +314,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     return set_error(KLAT_ERR_INVALID_ARG, "the batch was created without state_time: frame posteriors need it");
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   klat_frame_state& st = b->frame;
   int rc;
 
@@ -417,6 +420,7 @@ int klat_index_device_records(klat_batch* b, const void** dev_records, const int
   if (st.cached_mode == 0)
     return set_error(KLAT_ERR_STATE, "no index on this batch: call klat_segment_index / klat_position_index with records == NULL first");
   KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
   AccumArgs a;
   std::memset(&a, 0, sizeof(a));
   a.scratch_off = st.scratch_off.p;
@@ -434,6 +438,7 @@ int klat_index_device_records(klat_batch* b, const void** dev_records, const int
 int klat_get_accum_timings(klat_batch* b, float* index_ms, float* frame_ms) {
   if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
   KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
   if (index_ms) {
     *index_ms = 0.0f;
     if (b->accum.ev[1]) {
@@ -461,6 +466,7 @@ int klat_nbest(klat_batch* b, const float* arc_cost, int32_t k, int32_t max_labe
   if (b->U == 0) return KLAT_OK;
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   int64_t max_states = 1;
   for (int64_t u = 0; u < b->U; ++u) {
     max_states = std::max(max_states, b->h_state_off[u + 1] - b->h_state_off[u]);

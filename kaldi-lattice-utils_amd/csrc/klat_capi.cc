@@ -27,6 +27,11 @@ int set_error(int code, const std::string& msg) {
   return code;
 }
 
+DevPool*& current_pool() {
+  static thread_local DevPool* pool = nullptr;
+  return pool;
+}
+
 int hip_fail(hipError_t e, const char* what) {
   return set_error(e == hipErrorOutOfMemory ? KLAT_ERR_OOM : KLAT_ERR_HIP,
                    std::string(what) + ": " + hipGetErrorString(e));
@@ -94,6 +99,17 @@ int klat_device_count(int* count) {
   return KLAT_OK;
 }
 
+int klat_host_alloc(void** ptr, size_t bytes) {
+  if (!ptr) return set_error(KLAT_ERR_INVALID_ARG, "ptr is null");
+  *ptr = nullptr;
+  KLAT_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return KLAT_OK;
+}
+
+void klat_host_free(void* ptr) {
+  if (ptr) (void)hipHostFree(ptr);
+}
+
 int klat_ctx_create(int device, klat_ctx** out) {
   if (!out) return set_error(KLAT_ERR_INVALID_ARG, "out is null");
   *out = nullptr;
@@ -139,12 +155,14 @@ void klat_ctx_destroy(klat_ctx* c) {
   }
   if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  c->pool.clear();
   delete c;
 }
 
 int klat_ctx_sync(klat_ctx* c) {
   if (!c) return set_error(KLAT_ERR_INVALID_ARG, "ctx is null");
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   KLAT_HIP(hipStreamSynchronize(c->stream));
   return KLAT_OK;
 }
@@ -199,6 +217,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   }
 
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   klat_batch* b = new (std::nothrow) klat_batch();
   if (!b) return set_error(KLAT_ERR_OOM, "host allocation failed");
   b->ctx = c;
@@ -375,6 +394,7 @@ void klat_batch_destroy(klat_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
   (void)hipStreamSynchronize(b->ctx->stream);
+  PoolScope pool_scope(&b->ctx->pool);
   for (hipEvent_t e : {b->accum.ev[0], b->accum.ev[1], b->frame.ev[0], b->frame.ev[1]})
     if (e) (void)hipEventDestroy(e);
   delete b;
@@ -392,6 +412,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   if (sc) s = *sc;
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   ScaleParams sp;
   sp.gs_f = s.graph_scale;
   sp.as_f = s.acoustic_scale;
@@ -489,6 +510,7 @@ int klat_viterbi(klat_batch* b, const klat_scales* sc) {
   if (sc) s = *sc;
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   int rc;
   if (b->fwd_cost.n == 0) {
     if ((rc = b->fwd_cost.alloc((size_t)(b->S + b->U)))) return rc;
@@ -528,6 +550,7 @@ int klat_get_viterbi(klat_batch* b, double* fwd_cost, double* bwd_cost, double* 
   if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
   if (!b->viterbi_done) return set_error(KLAT_ERR_STATE, "klat_viterbi has not run on this batch");
   KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
   int rc;
   if (b->dense.n < (size_t)b->S && (rc = b->dense.alloc((size_t)b->S))) return rc;
   for (int which = 0; which < 2; ++which) {
@@ -560,6 +583,7 @@ int klat_prune_mask(klat_batch* b, float beam, uint8_t* keep_arc, uint8_t* keep_
   if (!(beam > 0.0f)) return set_error(KLAT_ERR_INVALID_ARG, "beam must be positive");
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   DevBuf<uint8_t> d_arc, d_fin;
   DevBuf<double> d_beam;
   int rc;
@@ -593,6 +617,7 @@ int klat_prune_mask(klat_batch* b, float beam, uint8_t* keep_arc, uint8_t* keep_
 int klat_batch_get_streams(klat_batch* b, int32_t* sw, float* sg, float* sa) {
   if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
   KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
   const size_t n = (size_t)(b->info.fwd_slots + b->info.bwd_slots);
   if (n == 0) return KLAT_OK;
   if (sw) KLAT_HIP(hipMemcpyAsync(sw, b->sw.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
@@ -607,6 +632,7 @@ int klat_get_timings(const klat_batch* b, klat_timings* t) {
   if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
   klat_ctx* c = b->ctx;
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   if (c->steps - b->timing_step > klat_ctx::kTimingSlots)
     return set_error(KLAT_ERR_STATE, "the timing events of this step have been reused by later steps");
   return read_timings(c, b->timing_step, t);
@@ -617,6 +643,7 @@ int klat_ctx_timing_history(klat_ctx* c, int32_t count, klat_timings* out) {
   if (count > klat_ctx::kTimingSlots || count > c->steps)
     return set_error(KLAT_ERR_INVALID_ARG, "klat_ctx_timing_history: more steps than were run or than the ring holds (512)");
   KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
   for (int32_t i = 0; i < count; ++i) {
     const int rc = read_timings(c, c->steps - count + i, &out[i]);
     if (rc != KLAT_OK) return rc;
@@ -628,6 +655,7 @@ int klat_get_exact_sweep_jobs(klat_batch* b, int32_t* count) {
   if (!b || !count) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
   if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
   KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
   std::vector<int32_t> flags((size_t)b->num_jobs);
   if (b->num_jobs > 0)
     KLAT_HIP(hipMemcpyAsync(flags.data(), b->job_flags.p, sizeof(int32_t) * flags.size(), hipMemcpyDeviceToHost,
@@ -649,6 +677,7 @@ int klat_get_alpha_beta(klat_batch* b, double* alpha, double* beta) {
   if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
   if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
   KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
   int rc;
   // the device keeps both arrays padded (one extra slot per lattice): compact, then copy
   if (b->dense.n < (size_t)b->S && (rc = b->dense.alloc((size_t)b->S))) return rc;
@@ -671,6 +700,7 @@ int klat_get_totals(klat_batch* b, double* total, double* tot_fwd, double* tot_b
   if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
   if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
   KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
   int rc;
   if ((rc = fetch(b, total, b->total.p, sizeof(double) * (size_t)b->U))) return rc;
   if ((rc = fetch(b, tot_fwd, b->tot_fwd.p, sizeof(double) * (size_t)b->U))) return rc;
@@ -683,6 +713,7 @@ int klat_get_arc_logpost(klat_batch* b, double* logpost) {
   if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
   if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
   KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
   int rc;
   if ((rc = fetch(b, logpost, b->logpost.p, sizeof(double) * (size_t)b->A))) return rc;
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,17 +26,60 @@ int hip_fail(hipError_t e, const char* what);
     if (_e != hipSuccess) return ::klat::hip_fail(_e, #expr); \
   } while (0)
 
+// Device allocations of a context are recycled: hipFree synchronises the whole device (a second
+// context's sweep stalls behind it) and hipMalloc + hipFree of a batch's ~20 arrays cost tens of
+// milliseconds, several times the sweep they serve.  A freed block goes to its context's pool and
+// is handed out again for a request of at most the same size and at least half of it (batches of
+// one shape recur); the pool is emptied when the context is destroyed or holds more than kMaxBytes.
+struct DevPool {
+  static constexpr size_t kMaxBytes = (size_t)96 << 30;
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;
+  size_t cached = 0;
+  void* take(size_t bytes, size_t* got) {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = free_blocks.lower_bound(bytes);
+    if (it == free_blocks.end() || it->first > 2 * bytes + 4096) return nullptr;
+    void* p = it->second;
+    *got = it->first;
+    cached -= it->first;
+    free_blocks.erase(it);
+    return p;
+  }
+  bool give(void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached + bytes > kMaxBytes) return false;
+    free_blocks.emplace(bytes, p);
+    cached += bytes;
+    return true;
+  }
+  void clear() {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    free_blocks.clear();
+    cached = 0;
+  }
+};
+// the pool the calling thread's current API call allocates from (set by PoolScope)
+DevPool*& current_pool();
+struct PoolScope {
+  DevPool* saved;
+  explicit PoolScope(DevPool* p) : saved(current_pool()) { current_pool() = p; }
+  ~PoolScope() { current_pool() = saved; }
+};
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;    // elements in use
   size_t cap = 0;  // elements allocated
+  DevPool* pool = nullptr;  // where the block came from and goes back to
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !(pool && pool->give(p, cap * sizeof(T)))) (void)hipFree(p);
     p = nullptr;
     n = cap = 0;
   }
@@ -47,7 +92,19 @@ struct DevBuf {
     }
     release();
     const size_t want = count == 0 ? 1 : count;  // keep pointers non-null for empty batches
+    pool = current_pool();
+    size_t got = 0;
+    if (pool && (p = static_cast<T*>(pool->take(want * sizeof(T), &got)))) {
+      n = count;
+      cap = got / sizeof(T);
+      return KLAT_OK;
+    }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    if (e == hipErrorOutOfMemory && pool) {  // give the cached blocks back and try once more
+      (void)hipGetLastError();
+      pool->clear();
+      e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    }
     if (e != hipSuccess) {
       p = nullptr;
       return hip_fail(e, "hipMalloc");
@@ -84,6 +141,7 @@ struct klat_ctx {
   hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[kSideStreams] = {nullptr, nullptr, nullptr};
   klat::DevBuf<klat::LnTabEntry> ln_table;  // table behind the sweep's natural log
+  klat::DevPool pool;                       // recycled device blocks of this context's batches
 };
 
 // device scratch + cached result of the accumulate stage (klat_accum_api.cc)

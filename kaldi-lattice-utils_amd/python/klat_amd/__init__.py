@@ -87,7 +87,7 @@ def lib():
         _lib.klat_version.restype = C.c_char_p
         _lib.klat_ctx_stream.restype = C.c_void_p
         _lib.klat_ctx_stream.argtypes = [C.c_void_p]
-        for name in ("klat_ctx_destroy", "klat_batch_destroy", "klat_packed_destroy"):
+        for name in ("klat_ctx_destroy", "klat_batch_destroy", "klat_packed_destroy", "klat_host_free"):
             getattr(_lib, name).restype = None
             getattr(_lib, name).argtypes = [C.c_void_p]
         atexit.register(_close_all)  # after the HIP runtime registered its own handlers: runs before them
@@ -101,6 +101,24 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def pinned_empty(shape, dtype):
+    """numpy array over page-locked host memory (klat_host_alloc); freed with the array."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    p = C.c_void_p()
+    _check(lib().klat_host_alloc(C.byref(p), C.c_size_t(max(n * dt.itemsize, 1))))
+    buf = (C.c_ubyte * max(n * dt.itemsize, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    weakref.finalize(buf, lib().klat_host_free, C.c_void_p(p.value))
+    return arr
+
+
+def pinned_copy(a):
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
 
 
 def device_count():
@@ -232,9 +250,8 @@ class Batch:
         _check(lib().klat_get_exact_sweep_jobs(self.h, C.byref(n)))
         return n.value
 
-    def alpha_beta(self):
-        a = np.empty(self.S, np.float64)
-        b = np.empty(self.S, np.float64)
+    def alpha_beta(self, out=None):
+        a, b = out if out is not None else (np.empty(self.S, np.float64), np.empty(self.S, np.float64))
         _check(lib().klat_get_alpha_beta(self.h, _p(a), _p(b)))
         return a, b
 
@@ -243,8 +260,8 @@ class Batch:
         _check(lib().klat_get_totals(self.h, _p(t), _p(f), _p(b)))
         return t, f, b
 
-    def arc_logpost(self):
-        x = np.empty(self.A, np.float64)
+    def arc_logpost(self, out=None):
+        x = out if out is not None else np.empty(self.A, np.float64)
         _check(lib().klat_get_arc_logpost(self.h, _p(x)))
         return x
 
