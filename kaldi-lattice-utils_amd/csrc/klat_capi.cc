@@ -320,11 +320,11 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, slot)
     std::vector<PackEntry> entries;
     for (size_t j = 0; j < job_lats.size(); ++j) {
-      const int LPW = 64 / ((P.jobs[j].tag >> 8) & 0xFF);
+      const int LPW = 64 / job_lanes(P.jobs[j].tag);
       for (int k = 0; k < LPW; ++k)
         entries.push_back(PackEntry{k < (int)job_lats[j].size() ? (int32_t)job_lats[j][(size_t)k] : -1, (int32_t)j, k, 0});
     }
-    const size_t nslots = (size_t)chunk_total * 64 * kChunkRounds;
+    const size_t nslots = (size_t)chunk_total * kChunkRounds;  // chunk_total counts 16-byte units
     AL(sw, nslots);
     AL(sg, nslots);
     AL(sa, nslots);

@@ -6,8 +6,11 @@
 //   * two lockstep arc streams (forward: terms grouped by destination state in ascending
 //     order; backward: terms grouped by source state in descending order), sliced 64 lanes
 //     wide: a wave owns 64/G lattices, G lanes each; one *round* is one term per lane; four
-//     rounds of one lane are contiguous (16 B) so that every stream load is a 1 KiB
-//     dwordx4 wave access;
+//     rounds of one lane are contiguous (16 B: a *unit*) so that every stream load is one
+//     contiguous dwordx4 wave access.  A job whose states never hold more than A < G terms in a
+//     round (out-degree 3 with G = 4: the whole backward stream) stores only the units of its first
+//     A lanes per lattice: a chunk row is A * (64/G) units, lane (slot, sub) owns unit
+//     sub * (64/G) + slot of it, and the lanes sub >= A carry padding the kernel makes up itself;
 //   * natural-log alpha/beta per state (written by the sweep itself), per-arc log posterior.
 #ifndef KLAT_DEVICE_H_
 #define KLAT_DEVICE_H_
@@ -51,14 +54,27 @@ static const int kExpMin = -(1 << 29); // exponent tag of log-zero (mantissa 0)
 
 // One wave of the sweep kernel.
 struct SweepJob {
-  int64_t chunk_off;  // first chunk of this job's stream (chunk = 64 lanes x 4 rounds)
+  int64_t chunk_off;  // first unit (16 B = 4 rounds of one lane) of this job's stream; a chunk row is A * (64/G) units
   int32_t nchunks;    // multiple of kPrefetchChunks
   int32_t dir;        // 0 forward, 1 backward
   int32_t lane_tab;   // first LaneInfo of this job (64/G entries)
-  int32_t tag;        // bits 0-1: wave priority (long chains first); 8-15: G; 16-27: W of its layout
+  int32_t tag;        // bits 0-1: wave priority (long chains first); 2-7: A - 1 (stored lanes per lattice); 8-15: G; 16-27: W
 };
 static const int kJobPrioMask = 3;
-inline int job_tag(int prio, int G, int W) { return prio | (G << 8) | (W << 16); }
+inline int job_tag(int prio, int G, int W, int A) { return prio | ((A - 1) << 2) | (G << 8) | (W << 16); }
+#if defined(__HIPCC__)
+#define KLAT_HD __host__ __device__
+#else
+#define KLAT_HD
+#endif
+KLAT_HD inline int job_lanes(int tag) { return (tag >> 8) & 0xFF; }
+KLAT_HD inline int job_ring(int tag) { return (tag >> 16) & 0xFFF; }
+KLAT_HD inline int job_stored_lanes(int tag) { return ((tag >> 2) & 0x3F) + 1; }
+// stream slot of (chunk c, lane, round r) of a job; only for lanes with lane % G < A
+KLAT_HD inline int64_t stream_slot(int64_t chunk_off, int G, int A, int64_t c, int lane, int r) {
+  const int LPW = 64 / G;
+  return ((chunk_off + c * (int64_t)(A * LPW) + (lane % G) * LPW + lane / G) * kChunkRounds) + r;
+}
 
 // What the count pass learns about one lattice: the rounds its forward and backward stream take
 // with G = 1, 2, 4 ... 64 lanes, and its longest arc span.  The layout planner (klat_pack.cc) picks
@@ -66,7 +82,8 @@ inline int job_tag(int prio, int G, int W) { return prio | (G << 8) | (W << 16);
 static const int kNumLaneChoices = 7;
 struct LatticeRounds {
   int32_t fwd[kNumLaneChoices], bwd[kNumLaneChoices];
-  int32_t max_rel, pad;
+  int32_t max_rel;
+  int32_t max_terms;  // most terms of one position, forward stream in bits 0-15, backward in 16-31 (capped at 64)
 };
 
 // One lattice inside a job.

@@ -179,9 +179,9 @@ void plan_layout(int64_t U, const int64_t* state_off, const int64_t* arc_off, co
   if (best_cost.cycles < 0.95 * base_cycles) g = best;  // otherwise not worth the extra lanes
 }
 
-int64_t slice_jobs(const int64_t* state_off, const std::vector<int64_t>& members, const std::vector<int64_t>& rf,
-                   const std::vector<int64_t>& rb, int G, int W, int64_t chunk_base, PackedBatch* out,
-                   std::vector<std::vector<int64_t>>* job_lats) {
+int64_t slice_jobs(const int64_t* state_off, const LatticeRounds* lr, const std::vector<int64_t>& members,
+                   const std::vector<int64_t>& rf, const std::vector<int64_t>& rb, int G, int W, int64_t chunk_base,
+                   PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats) {
   const int LPW = 64 / G;
   const int D = kPrefetchChunks;
   // ---- slicing: lattices of similar length share a wave ----
@@ -217,13 +217,17 @@ int64_t slice_jobs(const int64_t* state_off, const std::vector<int64_t>& members
     int64_t nch = ceil_div(proto[j].rounds, kChunkRounds);
     nch = ceil_div(nch, D) * D;
     SweepJob& job = P.jobs[j0 + j];
-    job.chunk_off = chunk_total;
+    // lanes per lattice that ever carry a term: only their units are stored
+    int A = 1;
+    for (int64_t u : proto[j].lat) A = std::max(A, (int)((proto[j].dir ? (uint32_t)lr[u].max_terms >> 16 : (uint32_t)lr[u].max_terms & 0xFFFFu)));
+    A = std::min(A, G);
+    job.chunk_off = chunk_total;  // in units of 16 B
     job.nchunks = (int32_t)nch;
     job.dir = proto[j].dir;
     job.lane_tab = (int32_t)(l0 + j * LPW);
-    job.tag = job_tag(0, G, W);
-    chunk_total += nch;
-    (proto[j].dir ? P.bwd_slots : P.fwd_slots) += nch * kChunkRounds * 64;
+    job.tag = job_tag(0, G, W, A);
+    chunk_total += nch * A * LPW;
+    (proto[j].dir ? P.bwd_slots : P.fwd_slots) += nch * kChunkRounds * A * LPW;
     P.max_rounds = std::max<int32_t>(P.max_rounds, (int32_t)(nch * kChunkRounds));
     for (size_t k = 0; k < proto[j].lat.size(); ++k) {
       const int64_t u = proto[j].lat[k];
@@ -273,7 +277,7 @@ int build_jobs(int64_t U, const int64_t* state_off, const LatticeRounds* lr, con
       return KLAT_ERR_INVALID_ARG;
     }
     for (int64_t u : c.members) rf[(size_t)u] = lr[u].fwd[c.k], rb[(size_t)u] = lr[u].bwd[c.k];
-    chunks = slice_jobs(state_off, c.members, rf, rb, G, W, chunks, &P, job_lats);
+    chunks = slice_jobs(state_off, lr, c.members, rf, rb, G, W, chunks, &P, job_lats);
     P.classes.back().far = c.max_rel >= W ? 1 : 0;
     if (c.slots > most_slots) most_slots = c.slots, P.G = G, P.W = W;  // what klat_batch_info reports
   }
@@ -350,6 +354,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
       mr = std::max<int64_t>(mr, t - s);
     }
     int64_t nfinal = 0, f[kNumLaneChoices] = {0}, b[kNumLaneChoices] = {0};
+    int64_t mtf = 1, mtb = 1;
     for (int64_t s = 0; s < S; ++s) {
       const bool fin = is_final(d, s0 + s);
       if (fin) {
@@ -358,6 +363,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
       }
       const int64_t nf = (s == 0) ? in_cnt[0] + 1 : std::max<int64_t>(in_cnt[s], 1);
       const int64_t nb = std::max<int64_t>(out_cnt[s] + (fin ? 1 : 0), 1);
+      mtf = std::max(mtf, nf);
+      mtb = std::max(mtb, nb);
       for (int k = 0; k < kNumLaneChoices; ++k) {
         f[k] += ceil_div(nf, (int64_t)1 << k);
         b[k] += ceil_div(nb, (int64_t)1 << k);
@@ -368,6 +375,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
       lr[(size_t)u].bwd[k] = (int32_t)b[k];
     }
     lr[(size_t)u].max_rel = (int32_t)mr;
+    mtf = std::max(mtf, nfinal);  // the virtual super-final position holds one term per final state
+    lr[(size_t)u].max_terms = (int32_t)(std::min<int64_t>(mtf, 64) | (std::min<int64_t>(mtb, 64) << 16));
   });
   if (bad.load() != 0) {
     *err = "lattice " + std::to_string(bad_lat.load()) +
@@ -384,7 +393,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   int64_t chunk_total = 0;
   const int rc = build_jobs(U, d.state_off, lr.data(), lat_g, opt, &P, &job_lats, &chunk_total, err);
   if (rc != KLAT_OK) return rc;
-  const size_t nslots = (size_t)chunk_total * 64 * kChunkRounds;
+  const size_t nslots = (size_t)chunk_total * kChunkRounds;  // chunk_total counts 16-byte units
   if (!P.sw.resize(nslots) || !P.sg.resize(nslots) || !P.sa.resize(nslots)) {
     *err = "out of host memory for the arc streams";
     return KLAT_ERR_OOM;
@@ -394,18 +403,21 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   std::atomic<int64_t> far(0);
   parallel_for((int64_t)job_lats.size(), threads, [&](int64_t j) {
     const SweepJob& job = P.jobs[j];
-    const int G = (job.tag >> 8) & 0xFF, W = (job.tag >> 16) & 0xFFF, LPW = 64 / G;
-    const size_t b0 = (size_t)job.chunk_off * 64 * kChunkRounds;
-    const size_t n = (size_t)job.nchunks * 64 * kChunkRounds;
+    const int G = job_lanes(job.tag), W = job_ring(job.tag), AL = job_stored_lanes(job.tag), LPW = 64 / G;
+    const size_t b0 = (size_t)job.chunk_off * kChunkRounds;
+    const size_t n = (size_t)job.nchunks * (size_t)(AL * LPW) * kChunkRounds;
     // padding: zero-weight terms that read cell 0 and park their (unused) result in the lane's
     // own dummy cell behind the ring, so that the consumer's ring write needs no predicate
-    for (size_t i = 0; i < n; ++i)
-      P.sw[b0 + i] = (int32_t)(kNil | ((uint32_t)(W * LPW + (int)((i / kChunkRounds) % 64)) << kWrShift));
+    for (size_t i = 0; i < n; ++i) {
+      const int unit = (int)((i / kChunkRounds) % (size_t)(AL * LPW));
+      const int lane = (unit % LPW) * G + unit / LPW;
+      P.sw[b0 + i] = (int32_t)(kNil | ((uint32_t)(W * LPW + lane) << kWrShift));
+    }
     std::fill(P.sg.data() + b0, P.sg.data() + b0 + n, std::numeric_limits<float>::infinity());
     std::memset(&P.sa[b0], 0, n * sizeof(float));
     int64_t far_local = 0;
     auto slot_index = [&](int64_t r, int lane) -> size_t {
-      return b0 + (((size_t)(r / kChunkRounds) * 64 + lane) * kChunkRounds + (size_t)(r % kChunkRounds));
+      return (size_t)stream_slot(job.chunk_off, G, AL, r / kChunkRounds, lane, (int)(r % kChunkRounds));
     };
     std::vector<int64_t> in_begin;
     std::vector<int32_t> in_arc, out_ord;
@@ -449,7 +461,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
         if (nterm == 0) emit(0, false, 0.f, 0.f, true);
         const int64_t nr = ceil_div(nterm, G);
         const int64_t lastr = r + nr - 1;
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < AL; ++g) {  // (the lanes beyond AL are not stored: the kernel copies these two bits)
           P.sw[slot_index(r, lane0 + g)] |= (int32_t)kFirst;
           P.sw[slot_index(lastr, lane0 + g)] |= (int32_t)kLast;
         }

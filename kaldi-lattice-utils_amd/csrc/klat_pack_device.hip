@@ -65,7 +65,7 @@ __device__ __forceinline__ int lower_bound_src(const int32_t* src, int n, int s)
 
 __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   __shared__ int sh[kT / 64];
-  __shared__ int sh_bad, sh_nfinal, sh_mr;
+  __shared__ int sh_bad, sh_nfinal, sh_mr, sh_mtf, sh_mtb;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   int32_t* in_arc = a.in_arc + a0;
   const int32_t* src = a.src + a0;
   const int32_t* dst = a.dst + a0;
-  if (tid == 0) sh_bad = 0, sh_nfinal = 0, sh_mr = 1;
+  if (tid == 0) sh_bad = 0, sh_nfinal = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
   for (int s = tid; s < S + 2; s += kT) cnt[s] = 0;
   __syncthreads();
@@ -130,13 +130,15 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   // forward: rounds of every position p = 0..S (S = the virtual super-final state) for every
   // number of lanes; in-degrees -> exclusive prefix in place (cnt[p] = first in-arc of p, cnt[S] = A)
   int fsum[kNumLaneChoices] = {0}, bsum[kNumLaneChoices] = {0};
-  int carry_c = 0;
+  int carry_c = 0, mtf = 1, mtb = 1;
   for (int base = 0; base <= S; base += kT) {
     const int p = base + tid;
     const int c = (p < S) ? cnt[p] : 0;
     const int nterm = (p < S) ? c + (p == 0 ? 1 : 0) : nfinal;
-    if (p <= S)
+    if (p <= S) {
+      mtf = max(mtf, nterm);
       for (int k = 0; k < kNumLaneChoices; ++k) fsum[k] += (max(nterm, 1) + (1 << k) - 1) >> k;
+    }
     int tot_c;
     const int ex_c = block_scan(c, &tot_c, sh);
     if (p <= S) cnt[p] = carry_c + ex_c;
@@ -164,8 +166,11 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
   // backward: position p = S-1-s holds the out-arcs of s (+ its final weight)
   for (int s = tid; s < S; s += kT) {
     const int nb = lower_bound_src(src, A, s + 1) - lower_bound_src(src, A, s) + (dev_is_final(a, s0 + s) ? 1 : 0);
+    mtb = max(mtb, nb);
     for (int k = 0; k < kNumLaneChoices; ++k) bsum[k] += (max(nb, 1) + (1 << k) - 1) >> k;
   }
+  atomicMax(&sh_mtf, mtf);
+  atomicMax(&sh_mtb, mtb);
   for (int k = 0; k < kNumLaneChoices; ++k) {
     if (fsum[k]) atomicAdd(&sh_rounds[k], fsum[k]);
     if (bsum[k]) atomicAdd(&sh_rounds[kNumLaneChoices + k], bsum[k]);
@@ -175,7 +180,10 @@ __global__ __launch_bounds__(kT) void pack_count_kernel(PackDevArgs a) {
     a.lat_rounds[u].fwd[tid] = sh_rounds[tid];
     a.lat_rounds[u].bwd[tid] = sh_rounds[kNumLaneChoices + tid];
   }
-  if (tid == 0) a.lat_rounds[u].max_rel = sh_mr;
+  if (tid == 0) {
+    a.lat_rounds[u].max_rel = sh_mr;
+    a.lat_rounds[u].max_terms = min(sh_mtf, 64) | (min(sh_mtb, 64) << 16);
+  }
 }
 
 __global__ __launch_bounds__(kT) void pack_rounds_kernel(PackDevArgs a) {
@@ -223,16 +231,16 @@ __global__ __launch_bounds__(kT) void pack_fill_kernel(PackDevArgs a) {
   __shared__ int sh_far;
   const PackEntry e = a.entries[blockIdx.x];
   const SweepJob job = a.jobs[e.job];
-  const int G = (job.tag >> 8) & 0xFF, W = (job.tag >> 16) & 0xFFF, LPW = 64 / G;
+  const int G = job_lanes(job.tag), W = job_ring(job.tag), AL = job_stored_lanes(job.tag), LPW = 64 / G;
   const int tid = threadIdx.x;
   const int lane0 = e.slot * G;
   const int total_rounds = job.nchunks * kChunkRounds;
-  const int64_t b0 = job.chunk_off * 64 * kChunkRounds;
   auto slot_index = [&](int rr, int lane) -> int64_t {
-    return b0 + ((int64_t)(rr / kChunkRounds) * 64 + lane) * kChunkRounds + (rr % kChunkRounds);
+    return stream_slot(job.chunk_off, G, AL, rr / kChunkRounds, lane, rr % kChunkRounds);
   };
   auto pad_word = [&](int lane) -> uint32_t { return kNil | ((uint32_t)(W * LPW + lane) << kWrShift); };
   auto put = [&](int rr, int lane, uint32_t w, float g, float ac) {
+    if (lane - lane0 >= AL) return;  // not stored: the kernel makes this lane's padding up itself
     const int64_t ix = slot_index(rr, lane);
     a.sw[ix] = (int32_t)w;
     a.sg[ix] = g;

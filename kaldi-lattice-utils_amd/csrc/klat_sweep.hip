@@ -210,18 +210,27 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       constexpr bool GENERAL = decltype(general_tag)::value;
       const ScaleParams sp = args.sp;
       const StreamCost sc = args.sc;
-      const int4* __restrict__ sw = reinterpret_cast<const int4*>(args.sw) + job.chunk_off * 64 + lane;
-      const float4* __restrict__ sg = reinterpret_cast<const float4*>(args.sg) + job.chunk_off * 64 + lane;
-      const float4* __restrict__ sa = reinterpret_cast<const float4*>(args.sa) + job.chunk_off * 64 + lane;
+      // The stream stores the units (16 B = 4 rounds) of the first AL lanes of every lattice only
+      // (klat_device.h): a chunk row is AL * LPW units, this lane's unit is sub * LPW + slot.  A lane
+      // beyond AL loads nothing; its padding words are made up when the chunk is staged.
+      const int AL = job_stored_lanes(job.tag);
+      const int row = AL * LPW;
+      const bool stored = sub < AL;
+      // (a lane beyond AL reads its lattice's first unit again -- the same cache line, no HBM
+      // traffic, and no branch around the prefetch loads -- and ignores it)
+      const int unit = (stored ? sub : 0) * LPW + slot;
+      const int4* __restrict__ sw = reinterpret_cast<const int4*>(args.sw) + job.chunk_off + unit;
+      const float4* __restrict__ sg = reinterpret_cast<const float4*>(args.sg) + job.chunk_off + unit;
+      const float4* __restrict__ sa = reinterpret_cast<const float4*>(args.sa) + job.chunk_off + unit;
       int4 wb[D];
       float4 gb[D], ab[D];
+      auto load_chunk = [&](int j, int64_t cn) {
+        wb[j] = sw[cn * row];
+        gb[j] = sg[cn * row];
+        ab[j] = sa[cn * row];
+      };
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const int64_t cn = min(j, nchunks - 1);
-        wb[j] = sw[cn * 64];
-        gb[j] = sg[cn * 64];
-        ab[j] = sa[cn * 64];
-      }
+      for (int j = 0; j < D; ++j) load_chunk(j, min(j, nchunks - 1));
       int p = 0;                  // position the lattice is accumulating at the current round
       // The consumer works on period n between barriers n and n+1, so the iteration that stages
       // period n can copy out the states of period n-2: out_* is that range, pend_* the range of
@@ -349,10 +358,26 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           *dst = v;
         }
       };
-      auto stage_chunk = [&](int cj, const int4& w4, const float4& g4, const float4& a4, const double (&v)[4]) {
+      const uint32_t pad_w = kNil | ((uint32_t)(W * LPW + lane) << kWrShift);
+      const uint64_t unstored = lane_mask(!stored);
+      auto stage_chunk = [&](int cj, int4 w4, float4 g4, const float4& a4, const double (&v)[4]) {
         // stage buffer: [barrier period parity][chunk within the period][round][lane]
         const int sidx = (((cj / CPB) & 1) * CPB + (cj % CPB)) * 256 + lane;
         StagedTerm* st = stage + sidx;
+        if (AL < G) {
+          // wave-uniform.  The lane holds its lattice's first unit: FIRST / LAST are uniform over a
+          // lattice's lanes, the rest of a padding word is fixed, its graph cost infinite.
+          const int fl = (int)(kFirst | kLast);
+          w4.x = select32(unstored, (w4.x & fl) | (int)pad_w, w4.x);
+          w4.y = select32(unstored, (w4.y & fl) | (int)pad_w, w4.y);
+          w4.z = select32(unstored, (w4.z & fl) | (int)pad_w, w4.z);
+          w4.w = select32(unstored, (w4.w & fl) | (int)pad_w, w4.w);
+          const int inf = 0x7F800000;
+          g4.x = __int_as_float(select32(unstored, inf, __float_as_int(g4.x)));
+          g4.y = __int_as_float(select32(unstored, inf, __float_as_int(g4.y)));
+          g4.z = __int_as_float(select32(unstored, inf, __float_as_int(g4.z)));
+          g4.w = __int_as_float(select32(unstored, inf, __float_as_int(g4.w)));
+        }
         const bool any_far = __any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0);
         if (FARP && any_far) {
           put_far_v(st, (uint32_t)w4.x, g4.x, a4.x, v[0]);
@@ -398,12 +423,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           if (!early_copy) copy_store();
           if (FARP) far_loads(c + j0 + CPB, wb[(j0 + CPB) % D], wb[(j0 + CPB + 1) % D]);
 #pragma unroll
-          for (int i = 0; i < CPB; ++i) {
-            const int64_t cn = min(c + j0 + i + D, nchunks - 1);
-            wb[j0 + i] = sw[cn * 64];
-            gb[j0 + i] = sg[cn * 64];
-            ab[j0 + i] = sa[cn * 64];
-          }
+          for (int i = 0; i < CPB; ++i) load_chunk(j0 + i, min(c + j0 + i + D, nchunks - 1));
           // this period is staged; the consumer has finished the previous one,
           producer_barrier<2 * (3 * CPB + kIters + (FARP ? 4 * CPB : 0))>();
           out_p0 = pend_p0;             // whose states are now stable in the ring (W >= 2 periods of states)

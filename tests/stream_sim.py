@@ -69,7 +69,12 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                 commit = None
                 for sub in range(G):
                     lane = slot * G + sub
-                    ix = ((int(job["chunk_off"]) + r // 4) * 64 + lane) * 4 + r % 4
+                    AL = ((int(job["tag"]) >> 2) & 0x3F) + 1  # lanes per lattice whose units are stored
+                    if sub >= AL:
+                        # not stored: the kernel makes up a padding word with the FIRST / LAST bits of
+                        # the lattice's first lane; nothing to interpret here
+                        continue
+                    ix = (int(job["chunk_off"]) + (r // 4) * (AL * LPW) + sub * LPW + slot) * 4 + r % 4
                     w = int(sw[ix])
                     if base < 0 or p >= npos:
                         assert w & NIL and not (w & (LAST | FIRST | COMMIT | FAR)), "padding must be plain NIL"
