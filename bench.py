@@ -150,6 +150,7 @@ def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=1
     arrays = klat_amd.synth(seed, ns, fo, host_threads=host_threads, wide=wide)
     b = klat_amd.Batch(ctx, arrays, host_threads=host_threads)
     info = b.info()
+    depth = b.topological_depth()
     for _ in range(warm):
         b.forward_backward(*SCALES)
     for _ in range(steps):
@@ -160,7 +161,8 @@ def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=1
     A, S = info["num_arcs"], info["num_states"]
     sweep, step = median([t["sweep_ms"] for t in hist]), median([t["total_ms"] for t in hist])
     out = {"workload": name, "lattices": int(len(ns)), "arcs": A, "states": S,
-           "topological_depth": int(info.get("max_depth", 0)) or None,
+           "topological_depth": {"max": int(depth.max()), "mean": float(depth.mean()),
+                                 "note": "states on a lattice's longest path; the sweep takes max_rounds rounds whatever the depth"},
            "lanes_per_lattice": info["lanes_per_lattice"], "layout_classes": info["num_layouts"],
            "sweep_waves": info["num_jobs"], "max_rounds": info["max_rounds"],
            "sweep_ms": sweep, "step_ms": step, "arcs_per_s": A / (step * 1e-3),

@@ -132,6 +132,11 @@ int klat_batch_create(klat_ctx* ctx, const klat_batch_desc* desc, const klat_pac
 void klat_batch_destroy(klat_batch* batch);
 int klat_batch_get_info(const klat_batch* batch, klat_batch_info* info);
 
+/* Topological depth of every lattice: the number of states on its longest path (the fewest
+ * dependent steps ANY forward-backward needs; the lockstep streams take one round per state or
+ * more).  Diagnostic: computed on the host from a copy of the arcs, on demand. */
+int klat_batch_topological_depth(klat_batch* batch, int32_t* depth /* [num_lattices] */);
+
 /* a2+a3+a7+a8: ScaleLattice / AddWordInsPen fused into the cost load, forward and backward
  * sweeps, per-lattice total = 0.5*(tot_fwd+tot_bwd), per-arc log posterior
  * alpha[src] - cost + beta[dst] - total, alpha/beta in natural log.  Asynchronous on the

@@ -406,6 +406,30 @@ int klat_batch_get_info(const klat_batch* b, klat_batch_info* info) {
   return KLAT_OK;
 }
 
+int klat_batch_topological_depth(klat_batch* b, int32_t* depth) {
+  if (!b || (b->U > 0 && !depth)) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  std::vector<int32_t> src((size_t)b->A), dst((size_t)b->A);
+  if (b->A > 0) {
+    KLAT_HIP(hipMemcpyAsync(src.data(), b->src.p, sizeof(int32_t) * src.size(), hipMemcpyDeviceToHost, b->ctx->stream));
+    KLAT_HIP(hipMemcpyAsync(dst.data(), b->dst.p, sizeof(int32_t) * dst.size(), hipMemcpyDeviceToHost, b->ctx->stream));
+    KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
+  }
+  std::vector<int32_t> level;
+  for (int64_t u = 0; u < b->U; ++u) {
+    const int64_t S = b->h_state_off[u + 1] - b->h_state_off[u];
+    level.assign((size_t)S, S > 0 ? 1 : 0);  // states on the longest path ending here (unreachable ones count from themselves)
+    int32_t best = S > 0 ? 1 : 0;
+    for (int64_t i = b->h_arc_off[u]; i < b->h_arc_off[u + 1]; ++i) {  // arcs are in source order, dst > src
+      int32_t& l = level[(size_t)dst[(size_t)i]];
+      l = std::max(l, level[(size_t)src[(size_t)i]] + 1);
+      best = std::max(best, l);
+    }
+    depth[u] = best;
+  }
+  return KLAT_OK;
+}
+
 int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
   klat_scales s = {1.0f, 1.0f, 0.0f};

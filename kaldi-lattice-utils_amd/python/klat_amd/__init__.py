@@ -236,6 +236,11 @@ class Batch:
         _check(lib().klat_batch_get_info(self.h, C.byref(i)))
         return i.as_dict()
 
+    def topological_depth(self):
+        d = np.zeros(max(self.U, 1), np.int32)
+        _check(lib().klat_batch_topological_depth(self.h, _p(d)))
+        return d[:self.U]
+
     def forward_backward(self, graph_scale=1.0, acoustic_scale=1.0, insertion_penalty=0.0):
         s = Scales(graph_scale, acoustic_scale, insertion_penalty)
         _check(lib().klat_forward_backward(self.h, C.byref(s)))

@@ -87,3 +87,65 @@ def test_prune_mask_needs_viterbi(ctx):
         b.prune_mask(2.0)
     assert e.value.code == klat_amd.ERR_STATE
     b.close()
+
+
+def test_c5_skewed_mix_viterbi_and_prune_properties(ctx):
+    """BASELINE configs[4] (first half) at its shape: the skewed mix of SURVEY.md 8d C5 (sizes
+    log-uniform in [200, 20 000] states, fanout in {2,3,4,6}), 400 lattices of it.  The oracle cannot
+    walk 20 000-state lattices in a test's time, so the tropical twin and the pruning masks are
+    checked through size-independent properties, and the lattices below 1 500 states against the
+    oracle as well."""
+    rng = np.random.RandomState(20260004)
+    U = 400
+    ns = np.exp(rng.uniform(np.log(200), np.log(20000), U)).astype(np.int32)
+    fo = rng.choice([2, 3, 4, 6], U).astype(np.int32)
+    arrays = klat_amd.synth(20260004, ns, fo, host_threads=8)
+    scales = (1.0, 0.1, 0.0)
+    b = klat_amd.Batch(ctx, arrays)
+    assert b.info()["num_layouts"] >= 2  # the mix really spans several layout classes
+    b.viterbi(*scales)
+    fw, bw, best = b.viterbi_costs()
+    b.forward_backward(*scales)
+    total, _, _ = b.totals()
+    so, ao = arrays["state_off"], arrays["arc_off"]
+    cost = arrays["graph"].astype(np.float64) * 1.0 + (np.float32(0.1) * arrays["acoustic"]).astype(np.float64)  # ScaleLattice's float product
+    lat_of_arc = np.repeat(np.arange(U), np.diff(ao))
+    gsrc, gdst = arrays["src"] + so[:-1][lat_of_arc], arrays["dst"] + so[:-1][lat_of_arc]
+    # 1. the best path's cost is both fwd[last] and bwd[start]; it bounds the log-semiring total
+    assert np.allclose(fw[so[1:] - 1], best, rtol=1e-12) and np.allclose(bw[so[:-1]], best, rtol=1e-12)
+    assert np.all(-total <= best + 1e-9) and np.all(best <= -total + np.log(6.0) * ns)  # at most fanout^S paths
+    # 2. Bellman: no arc beats its destination's forward cost or its source's backward cost, and every
+    #    state but the start has an arc that attains it
+    through = fw[gsrc] + cost + bw[gdst]
+    assert np.all(fw[gsrc] + cost >= fw[gdst] - 1e-9) and np.all(bw[gdst] + cost >= bw[gsrc] - 1e-9)
+    attained = np.zeros(len(fw), bool)
+    np.logical_or.at(attained, gdst, np.abs(fw[gsrc] + cost - fw[gdst]) <= 1e-9 * np.maximum(1.0, np.abs(fw[gdst])))
+    attained[so[:-1]] = True
+    assert attained.all()
+    assert np.all(through >= best[lat_of_arc] - 1e-9)
+    # 3. PruneLattice masks: exactly the arcs within the beam; monotone in the beam; a beam above the
+    #    lattice's own beam keeps every arc; the best path always survives
+    prev = None
+    for beam in (0.5, 4.0, 50.0):
+        ka, kf, lbeam = b.prune_mask(beam)
+        sure = np.abs(through - (best[lat_of_arc] + beam)) > 1e-7
+        assert np.array_equal(ka[sure].astype(bool), (through <= best[lat_of_arc] + beam)[sure])
+        if prev is not None:
+            assert np.all(ka >= prev)
+        prev = ka
+        assert np.all(lbeam >= -1e-9)
+        per_lat_kept = np.bincount(lat_of_arc, weights=ka, minlength=U)
+        assert np.all(per_lat_kept >= 1)
+        roomy = lbeam < beam - 1e-6
+        assert np.all(per_lat_kept[roomy] == np.diff(ao)[roomy])
+        assert np.all(kf[so[1:] - 1] == 1)  # the only final state of a generated lattice ends the best path
+    # 4. the lattices the oracle can walk: against its ComputeLatticeBeam restatement
+    checked = 0
+    for u, lat in enumerate(_split(arrays)):
+        if ns[u] > 1500 or checked >= 12:
+            continue
+        wbeam, wfw, wbw = orc.lattice_beam(orc.scale_and_penalize(lat, *scales))
+        assert np.allclose(fw[so[u]:so[u + 1]], wfw, rtol=1e-12, atol=1e-9) and np.allclose(bw[so[u]:so[u + 1]], wbw, rtol=1e-12, atol=1e-9)
+        checked += 1
+    assert checked >= 8
+    b.close()

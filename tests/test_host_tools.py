@@ -511,3 +511,49 @@ def test_tools_on_a_multi_lattice_archive(tmp_path):
     assert sorted(g[:3] for g in got) == sorted(w[:3] for w in want)
     wk = {w[:3]: w[3] for w in want}
     assert all(abs(g[3] - wk[g[:3]]) < 1e-5 for g in got)
+
+
+@pytest.mark.gpu
+def test_prune_dyn_beam_tool_on_a_skewed_mix(tmp_path):
+    """BASELINE configs[4], first half, through the tool: lattice-prune-dyn-beam over a skewed mix
+    (sizes log-uniform in [200, 6 000] states, fanout in {2,3,4,6}; one Viterbi sweep of the whole
+    batch decides every iteration of the reference's loop, latbin/lattice-prune-dyn-beam.cc:169-186).
+    Size-independent properties on every lattice, the oracle's literal loop on the small ones."""
+    rng = np.random.RandomState(4)
+    U = 36
+    ns = np.exp(rng.uniform(np.log(200), np.log(6000), U)).astype(np.int32)
+    fo = rng.choice([2, 3, 4, 6], U).astype(np.int32)
+    arrays = klat_amd.synth(20260004, ns, fo)
+    txt, out = str(tmp_path / "in.txt"), str(tmp_path / "out.txt")
+    with open(txt, "w") as f:
+        latfmt.write_synth_text(arrays, f, ["u%02d" % i for i in range(U)])
+    max_arcs = 900
+    rc, _, err = run("lattice-prune-dyn-beam", "--acoustic-scale=0.1", "--max-arcs=%d" % max_arcs, "ark:" + txt, "ark,t:" + out)
+    assert rc == 0, err
+    ins, outs = latfmt.read_text_archive(txt), latfmt.read_text_archive(out)
+    assert [o.key for o in outs] == [i.key for i in ins]
+    checked = 0
+    for lat, got in zip(ins, outs):
+        assert 1 <= got.A <= lat.A and got.S <= lat.S
+        # within the limit -- or pruned down to (nearly) the best path when even that is longer than the
+        # limit: the reference's loop gives up below --min-beam (latbin/lattice-prune-dyn-beam.cc:169-186)
+        assert got.A <= max_arcs or got.A <= 1.05 * (got.S - 1)
+        # still one connected lattice from the start to a final state, every arc forward
+        src = got.src()
+        assert np.all(got.dst > src)
+        reach = np.zeros(got.S, bool)
+        reach[0] = True
+        for s, d in zip(src, got.dst):
+            reach[d] |= reach[s]
+        assert reach.all() and np.isfinite(got.final_graph[-1])
+        # its arcs are arcs of the input (weights untouched: the tool writes the stored weights back)
+        by_label = {}
+        for g, a, l in zip(lat.graph, lat.acoustic, lat.ilabel):
+            by_label.setdefault(int(l), []).append((float(g), float(a)))
+        for g, a, l in zip(got.graph, got.acoustic, got.ilabel):  # text output carries ~7 significant digits
+            assert any(abs(g - g0) <= 1e-5 * max(1.0, abs(g0)) and abs(a - a0) <= 1e-5 * max(1.0, abs(a0)) for g0, a0 in by_label.get(int(l), []))
+        if lat.S <= 700:
+            arcs, states, beam = orc.prune_dyn_beam(orc.scale_and_penalize(latfmt.prepare(lat), 1.0, 0.1, 0.0), max_arcs, 2 ** 31 - 1)
+            assert got.A == len(arcs) and got.S == len(states), (lat.key, got.A, len(arcs))
+            checked += 1
+    assert checked >= 5
