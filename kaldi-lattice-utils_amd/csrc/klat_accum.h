@@ -115,6 +115,7 @@ struct FrameArgs {
   int64_t* num_expansions;  // [U] (count kernel)
   int32_t* num_records;     // [U]
   ScaleParams sp;
+  long long* phase_clock;   // [U][8] or null: shader cycles of the frame kernel's phases (KLAT_ACCUM_PROFILE)
 };
 
 hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t stream);

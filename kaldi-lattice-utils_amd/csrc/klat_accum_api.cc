@@ -373,7 +373,24 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     a.key_scratch = st.key_scratch.p;
     a.rec_scratch = st.rec_scratch.p;
     a.arc_info = reinterpret_cast<FrameArc*>(st.arc_scratch.p);
+    DevBuf<long long> d_clock;
+    if (std::getenv("KLAT_ACCUM_PROFILE")) {
+      if ((rc = d_clock.alloc((size_t)b->U * 8))) return rc;
+      KLAT_HIP(hipMemsetAsync(d_clock.p, 0, sizeof(long long) * (size_t)b->U * 8, c->stream));
+      a.phase_clock = d_clock.p;
+    }
     KLAT_HIP(launch_frame(a, (int)b->U, c->stream));
+    if (a.phase_clock) {
+      std::vector<long long> clk((size_t)b->U * 8);
+      KLAT_HIP(hipMemcpyAsync(clk.data(), d_clock.p, sizeof(long long) * clk.size(), hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipStreamSynchronize(c->stream));
+      double sum[5] = {0};
+      for (int64_t u = 0; u < b->U; ++u)
+        for (int k = 0; k < 5; ++k) sum[k] += (double)clk[(size_t)u * 8 + k];
+      std::fprintf(stderr, "frame_kernel: mean shader cycles per workgroup over %lld lattices: spans %.0f  counts+scan %.0f  scatter %.0f  crowded %.0f  frames %.0f\n",
+                   (long long)b->U, sum[0] / b->U, sum[1] / b->U, sum[2] / b->U, sum[3] / b->U, sum[4] / b->U);
+      a.phase_clock = nullptr;
+    }
     KLAT_HIP(hipEventRecord(st.ev[1], c->stream));
     std::vector<int32_t> counts((size_t)b->U);
     if (b->U > 0)

@@ -228,6 +228,27 @@ __device__ __forceinline__ void fr_sort_regs(uint64_t (&k)[kFrRegs], double (&v)
   fr_sort_sizes<N, 2, WITH_VAL>(k, v);
 }
 
+// The same network over 32-bit keys without payload: a compare-exchange is v_min_u32 + v_max_u32.
+template <int N, int SIZE, int STRIDE>
+__device__ __forceinline__ void fr_sort32_stage(uint32_t (&k)[kFrRegs]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int l = i ^ STRIDE;
+    if (l > i) {
+      const bool up = (i & SIZE) == 0;
+      const uint32_t lo = min(k[i], k[l]), hi = max(k[i], k[l]);
+      k[i] = up ? lo : hi;
+      k[l] = up ? hi : lo;
+    }
+  }
+  if constexpr (STRIDE > 1) fr_sort32_stage<N, SIZE, STRIDE / 2>(k);
+}
+template <int N, int SIZE>
+__device__ __forceinline__ void fr_sort32_sizes(uint32_t (&k)[kFrRegs]) {
+  fr_sort32_stage<N, SIZE, SIZE / 2>(k);
+  if constexpr (SIZE < N) fr_sort32_sizes<N, SIZE * 2>(k);
+}
+
 // Sorts a bucket of w entries by (label, arc), folds the runs of one label in arc order, sorts the
 // folded keys (desc(float logp) | label); returns their number.  E(j) is the j-th entry.
 template <class Entry>
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
   FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrTile]: the cooperative sort's tile
   uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kFrLdsEntries]: a tile's buckets as arc numbers (same memory)
-  __shared__ int tile_max;
+  __shared__ int tile_max, lab_min, lab_max;
   __shared__ int lboff[kFrTileFrames + 1];  // first expansion of every frame of the tile (tile-local)
   __shared__ int lcur[kFrTileFrames];       // scatter cursors; then -(folded entries) - 1 for a bucket the workgroup folded
   __shared__ int sh[kFrThreads / 64];
@@ -288,24 +309,72 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   // the last frame_sort_slots(nA) record rows of the lattice are the cooperative sort's scratch
   FKey* tmp = recs + ((a.scratch_off[u + 1] - a.scratch_off[u]) - frame_sort_slots(nA));
 
-  // ---- 0. clipped span and x of every arc ----
-  for (int i = tid; i < nA; i += kFrThreads) {
-    FrameArc r;
-    fr_span(a, a0, s0, T, i, r.k0, r.k1);
-    r.x = 0.0;
-    if (r.k1 > r.k0) {
-      // logpost holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
-      // cost here as a float sum, so swap the double sum for the float one
-      float g, ac;
-      arc_cost_parts(a.graph[a0 + i], a.acoustic[a0 + i], true, sp, g, ac);
-      // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
-      const double lpa = a.logpost[a0 + i];
-      r.x = (lpa > -INFINITY) ? lpa + ((double)g + (double)ac) - (double)(g + ac) : lpa;
-    }
-    ai[i] = r;
-  }
+  long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, crowded, frames, (unused)
+  long long t_prev = (long long)__builtin_amdgcn_s_memtime();
+#define FR_LAP(k)                                                      \
+  do {                                                                 \
+    if (a.phase_clock) {                                               \
+      const long long t_now = (long long)__builtin_amdgcn_s_memtime(); \
+      clk[k] += t_now - t_prev;                                        \
+      t_prev = t_now;                                                  \
+    }                                                                  \
+  } while (0)
+  // ---- 0. clipped span and x of every arc; the label range of the lattice ----
+  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000;
   __syncthreads();
+  int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000;
+  for (int base = 0; base < nA; base += 4 * kFrThreads) {  // four arcs per thread at a time: loads batched, no branch around them
+    int il[4], t0[4], t1[4];
+    float gr[4], ac4[4];
+    double lp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = min(base + q * kFrThreads + tid, nA - 1);
+      il[q] = a.ilabel[a0 + i];
+      t0[q] = a.src[a0 + i];
+      t1[q] = a.dst[a0 + i];
+      gr[q] = a.graph[a0 + i];
+      ac4[q] = a.acoustic[a0 + i];
+      lp[q] = a.logpost[a0 + i];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      t0[q] = a.state_time[s0 + t0[q]];
+      t1[q] = a.state_time[s0 + t1[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + q * kFrThreads + tid;
+      if (i >= nA) continue;
+      FrameArc r;
+      r.k0 = r.k1 = 0;
+      r.x = 0.0;
+      const int lo = max(t0[q], 0), hi = min(t1[q], T);
+      if (il[q] != 0 && hi > lo) {
+        r.k0 = lo;
+        r.k1 = hi;
+        lmin_t = min(lmin_t, il[q]), lmax_t = max(lmax_t, il[q]);
+        // logpost holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
+        // cost here as a float sum, so swap the double sum for the float one
+        float g, ac;
+        arc_cost_parts(gr[q], ac4[q], true, sp, g, ac);
+        // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
+        r.x = (lp[q] > -INFINITY) ? lp[q] + ((double)g + (double)ac) - (double)(g + ac) : lp[q];
+      }
+      ai[i] = r;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) lmin_t = min(lmin_t, __shfl_xor(lmin_t, d, 64)), lmax_t = max(lmax_t, __shfl_xor(lmax_t, d, 64));
+  if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t);
+  __syncthreads();
+  // (label - lab_min) and the arc number fit one 32-bit sort key?  (0xFFFFFFFF stays free for padding)
+  int abits = 1;
+  while ((1 << abits) < nA) ++abits;
+  const bool key32 = nA <= 65535 && lab_max >= lab_min &&
+                     (uint64_t)((int64_t)lab_max - (int64_t)lab_min) < ((1ull << (32 - abits)) - 1ull);
+  const int lab_base = lab_min;
 
+  FR_LAP(0);
   int nbase = 0;  // expansions of the tiles before this one
   int mbase = 0;  // records written so far
   for (int f0 = 0; f0 < T; f0 += kFrTileFrames) {
@@ -322,19 +391,38 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
       }
     }
     __syncthreads();
-    int carry_c = 0, n = 0, cmax = 0;
-    for (int base = 0; base <= tf; base += kFrThreads) {
-      const int k = base + tid;
-      const int d = (k <= tf) ? lboff[k] : 0;
+    // every thread owns kCh consecutive frames: two block scans per tile (difference array -> entries
+    // per frame -> bucket offsets) instead of two per 256 frames
+    constexpr int kCh = (kFrTileFrames + 1 + kFrThreads - 1) / kFrThreads;
+    int n = 0, cmax = 0;
+    {
+      int dl[kCh], sum_d = 0;
+#pragma unroll
+      for (int q = 0; q < kCh; ++q) {
+        const int k = tid * kCh + q;
+        dl[q] = (k <= tf) ? lboff[k] : 0;
+        sum_d += dl[q];
+      }
       int tot_d, tot_c;
-      const int ex = fr_block_scan(d, &tot_d, sh);
-      const int c = (k < tf) ? carry_c + ex + d : 0;  // entries of frame k
-      cmax = max(cmax, c);
-      const int o = n + fr_block_scan(c, &tot_c, sh);
-      if (k <= tf) lboff[k] = o;
-      if (k < tf) lcur[k] = o;
-      carry_c += tot_d;
-      n += tot_c;
+      int run = fr_block_scan(sum_d, &tot_d, sh);  // difference entries before this thread's frames
+      int cl[kCh], sum_c = 0;
+#pragma unroll
+      for (int q = 0; q < kCh; ++q) {
+        const int k = tid * kCh + q;
+        run += dl[q];
+        cl[q] = (k < tf) ? run : 0;  // entries of frame k
+        cmax = max(cmax, cl[q]);
+        sum_c += cl[q];
+      }
+      int off = fr_block_scan(sum_c, &tot_c, sh);
+#pragma unroll
+      for (int q = 0; q < kCh; ++q) {
+        const int k = tid * kCh + q;
+        if (k <= tf) lboff[k] = off;
+        if (k < tf) lcur[k] = off;
+        off += cl[q];
+      }
+      n = tot_c;
     }
     if (tid == 0) tile_max = 0;
     __syncthreads();
@@ -343,6 +431,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
     __syncthreads();
     const bool in_lds = nA <= 65535 && n <= kFrLdsEntries && tile_max <= kFrSerialMax;  // workgroup-uniform
 
+    FR_LAP(1);
     // ---- 2. every arc drops itself into the buckets of its frames ----
     if (in_lds) {
       for (int i = tid; i < nA; i += kFrThreads) {
@@ -363,6 +452,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
     }
     __syncthreads();
 
+    FR_LAP(2);
     // ---- 3a. buckets above kFrSerialMax entries, kFrBigList at a time: sorted through the LDS
     // tile (which overlays the slabs), folded by the heads of the runs, sorted again; the folded
     // keys stay at the bucket's start ----
@@ -428,6 +518,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
       __syncthreads();
     }
 
+    FR_LAP(3);
     // ---- 3b. one thread per frame, kFrThreads frames at a time: sort, fold, sort, place ----
     for (int r0 = 0; r0 < tf; r0 += kFrThreads) {
       const int k = r0 + tid;
@@ -454,37 +545,66 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
       }
       uint64_t ek[kFrRegs];
       double ex[kFrRegs];
-      if (in_lds) {
-        int arc[kFrRegs];
+      bool narrow;
+      if (in_lds && key32) {
+        // sort keys (label - lab_base | arc number) in 32 bits: a compare-exchange is two instructions
+        // and no payload moves; x is fetched by arc number after the sort
+        uint32_t k32[kFrRegs];
         const int lo = (k < tf) ? lboff[k] : 0;
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) arc[j] = (in_regs && j < w) ? (int)lbucket[lo + j] : -1;
+        for (int j = 0; j < kFrRegs; ++j) k32[j] = (in_regs && j < w) ? (uint32_t)lbucket[lo + j] : 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) {  // (label, x) of the arcs: gathers served by L2, all in flight together
-          ek[j] = ~0ull;
-          ex[j] = 0.0;
-          if (arc[j] >= 0) {
-            ek[j] = ((uint64_t)fr_bias(a.ilabel[a0 + arc[j]]) << 32) | (uint32_t)arc[j];
-            ex[j] = ai[arc[j]].x;
-          }
-        }
-      } else {
+        for (int j = 0; j < kFrRegs; ++j)
+          if (k32[j] != 0xFFFFFFFFu) k32[j] |= (uint32_t)(a.ilabel[a0 + (int)k32[j]] - lab_base) << abits;  // gathers served by L2
+        narrow = __all(!in_regs || w <= 8);  // wave-uniform: the 8-wide network is enough
+        if (narrow)
+          fr_sort32_sizes<8, 2>(k32);
+        else
+          fr_sort32_sizes<kFrRegs, 2>(k32);
+        const uint32_t amask = (1u << abits) - 1u;
 #pragma unroll
         for (int j = 0; j < kFrRegs; ++j) {
           ek[j] = ~0ull;
           ex[j] = 0.0;
-          if (in_regs && j < w) {
-            const FKey e = keys[o + j];
-            ek[j] = e.a;
-            ex[j] = __longlong_as_double((long long)e.b);
+          if (k32[j] != 0xFFFFFFFFu) {
+            const int arc = (int)(k32[j] & amask);
+            ek[j] = ((uint64_t)fr_bias((int32_t)(k32[j] >> abits) + lab_base) << 32) | (uint32_t)arc;
+            ex[j] = ai[arc].x;
           }
         }
+      } else {
+        if (in_lds) {
+          int arc[kFrRegs];
+          const int lo = (k < tf) ? lboff[k] : 0;
+#pragma unroll
+          for (int j = 0; j < kFrRegs; ++j) arc[j] = (in_regs && j < w) ? (int)lbucket[lo + j] : -1;
+#pragma unroll
+          for (int j = 0; j < kFrRegs; ++j) {  // (label, x) of the arcs: gathers served by L2, all in flight together
+            ek[j] = ~0ull;
+            ex[j] = 0.0;
+            if (arc[j] >= 0) {
+              ek[j] = ((uint64_t)fr_bias(a.ilabel[a0 + arc[j]]) << 32) | (uint32_t)arc[j];
+              ex[j] = ai[arc[j]].x;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < kFrRegs; ++j) {
+            ek[j] = ~0ull;
+            ex[j] = 0.0;
+            if (in_regs && j < w) {
+              const FKey e = keys[o + j];
+              ek[j] = e.a;
+              ex[j] = __longlong_as_double((long long)e.b);
+            }
+          }
+        }
+        narrow = __all(!in_regs || w <= 8);  // wave-uniform: the 8-wide network is enough
+        if (narrow)
+          fr_sort_regs<8, true>(ek, ex);
+        else
+          fr_sort_regs<kFrRegs, true>(ek, ex);
       }
-      const bool narrow = __all(!in_regs || w <= 8);  // wave-uniform: the 8-wide network is enough
-      if (narrow)
-        fr_sort_regs<8, true>(ek, ex);
-      else
-        fr_sort_regs<kFrRegs, true>(ek, ex);
       // fold: the key of a run is emitted at its last entry, the other entries turn into padding
       double acc = ex[0];
 #pragma unroll
@@ -530,8 +650,12 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
     }
     nbase += n;
     __syncthreads();
+    FR_LAP(4);
   }
   if (tid == 0) a.num_records[u] = mbase;
+  if (a.phase_clock && tid == 0)
+    for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
+#undef FR_LAP
 }
 
 // Dense output: entries of lattice u at entry_off[u].., frame offsets at frame_base[u]...
