@@ -116,6 +116,8 @@ struct FrameArgs {
   int32_t* num_records;     // [U]
   ScaleParams sp;
   long long* phase_clock;   // [U][8] or null: shader cycles of the frame kernel's phases (KLAT_ACCUM_PROFILE)
+  const int64_t* frame_base;  // [U+1] first frame of every lattice in the batch-wide frame numbering
+  int32_t* frame_count;       // [sum of num_frames] records per frame
 };
 
 hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t stream);

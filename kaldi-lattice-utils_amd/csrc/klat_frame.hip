@@ -304,6 +304,8 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   const int T = a.num_frames[u];
   FKey* keys = reinterpret_cast<FKey*>(a.key_scratch) + a.scratch_off[u];
   FKey* recs = reinterpret_cast<FKey*>(a.rec_scratch) + a.scratch_off[u];
+  uint64_t* rec8 = reinterpret_cast<uint64_t*>(recs);  // the records, 8 bytes each, from the front of the lattice's rows
+  const int64_t fbase = a.frame_base[u];
   FrameArc* ai = a.arc_info + a0;
   const ScaleParams sp = a.sp;
   // the last frame_sort_slots(nA) record rows of the lattice are the cooperative sort's scratch
@@ -627,24 +629,16 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
         fr_sort_regs<kFrRegs, false>(ek, ex);
       int tot;
       const int dst = mbase + fr_block_scan(mk, &tot, sh);
-      const uint64_t frame_hi = (uint64_t)(uint32_t)(f0 + k) << 32;
+      // 8 bytes per record -- desc(float logp) | biased label, the sort key itself -- plus one count per
+      // frame: the frame of a record is implied by the counts (the first version wrote 16-byte rows
+      // carrying the frame number: twice the bytes, written here and read by the gather kernel)
+      if (k < tf) a.frame_count[fbase + f0 + k] = mk;
       if (in_regs) {
 #pragma unroll
         for (int j = 0; j < kFrRegs; ++j)
-          if (j < mk) {
-            FKey r;
-            r.a = frame_hi | (ek[j] >> 32);
-            r.b = (uint32_t)ek[j];  // biased label
-            recs[dst + j] = r;
-          }
+          if (j < mk) rec8[dst + j] = ek[j];
       } else {
-        for (int j = 0; j < mk; ++j) {
-          const uint64_t key = keys[o + j].a;
-          FKey r;
-          r.a = frame_hi | (key >> 32);
-          r.b = (uint32_t)key;
-          recs[dst + j] = r;
-        }
+        for (int j = 0; j < mk; ++j) rec8[dst + j] = keys[o + j].a;
       }
       mbase += tot;
     }
@@ -662,23 +656,27 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
 __global__ __launch_bounds__(256) void frame_gather_kernel(FrameArgs a, const int64_t* entry_off,
                                                            const int64_t* frame_base, int64_t* frame_off,
                                                            int32_t* labels, float* logps) {
+  __shared__ int sh[kFrThreads / 64];
   const int u = blockIdx.x;
-  const FKey* recs = reinterpret_cast<const FKey*>(a.rec_scratch) + a.scratch_off[u];
+  const uint64_t* rec8 = reinterpret_cast<const uint64_t*>(reinterpret_cast<const FKey*>(a.rec_scratch) + a.scratch_off[u]);
   const int64_t o = entry_off[u];
   const int m = (int)(entry_off[u + 1] - o);
   const int64_t fb = frame_base[u];
   const int T = a.num_frames[u];
   for (int i = threadIdx.x; i < m; i += 256) {
-    const FKey r = recs[i];
-    labels[o + i] = fr_unbias((uint32_t)r.b);
-    logps[o + i] = fr_desc_unkey((uint32_t)r.a);
-    const int f = (int)(uint32_t)(r.a >> 32);
-    const int fp = (i == 0) ? -1 : (int)(uint32_t)(recs[i - 1].a >> 32);
-    for (int g = fp + 1; g <= f; ++g) frame_off[fb + g] = o + i;
+    const uint64_t r = rec8[i];
+    labels[o + i] = fr_unbias((uint32_t)r);
+    logps[o + i] = fr_desc_unkey((uint32_t)(r >> 32));
   }
-  if (threadIdx.x == 0) {
-    const int fl = (m == 0) ? -1 : (int)(uint32_t)(recs[m - 1].a >> 32);
-    for (int g = fl + 1; g < T; ++g) frame_off[fb + g] = o + m;
+  // frame offsets: exclusive prefix sums of the per-frame record counts
+  int carry = 0;
+  for (int base = 0; base < T; base += 256) {
+    const int k = base + (int)threadIdx.x;
+    const int c = k < T ? a.frame_count[fb + k] : 0;
+    int tot;
+    const int ex = fr_block_scan(c, &tot, sh);
+    if (k < T) frame_off[fb + k] = o + carry + ex;
+    carry += tot;
   }
 }
 
