@@ -36,14 +36,17 @@ inline StreamCost make_stream_cost(const ScaleParams& sp) {
 // way (its extra slot is unused).
 __host__ __device__ inline int64_t padded_state_base(int64_t state_off_u, int64_t u) { return state_off_u + u; }
 
-// One entry of the table behind the sweep's natural log: interval i of 128 covers mantissas with
-// 2m in [1 + i/128, 1 + (i+1)/128); c is its midpoint.  (128 entries = 2 KiB of LDS: the sweep's
-// workgroup has to stay below 32 KiB for five of them to share a CU.)
+// One entry of the table behind the sweep's natural log: interval i of 16 covers mantissas with
+// 2m in [1 + i/16, 1 + (i+1)/16); c is its midpoint.  (16 entries = 256 B of LDS and a degree-10
+// series, where 128 entries took 2 KiB and degree 6: with the ring's dummy cells shared per lattice a
+// workgroup needs 22 976 B at W = 32 and SEVEN of them fit a CU's 160 KiB -- a batch of 1 564 jobs,
+// the 12 500 x 5 000-state shard, then runs as one wave of workgroups instead of 1 536 + 28, which
+// cost 0.4 ms of 2.2: tools/tail_scan.py.)
 struct __attribute__((aligned(16))) LnTabEntry {
   double inv2;  // 2 / c
   double lnc;   // ln(c / 2)
 };
-static const int kLnTabSize = 128;
+static const int kLnTabSize = 16;
 
 struct SweepArgs {
   const SweepJob* jobs;

@@ -411,7 +411,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
     for (size_t i = 0; i < n; ++i) {
       const int unit = (int)((i / kChunkRounds) % (size_t)(AL * LPW));
       const int lane = (unit % LPW) * G + unit / LPW;
-      P.sw[b0 + i] = (int32_t)(kNil | ((uint32_t)(W * LPW + lane) << kWrShift));
+      P.sw[b0 + i] = (int32_t)(kNil | ((uint32_t)(W * LPW + lane / G) << kWrShift));
     }
     std::fill(P.sg.data() + b0, P.sg.data() + b0 + n, std::numeric_limits<float>::infinity());
     std::memset(&P.sa[b0], 0, n * sizeof(float));
@@ -450,7 +450,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
           if (rel == 1 && nterm < G) w |= kBypass;  // first round: the source was finished just before
         }
         if (word) w |= kWord;
-        if ((w & kFar) == 0) w |= (uint32_t)(W * LPW + lane) << kWrShift;  // dummy cell unless COMMIT (end_pos)
+        if ((w & kFar) == 0) w |= (uint32_t)(W * LPW + lane / G) << kWrShift;  // the lattice's dummy cell unless COMMIT (end_pos)
         const size_t ix = slot_index(rr, lane);
         P.sw[ix] = (int32_t)w;
         P.sg[ix] = nil ? std::numeric_limits<float>::infinity() : g;

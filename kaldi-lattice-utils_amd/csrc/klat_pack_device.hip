@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kT) void pack_fill_kernel(PackDevArgs a) {
   auto slot_index = [&](int rr, int lane) -> int64_t {
     return stream_slot(job.chunk_off, G, AL, rr / kChunkRounds, lane, rr % kChunkRounds);
   };
-  auto pad_word = [&](int lane) -> uint32_t { return kNil | ((uint32_t)(W * LPW + lane) << kWrShift); };
+  auto pad_word = [&](int lane) -> uint32_t { return kNil | ((uint32_t)(W * LPW + lane / G) << kWrShift); };
   auto put = [&](int rr, int lane, uint32_t w, float g, float ac) {
     if (lane - lane0 >= AL) return;  // not stored: the kernel makes this lane's padding up itself
     const int64_t ix = slot_index(rr, lane);
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kT) void pack_fill_kernel(PackDevArgs a) {
         if (rel == 1 && j < G) w |= kBypass;
       }
       if (word) w |= kWord;
-      if (!far) w |= (uint32_t)(W * LPW + lane) << kWrShift;
+      if (!far) w |= (uint32_t)(W * LPW + lane / G) << kWrShift;
       if (rr == r) w |= kFirst;
       if (rr == r + nr - 1) {
         w |= kLast;

@@ -83,25 +83,29 @@ __device__ __forceinline__ void consumer_barrier() {
 // a quarter of the banks -- the kernel ran with LDS 57 % busy, two thirds of it bank conflicts
 // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE); the split arrays spread a wave's cells over all banks.
 
-// ln(m * 2^e) for a normalised mantissa m in [0.5,1) (or 0 = log-zero) with a 128-entry table in
-// LDS instead of the library log (~50 instructions): 2m = c_i * (1 + r), |r| <= 1/256, and
-// log1p(r) by its degree-6 series (next term < 2e-18).  The series runs as one block of
+// ln(m * 2^e) for a normalised mantissa m in [0.5,1) (or 0 = log-zero) with a 16-entry table in
+// LDS instead of the library log (~50 instructions): 2m = c_i * (1 + r), |r| <= 1/32, and
+// log1p(r) by its degree-10 series (next term < 3e-18).  The series runs as one block of
 // v_fma_f64 with its constants in scalar registers or inline (see arc_weight).
 // The table read is a separate step so that callers can overlap its LDS latency with other work.
 __device__ __forceinline__ int ln_table_index(double m) {
-  return (__double2hiint(m) >> 13) & (kLnTabSize - 1);  // top seven mantissa bits
+  return (__double2hiint(m) >> 16) & (kLnTabSize - 1);  // top four mantissa bits
 }
 __device__ __forceinline__ double table_ln(double m, int e, const LnTabEntry& t) {
   const double r = fma(m, t.inv2, -1.0);
-  const double c6 = -1.0 / 6.0;
+  const double c10 = -0.1;
   double p, v;
   asm("v_fma_f64 %0, %1, %2, %3\n\t"
       "v_fma_f64 %0, %0, %2, %4\n\t"
       "v_fma_f64 %0, %0, %2, %5\n\t"
+      "v_fma_f64 %0, %0, %2, %6\n\t"
+      "v_fma_f64 %0, %0, %2, %7\n\t"
+      "v_fma_f64 %0, %0, %2, %8\n\t"
+      "v_fma_f64 %0, %0, %2, %9\n\t"
       "v_fma_f64 %0, %0, %2, -0.5\n\t"
       "v_fma_f64 %0, %0, %2, 1.0"
       : "=&v"(p)
-      : "v"(c6), "v"(r), "s"(0.2), "s"(-0.25), "s"(1.0 / 3.0));
+      : "v"(c10), "v"(r), "s"(1.0 / 9.0), "s"(-0.125), "s"(1.0 / 7.0), "s"(-1.0 / 6.0), "s"(0.2), "s"(-0.25), "s"(1.0 / 3.0));
   const double lnm = fma(p, r, t.lnc);
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(v) : "v"((double)e), "s"(kLn2), "v"(lnm));
   return select64(lane_mask(m == 0.0), -INFINITY, v);
@@ -172,9 +176,10 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   const int W = args.ring_slots;
   if (!FAST && args.job_flags[blockIdx.x] == 0) return;  // workgroup-uniform
 
-  // ring cells [W][LPW] plus 64 dummy cells (one per lane), mantissas and exponents in separate
+  // ring cells [W][LPW] plus LPW dummy cells (one per lattice: its lanes without a state to commit
+  // all write there; nothing reads it), mantissas and exponents in separate
   // arrays (see RingLayout); then the stage buffers [2][CPB][4][64]
-  const int ncell = W * LPW + 64;
+  const int ncell = W * LPW + LPW;  // ring cells + one dummy cell per lattice slot
   double* ringM = smem;
   int32_t* ringE = reinterpret_cast<int32_t*>(smem + ncell);
   StagedTerm* stage = reinterpret_cast<StagedTerm*>(ringE + ncell);
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           if (last && sub == 0)
             ctl |= kCommit | ((uint32_t)((p & (W - 1)) * LPW + slot) << kWrShift);
           else
-            ctl |= (uint32_t)(W * LPW + lane) << kWrShift;  // the lane's dummy cell
+            ctl |= (uint32_t)(W * LPW + slot) << kWrShift;  // the lattice's dummy cell
         }
         if (TROPICAL) {
           t.wm = (c < 1.0e30) ? c : INFINITY;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           *dst = v;
         }
       };
-      const uint32_t pad_w = kNil | ((uint32_t)(W * LPW + lane) << kWrShift);
+      const uint32_t pad_w = kNil | ((uint32_t)(W * LPW + slot) << kWrShift);
       const uint64_t unstored = lane_mask(!stored);
       auto stage_chunk = [&](int cj, int4 w4, float4 g4, const float4& a4, const double (&v)[4]) {
         // stage buffer: [barrier period parity][chunk within the period][round][lane]
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 }
 
 static size_t sweep_lds_bytes(int ring_slots, int LPW, int cpb) {
-  return ((size_t)ring_slots * LPW + 64) * (sizeof(double) + sizeof(int32_t)) +
+  return ((size_t)ring_slots * LPW + LPW) * (sizeof(double) + sizeof(int32_t)) +
          (size_t)2 * cpb * 256 * sizeof(StagedTerm) + kLnTabSize * sizeof(LnTabEntry);
 }
 

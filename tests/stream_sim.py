@@ -54,7 +54,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
         d = int(job["dir"])
         G, W = (int(job["tag"]) >> 8) & 0xFF, (int(job["tag"]) >> 16) & 0xFFF  # the job's layout class
         LPW = 64 // G
-        assert W * LPW + 64 <= CELL_MASK + 1
+        assert W * LPW + LPW <= CELL_MASK + 1
         ring = {}  # cell index -> (m, e); shared by the job's lattices like the LDS ring
         for slot in range(LPW):
             li = packed["lanes"][int(job["lane_tab"]) + slot]
@@ -79,7 +79,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                     if base < 0 or p >= npos:
                         assert w & NIL and not (w & (LAST | FIRST | COMMIT | FAR)), "padding must be plain NIL"
                         assert sg[ix] == np.inf, "NIL terms carry an infinite graph cost"
-                        assert (w >> WR_SHIFT) & CELL_MASK == W * LPW + lane
+                        assert (w >> WR_SHIFT) & CELL_MASK == W * LPW + lane // G
                         continue
                     assert bool(w & FIRST) == (nround == 0), "FIRST marks exactly the first round of a state"
                     c = _cost(sg[ix], sa[ix], bool(w & WORD), graph_scale, acoustic_scale, insertion_penalty)
@@ -122,7 +122,7 @@ def run(packed, state_off, graph_scale=1.0, acoustic_scale=1.0, insertion_penalt
                         assert sub == 0 and (w & LAST)
                         commit = (w >> WR_SHIFT) & CELL_MASK
                     elif not (w & FAR):
-                        assert (w >> WR_SHIFT) & CELL_MASK == W * LPW + lane, "non-commit lanes write their dummy cell"
+                        assert (w >> WR_SHIFT) & CELL_MASK == W * LPW + lane // G, "non-commit lanes write their lattice's dummy cell"
                     elif (w & LAST) and sub == 0:
                         assert w & FAR, "the first lane of a LAST round commits (FAR terms: resolved by the kernel)"
                         commit = (p & (W - 1)) * LPW + slot
