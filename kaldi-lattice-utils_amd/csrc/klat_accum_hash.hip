@@ -266,14 +266,17 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
     seen[j] = kEmpty;
     if (valid & (1u << j)) seen[j] = atomicCAS(&table[slot[j]], kEmpty, mine);
   }
-  // a second batch for the arcs whose home slot was taken by another key's fingerprint: the next slot
+  // three more batches for the arcs whose slot was taken by another key's fingerprint: the next slots
 #pragma unroll
-  for (int j = 0; j < kPerThread; ++j) {
-    const uint64_t hsh = key[j] * 0x9E3779B97F4A7C15ull;
-    const uint32_t fp = (uint32_t)(hsh >> (64 - LOGH - 18)) & 0x3FFFFu;
-    if (seen[j] != kEmpty && (seen[j] >> 14) != fp) {
-      slot[j] = (slot[j] + 1) & (H - 1);
-      seen[j] = atomicCAS(&table[slot[j]], kEmpty, (fp << 14) | (uint32_t)(j * T + tid));
+  for (int round = 0; round < 3; ++round) {
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      const uint64_t hsh = key[j] * 0x9E3779B97F4A7C15ull;
+      const uint32_t fp = (uint32_t)(hsh >> (64 - LOGH - 18)) & 0x3FFFFu;
+      if (seen[j] != kEmpty && (seen[j] >> 14) != fp) {
+        slot[j] = (slot[j] + 1) & (H - 1);
+        seen[j] = atomicCAS(&table[slot[j]], kEmpty, (fp << 14) | (uint32_t)(j * T + tid));
+      }
     }
   }
   // the few left: linear probing from there; a fingerprint match is checked against the inserter's
