@@ -145,10 +145,12 @@ def median(xs):
     return float(np.median(np.asarray(xs, dtype=np.float64))) if len(xs) else 0.0
 
 
-def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=10, wide=0):
-    """sweep / step time of one more batch shape on this GPU (medians over `steps` steps)."""
+def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=10, wide=0, lanes=0):
+    """sweep / step time of one more batch shape on this GPU (medians over `steps` steps).  A batch
+    of few lattices that are far wider than deep runs on the level path (klat_level.hip); for such
+    a batch the time through the streams (lanes fixed by the caller) is reported beside it."""
     arrays = klat_amd.synth(seed, ns, fo, host_threads=host_threads, wide=wide)
-    b = klat_amd.Batch(ctx, arrays, host_threads=host_threads)
+    b = klat_amd.Batch(ctx, arrays, host_threads=host_threads, lanes_per_lattice=lanes)
     info = b.info()
     depth = b.topological_depth()
     for _ in range(warm):
@@ -170,6 +172,10 @@ def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=1
            "step_frac": (56.0 * A + 48.0 * S) / (step * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "fwd_bwd_totals_agree": ok}
     b.close()
+    if info["level_lattices"] and lanes == 0:
+        out["level_lattices"] = info["level_lattices"]
+        through = time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps, warm, wide, lanes=4)
+        out["streams_instead"] = {k: through[k] for k in ("sweep_ms", "step_ms", "lanes_per_lattice", "max_rounds")}
     return out
 
 
@@ -477,7 +483,9 @@ def main():
                  np.full(12500, 5000, np.int32), np.full(12500, 3, np.int32), 0),
                 ("C5/8 shard (configs[4] mix): 2500 lattices, 200..20000 states log-uniform, fanout {2,3,4,6}", 20260004, c5n, c5f, 0),
                 ("wide: 10000 lattices x 2000 states x fanout 3 in levels of 32 states (depth ~63)", 20260005,
-                 np.full(10000, 2000, np.int32), np.full(10000, 3, np.int32), 32)):
+                 np.full(10000, 2000, np.int32), np.full(10000, 3, np.int32), 32),
+                ("few and wide: 64 lattices x 2000 states x fanout 3 in levels of 64 states (depth ~32), the level path", 20260006,
+                 np.full(64, 2000, np.int32), np.full(64, 3, np.int32), 64)):
             try:
                 shapes.append(time_shape(ctx, klat_amd, name, seed, sn, sf, host_threads, wide=wide))
             except Exception as e:  # a shape that fails must not take the headline with it

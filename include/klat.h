@@ -91,7 +91,7 @@ typedef struct {
   int32_t num_jobs;                   /* workgroups launched by the sweep kernel */
   int32_t max_rounds;                 /* longest lockstep stream, in rounds */
   int32_t num_layouts;                /* layout classes (distinct lanes_per_lattice) = sweep launches */
-  int32_t reserved;
+  int32_t level_lattices;             /* lattices on the level-synchronous path (wide lattices; no stream job) */
 } klat_batch_info;
 
 /* Per-kernel device times of the last klat_forward_backward (HIP events on the ctx stream). */
@@ -109,7 +109,10 @@ const char* klat_version(void);
 int klat_device_count(int* count);
 
 int klat_ctx_create(int device, klat_ctx** out);
+/* The handle is gone after this call; the stream and the recycled device blocks behind it live on
+ * until the last batch created on the context is destroyed (batches may outlive their context). */
 void klat_ctx_destroy(klat_ctx* ctx);
+void klat_ctx_retain(klat_ctx* ctx);  /* one more owner (libklat_dist's communicators); paired with klat_ctx_destroy */
 int klat_ctx_sync(klat_ctx* ctx);
 /* the ctx's hipStream_t, for callers that enqueue their own work or events behind it */
 void* klat_ctx_stream(klat_ctx* ctx);

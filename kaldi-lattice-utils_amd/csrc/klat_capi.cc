@@ -16,6 +16,7 @@
 
 #include "../../include/klat.h"
 #include "klat_internal.h"
+#include "klat_level.h"
 #include "klat_pack_device.h"
 
 namespace klat {
@@ -68,6 +69,23 @@ static int for_each_class(klat_batch* b, F launch) {
     KLAT_HIP(hipStreamWaitEvent(c->stream, c->join_ev[i], 0));
   }
   return KLAT_OK;
+}
+
+// the lattices on the level-synchronous path (klat_level.hip), on the context's stream
+static hipError_t launch_level(klat_batch* b, double* fwd, double* bwd, const ScaleParams& sp, bool tropical) {
+  LevelSweepArgs la;
+  la.lattices = b->lv_lattices.p;
+  la.state_off = b->state_off.p;
+  la.arc_off = b->arc_off.p;
+  la.final_graph = b->final_graph.p;
+  la.final_acoustic = b->final_acoustic.p;
+  la.records = b->lv_records.p;
+  la.stream_off = b->lv_stream_off.p;
+  la.stream = b->lv_stream.p;
+  la.alpha = fwd;
+  la.beta = bwd;
+  la.sp = sp;
+  return launch_level_sweep(la, b->num_level, b->level_max_states, tropical, b->ctx->stream);
 }
 
 // kernel times of step `step` of the context (its events are in the ring)
@@ -143,8 +161,8 @@ int klat_ctx_create(int device, klat_ctx** out) {
   return KLAT_OK;
 }
 
-void klat_ctx_destroy(klat_ctx* c) {
-  if (!c) return;
+static void ctx_release(klat_ctx* c) {
+  if (c->refs.fetch_sub(1) != 1) return;  // batches (or a communicator) still use its stream
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < klat_ctx::kTimingSlots * 4; ++i)
@@ -157,6 +175,16 @@ void klat_ctx_destroy(klat_ctx* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   c->pool.clear();
   delete c;
+}
+
+void klat_ctx_destroy(klat_ctx* c) {
+  if (!c) return;
+  ctx_release(c);
+}
+
+// for libklat_dist: a communicator keeps its context's stream alive the same way
+void klat_ctx_retain(klat_ctx* c) {
+  if (c) c->refs.fetch_add(1);
 }
 
 int klat_ctx_sync(klat_ctx* c) {
@@ -221,6 +249,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   klat_batch* b = new (std::nothrow) klat_batch();
   if (!b) return set_error(KLAT_ERR_OOM, "host allocation failed");
   b->ctx = c;
+  c->refs.fetch_add(1);
   b->U = U;
   b->S = S_tot;
   b->A = A_tot;
@@ -310,9 +339,79 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
            "lattice " + std::to_string(h_status[1]) +
                (h_status[0] == 2 ? ": arc with dst <= src or out of range (lattice is not topologically sorted)"
                                  : ": malformed CSR (state ids out of range or arcs not grouped by source)"));
+    // Lattices whose topological depth is far below their states take the level-synchronous path
+    // (klat_level.hip) instead of a stream: Kahn's levels on the device, the choice on the host.
+    // Only with the automatic layout (a caller that fixes the lanes asks for streams).
+    std::vector<uint8_t> on_level((size_t)U, 0);
+    DevBuf<int32_t> order, lvoff, row, depth;  // level planning's tables, until the level streams are written
+    int64_t lv_blocks = 0;
+    // KLAT_LEVEL=0 keeps every lattice on the streams, KLAT_LEVEL=1 sends every lattice that qualifies
+    // to the level path; by default the level path takes them when they fit the chip in ONE round of
+    // waves (its wave is faster than a stream for a lone lattice, and slower per lattice in bulk).
+    const char* level_env = std::getenv("KLAT_LEVEL");
+    const int level_mode = level_env == nullptr ? -1 : std::atoi(level_env);
+    if (o.lanes_per_lattice == 0 && level_mode != 0 && U > 0) {
+      DevBuf<int32_t> counters, records;
+      if ((rc = counters.alloc((size_t)(S_tot + 2 * U))) || (rc = order.alloc((size_t)S_tot)) || (rc = lvoff.alloc((size_t)(S_tot + 2 * U))) ||
+          (rc = row.alloc((size_t)(S_tot + 2 * U))) || (rc = depth.alloc((size_t)U)) || (rc = records.alloc((size_t)U))) {
+        klat_batch_destroy(b);
+        return rc;
+      }
+      LevelPlanArgs lp;
+      lp.state_off = b->state_off.p;
+      lp.arc_off = b->arc_off.p;
+      lp.src = b->src.p;
+      lp.dst = b->dst.p;
+      lp.cnt = cnt.p;
+      lp.counters = counters.p;
+      lp.order = order.p;
+      lp.level_off = lvoff.p;
+      lp.out_begin = row.p;
+      lp.depth = depth.p;
+      lp.records = records.p;
+      std::vector<int32_t> h_depth((size_t)U), h_records((size_t)U);
+      he = launch_level_plan(lp, (int)U, c->stream);
+      if (he == hipSuccess) he = hipMemcpyAsync(h_depth.data(), depth.p, sizeof(int32_t) * (size_t)U, hipMemcpyDeviceToHost, c->stream);
+      if (he == hipSuccess) he = hipMemcpyAsync(h_records.data(), records.p, sizeof(int32_t) * (size_t)U, hipMemcpyDeviceToHost, c->stream);
+      if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+      if (he != hipSuccess) {
+        klat_batch_destroy(b);
+        return hip_fail(he, "level planning");
+      }
+      std::vector<int32_t> lv;
+      std::vector<int64_t> lv_first;  // first block of every level stream
+      for (int64_t u = 0; u < U; ++u)
+        if (h_depth[(size_t)u] > 0) {
+          on_level[(size_t)u] = 1;
+          lv.push_back((int32_t)u);
+          b->level_max_states = std::max<int32_t>(b->level_max_states, (int32_t)(d->state_off[u + 1] - d->state_off[u]));
+          lv_first.push_back(lv_blocks);
+          lv_blocks += (level_stream_dwords(h_records[(size_t)u], d->state_off[u + 1] - d->state_off[u], d->arc_off[u + 1] - d->arc_off[u]) +
+                        kLevelBlockDwords - 1) / kLevelBlockDwords;
+        }
+      if (!lv.empty() && level_mode < 0) {
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const size_t per_cu = (size_t)160 * 1024 / level_sweep_lds_bytes(b->level_max_states);
+        if (lv.size() > per_cu * (size_t)cus) {  // more than one round of waves: the streams are the faster path
+          lv.clear();
+          std::fill(on_level.begin(), on_level.end(), 0);
+          b->level_max_states = 0;
+        }
+      }
+      if (!lv.empty()) {  // keep what the level sweep reads; the count pass's tables go with it
+        b->num_level = (int32_t)lv.size();
+        if ((rc = b->lv_lattices.upload(lv.data(), lv.size(), c->stream)) || (rc = b->lv_stream_off.upload(lv_first.data(), lv_first.size(), c->stream))) {
+          klat_batch_destroy(b);
+          return rc;
+        }
+        KLAT_HIP(hipStreamSynchronize(c->stream));
+        b->lv_records.take(records);
+      }
+    }
     // the plan: lanes per lattice, layout classes, jobs
     std::vector<int8_t> lat_g;
-    plan_layout(U, d->state_off, d->arc_off, h_rounds.data(), o, &lat_g);
+    plan_layout(U, d->state_off, d->arc_off, h_rounds.data(), o, &lat_g, on_level.data());
     std::vector<std::vector<int64_t>> job_lats;
     int64_t chunk_total = 0;
     rc = build_jobs(U, d->state_off, h_rounds.data(), lat_g, o, &P, &job_lats, &chunk_total, &err);
@@ -348,6 +447,37 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       return hip_fail(he, "stream packing (fill pass)");
     }
     P.far_terms = h_status[3];
+    if (b->num_level > 0) {  // the level streams: the arcs as the level sweep consumes them
+      if ((rc = b->lv_stream.alloc((size_t)lv_blocks * kLevelBlockDwords))) {
+        klat_batch_destroy(b);
+        return rc;
+      }
+      LevelBuildArgs lb;
+      lb.lattices = b->lv_lattices.p;
+      lb.state_off = b->state_off.p;
+      lb.arc_off = b->arc_off.p;
+      lb.src = b->src.p;
+      lb.dst = b->dst.p;
+      lb.ilabel = b->ilabel.p;
+      lb.graph = b->graph.p;
+      lb.acoustic = b->acoustic.p;
+      lb.final_graph = b->final_graph.p;
+      lb.final_acoustic = b->final_acoustic.p;
+      lb.cnt = cnt.p;
+      lb.in_arc = in_arc.p;
+      lb.order = order.p;
+      lb.level_off = lvoff.p;
+      lb.out_begin = row.p;
+      lb.depth = depth.p;
+      lb.stream_off = b->lv_stream_off.p;
+      lb.stream = b->lv_stream.p;
+      he = launch_level_build(lb, b->num_level, c->stream);
+      if (he == hipSuccess) he = hipStreamSynchronize(c->stream);  // the planning tables go out of scope below
+      if (he != hipSuccess) {
+        klat_batch_destroy(b);
+        return hip_fail(he, "level streams");
+      }
+    }
     for (int64_t u = 0; u < U; ++u)
       for (int64_t a0 = d->arc_off[u]; a0 < d->arc_off[u + 1]; a0 += kPostItemArcs)
         P.items.push_back(PostItem{a0, (int32_t)std::min<int64_t>(kPostItemArcs, d->arc_off[u + 1] - a0), (int32_t)u});
@@ -367,6 +497,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   b->info.num_jobs = b->num_jobs;
   b->info.max_rounds = P.max_rounds;
   b->info.num_layouts = (int32_t)P.classes.size();
+  b->info.level_lattices = b->num_level;  // lattices on the level-synchronous path
   if (host_pack) UP(jobs, P.jobs.data(), P.jobs.size());
   UP(lanes, P.lanes.data(), P.lanes.size());
   UP(items, P.items.data(), P.items.size());
@@ -392,12 +523,16 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
 
 void klat_batch_destroy(klat_batch* b) {
   if (!b) return;
-  (void)hipSetDevice(b->ctx->device);
-  (void)hipStreamSynchronize(b->ctx->stream);
-  PoolScope pool_scope(&b->ctx->pool);
-  for (hipEvent_t e : {b->accum.ev[0], b->accum.ev[1], b->frame.ev[0], b->frame.ev[1]})
-    if (e) (void)hipEventDestroy(e);
-  delete b;
+  klat_ctx* c = b->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  {
+    PoolScope pool_scope(&c->pool);
+    for (hipEvent_t e : {b->accum.ev[0], b->accum.ev[1], b->frame.ev[0], b->frame.ev[1]})
+      if (e) (void)hipEventDestroy(e);
+    delete b;
+  }
+  ctx_release(c);  // the context itself goes with its last batch if its handle was destroyed first
 }
 
 int klat_batch_get_info(const klat_batch* b, klat_batch_info* info) {
@@ -487,7 +622,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   // sweep_ms of a one-class batch is the fast sweep kernel alone (what rocprofv3 lists under its
   // name): the events sit right around its launch.  The exact sweep's launch after it (all of its
   // workgroups exit at once unless the fast sweep flagged a job) falls to totals_ms.
-  const bool one_class = b->classes.size() == 1;
+  const bool one_class = b->classes.size() == 1 && b->num_level == 0;
   hipEvent_t* ev = c->evring[c->steps % klat_ctx::kTimingSlots];
   for (int i = 0; i < 4; ++i)
     if (!ev[i]) KLAT_HIP(hipEventCreate(&ev[i]));
@@ -495,6 +630,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   b->accum.cached_mode = b->accum.dense_mode = 0;
   b->frame.ready = false;
   if (!one_class) KLAT_HIP(hipEventRecord(ev[0], c->stream));
+  if (b->num_level > 0) KLAT_HIP(launch_level(b, b->alpha.p, b->beta.p, sp, false));
   {
     const int rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
       SweepArgs ca = sa;
@@ -556,6 +692,7 @@ int klat_viterbi(klat_batch* b, const klat_scales* sc) {
   va.sc = make_stream_cost(va.sp);
   va.ring_slots = 0;
   va.far_prefetch = 0;
+  if (b->num_level > 0) KLAT_HIP(launch_level(b, b->fwd_cost.p, b->bwd_cost.p, va.sp, true));
   rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
     SweepArgs ca = va;
     ca.jobs = va.jobs + lc.job_begin;

@@ -200,11 +200,13 @@ int klat_comm_create_rccl(klat_ctx* ctx, int32_t rank, int32_t world, const void
   c->world = world;
   c->rccl = true;
   c->ctx = ctx;
+  klat_ctx_retain(ctx);  // the communicator works on the context's stream
   c->stream = static_cast<hipStream_t>(klat_ctx_stream(ctx));
   c->meta_dev.device = c->records.device = c->counts.device = c->send_counts.device = true;
   hipError_t e = hipGetDevice(&c->device);  // klat_ctx_create left the calling thread on the context's device
   if (e != hipSuccess) {
     delete c;
+    klat_ctx_destroy(ctx);
     return hip_err(e, "hipGetDevice");
   }
   ncclUniqueId u;
@@ -212,6 +214,7 @@ int klat_comm_create_rccl(klat_ctx* ctx, int32_t rank, int32_t world, const void
   ncclResult_t r = ncclCommInitRank(&c->nccl, world, u, rank);
   if (r != ncclSuccess) {
     delete c;
+    klat_ctx_destroy(ctx);
     return nccl_err(r, "ncclCommInitRank");
   }
   *out = c;
@@ -253,7 +256,9 @@ void klat_comm_destroy(klat_comm* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->nccl) (void)ncclCommDestroy(c->nccl);
   }
-  delete c;
+  klat_ctx* ctx = c->rccl ? c->ctx : nullptr;
+  delete c;  // (its device buffers first)
+  if (ctx) klat_ctx_destroy(ctx);
 }
 
 int klat_gather_records(klat_comm* c, const void* records, int32_t record_bytes, const int64_t* record_off,

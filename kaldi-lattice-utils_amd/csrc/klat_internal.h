@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -13,6 +14,7 @@
 #include "klat_device.h"
 #include "klat_accum.h"
 #include "klat_kernels.h"
+#include "klat_level.h"
 #include "klat_pack.h"
 
 namespace klat {
@@ -113,6 +115,12 @@ struct DevBuf {
     cap = want;
     return KLAT_OK;
   }
+  void take(DevBuf& o) {  // steals o's block
+    release();
+    p = o.p, n = o.n, cap = o.cap, pool = o.pool;
+    o.p = nullptr;
+    o.n = o.cap = 0;
+  }
   int upload(const T* host, size_t count, hipStream_t s) {
     int rc = alloc(count);
     if (rc != KLAT_OK) return rc;
@@ -128,6 +136,11 @@ struct DevBuf {
 }  // namespace klat
 
 struct klat_ctx {
+  // A context lives until its handle AND every batch created on it are gone: a caller that destroys
+  // the context first (a test fixture torn down while a failed test still holds its batch, an exit
+  // handler closing things in the wrong order) must not leave the batches with a dangling stream --
+  // that ended in `std::bad_variant_access` out of the HIP runtime, or in a hang, at process exit.
+  std::atomic<int> refs{1};
   int device = 0;
   hipStream_t stream = nullptr;
   // timing events of the last kTimingSlots calls of klat_forward_backward on this context (a ring:
@@ -204,6 +217,10 @@ struct klat_batch {
   klat::DevBuf<float> final_graph, final_acoustic;
   bool viterbi_done = false;
   klat_scales viterbi_scales = {1.f, 1.f, 0.f};
+  // lattices on the level-synchronous path (klat_level.hip): not in any stream job
+  int32_t num_level = 0, level_max_states = 0;
+  klat::DevBuf<int32_t> lv_lattices, lv_records, lv_stream;
+  klat::DevBuf<int64_t> lv_stream_off;
 };
 
 #endif

@@ -122,20 +122,20 @@ PlanCost plan_cost(int64_t U, const LatticeRounds* lr, const std::vector<int8_t>
 }  // namespace
 
 void plan_layout(int64_t U, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* lr,
-                 const klat_pack_options& opt, std::vector<int8_t>* lat_g) {
+                 const klat_pack_options& opt, std::vector<int8_t>* lat_g, const uint8_t* skip) {
   std::vector<int8_t>& g = *lat_g;
   g.assign((size_t)U, -1);
   if (opt.lanes_per_lattice != 0) {
     int k = 0;
     while ((1 << k) < opt.lanes_per_lattice) ++k;
     for (int64_t u = 0; u < U; ++u)
-      if (state_off[u + 1] > state_off[u]) g[(size_t)u] = (int8_t)k;
+      if (state_off[u + 1] > state_off[u] && !(skip && skip[u])) g[(size_t)u] = (int8_t)k;
     return;
   }
   double jobs = 0;
   for (int64_t u = 0; u < U; ++u) {
     const int64_t S = state_off[u + 1] - state_off[u], A = arc_off[u + 1] - arc_off[u];
-    if (S <= 0) continue;
+    if (S <= 0 || (skip && skip[u])) continue;
     const double fan = (double)A / (double)S;
     int k = 0;
     while ((1 << k) < fan && k < kNumLaneChoices - 1) ++k;

@@ -69,7 +69,8 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
 // by round count, 64/G per job, longest first), fills out->classes / jobs / lanes / slot totals /
 // max_rounds and returns the number of chunks and, per job, its lattices in slot order.
 void plan_layout(int64_t num_lattices, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* rounds,
-                 const klat_pack_options& opt, std::vector<int8_t>* lat_g);
+                 const klat_pack_options& opt, std::vector<int8_t>* lat_g,
+                 const uint8_t* skip = nullptr /* [num_lattices] lattices that take no stream (level path) */);
 int build_jobs(int64_t num_lattices, const int64_t* state_off, const LatticeRounds* rounds, const std::vector<int8_t>& lat_g,
                const klat_pack_options& opt, PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats,
                int64_t* chunk_total, std::string* err);

@@ -150,3 +150,32 @@ def test_b2_mirror_from_worker_threads(tmp_path, golden_dir):
         assert f[0] == "utt%07d" % u
         assert abs(float(f[1]) - wt[u]) <= 1e-8 * max(1.0, abs(wt[u]))
         assert abs(float(f[3]) - wb[arrays["state_off"][u]]) <= 1e-8 * max(1.0, abs(wt[u]))
+
+
+OUTLIVE = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(%(root)r, "kaldi-lattice-utils_amd", "python"))
+    import klat_amd
+    ns = np.full(64, 300, np.int32); fo = np.full(64, 3, np.int32)
+    ctx = klat_amd.Ctx(0)
+    b = klat_amd.Batch(ctx, klat_amd.synth(1, ns, fo))
+    b.forward_backward(1.0, 0.1, 0.0)
+    ctx.close()                      # the context's handle goes first ...
+    t = b.totals()[0]                # ... the batch still works on its stream
+    assert np.all(np.isfinite(t))
+    b2 = klat_amd.Batch(klat_amd.Ctx(0), klat_amd.synth(2, ns, fo))
+    print("OUTLIVE_DONE", flush=True)   # b and b2 are closed by the exit handler, b2 after its (collected) context
+""")
+
+
+def test_a_batch_may_outlive_its_context(tmp_path):
+    """The abort at exit round 1 saw (`std::bad_variant_access` out of the HIP runtime) was a batch
+    destroyed after its context -- a test fixture torn down while a failed test's traceback still
+    held the batch, a dangling stream in klat_batch_destroy.  A context now lives until its last
+    batch is gone."""
+    script = tmp_path / "outlive.py"
+    script.write_text(OUTLIVE % {"root": ROOT})
+    for attempt in range(2):
+        p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "OUTLIVE_DONE" in p.stdout and "terminate" not in p.stderr, (p.returncode, p.stdout[-300:], p.stderr[-2000:])
