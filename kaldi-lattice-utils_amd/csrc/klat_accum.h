@@ -121,7 +121,7 @@ struct FrameArgs {
 };
 
 hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t stream);
-hipError_t launch_frame(const FrameArgs& a, int num_lattices, hipStream_t stream);
+hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream);
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
                                const int64_t* frame_base, int64_t* frame_off, int32_t* labels, float* logps,
                                hipStream_t stream);

@@ -383,7 +383,9 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       KLAT_HIP(hipMemsetAsync(d_clock.p, 0, sizeof(long long) * (size_t)b->U * 8, c->stream));
       a.phase_clock = d_clock.p;
     }
-    KLAT_HIP(launch_frame(a, (int)b->U, c->stream));
+    int64_t fr_max_arcs = 0;
+    for (int64_t u = 0; u < b->U; ++u) fr_max_arcs = std::max(fr_max_arcs, b->h_arc_off[u + 1] - b->h_arc_off[u]);
+    KLAT_HIP(launch_frame(a, (int)b->U, (int)std::min<int64_t>(fr_max_arcs, 1 << 30), c->stream));
     if (a.phase_clock) {
       std::vector<long long> clk((size_t)b->U * 8);
       KLAT_HIP(hipMemcpyAsync(clk.data(), d_clock.p, sizeof(long long) * clk.size(), hipMemcpyDeviceToHost, c->stream));

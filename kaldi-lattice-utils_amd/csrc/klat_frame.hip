@@ -37,7 +37,9 @@ static constexpr int kFrTile = 2048;    // 16-byte keys per LDS tile of the coop
 static constexpr int kFrRegs = 16;      // bucket entries a frame's thread sorts in registers
 static constexpr int kFrBigList = 64;
 static constexpr int kFrTileFrames = 1920;  // frames whose counters live in LDS at a time (15 KiB; two workgroups per CU)
-static constexpr int kFrLdsEntries = 20480; // bucket entries of a tile kept in LDS as 16-bit arc numbers (40 KiB, over the sort tile)
+static constexpr int kFrLdsEntries = 16384; // bucket entries of a tile kept in LDS as 16-bit arc numbers (32 KiB, over the sort tile)
+static constexpr int kFrSpanBatch = 8;      // arcs a thread loads together in the span pass
+static constexpr int kFrLdsSpans = 6144;    // arcs whose clipped spans stay in LDS as two 16-bit frame numbers (24 KiB: two workgroups per CU)
 
 __device__ __forceinline__ double fr_log_add(double x, double y) {
   double diff;
@@ -155,6 +157,26 @@ __device__ int fr_block_scan(int v, int* total, int* sh /* [kFrThreads/64] */) {
   __syncthreads();
   *total = tot;
   return pre + inc - v;
+}
+
+// the same for two ints per thread at once (one pair of barriers)
+__device__ int2 fr_block_scan2(int v, int w, int* total_v, int* total_w, int* sh /* [2 * kFrThreads/64] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int iv = v, iw = w;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(iv, off, 64), x = __shfl_up(iw, off, 64);
+    if (lane >= off) iv += t, iw += x;
+  }
+  if (lane == 63) sh[wave] = iv, sh[kFrThreads / 64 + wave] = iw;
+  __syncthreads();
+  int pv = 0, tv = 0, pw = 0, tw = 0;
+  for (int k = 0; k < kFrThreads / 64; ++k) {
+    if (k < wave) pv += sh[k], pw += sh[kFrThreads / 64 + k];
+    tv += sh[k], tw += sh[kFrThreads / 64 + k];
+  }
+  __syncthreads();
+  *total_v = tv, *total_w = tw;
+  return make_int2(pv + iv - v, pw + iw - w);
 }
 
 // clipped frame span of arc i of lattice u (0 for epsilon / empty spans)
@@ -286,14 +308,21 @@ __device__ __forceinline__ int fr_fold_bucket(int w, Entry E) {
   return m;
 }
 
-__global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
+__global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
   FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrTile]: the cooperative sort's tile
   uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kFrLdsEntries]: a tile's buckets as arc numbers (same memory)
+  // [span_cap]: k0 | k1 << 16 of every arc -- the two passes over all arcs that every tile makes
+  // (counts, scatter) read 4 bytes of LDS instead of a 16-byte row of L2 behind a dependent loop
+  uint32_t* lspan = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * kFrLdsEntries);
   __shared__ int tile_max, lab_min, lab_max;
-  __shared__ int lboff[kFrTileFrames + 1];  // first expansion of every frame of the tile (tile-local)
+  // Only the frames at which some arc starts or ends (and the tile's first) differ from the frame
+  // before them: those CHANGED frames get a bucket, the others repeat their predecessor's records.
+  __shared__ uint16_t cidx[kFrTileFrames + 2];    // changed frames before frame k of the tile (cidx[tf] = their number)
+  __shared__ uint16_t cframe[kFrTileFrames + 2];  // the c-th changed frame (cframe[nc] = tf)
+  __shared__ int lboff[kFrTileFrames + 1];  // first expansion of every changed frame of the tile (tile-local)
   __shared__ int lcur[kFrTileFrames];       // scatter cursors; then -(folded entries) - 1 for a bucket the workgroup folded
-  __shared__ int sh[kFrThreads / 64];
+  __shared__ int sh[2 * kFrThreads / 64];
   __shared__ int big_list[kFrBigList];
   __shared__ int big_n;
   const int u = blockIdx.x;
@@ -311,6 +340,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   // the last frame_sort_slots(nA) record rows of the lattice are the cooperative sort's scratch
   FKey* tmp = recs + ((a.scratch_off[u + 1] - a.scratch_off[u]) - frame_sort_slots(nA));
 
+  const bool spans_lds = nA <= span_cap && T <= 65535;  // workgroup-uniform
   long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, crowded, frames, (unused)
   long long t_prev = (long long)__builtin_amdgcn_s_memtime();
 #define FR_LAP(k)                                                      \
@@ -325,12 +355,12 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000;
   __syncthreads();
   int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000;
-  for (int base = 0; base < nA; base += 4 * kFrThreads) {  // four arcs per thread at a time: loads batched, no branch around them
-    int il[4], t0[4], t1[4];
-    float gr[4], ac4[4];
-    double lp[4];
+  for (int base = 0; base < nA; base += kFrSpanBatch * kFrThreads) {  // eight arcs per thread at a time: loads batched, no branch around them
+    int il[kFrSpanBatch], t0[kFrSpanBatch], t1[kFrSpanBatch];
+    float gr[kFrSpanBatch], ac4[kFrSpanBatch];
+    double lp[kFrSpanBatch];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kFrSpanBatch; ++q) {
       const int i = min(base + q * kFrThreads + tid, nA - 1);
       il[q] = a.ilabel[a0 + i];
       t0[q] = a.src[a0 + i];
@@ -340,12 +370,12 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
       lp[q] = a.logpost[a0 + i];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kFrSpanBatch; ++q) {
       t0[q] = a.state_time[s0 + t0[q]];
       t1[q] = a.state_time[s0 + t1[q]];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kFrSpanBatch; ++q) {
       const int i = base + q * kFrThreads + tid;
       if (i >= nA) continue;
       FrameArc r;
@@ -364,6 +394,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
         r.x = (lp[q] > -INFINITY) ? lp[q] + ((double)g + (double)ac) - (double)(g + ac) : lp[q];
       }
       ai[i] = r;
+      if (spans_lds) lspan[i] = (uint32_t)r.k0 | ((uint32_t)r.k1 << 16);
     }
   }
   for (int d = 32; d > 0; d >>= 1) lmin_t = min(lmin_t, __shfl_xor(lmin_t, d, 64)), lmax_t = max(lmax_t, __shfl_xor(lmax_t, d, 64));
@@ -381,50 +412,65 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
   int mbase = 0;  // records written so far
   for (int f0 = 0; f0 < T; f0 += kFrTileFrames) {
     const int tf = min(kFrTileFrames, T - f0);
-    // ---- 1. entries per frame: difference array over the spans, prefix sums ----
-    for (int k = tid; k <= tf; k += kFrThreads) lboff[k] = 0;
+    // ---- 1. entries per frame from a difference array over the spans, the changed frames of the
+    // tile, and the bucket offsets of the changed frames: one pass over the arcs, three scans ----
+    constexpr int kCh = (kFrTileFrames + 1 + kFrThreads - 1) / kFrThreads;
+    for (int k = tid; k <= tf; k += kFrThreads) lboff[k] = 0, cidx[k] = (k == 0) ? 1 : 0;
     if (tid == 0) big_n = 0;
     __syncthreads();
+    auto span_of = [&](int i, int& lo, int& hi) {
+      const uint32_t sp32 = spans_lds ? lspan[i] : 0u;
+      const int k0 = spans_lds ? (int)(sp32 & 0xFFFFu) : ai[i].k0, k1 = spans_lds ? (int)(sp32 >> 16) : ai[i].k1;
+      lo = max(k0, f0) - f0, hi = min(k1, f0 + tf) - f0;
+    };
     for (int i = tid; i < nA; i += kFrThreads) {
-      const int lo = max(ai[i].k0, f0) - f0, hi = min(ai[i].k1, f0 + tf) - f0;
+      int lo, hi;
+      span_of(i, lo, hi);
       if (hi > lo) {
         atomicAdd(&lboff[lo], 1);
         atomicAdd(&lboff[hi], -1);
+        cidx[lo] = 1;  // (plain stores of the same value)
+        if (hi < tf) cidx[hi] = 1;
       }
     }
     __syncthreads();
-    // every thread owns kCh consecutive frames: two block scans per tile (difference array -> entries
-    // per frame -> bucket offsets) instead of two per 256 frames
-    constexpr int kCh = (kFrTileFrames + 1 + kFrThreads - 1) / kFrThreads;
-    int n = 0, cmax = 0;
+    // every thread owns kCh consecutive frames
+    int n = 0, cmax = 0, nc = 0;
     {
-      int dl[kCh], sum_d = 0;
+      int dl[kCh], fl[kCh], sum_d = 0, sum_f = 0;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
         const int k = tid * kCh + q;
         dl[q] = (k <= tf) ? lboff[k] : 0;
+        fl[q] = (k < tf) ? (int)cidx[k] : 0;
         sum_d += dl[q];
+        sum_f += fl[q];
       }
-      int tot_d, tot_c;
-      int run = fr_block_scan(sum_d, &tot_d, sh);  // difference entries before this thread's frames
-      int cl[kCh], sum_c = 0;
+      int tot_d;
+      const int2 pre = fr_block_scan2(sum_d, sum_f, &tot_d, &nc, sh);  // (all reads of the two arrays are done)
+      int run = pre.x, sum_c = 0;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
-        const int k = tid * kCh + q;
         run += dl[q];
-        cl[q] = (k < tf) ? run : 0;  // entries of frame k
-        cmax = max(cmax, cl[q]);
-        sum_c += cl[q];
+        dl[q] = fl[q] ? run : 0;  // entries of a changed frame
+        cmax = max(cmax, dl[q]);
+        sum_c += dl[q];
       }
-      int off = fr_block_scan(sum_c, &tot_c, sh);
+      int off = fr_block_scan(sum_c, &n, sh);
+      int c = pre.y;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
         const int k = tid * kCh + q;
-        if (k <= tf) lboff[k] = off;
-        if (k < tf) lcur[k] = off;
-        off += cl[q];
+        if (k <= tf) cidx[k] = (uint16_t)c;
+        if (fl[q]) {
+          cframe[c] = (uint16_t)k;
+          lboff[c] = off;
+          lcur[c] = off;
+          off += dl[q];
+          ++c;
+        }
       }
-      n = tot_c;
+      if (tid == 0) cframe[nc] = (uint16_t)tf, lboff[nc] = n;
     }
     if (tid == 0) tile_max = 0;
     __syncthreads();
@@ -437,19 +483,29 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
     // ---- 2. every arc drops itself into the buckets of its frames ----
     if (in_lds) {
       for (int i = tid; i < nA; i += kFrThreads) {
-        const FrameArc r = ai[i];
-        const int lo = max(r.k0, f0) - f0, hi = min(r.k1, f0 + tf) - f0;
-        for (int k = lo; k < hi; ++k) lbucket[atomicAdd(&lcur[k], 1)] = (uint16_t)i;
+        int lo, hi;
+        span_of(i, lo, hi);
+        if (hi <= lo) continue;
+        const int c1 = cidx[hi];
+        for (int c = cidx[lo]; c < c1; c += 4) {  // four cursors at a time: the atomics' round trips overlap
+          int at[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) at[q] = (c + q < c1) ? atomicAdd(&lcur[c + q], 1) : -1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (at[q] >= 0) lbucket[at[q]] = (uint16_t)i;
+        }
       }
     } else {
       for (int i = tid; i < nA; i += kFrThreads) {
-        const FrameArc r = ai[i];
-        const int lo = max(r.k0, f0) - f0, hi = min(r.k1, f0 + tf) - f0;
+        int lo, hi;
+        span_of(i, lo, hi);
         if (hi <= lo) continue;
         FKey e;
         e.a = ((uint64_t)fr_bias(a.ilabel[a0 + i]) << 32) | (uint32_t)i;
-        e.b = (uint64_t)__double_as_longlong(r.x);
-        for (int k = lo; k < hi; ++k) keys[nbase + atomicAdd(&lcur[k], 1)] = e;
+        e.b = (uint64_t)__double_as_longlong(ai[i].x);
+        const int c1 = cidx[hi];
+        for (int c = cidx[lo]; c < c1; ++c) keys[nbase + atomicAdd(&lcur[c], 1)] = e;
       }
     }
     __syncthreads();
@@ -459,7 +515,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
     // tile (which overlays the slabs), folded by the heads of the runs, sorted again; the folded
     // keys stay at the bucket's start ----
     for (; !in_lds;) {  // (a tile whose buckets sit in LDS has no such frame)
-      for (int k = tid; k < tf; k += kFrThreads)
+      for (int k = tid; k < nc; k += kFrThreads)
         if (lboff[k + 1] - lboff[k] > kFrSerialMax && lcur[k] >= 0) {
           const int slot = atomicAdd(&big_n, 1);
           if (slot < kFrBigList) big_list[slot] = k;
@@ -521,12 +577,13 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
     }
 
     FR_LAP(3);
-    // ---- 3b. one thread per frame, kFrThreads frames at a time: sort, fold, sort, place ----
-    for (int r0 = 0; r0 < tf; r0 += kFrThreads) {
+    // ---- 3b. one thread per changed frame, kFrThreads at a time: sort, fold, sort, place (once
+    // for the frame and once more for every unchanged frame that follows it) ----
+    for (int r0 = 0; r0 < nc; r0 += kFrThreads) {
       const int k = r0 + tid;
       int o = 0, w = 0, mk = 0;
       bool in_regs = false;
-      if (k < tf) {
+      if (k < nc) {
         o = nbase + lboff[k];
         w = lboff[k + 1] - lboff[k];
         if (lcur[k] < 0) {
@@ -552,7 +609,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
         // sort keys (label - lab_base | arc number) in 32 bits: a compare-exchange is two instructions
         // and no payload moves; x is fetched by arc number after the sort
         uint32_t k32[kFrRegs];
-        const int lo = (k < tf) ? lboff[k] : 0;
+        const int lo = (k < nc) ? lboff[k] : 0;
 #pragma unroll
         for (int j = 0; j < kFrRegs; ++j) k32[j] = (in_regs && j < w) ? (uint32_t)lbucket[lo + j] : 0xFFFFFFFFu;
 #pragma unroll
@@ -577,7 +634,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
       } else {
         if (in_lds) {
           int arc[kFrRegs];
-          const int lo = (k < tf) ? lboff[k] : 0;
+          const int lo = (k < nc) ? lboff[k] : 0;
 #pragma unroll
           for (int j = 0; j < kFrRegs; ++j) arc[j] = (in_regs && j < w) ? (int)lbucket[lo + j] : -1;
 #pragma unroll
@@ -617,28 +674,32 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a) {
         ek[j - 1] = emit ? (((uint64_t)fr_desc_key((float)acc) << 32) | lab) : ~0ull;  // BaseFloat narrowing of :126
         mk += emit ? 1 : 0;
         if (j < kFrRegs) {
-          if (cont)
-            acc = fr_log_add(acc, ex[j]);
-          else
-            acc = ex[j];
+          // (LogAdd is ~200 instructions of double exp / log1p: skipped unless some frame of the wave
+          // has two arcs of one word here)
+          double folded = ex[j];
+          if (__any(in_regs && cont)) folded = fr_log_add(acc, ex[j]);
+          acc = cont ? folded : ex[j];
         }
       }
       if (narrow)
         fr_sort_regs<8, false>(ek, ex);
       else
         fr_sort_regs<kFrRegs, false>(ek, ex);
+      const int frame = (k < nc) ? (int)cframe[k] : 0, run = (k < nc) ? (int)cframe[k + 1] - frame : 0;
       int tot;
-      const int dst = mbase + fr_block_scan(mk, &tot, sh);
+      const int dst = mbase + fr_block_scan(mk * run, &tot, sh);
       // 8 bytes per record -- desc(float logp) | biased label, the sort key itself -- plus one count per
       // frame: the frame of a record is implied by the counts (the first version wrote 16-byte rows
       // carrying the frame number: twice the bytes, written here and read by the gather kernel)
-      if (k < tf) a.frame_count[fbase + f0 + k] = mk;
-      if (in_regs) {
+      for (int r = 0; r < run; ++r) {
+        a.frame_count[fbase + f0 + frame + r] = mk;
+        if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j)
-          if (j < mk) rec8[dst + j] = ek[j];
-      } else {
-        for (int j = 0; j < mk; ++j) rec8[dst + j] = keys[o + j].a;
+          for (int j = 0; j < kFrRegs; ++j)
+            if (j < mk) rec8[dst + r * mk + j] = ek[j];
+        } else {
+          for (int j = 0; j < mk; ++j) rec8[dst + r * mk + j] = keys[o + j].a;
+        }
       }
       mbase += tot;
     }
@@ -685,12 +746,14 @@ hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t 
   hipLaunchKernelGGL(frame_count_kernel, dim3(num_lattices), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
-hipError_t launch_frame(const FrameArgs& a, int num_lattices, hipStream_t stream) {
+hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
-  const size_t lds = sizeof(FKey) * kFrTile > sizeof(uint16_t) * kFrLdsEntries ? sizeof(FKey) * kFrTile : sizeof(uint16_t) * kFrLdsEntries;
+  static_assert(sizeof(FKey) * kFrTile <= sizeof(uint16_t) * kFrLdsEntries, "the sort tile lies under the buckets");
+  const int span_cap = max_arcs < kFrLdsSpans ? (max_arcs > 0 ? max_arcs : 0) : kFrLdsSpans;
+  const size_t lds = sizeof(uint16_t) * kFrLdsEntries + sizeof(uint32_t) * (size_t)span_cap;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a);
+  hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
   return hipGetLastError();
 }
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
