@@ -204,15 +204,18 @@ def accumulate_leg(klat_amd, batch, arrays, A):
         klat_amd._check(L.klat_get_accum_timings(batch.h, None, C.byref(fms)))
         fr.append(fms.value)
     seg_ms, fr_ms = median(seg), median(fr)
+    stored = C.c_int64(0)
+    klat_amd._check(L.klat_frame_stored_records(batch.h, C.byref(stored)))
     # algorithmic bytes: src,dst,olabel (12) + logpost (8) per arc + state_time 4 B/state in, 24 B/record out;
-    # frames: src,dst,ilabel,graph,acoustic (20) + logpost (8) per arc in, 8 B per (frame, word) entry out
+    # frames: src,dst,ilabel,graph,acoustic (20) + logpost (8) per arc in; out 8 B per STORED record
+    # (frames without an arc boundary share their predecessor's records) + 8 B per frame (first record, count)
     S = int(arrays["state_off"][-1])
     seg_bytes = 20.0 * A + 4.0 * S + 24.0 * records
-    fr_bytes = 28.0 * A + 4.0 * S + 8.0 * ne.value + 8.0 * int(nf.sum())
+    fr_bytes = 28.0 * A + 4.0 * S + 8.0 * stored.value + 8.0 * int(nf.sum())
     return {"workload": "the C2 batch of this run", "segment_ms": seg_ms, "segment_records": records,
             "segment_frac": seg_bytes / (seg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if seg_ms > 0 else None,
             "segment_algorithmic_bytes": seg_bytes,
-            "frame_ms": fr_ms, "frame_entries": ne.value,
+            "frame_ms": fr_ms, "frame_entries": ne.value, "frame_records_stored": stored.value,
             "frame_frac": fr_bytes / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fr_ms > 0 else None,
             "frame_algorithmic_bytes": fr_bytes,
             "frac": min(x for x in (seg_bytes / (seg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if seg_ms > 0 else 1e9,

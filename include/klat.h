@@ -213,6 +213,13 @@ int klat_position_index(klat_batch* batch, const int32_t* state_len,
 int klat_index_device_records(klat_batch* batch, const void** dev_records, const int64_t** record_off,
                               int64_t* num_lattices, int64_t* num_records);
 
+/* Records the last sizing call of klat_frame_post stored on the device.  A frame at which no word arc
+ * starts or ends has the posteriors of the frame before it (the accumulation of
+ * latbin/lattice-to-word-frame-post.cc:93-117 adds the same arcs to both), so such frames share their
+ * predecessor's records; the fetching call of klat_frame_post expands them into the dense output.
+ * (num_entries of klat_frame_post counts every frame's entries, shared or not.) */
+int klat_frame_stored_records(klat_batch* batch, int64_t* num_records);
+
 /* Device time (HIP events on the ctx stream) of the index kernels / the frame-posterior kernels of
  * the last sizing call on this batch; 0 if none ran.  Either pointer may be NULL. */
 int klat_get_accum_timings(klat_batch* batch, float* index_ms, float* frame_ms);

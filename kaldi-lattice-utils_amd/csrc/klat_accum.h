@@ -113,11 +113,13 @@ struct FrameArgs {
   void* key_scratch;  // 16 B per slot
   void* rec_scratch;  // 16 B per slot
   int64_t* num_expansions;  // [U] (count kernel)
-  int32_t* num_records;     // [U]
+  int32_t* num_records;     // [U] (frame, word) entries of the lattice (every frame counts its records)
+  int32_t* num_stored;      // [U] records stored (frames without an arc boundary share their predecessor's)
   ScaleParams sp;
   long long* phase_clock;   // [U][8] or null: shader cycles of the frame kernel's phases (KLAT_ACCUM_PROFILE)
   const int64_t* frame_base;  // [U+1] first frame of every lattice in the batch-wide frame numbering
   int32_t* frame_count;       // [sum of num_frames] records per frame
+  int32_t* frame_src;         // [sum of num_frames] first record of the frame in the lattice's record rows
 };
 
 hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t stream);

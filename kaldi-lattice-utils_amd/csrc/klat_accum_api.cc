@@ -346,11 +346,15 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     if ((rc = st.num_frames.upload(num_frames, (size_t)b->U, c->stream))) return rc;
     if ((rc = st.d_frame_base.upload(st.frame_base.data(), st.frame_base.size(), c->stream))) return rc;
     if ((rc = st.frame_count.alloc((size_t)st.frame_base[b->U]))) return rc;
+    if ((rc = st.frame_src.alloc((size_t)st.frame_base[b->U]))) return rc;
     a.frame_base = st.d_frame_base.p;
     a.frame_count = st.frame_count.p;
+    a.frame_src = st.frame_src.p;
     if ((rc = st.arc_scratch.alloc((size_t)b->A * sizeof(FrameArc)))) return rc;
     if ((rc = st.num_expansions.alloc((size_t)b->U))) return rc;
     if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
+    if ((rc = st.num_stored.alloc((size_t)b->U))) return rc;
+    a.num_stored = st.num_stored.p;
     a.num_frames = st.num_frames.p;
     a.num_expansions = st.num_expansions.p;
     a.num_records = st.num_records.p;
@@ -398,13 +402,20 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       a.phase_clock = nullptr;
     }
     KLAT_HIP(hipEventRecord(st.ev[1], c->stream));
-    std::vector<int32_t> counts((size_t)b->U);
-    if (b->U > 0)
+    std::vector<int32_t> counts((size_t)b->U), stored((size_t)b->U);
+    if (b->U > 0) {
       KLAT_HIP(hipMemcpyAsync(counts.data(), st.num_records.p, sizeof(int32_t) * (size_t)b->U,
                               hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipMemcpyAsync(stored.data(), st.num_stored.p, sizeof(int32_t) * (size_t)b->U,
+                              hipMemcpyDeviceToHost, c->stream));
+    }
     KLAT_HIP(hipStreamSynchronize(c->stream));
     st.entry_off.assign((size_t)b->U + 1, 0);
-    for (int64_t u = 0; u < b->U; ++u) st.entry_off[u + 1] = st.entry_off[u] + counts[u];
+    st.stored_records = 0;
+    for (int64_t u = 0; u < b->U; ++u) {
+      st.entry_off[u + 1] = st.entry_off[u] + counts[u];
+      st.stored_records += stored[u];
+    }
     st.ready = true;
     *num_entries = st.entry_off[b->U];
     return KLAT_OK;
@@ -418,6 +429,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
   a.rec_scratch = st.rec_scratch.p;
   a.frame_base = st.d_frame_base.p;
   a.frame_count = st.frame_count.p;
+  a.frame_src = st.frame_src.p;
   DevBuf<int64_t> d_eoff, d_fbase, d_foff;
   DevBuf<int32_t> d_lab;
   DevBuf<float> d_lp;
@@ -457,6 +469,13 @@ int klat_index_device_records(klat_batch* b, const void** dev_records, const int
   if (record_off) *record_off = st.record_off.data();
   if (num_lattices) *num_lattices = b->U;
   *num_records = st.record_off[b->U];
+  return KLAT_OK;
+}
+
+int klat_frame_stored_records(klat_batch* b, int64_t* num_records) {
+  if (!b || !num_records) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  if (!b->frame.ready) return set_error(KLAT_ERR_STATE, "no frame posteriors on this batch: call klat_frame_post with labels == NULL first");
+  *num_records = b->frame.stored_records;
   return KLAT_OK;
 }
 

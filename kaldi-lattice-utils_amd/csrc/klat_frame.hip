@@ -410,6 +410,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   FR_LAP(0);
   int nbase = 0;  // expansions of the tiles before this one
   int mbase = 0;  // records written so far
+  int dense = 0;  // (frame, word) entries so far: every frame counts its records, shared or not
   for (int f0 = 0; f0 < T; f0 += kFrTileFrames) {
     const int tf = min(kFrTileFrames, T - f0);
     // ---- 1. entries per frame from a difference array over the spans, the changed frames of the
@@ -686,57 +687,75 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
       else
         fr_sort_regs<kFrRegs, false>(ek, ex);
       const int frame = (k < nc) ? (int)cframe[k] : 0, run = (k < nc) ? (int)cframe[k + 1] - frame : 0;
-      int tot;
-      const int dst = mbase + fr_block_scan(mk * run, &tot, sh);
-      // 8 bytes per record -- desc(float logp) | biased label, the sort key itself -- plus one count per
-      // frame: the frame of a record is implied by the counts (the first version wrote 16-byte rows
-      // carrying the frame number: twice the bytes, written here and read by the gather kernel)
+      int tot, tot_dense;
+      const int dst = mbase + fr_block_scan2(mk, mk * run, &tot, &tot_dense, sh).x;
+      // 8 bytes per record -- desc(float logp) | biased label, the sort key itself -- written ONCE per
+      // changed frame; every frame names its records by (first record, count), so the unchanged frames
+      // that follow share them, and the gather kernel expands the runs into the dense output
       for (int r = 0; r < run; ++r) {
         a.frame_count[fbase + f0 + frame + r] = mk;
-        if (in_regs) {
-#pragma unroll
-          for (int j = 0; j < kFrRegs; ++j)
-            if (j < mk) rec8[dst + r * mk + j] = ek[j];
-        } else {
-          for (int j = 0; j < mk; ++j) rec8[dst + r * mk + j] = keys[o + j].a;
-        }
+        a.frame_src[fbase + f0 + frame + r] = dst;
       }
+      if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j)
+          if (j < mk) rec8[dst + j] = ek[j];
+      } else {
+        for (int j = 0; j < mk; ++j) rec8[dst + j] = keys[o + j].a;
+      }
+      dense += tot_dense;
       mbase += tot;
     }
     nbase += n;
     __syncthreads();
     FR_LAP(4);
   }
-  if (tid == 0) a.num_records[u] = mbase;
+  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase;
   if (a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
 }
 
-// Dense output: entries of lattice u at entry_off[u].., frame offsets at frame_base[u]...
+// Dense output: entries of lattice u at entry_off[u].., frame offsets at frame_base[u]...  A wave
+// takes 64 frames at a time: the frames' (first record, count) pairs, a prefix sum of the counts, and
+// then one lane per output entry -- its frame found by a binary search over the wave's prefix sums
+// (shuffles) -- so the expansion of shared records reads and writes full lines.
 __global__ __launch_bounds__(256) void frame_gather_kernel(FrameArgs a, const int64_t* entry_off,
                                                            const int64_t* frame_base, int64_t* frame_off,
                                                            int32_t* labels, float* logps) {
-  __shared__ int sh[kFrThreads / 64];
+  __shared__ int sh[2 * kFrThreads / 64];
   const int u = blockIdx.x;
+  const int lane = threadIdx.x & 63;
   const uint64_t* rec8 = reinterpret_cast<const uint64_t*>(reinterpret_cast<const FKey*>(a.rec_scratch) + a.scratch_off[u]);
   const int64_t o = entry_off[u];
-  const int m = (int)(entry_off[u + 1] - o);
   const int64_t fb = frame_base[u];
   const int T = a.num_frames[u];
-  for (int i = threadIdx.x; i < m; i += 256) {
-    const uint64_t r = rec8[i];
-    labels[o + i] = fr_unbias((uint32_t)r);
-    logps[o + i] = fr_desc_unkey((uint32_t)(r >> 32));
-  }
-  // frame offsets: exclusive prefix sums of the per-frame record counts
   int carry = 0;
   for (int base = 0; base < T; base += 256) {
     const int k = base + (int)threadIdx.x;
     const int c = k < T ? a.frame_count[fb + k] : 0;
+    const int src = k < T ? a.frame_src[fb + k] : 0;
     int tot;
-    const int ex = fr_block_scan(c, &tot, sh);
+    const int ex = fr_block_scan(c, &tot, sh);  // entries of this block's frames before frame k
     if (k < T) frame_off[fb + k] = o + carry + ex;
+    const int first = __shfl(ex, 0, 64);                  // of the wave's 64 frames
+    const int count = __shfl(ex + c, 63, 64) - first;     // entries of the wave's frames
+    const int64_t out = o + carry + first;
+    for (int e0 = 0; e0 < count; e0 += 64) {  // (wave-uniform trips: the shuffles read every lane)
+      const int e = e0 + lane;
+      int g = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) {
+        const int v = __shfl(ex, min(g + step, 63), 64) - first;
+        if (v <= e) g += step;  // the LAST frame that starts at or before e: empty frames before it share its start
+      }
+      const int at = __shfl(src, g, 64) + (e - (__shfl(ex, g, 64) - first));
+      if (e < count) {
+        const uint64_t r = rec8[at];
+        labels[out + e] = fr_unbias((uint32_t)r);
+        logps[out + e] = fr_desc_unkey((uint32_t)(r >> 32));
+      }
+    }
     carry += tot;
   }
 }

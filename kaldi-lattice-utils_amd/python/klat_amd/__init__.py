@@ -308,6 +308,13 @@ class Batch:
         _check(lib().klat_frame_post(self.h, _p(nf), _p(off), _p(labels), _p(logps), C.c_int64(len(labels)), C.byref(n)))
         return off, labels[:n.value], logps[:n.value]
 
+    def frame_stored_records(self):
+        """Records the last frame_post kept on the device: frames without an arc boundary share
+        their predecessor's (klat_frame_stored_records)."""
+        n = C.c_int64(0)
+        _check(lib().klat_frame_stored_records(self.h, C.byref(n)))
+        return n.value
+
     def streams(self):
         """(sw, sg, sa) as built on the device by klat_batch_create."""
         i = self.info()

@@ -359,3 +359,33 @@ def test_frame_post_wide_frames(ctx, width):
         _check_frames(off, labels, logps, fb, want)
         fb += nframes[u]
     assert off[-1] == len(labels)
+
+
+def test_frames_without_an_arc_boundary_share_their_records(ctx):
+    """latbin/lattice-to-word-frame-post.cc:93-117 adds an arc to every frame of its span, so two
+    consecutive frames with no arc starting or ending between them hold the same posteriors: the
+    kernel stores them once (klat_frame_stored_records) and the fetch expands them.  Stretching
+    the state times by 3 must give every frame's entries three times over and (nearly) the same
+    stored records; the dense output is checked against the oracle either way."""
+    ns = np.array([40, 300, 1], np.int32)
+    fo = np.array([3, 2, 1], np.int32)
+    arrays = klat_amd.synth(31, ns, fo)
+    res = []
+    for stretch in (1, 3):
+        arr = dict(arrays)
+        arr["state_time"] = (arrays["state_time"] * stretch).astype(np.int32)
+        nframes = [int(arr["state_time"][arr["state_off"][u + 1] - 1]) for u in range(len(ns))]
+        b = klat_amd.Batch(ctx, arr)
+        b.forward_backward()
+        off, labels, logps = b.frame_post(nframes)
+        res.append((len(labels), b.frame_stored_records()))
+        b.close()
+        fb = 0
+        for u, lat in enumerate(_split(arr)):
+            alpha, beta, total, _, _ = orc.alphas_betas(lat)
+            t = arr["state_time"][arr["state_off"][u]:arr["state_off"][u + 1]]
+            want, _ = orc.frame_post(lat, t, nframes[u], alpha, beta, total)
+            _check_frames(off, labels, logps, fb, want)
+            fb += nframes[u]
+    # (a tile of 1 920 frames starts with a stored frame: the stretched run has a few more of those)
+    assert res[1][0] == 3 * res[0][0] and res[0][1] <= res[1][1] <= res[0][1] + 64 and res[0][1] <= res[0][0]
