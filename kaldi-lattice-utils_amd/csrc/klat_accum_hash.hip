@@ -525,19 +525,35 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
   }
   KLAT_STAMP(6);
 
-  // ---- 4. the records at their final positions ----
+  // ---- 4. the records at their final positions: through LDS (the sort's array is free now), so
+  // that they leave as full lines -- as scattered 24-byte stores they cost 1.8 x their bytes in HBM
+  // writes and a store instruction per record and thread ----
+  __syncthreads();  // every thread is done with `order` (and with the counters behind it)
+  {
+    // (only LDS has to be ordered between the passes: __syncthreads() would also wait for the
+    // record stores of the pass before, a full HBM write latency each time)
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    constexpr int kStageRecs = (H * 4 + H / 8 + B * 2) / (int)sizeof(Rec);  // the whole dynamic LDS of the kernel
+    uint64_t* stage = reinterpret_cast<uint64_t*>(smem);  // [kStageRecs][3]
+    uint64_t* out64 = reinterpret_cast<uint64_t*>(recs);
+    for (int base = 0; base < m; base += kStageRecs) {  // (m is workgroup-uniform)
 #pragma unroll
-  for (int j = 0; j < kPerThread; ++j) {
-    if (!(recmask & (1u << j))) continue;
-    const int i = j * T + tid;
-    const int p = (int)((finalpos[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
-    const Payload q = (POSITION && (dupmask & (1u << j))) ? payload[i]  // (t0,t1) of the first arc attaining the maximum
-                                                          : make_payload<POSITION>(a, pk, a0, s0, key[j], i);
-    Rec out;
-    out.k0 = hdesc_key(val[j]);
-    out.k1 = q.k1;
-    out.k2 = q.k2;
-    recs[p] = out;
+      for (int j = 0; j < kPerThread; ++j) {
+        if (!(recmask & (1u << j))) continue;
+        const int p = (int)((finalpos[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu) - base;
+        if ((unsigned)p >= (unsigned)kStageRecs) continue;
+        const int i = j * T + tid;
+        const Payload q = (POSITION && (dupmask & (1u << j))) ? payload[i]  // (t0,t1) of the first arc attaining the maximum
+                                                              : make_payload<POSITION>(a, pk, a0, s0, key[j], i);
+        stage[p * 3 + 0] = hdesc_key(val[j]);
+        stage[p * 3 + 1] = q.k1;
+        stage[p * 3 + 2] = q.k2;
+      }
+      lds_barrier();
+      const int cnt = min(kStageRecs, m - base) * 3;
+      for (int i = tid; i < cnt; i += T) out64[(size_t)base * 3 + i] = stage[i];
+      lds_barrier();
+    }
   }
   if (tid == 0) a.num_records[u] = m;
   KLAT_STAMP(7);
