@@ -60,6 +60,24 @@ __global__ __launch_bounds__(64) void level_plan_kernel(LevelPlanArgs a) {
   const int32_t* dst = a.dst + a0;
   const int max_depth = S / kLevelMinWidth;
 
+  // A time-ordered chain (nearly every state linked to its successor) is as deep as it is long:
+  // tell it from one pass over the arcs instead of from max_depth steps of Kahn's algorithm.
+  // With g states lacking the link, some run of linked states is at least (S - g) / (g + 1) long.
+  for (int s = lane; s < S; s += 64) left[s] = 0;
+  __threadfence_block();
+  __syncthreads();
+  for (int i = lane; i < A; i += 64)
+    if (dst[i] == src[i] + 1) left[src[i]] = 1;
+  __threadfence_block();
+  __syncthreads();
+  int linked = 0;
+  for (int s = lane; s < S; s += 64) linked += left[s];
+  for (int d = 32; d > 0; d >>= 1) linked += __shfl_xor(linked, d, 64);
+  if (linked > (S - linked + 1) * max_depth) {
+    if (lane == 0) a.depth[u] = -1;
+    return;
+  }
+
   // row table of the out-arcs (arcs are grouped by source): mark the first arc of every source,
   // then give the states without arcs the row of the next state that has some (suffix minimum)
   for (int s = lane; s <= S; s += 64) row[s] = A;
