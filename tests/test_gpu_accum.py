@@ -389,3 +389,31 @@ def test_frames_without_an_arc_boundary_share_their_records(ctx):
             fb += nframes[u]
     # (a tile of 1 920 frames starts with a stored frame: the stretched run has a few more of those)
     assert res[1][0] == 3 * res[0][0] and res[0][1] <= res[1][1] <= res[0][1] + 64 and res[0][1] <= res[0][0]
+
+
+@pytest.mark.parametrize("case", ["many_arcs", "many_frames"])
+def test_frame_post_beyond_the_lds_spans(ctx, case):
+    """The frame kernel keeps an arc's clipped span in LDS as two 16-bit frame numbers when the
+    lattice has at most 6 144 arcs and 65 535 frames; beyond either bound the spans stay in the
+    arc's scratch row.  Both bounds are crossed here, next to a small lattice in the same batch."""
+    if case == "many_arcs":
+        ns, fo, stretch = np.array([2600, 50], np.int32), np.array([3, 2], np.int32), 1
+    else:
+        ns, fo, stretch = np.array([300, 50], np.int32), np.array([3, 2], np.int32), 100
+    arrays = klat_amd.synth(47, ns, fo)
+    arrays["state_time"] = (arrays["state_time"] * stretch).astype(np.int32)
+    nframes = [int(arrays["state_time"][arrays["state_off"][u + 1] - 1]) for u in range(len(ns))]
+    assert (case == "many_arcs" and np.diff(arrays["arc_off"])[0] > 6144) or (case == "many_frames" and nframes[0] > 65535)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.2, 0.0)
+    off, labels, logps = b.frame_post(nframes)
+    b.close()
+    fb = 0
+    for u, lat in enumerate(_split(arrays)):
+        sl = orc.scale_and_penalize(lat, 1.0, 0.2, 0.0)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        t = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
+        want, _ = orc.frame_post(sl, t, nframes[u], alpha, beta, total)
+        _check_frames(off, labels, logps, fb, want)
+        fb += nframes[u]
+    assert off[-1] == len(labels)
