@@ -129,6 +129,11 @@ void klat_host_free(void* ptr) {
 }
 
 int klat_ctx_create(int device, klat_ctx** out) {
+  // The layout classes of a skewed batch run on four streams at once (for_each_class).  The HIP
+  // runtime reads GPU_MAX_HW_QUEUES (default 4) when it starts: a host that has streams of its own
+  // leaves fewer than four queues and two classes would run one after the other.  No effect when
+  // the runtime is already up (such a host sets it itself).
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   if (!out) return set_error(KLAT_ERR_INVALID_ARG, "out is null");
   *out = nullptr;
   int n = 0;
