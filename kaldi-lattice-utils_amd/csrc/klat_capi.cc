@@ -490,6 +490,11 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   b->G = P.G;
   b->W = P.W;
   b->classes = P.classes;
+  {  // six workgroups of the deep-prefetch sweep fit a CU (157 VGPRs): use it when no job would have to wait for a slot
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 256;
+    b->deep_prefetch = (int64_t)P.jobs.size() <= (int64_t)6 * cus && std::getenv("KLAT_NO_DEEP_PREFETCH") == nullptr ? 1 : 0;
+  }
   b->num_jobs = (int)P.jobs.size();
   b->num_items = (int)P.items.size();
   b->info.num_states = b->S;
@@ -644,6 +649,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
       ca.sink = sa.sink + (size_t)lc.job_begin * 64;
       ca.ring_slots = lc.W;
       ca.far_prefetch = lc.far;
+      ca.deep_prefetch = b->deep_prefetch;
       return launch_sweep(ca, lc.job_end - lc.job_begin, lc.G, stream, one_class ? ev[0] : nullptr,
                           one_class ? ev[1] : nullptr);
     });

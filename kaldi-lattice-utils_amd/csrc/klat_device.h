@@ -49,13 +49,14 @@ static const uint32_t kWord = 1u << 30;
 static const uint32_t kFirst = 1u << 31;
 
 static const int kChunkRounds = 4;    // rounds per 16-byte lane load
-static const int kPrefetchChunks = 4; // register prefetch depth of the sweep kernel
+static const int kPrefetchChunks = 4; // register prefetch depth of the sweep kernel (chunks of 4 rounds)
+static const int kDeepPrefetchChunks = 8; // the same for the deep instantiation; jobs are padded to whole multiples of it
 static const int kExpMin = -(1 << 29); // exponent tag of log-zero (mantissa 0)
 
 // One wave of the sweep kernel.
 struct SweepJob {
   int64_t chunk_off;  // first unit (16 B = 4 rounds of one lane) of this job's stream; a chunk row is A * (64/G) units
-  int32_t nchunks;    // multiple of kPrefetchChunks
+  int32_t nchunks;    // multiple of kDeepPrefetchChunks
   int32_t dir;        // 0 forward, 1 backward
   int32_t lane_tab;   // first LaneInfo of this job (64/G entries)
   int32_t tag;        // bits 0-1: wave priority (long chains first); 2-7: A - 1 (stored lanes per lattice); 8-15: G; 16-27: W

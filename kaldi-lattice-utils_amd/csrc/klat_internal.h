@@ -193,6 +193,7 @@ struct klat_batch {
   int64_t U = 0, S = 0, A = 0;
   int G = 1, W = 8, num_jobs = 0, num_items = 0;  // G, W: of the largest layout class (info only)
   std::vector<klat::LayoutClass> classes;
+  int32_t deep_prefetch = 0;  // SweepArgs.deep_prefetch of this batch
   bool swept = false;
   int64_t timing_step = -1;  // the context's step counter at this batch's last klat_forward_backward
   klat_scales scales = {1.f, 1.f, 0.f};

@@ -63,6 +63,7 @@ struct SweepArgs {
   StreamCost sc;  // = make_stream_cost(sp)
   int32_t ring_slots;
   int32_t far_prefetch;  // the jobs hold sources older than the ring: prefetch their values (W >= 32)
+  int32_t deep_prefetch = 0;  // the batch's workgroups fit six per CU: the fast sweep may hold 8 chunks per lane in registers
 };
 
 struct TotalsArgs {

@@ -183,7 +183,7 @@ int64_t slice_jobs(const int64_t* state_off, const LatticeRounds* lr, const std:
                    const std::vector<int64_t>& rf, const std::vector<int64_t>& rb, int G, int W, int64_t chunk_base,
                    PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats) {
   const int LPW = 64 / G;
-  const int D = kPrefetchChunks;
+  const int D = kDeepPrefetchChunks;
   // ---- slicing: lattices of similar length share a wave ----
   struct ProtoJob {
     int dir;

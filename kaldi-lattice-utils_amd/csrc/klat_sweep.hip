@@ -168,11 +168,14 @@ static constexpr uint32_t kCtlOne = kOne;
 // the arc cost itself, a state is the cheapest cost of reaching it (no exponents, no logarithm,
 // nothing to flag), alpha / beta receive the Viterbi forward / backward costs
 // (ComputeLatticeBeam / PruneLattice, latbin/lattice-prune-dyn-beam.cc:27-90).
-template <int G, bool FAST, int CPB, bool FARP, bool TROPICAL = false>
+// D = chunks of the stream a producer lane holds in registers ahead of the one it stages: 4 (16 rounds,
+// ~112 VGPRs: seven workgroups per CU) or 8 (32 rounds, 157 VGPRs: six per CU) -- the deep form is
+// worth 3-4 % where the batch leaves room for it (launch_pair).
+template <int G, bool FAST, int CPB, bool FARP, bool TROPICAL = false, int D = kPrefetchChunks>
 __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   extern __shared__ double smem[];
   constexpr int LPW = 64 / G;
-  constexpr int D = kPrefetchChunks;
+  static_assert(kDeepPrefetchChunks % D == 0, "jobs are padded to multiples of the deepest prefetch");
   const int W = args.ring_slots;
   if (!FAST && args.job_flags[blockIdx.x] == 0) return;  // workgroup-uniform
 
@@ -635,6 +638,9 @@ static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream,
   if (cpb == 2 && args.far_prefetch) {
     launch_fast(&sweep_kernel<G, true, 2, true>);
     launch(&sweep_kernel<G, false, 2, true>);
+  } else if (cpb == 2 && args.deep_prefetch) {
+    launch_fast(&sweep_kernel<G, true, 2, false, false, kDeepPrefetchChunks>);
+    launch(&sweep_kernel<G, false, 2, false>);
   } else if (cpb == 2) {
     launch_fast(&sweep_kernel<G, true, 2, false>);
     launch(&sweep_kernel<G, false, 2, false>);
