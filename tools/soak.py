@@ -15,15 +15,21 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = klat_amd.Ctx(0)
 t_end = time.time() + budget
 it = 0
+n_level = 0
 while time.time() < t_end:
     seed = seed0 * 100003 + it
     rng = np.random.RandomState(seed)
     U = int(rng.choice([1, 3, 17, 64, 200]))
     ns = np.maximum(1, np.exp(rng.uniform(0, np.log(rng.choice([30, 300, 1500])), U))).astype(np.int32)
     fo = rng.choice([1, 2, 3, 4, 6, 9], U).astype(np.int32)
-    a = klat_amd.synth(seed, ns, fo)
+    wide = int(rng.choice([0, 0, 6, 12, 40]))  # wide > 0: levels of that many states (the level path takes them)
+    if wide:
+        ns = np.maximum(ns, 8)
+    a = klat_amd.synth(seed, ns, fo, wide=wide)
+    if rng.rand() < 0.4:  # state times apart: frames without an arc boundary share their records
+        a["state_time"] = (a["state_time"] * int(rng.choice([2, 5]))).astype(np.int32)
     lat = np.repeat(np.arange(U), np.diff(a["arc_off"]))
-    if rng.rand() < 0.5 and len(a["dst"]):  # long-span arcs
+    if not wide and rng.rand() < 0.5 and len(a["dst"]):  # long-span arcs
         src, dst = a["src"], a["dst"].copy()
         st = (rng.rand(len(dst)) < 0.3) & (dst != src + 1)
         dst[st] = np.minimum(src[st] + rng.randint(2, 200, size=int(st.sum())), ns[lat][st] - 1)
@@ -45,6 +51,7 @@ while time.time() < t_end:
         W = 16
     scales = [(1.0, 1.0, 0.0), (1.0, 0.1, 0.0), (0.5, 0.2, 0.7), (0.0, 1.0, 0.0)][rng.randint(4)]
     b = klat_amd.Batch(ctx, a, lanes_per_lattice=G, ring_slots=W)
+    n_level += b.info()["level_lattices"]
     b.forward_backward(*scales)
     alpha, beta = b.alpha_beta(); total, tf, tb = b.totals(); post = b.arc_logpost()
     wa, wb, wt, wpost = _oracle_batch(a, *scales)
@@ -123,4 +130,4 @@ while time.time() < t_end:
     it += 1
     if it % 20 == 0:
         print("iteration %d ok (last: U=%d arcs=%d G=%d W=%d far=%d scales=%s)" % (it, U, len(a["dst"]), info["lanes_per_lattice"], info["ring_slots"], info["far_terms"], scales), flush=True)
-print("soak ok: %d random batches" % it)
+print("soak ok: %d random batches, %d lattices through the level path" % (it, n_level))
