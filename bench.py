@@ -450,37 +450,41 @@ def main():
 
     # ---- N > 1: segment index of every shard gathered to rank 0 over RCCL, from device buffers
     if world > 1:
-        from klat_amd import dist as kdist
-        uid = [kdist.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = kdist.Comm.rccl(ctx, rank, world, uid[0])
-        nranks = comm.info()["transport_ranks"]
-        assert nranks == world, "RCCL communicator has %d ranks, expected %d" % (nranks, world)
-        import ctypes as C
-        f, keep = klat_amd.Batch._filter(None, None)
-        off = np.zeros(batch.U + 1, np.int64)
-        n = C.c_int64(0)
-        klat_amd._check(klat_amd.lib().klat_segment_index(batch.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
-        comm.gather_index(batch, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)  # warm-up: buffers, RCCL channels
-        times = []
-        for _ in range(3):
-            barrier()
-            t0 = time.perf_counter()
-            tu, tr = comm.gather_index(batch, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)
-            barrier()
-            times.append(time.perf_counter() - t0)
-        if rank == 0:
-            st = comm.stats()
-            sec = median(times)
-            assert tu == world * batch.U, (tu, world, batch.U)
-            rec, roff = comm._fetch(klat_amd.SEGMENT_DTYPE, 0, tu, tr)  # order check on the host, outside the timing
-            assert roff[-1] == tr and np.array_equal(roff[:batch.U + 1], off), "rank 0's own records must come first, unchanged"
-            out["index_gather"] = {"ranks": nranks, "transport": "RCCL send/recv from device buffers, all-gather of sizes",
-                                   "utterances": int(tu), "records": int(tr), "payload_bytes_into_rank0": st["payload_bytes"],
-                                   "seconds": sec, "GB_per_s_into_rank0": st["payload_bytes"] / sec / 1e9 if sec > 0 else None,
-                                   "order": "rank order = input order (checked)"}
-            del rec, roff
-        comm.close()
+        try:  # (a failure of this leg must not take the headline line with it)
+            from klat_amd import dist as kdist
+            uid = [kdist.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = kdist.Comm.rccl(ctx, rank, world, uid[0])
+            nranks = comm.info()["transport_ranks"]
+            assert nranks == world, "RCCL communicator has %d ranks, expected %d" % (nranks, world)
+            import ctypes as C
+            f, keep = klat_amd.Batch._filter(None, None)
+            off = np.zeros(batch.U + 1, np.int64)
+            n = C.c_int64(0)
+            klat_amd._check(klat_amd.lib().klat_segment_index(batch.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
+            comm.gather_index(batch, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)  # warm-up: buffers, RCCL channels
+            times = []
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                tu, tr = comm.gather_index(batch, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)
+                barrier()
+                times.append(time.perf_counter() - t0)
+            if rank == 0:
+                st = comm.stats()
+                sec = median(times)
+                assert tu == world * batch.U, (tu, world, batch.U)
+                rec, roff = comm._fetch(klat_amd.SEGMENT_DTYPE, 0, tu, tr)  # order check on the host, outside the timing
+                assert roff[-1] == tr and np.array_equal(roff[:batch.U + 1], off), "rank 0's own records must come first, unchanged"
+                out["index_gather"] = {"ranks": nranks, "transport": "RCCL send/recv from device buffers, all-gather of sizes",
+                                       "utterances": int(tu), "records": int(tr), "payload_bytes_into_rank0": st["payload_bytes"],
+                                       "seconds": sec, "GB_per_s_into_rank0": st["payload_bytes"] / sec / 1e9 if sec > 0 else None,
+                                       "order": "rank order = input order (checked)"}
+                del rec, roff
+            comm.close()
+        except Exception as e:
+            if rank == 0:
+                out["index_gather"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     # ---- other BASELINE shapes, on rank 0 (the others wait at the barrier below)
     if rank == 0 and not args.no_shapes:
