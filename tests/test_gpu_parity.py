@@ -298,3 +298,23 @@ def test_timing_history_of_a_context():
         c.timing_history(6)  # only five steps were run
     b.close()
     c.close()
+
+
+def test_deep_prefetch_sweep_is_the_same_arithmetic(ctx, monkeypatch):
+    """A batch whose workgroups fit six per CU runs the sweep instantiation that holds eight chunks
+    of the stream per producer lane in registers instead of four; only the distance
+    of the loads changes, so alpha, beta and the posteriors are the same bit for bit."""
+    arrays = klat_amd.synth(99, np.array([300, 1200, 40, 777], np.int32), np.array([3, 2, 4, 3], np.int32))
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("KLAT_NO_DEEP_PREFETCH", "1")
+        else:
+            monkeypatch.delenv("KLAT_NO_DEEP_PREFETCH", raising=False)
+        b = klat_amd.Batch(ctx, arrays, lanes_per_lattice=4, ring_slots=32)
+        b.forward_backward(1.0, 0.3, 0.2)
+        res.append((b.alpha_beta(), b.arc_logpost()))
+        b.close()
+    monkeypatch.delenv("KLAT_NO_DEEP_PREFETCH", raising=False)
+    assert np.array_equal(res[0][0][0], res[1][0][0]) and np.array_equal(res[0][0][1], res[1][0][1])
+    assert np.array_equal(res[0][1], res[1][1], equal_nan=True)
