@@ -105,6 +105,41 @@ def test_two_thousand_state_lattices_against_the_oracle_dp(ctx):
     b.close()
 
 
+def test_config2_shard_nbest_properties(ctx):
+    """BASELINE configs[2] is lattice-best-path2 with n-best = 100 on 50 000 lattices of 2 000 states:
+    a quarter of the shard one GPU of eight holds (1 500 lattices, same generator and seed), checked
+    through what does not need the oracle at that size -- 100 paths per lattice, costs in order, the
+    best cost equal to the tropical sweep's best cost over the same arc costs, every path's label
+    count within the lattice's depth -- and against the oracle's k-best DP on a sample."""
+    U = 1500
+    arrays = klat_amd.synth(20260002, np.full(U, 2000, np.int32), np.full(U, 3, np.int32), host_threads=8)
+    rng = np.random.RandomState(2)
+    A = int(arrays["arc_off"][-1])
+    cost = rng.rand(A).astype(np.float32)
+    cost[arrays["olabel"] == 0] = 0.0
+    b = klat_amd.Batch(ctx, arrays, host_threads=8)
+    npaths, pcost, plen, plab = b.nbest(cost, 100, 2048)
+    assert np.all(npaths == 100)
+    assert np.all(np.diff(pcost, axis=1) >= 0) and np.all(np.isfinite(pcost))
+    assert plen.min() >= 1 and plen.max() <= 2000
+    # the best path over these costs is what the (min,+) sweep finds with graph = cost, acoustic = 0
+    trop = dict(arrays)
+    trop["graph"] = cost.copy()
+    trop["acoustic"] = np.zeros(A, np.float32)
+    trop["final_graph"] = np.where(np.isfinite(arrays["final_graph"]), 0.0, np.inf).astype(np.float32)
+    trop["final_acoustic"] = np.where(np.isfinite(arrays["final_acoustic"]), 0.0, np.inf).astype(np.float32)
+    bt = klat_amd.Batch(ctx, trop, host_threads=8)
+    bt.viterbi(1.0, 1.0, 0.0)
+    best = bt.viterbi_costs()[2]
+    bt.close()
+    assert np.allclose(pcost[:, 0], best, rtol=2e-6, atol=1e-5)  # float32 path sums against the double sweep
+    for u in rng.choice(U, 6, replace=False):
+        lat = _lat(arrays, int(u))
+        want = orc.kbest_paths(lat, cost[arrays["arc_off"][u]:arrays["arc_off"][u + 1]], 100)
+        assert pcost[u].tolist() == [float(c) for c, _ in want]
+    b.close()
+
+
 def test_nbest_rejects_bad_arguments(ctx):
     arrays = klat_amd.synth(3, np.array([20, 30], np.int32), np.array([2, 3], np.int32))
     b = klat_amd.Batch(ctx, arrays)
