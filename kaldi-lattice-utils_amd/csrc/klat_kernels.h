@@ -19,6 +19,7 @@ struct ScaleParams {
 struct StreamCost {
   float gs, as, half_pen;
   int general;  // graph_scale < 0 or NaN, or pen/2 not exact: the sweep uses arc_cost() instead
+  int plain;    // graph scale 1 and no penalty: the graph cost of a term is the stored float itself
 };
 inline StreamCost make_stream_cost(const ScaleParams& sp) {
   StreamCost c;
@@ -26,6 +27,7 @@ inline StreamCost make_stream_cost(const ScaleParams& sp) {
   c.as = sp.scaled ? sp.as_f : 1.0f;
   c.half_pen = sp.penalized ? 0.5f * sp.pen : 0.0f;
   c.general = (!(c.gs >= 0.0f) || 2.0f * c.half_pen != (sp.penalized ? sp.pen : 0.0f)) ? 1 : 0;
+  c.plain = (!c.general && c.gs == 1.0f && c.half_pen == 0.0f) ? 1 : 0;
   return c;
 }
 

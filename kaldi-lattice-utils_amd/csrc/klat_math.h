@@ -90,7 +90,10 @@ __device__ __forceinline__ double select64_or_zero(uint64_t mask, double if_set)
 // registers: hipcc otherwise keeps them in VGPRs and emits v_mov_b64 + v_fmac_f64 per step.
 __device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& dead) {
   dead = !(c < 1.0e30);
-  const double cc = fmax(c, -1.0e8);  // NaN -> -1e8; +inf stays (wm is forced to 0 below)
+  // NaN -> -1e8; +inf stays (wm is forced to 0 below).  The bare instruction: fmax() first quiets a
+  // possible signalling NaN with a second v_max_f64, and c comes out of arithmetic (always quiet)
+  double cc;
+  asm("v_max_f64 %0, %1, %2" : "=v"(cc) : "v"(c), "s"(-1.0e8));
   const double kf = rint(-cc * kLog2e);
   const double f = fma(-cc, kLog2e, -kf);
   // the instruction saturates (kf is -inf for a dead term); a C++ cast would be undefined there

@@ -214,8 +214,12 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     const bool live = li.state_base >= 0;
     const bool early_copy = W < 12 * CPB;  // see the period schedule below
 
-    auto run = [&](auto general_tag) {
-      constexpr bool GENERAL = decltype(general_tag)::value;
+    // cost_mode: 0 = stream_cost(), 1 = arc_cost() (StreamCost::general), 2 = graph scale 1 and no
+    // insertion penalty (StreamCost::plain: the usual --acoustic-scale-only call): the graph cost is
+    // the stored float itself, three instructions per term less
+    auto run = [&](auto cost_mode) {
+      constexpr bool GENERAL = decltype(cost_mode)::value == 1;
+      constexpr bool PLAIN = decltype(cost_mode)::value == 2;
       const ScaleParams sp = args.sp;
       const StreamCost sc = args.sc;
       // The stream stores the units (16 B = 4 rounds) of the first AL lanes of every lattice only
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       int out_p0 = 0, out_n = 0, pend_p0 = 0, pend_n = 0;
 
       auto weigh = [&](StagedTerm& t, uint32_t w, float g, float a) {
-        const double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : stream_cost(w, g, a, sc);
+        const double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : PLAIN ? (double)g + (double)(sc.as * a) : stream_cost(w, g, a, sc);
         if (TROPICAL) {
           t.wm = (c < 1.0e30) ? c : INFINITY;  // Zero weights, NaN, padding
           t.k = 0;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       // v = the source's value when the term is FAR (ignored otherwise)
       auto put_far_v = [&](StagedTerm* dst, uint32_t w, float g, float a, double v) {
         StagedTerm t;
-        double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : stream_cost(w, g, a, sc);
+        double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : PLAIN ? (double)g + (double)(sc.as * a) : stream_cost(w, g, a, sc);
         const bool last = (w & kLast) != 0;
         uint32_t ctl = w;
         if (w & kFar) {
@@ -451,9 +455,11 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       copy_store();
     };
     if (args.sc.general)
-      run(std::true_type());
+      run(std::integral_constant<int, 1>());
+    else if (args.sc.plain)
+      run(std::integral_constant<int, 2>());
     else
-      run(std::false_type());
+      run(std::integral_constant<int, 0>());
     return;
   }
 
@@ -523,8 +529,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     if (FAST) {
       const int shift = (int)((uint32_t)te_raw - (uint32_t)refE);
       sticky |= (tm != 0.0) & ((unsigned)(shift + 900) > 1800u);
-      const double add = ldexp(tm, shift);
-      accM = select64(lane_mask(first), add, accM + add);
+      // (no test of FIRST: the round that closed the previous state left 0 in the accumulator -- one
+      // compare less per round, and the select is off the chain)
+      accM += ldexp(tm, shift);
       cM = G > 1 ? group_sum<G>(accM) : accM;
       cE = refE;
     } else {
@@ -557,7 +564,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
     if (FAST) {
       // a zero state keeps the reference exponent as its (irrelevant) exponent: frexp gives 0, 0
       e = cE + __builtin_amdgcn_frexp_exp(cM);
-      refE = select32(lane_mask(last), e, refE);
+      const uint64_t closing = lane_mask(last);
+      refE = select32(closing, e, refE);
+      accM = select64(closing, 0.0, accM);
     } else {
       e = (cM != 0.0) ? cE + __builtin_amdgcn_frexp_exp(cM) : kExpMin;
     }
