@@ -147,3 +147,18 @@ def test_the_level_path_takes_what_fits_one_round_of_waves(ctx, monkeypatch):
     for mode in ("1", "0"):
         _check(res[mode][0][0], res[None][0][0], 1e-9), _check(res[mode][0][1], res[None][0][1], 1e-9)
         _check(res[mode][1], res[None][1], 1e-9), _check(res[mode][2], res[None][2], 1e-9)
+
+
+def test_level_path_at_its_largest_lattice(ctx):
+    """8 192 states is the bound of the level path (8 B of LDS per state beside the 64-KiB ring: a
+    128-KiB workgroup); just below it, and one lattice just above it that must stay with the streams."""
+    arrays = _wide(3, [8100, 8300], [3, 3], 500)
+    b = klat_amd.Batch(ctx, arrays)
+    assert b.info()["level_lattices"] == 1
+    scales = (1.0, 0.2, 0.0)
+    b.forward_backward(*scales)
+    alpha, beta = b.alpha_beta()
+    total, tf, tb = b.totals()
+    wa, wb, wt, wpost = _oracle_batch(arrays, *scales)
+    _check(alpha, wa, 1e-9), _check(beta, wb, 1e-9), _check(total, wt, 1e-9), _check(b.arc_logpost(), wpost, 1e-9)
+    b.close()
