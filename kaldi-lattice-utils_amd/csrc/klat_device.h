@@ -24,29 +24,30 @@ namespace klat {
 // bits 0..11  RD    ring cell ((target position - rel) mod W) * (64/G) + lattice slot to read
 // bits 12..23 WR    ring cell of the target state (only on the COMMIT lane)
 // bit  24     COMMIT  LAST round and this lane (first of the lattice's G) stores the result
-// bit  25     BYPASS  source = state finished by the previous round (first round, rel == 1):
-//                     its value is taken from registers, not from the ring
+// bit  25     NIL   padding term, contributes log-zero; its graph cost in the stream is +inf, so
+//                   the kernel needs no test of this bit to give it weight zero (never with FAR)
 // bit  26     ONE   constant-one source (alpha[start] = 0, final weights)
 // bit  27     FAR   source older than the ring: bits 0..26 then hold rel = target position -
 //                   source position and RD/WR/COMMIT are resolved by the kernel
 // bit  28     LAST  last round of this target state (uniform over the lattice's G lanes)
-// bit  29     NIL   padding term, contributes log-zero; its graph cost in the stream is +inf, so
-//                   the kernel needs no test of this bit to give it weight zero
+// bit  29     FIRST first round of this target state (uniform over the lattice's G lanes)
 // bit  30     WORD  ilabel != 0 (AddWordInsPenToCompactLattice applies).  Bit 30 alone is the
 //                   float 2.0f: the kernel adds the penalty as fma(bits, pen/2, graph)
-// bit  31     FIRST first round of this target state (uniform over the lattice's G lanes)
+// bit  31     BYPASS  source = state finished by the previous round (first round, rel == 1): its
+//                     value is taken from registers, not from the ring.  The sign bit: the one flag
+//                     the chain wave tests every round costs it a compare and no AND
 static const uint32_t kCellMask = 0xFFFu;  // ring cells + 64 dummy cells per workgroup <= 4096
 static const int kWrShift = 12;
 static const uint32_t kCommit = 1u << 24;
-static const uint32_t kBypass = 1u << 25;
+static const uint32_t kNil = 1u << 25;
 static const uint32_t kOne = 1u << 26;
 static const int kMaxRingCells = 4096 - 64;  // W * (64/G) may not exceed this
 static const uint32_t kRelMask = (1u << 27) - 1u;  // FAR terms only
 static const uint32_t kFar = 1u << 27;
 static const uint32_t kLast = 1u << 28;
-static const uint32_t kNil = 1u << 29;
+static const uint32_t kFirst = 1u << 29;
 static const uint32_t kWord = 1u << 30;
-static const uint32_t kFirst = 1u << 31;
+static const uint32_t kBypass = 1u << 31;
 
 static const int kChunkRounds = 4;    // rounds per 16-byte lane load
 static const int kPrefetchChunks = 4; // register prefetch depth of the sweep kernel (chunks of 4 rounds)

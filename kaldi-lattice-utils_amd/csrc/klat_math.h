@@ -88,7 +88,9 @@ __device__ __forceinline__ double select64_or_zero(uint64_t mask, double if_set)
 // 2^f by the degree-9 polynomial of tools/exp2_poly.py (Chebyshev interpolant, relative error
 // < 1.9e-14), evaluated as one block of nine v_fma_f64 with the coefficients in scalar
 // registers: hipcc otherwise keeps them in VGPRs and emits v_mov_b64 + v_fmac_f64 per step.
-__device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& dead) {
+// `live`: lanes whose term counts at all (a lane beyond a job's stored lanes carries its lattice's
+// first term a second time and must weigh nothing)
+__device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& dead, uint64_t live = ~0ull) {
   dead = !(c < 1.0e30);
   // NaN -> -1e8; +inf stays (wm is forced to 0 below).  The bare instruction: fmax() first quiets a
   // possible signalling NaN with a second v_max_f64, and c comes out of arithmetic (always quiet)
@@ -115,7 +117,7 @@ __device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& d
         "s"(9.61812919393431262072e-03), "s"(5.55041086646516704239e-02),
         "s"(2.40226506956403407234e-01), "s"(6.93147180559946174405e-01),
         "s"(1.00000000000001354472e+00));
-  wm = select64_or_zero(lane_mask(c < 1.0e30), p);
+  wm = select64_or_zero(lane_mask(c < 1.0e30) & live, p);
 }
 
 // (M,E) += (tm,te) in the scaled-linear domain, safe for any exponent gap.

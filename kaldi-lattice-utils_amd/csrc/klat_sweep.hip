@@ -228,6 +228,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       const int AL = job_stored_lanes(job.tag);
       const int row = AL * LPW;
       const bool stored = sub < AL;
+      const uint64_t live = lane_mask(stored);
       // (a lane beyond AL reads its lattice's first unit again -- the same cache line, no HBM
       // traffic, and no branch around the prefetch loads -- and ignores it)
       const int unit = (stored ? sub : 0) * LPW + slot;
@@ -252,11 +253,11 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       auto weigh = [&](StagedTerm& t, uint32_t w, float g, float a) {
         const double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : PLAIN ? (double)g + (double)(sc.as * a) : stream_cost(w, g, a, sc);
         if (TROPICAL) {
-          t.wm = (c < 1.0e30) ? c : INFINITY;  // Zero weights, NaN, padding
+          t.wm = (c < 1.0e30 && stored) ? c : INFINITY;  // Zero weights, NaN, padding
           t.k = 0;
         } else {
           bool dead;
-          arc_weight(c, t.wm, t.k, dead);
+          arc_weight(c, t.wm, t.k, dead, live);
         }
       };
       auto put = [&](StagedTerm* dst, uint32_t w, float g, float a) {
@@ -289,11 +290,11 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
             ctl |= (uint32_t)(W * LPW + slot) << kWrShift;  // the lattice's dummy cell
         }
         if (TROPICAL) {
-          t.wm = (c < 1.0e30) ? c : INFINITY;
+          t.wm = (c < 1.0e30 && stored) ? c : INFINITY;
           t.k = 0;
         } else {
           bool dead;
-          arc_weight(c, t.wm, t.k, dead);
+          arc_weight(c, t.wm, t.k, dead, live);
         }
         t.ctl = ctl;
         store_staged(dst, t);
@@ -370,26 +371,13 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           *dst = v;
         }
       };
-      const uint32_t pad_w = kNil | ((uint32_t)(W * LPW + slot) << kWrShift);
-      const uint64_t unstored = lane_mask(!stored);
       auto stage_chunk = [&](int cj, int4 w4, float4 g4, const float4& a4, const double (&v)[4]) {
         // stage buffer: [barrier period parity][chunk within the period][round][lane]
         const int sidx = (((cj / CPB) & 1) * CPB + (cj % CPB)) * 256 + lane;
         StagedTerm* st = stage + sidx;
-        if (AL < G) {
-          // wave-uniform.  The lane holds its lattice's first unit: FIRST / LAST are uniform over a
-          // lattice's lanes, the rest of a padding word is fixed, its graph cost infinite.
-          const int fl = (int)(kFirst | kLast);
-          w4.x = select32(unstored, (w4.x & fl) | (int)pad_w, w4.x);
-          w4.y = select32(unstored, (w4.y & fl) | (int)pad_w, w4.y);
-          w4.z = select32(unstored, (w4.z & fl) | (int)pad_w, w4.z);
-          w4.w = select32(unstored, (w4.w & fl) | (int)pad_w, w4.w);
-          const int inf = 0x7F800000;
-          g4.x = __int_as_float(select32(unstored, inf, __float_as_int(g4.x)));
-          g4.y = __int_as_float(select32(unstored, inf, __float_as_int(g4.y)));
-          g4.z = __int_as_float(select32(unstored, inf, __float_as_int(g4.z)));
-          g4.w = __int_as_float(select32(unstored, inf, __float_as_int(g4.w)));
-        }
+        // (a lane beyond the job's stored lanes holds its lattice's first unit a second time: the same
+        // flags, cells and source as lane 0 of the lattice -- it reads what that lane reads and, on a
+        // commit, writes the same value to the same cell -- and `live` takes its weight away)
         const bool any_far = __any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0);
         if (FARP && any_far) {
           put_far_v(st, (uint32_t)w4.x, g4.x, a4.x, v[0]);

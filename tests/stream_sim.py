@@ -9,9 +9,9 @@ import math
 import numpy as np
 
 CELL_MASK, WR_SHIFT = 0xFFF, 12
-COMMIT, BYPASS, ONE = 1 << 24, 1 << 25, 1 << 26
+COMMIT, NIL, ONE = 1 << 24, 1 << 25, 1 << 26
 REL_MASK = (1 << 27) - 1
-FAR, LAST, NIL, WORD, FIRST = 1 << 27, 1 << 28, 1 << 29, 1 << 30, 1 << 31
+FAR, LAST, FIRST, WORD, BYPASS = 1 << 27, 1 << 28, 1 << 29, 1 << 30, 1 << 31
 EXP_MIN = -(1 << 29)
 LOG2E = 1.4426950408889634
 LN2 = 0.6931471805599453
