@@ -484,8 +484,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       }
     }
     for (int64_t u = 0; u < U; ++u)
-      for (int64_t a0 = d->arc_off[u]; a0 < d->arc_off[u + 1]; a0 += kPostItemArcs)
-        P.items.push_back(PostItem{a0, (int32_t)std::min<int64_t>(kPostItemArcs, d->arc_off[u + 1] - a0), (int32_t)u});
+      append_post_items(&P.items, d->arc_off[u], d->arc_off[u + 1], u);
   }
   b->G = P.G;
   b->W = P.W;
@@ -606,15 +605,6 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.ring_slots = 0;  // per layout class below
   sa.far_prefetch = 0;
 
-  TotalsArgs ta;
-  ta.num_lattices = (int32_t)b->U;
-  ta.state_off = b->state_off.p;
-  ta.alpha = b->alpha.p;
-  ta.beta = b->beta.p;
-  ta.total = b->total.p;
-  ta.tot_fwd = b->tot_fwd.p;
-  ta.tot_bwd = b->tot_bwd.p;
-
   PosteriorArgs pa;
   pa.items = b->items.p;
   pa.state_off = b->state_off.p;
@@ -626,6 +616,8 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   pa.alpha = b->alpha.p;
   pa.beta = b->beta.p;
   pa.total = b->total.p;
+  pa.tot_fwd = b->tot_fwd.p;
+  pa.tot_bwd = b->tot_bwd.p;
   pa.logpost = b->logpost.p;
   pa.sp = sp;
 
@@ -656,7 +648,8 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
     if (rc != KLAT_OK) return rc;
   }
   if (!one_class) KLAT_HIP(hipEventRecord(ev[1], c->stream));
-  KLAT_HIP(launch_totals(ta, c->stream));
+  // (the totals are formed by the posterior kernel's first item of every lattice; totals_ms of the
+  // timings is what is left between the two events: the exact sweep's launch)
   KLAT_HIP(hipEventRecord(ev[2], c->stream));
   KLAT_HIP(launch_posterior(pa, b->num_items, c->stream));
   KLAT_HIP(hipEventRecord(ev[3], c->stream));

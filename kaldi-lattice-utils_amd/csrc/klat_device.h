@@ -98,9 +98,11 @@ struct LaneInfo {
 // Work item of the posterior kernel: <=kPostItemArcs consecutive arcs of one lattice.
 struct PostItem {
   int64_t arc_begin;
-  int32_t count;
+  int32_t count;    // | kPostItemFirst on the first item of its lattice (which also writes the lattice's totals;
+                    //   a lattice without arcs has one item of count 0 for that)
   int32_t lattice;
 };
+static const int32_t kPostItemFirst = 1 << 30;
 
 static const int kPostItemArcs = 1024;
 

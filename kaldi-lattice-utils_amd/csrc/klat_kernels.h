@@ -90,7 +90,7 @@ struct PosteriorArgs {
   const int32_t* src; const int32_t* dst; const int32_t* ilabel;
   const float* graph; const float* acoustic;
   const double* alpha; const double* beta;  // padded
-  const double* total;
+  double* total; double* tot_fwd; double* tot_bwd;  // [U] written by the first item of every lattice
   double* logpost;
   ScaleParams sp;
 };

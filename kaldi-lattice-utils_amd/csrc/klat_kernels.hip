@@ -37,12 +37,24 @@ __global__ __launch_bounds__(256) void totals_kernel(TotalsArgs a) {
 template <bool PEN>
 __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
   const PostItem item = a.items[blockIdx.x];
-  const int64_t base = padded_state_base(a.state_off[item.lattice], item.lattice);
+  const int64_t s0 = a.state_off[item.lattice];
+  const int64_t S = a.state_off[item.lattice + 1] - s0;
+  const int64_t base = padded_state_base(s0, item.lattice);
   const double* __restrict__ alpha = a.alpha + base;
   const double* __restrict__ beta = a.beta + base;
-  const double tot = a.total[item.lattice];
+  // total = (tot_forward + beta[start]) / 2, 0 for an empty lattice (see totals_kernel: this kernel
+  // took its work over, one launch less between the sweep and the posteriors); the lattice's first
+  // item leaves the three numbers for klat_get_totals and the accumulators
+  const double tf = S > 0 ? alpha[S] : 0.0, tb = S > 0 ? beta[0] : 0.0;
+  const double tot = 0.5 * (tb + tf);
+  if ((item.count & kPostItemFirst) && threadIdx.x == 0) {
+    a.tot_fwd[item.lattice] = tf;
+    a.tot_bwd[item.lattice] = tb;
+    a.total[item.lattice] = tot;
+  }
+  const int count = item.count & (kPostItemFirst - 1);
   const ScaleParams sp = a.sp;
-  for (int t = threadIdx.x; t < item.count; t += 256) {
+  for (int t = threadIdx.x; t < count; t += 256) {
     const int64_t i = item.arc_begin + t;
     const int s = a.src[i];
     const int d = a.dst[i];

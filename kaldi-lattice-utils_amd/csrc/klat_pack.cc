@@ -294,6 +294,14 @@ int build_jobs(int64_t U, const int64_t* state_off, const LatticeRounds* lr, con
   return KLAT_OK;
 }
 
+void append_post_items(std::vector<PostItem>* items, int64_t a0, int64_t a1, int64_t u) {
+  int32_t first = kPostItemFirst;
+  for (int64_t a = a0; a < a1 || first; a += kPostItemArcs) {
+    items->push_back(PostItem{a, (int32_t)std::max<int64_t>(0, std::min<int64_t>(kPostItemArcs, a1 - a)) | first, (int32_t)u});
+    first = 0;
+  }
+}
+
 int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBatch* out,
                std::string* err) {
   const int64_t U = d.num_lattices;
@@ -521,8 +529,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
   // ---- posterior work items ----
   for (int64_t u = 0; u < U; ++u) {
     const int64_t a0 = d.arc_off[u], a1 = d.arc_off[u + 1];
-    for (int64_t a = a0; a < a1; a += kPostItemArcs)
-      P.items.push_back(PostItem{a, (int32_t)std::min<int64_t>(kPostItemArcs, a1 - a), (int32_t)u});
+    append_post_items(&P.items, a0, a1, u);
   }
   return KLAT_OK;
 }

@@ -46,6 +46,9 @@ struct LayoutClass {
   int32_t far;  // some lattice of the class has arcs (or final states) W or more positions long
 };
 
+// The posterior kernel's work items of lattice u (arcs [a0, a1)): at least one, the first one marked.
+void append_post_items(std::vector<PostItem>* items, int64_t a0, int64_t a1, int64_t u);
+
 struct PackedBatch {
   int G = 0, W = 0;  // of the class that holds most of the stream (klat_batch_info)
   std::vector<LayoutClass> classes;

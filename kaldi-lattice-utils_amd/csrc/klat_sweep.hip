@@ -228,7 +228,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       const int AL = job_stored_lanes(job.tag);
       const int row = AL * LPW;
       const bool stored = sub < AL;
-      const uint64_t live = lane_mask(stored);
+      const uint64_t stored_mask = lane_mask(stored);
       // (a lane beyond AL reads its lattice's first unit again -- the same cache line, no HBM
       // traffic, and no branch around the prefetch loads -- and ignores it)
       const int unit = (stored ? sub : 0) * LPW + slot;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           t.k = 0;
         } else {
           bool dead;
-          arc_weight(c, t.wm, t.k, dead, live);
+          arc_weight(c, t.wm, t.k, dead, stored_mask);
         }
       };
       auto put = [&](StagedTerm* dst, uint32_t w, float g, float a) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           t.k = 0;
         } else {
           bool dead;
-          arc_weight(c, t.wm, t.k, dead, live);
+          arc_weight(c, t.wm, t.k, dead, stored_mask);
         }
         t.ctl = ctl;
         store_staged(dst, t);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         StagedTerm* st = stage + sidx;
         // (a lane beyond the job's stored lanes holds its lattice's first unit a second time: the same
         // flags, cells and source as lane 0 of the lattice -- it reads what that lane reads and, on a
-        // commit, writes the same value to the same cell -- and `live` takes its weight away)
+        // commit, writes the same value to the same cell -- and arc_weight's `live` mask takes its weight away)
         const bool any_far = __any(((uint32_t)(w4.x | w4.y | w4.z | w4.w) & kFar) != 0);
         if (FARP && any_far) {
           put_far_v(st, (uint32_t)w4.x, g4.x, a4.x, v[0]);
@@ -606,7 +606,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   }
   __syncthreads();  // lets the producer copy out the last period's states
   if (FAST && !TROPICAL) {
-    if (__any(sticky) && lane == 0) args.job_flags[blockIdx.x] = 1;
+    // every job's flag is written, set or not: no clearing pass before the launch
+    const bool flagged = __any(sticky);
+    if (lane == 0) args.job_flags[blockIdx.x] = flagged ? 1 : 0;
   }
 }
 
@@ -684,7 +686,7 @@ hipError_t launch_sweep_tropical(const SweepArgs& args, int num_jobs, int G, hip
   return hipGetLastError();
 }
 
-// Clears the job flags, runs the fast sweep over every job and the exact sweep over the jobs the
+// Runs the fast sweep over every job (it writes every job's flag) and the exact sweep over the jobs the
 // fast one flagged (normally none: those workgroups exit at once).
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream, hipEvent_t fast_begin,
                         hipEvent_t fast_end) {
@@ -695,8 +697,6 @@ hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t 
   }
   const int LPW = 64 / G;
   if ((size_t)args.ring_slots * LPW + 64 > kCellMask + 1) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(args.job_flags, 0, sizeof(int32_t) * (size_t)num_jobs, stream);
-  if (e != hipSuccess) return e;
   switch (G) {
     case 1: launch_pair<1>(args, num_jobs, stream, fast_begin, fast_end); break;
     case 2: launch_pair<2>(args, num_jobs, stream, fast_begin, fast_end); break;
