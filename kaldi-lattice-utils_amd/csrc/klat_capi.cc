@@ -521,6 +521,30 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
 #undef UP
 #undef AL
 #undef FAIL
+  if (std::getenv("KLAT_NO_SRC_DELTA") == nullptr && b->A > 0) {  // src as one-byte steps for the posterior pass
+    DevBuf<int32_t> over;
+    int rc2;
+    if ((rc2 = b->src_delta.alloc((size_t)b->A)) || (rc2 = b->item_src.alloc(P.items.size())) || (rc2 = over.alloc(1))) {
+      klat_batch_destroy(b);
+      return rc2;
+    }
+    PosteriorPrepArgs pp;
+    pp.items = b->items.p;
+    pp.src = b->src.p;
+    pp.src_delta = b->src_delta.p;
+    pp.item_src = b->item_src.p;
+    pp.overflow = over.p;
+    int32_t h_over = 0;
+    hipError_t pe = hipMemsetAsync(over.p, 0, sizeof(int32_t), c->stream);
+    if (pe == hipSuccess) pe = launch_posterior_prep(pp, (int)P.items.size(), c->stream);
+    if (pe == hipSuccess) pe = hipMemcpyAsync(&h_over, over.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (pe == hipSuccess) pe = hipStreamSynchronize(c->stream);
+    if (pe != hipSuccess) {
+      klat_batch_destroy(b);
+      return hip_fail(pe, "posterior preparation");
+    }
+    if (h_over) b->src_delta.release(), b->item_src.release();  // a step above 255: the pass reads src itself
+  }
   hipError_t e = hipStreamSynchronize(c->stream);  // uploads read pageable host memory of P
   if (e != hipSuccess) {
     klat_batch_destroy(b);
@@ -620,6 +644,8 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   pa.tot_bwd = b->tot_bwd.p;
   pa.logpost = b->logpost.p;
   pa.sp = sp;
+  pa.src_delta = b->src_delta.p;
+  pa.item_src = b->item_src.p;
 
   // sweep_ms of a one-class batch is the fast sweep kernel alone (what rocprofv3 lists under its
   // name): the events sit right around its launch.  The exact sweep's launch after it (all of its

@@ -93,7 +93,21 @@ struct PosteriorArgs {
   double* total; double* tot_fwd; double* tot_bwd;  // [U] written by the first item of every lattice
   double* logpost;
   ScaleParams sp;
+  // src as one byte per arc: src[i] - src[i - 1] (0 on the first arc of an item) and the source of
+  // every item's first arc -- the posterior pass then reads 21 B per arc instead of 24.  Null when
+  // some step is above 255 (a run of 255 states without arcs): the pass reads src itself.
+  const uint8_t* src_delta;
+  const int32_t* item_src;
 };
+
+struct PosteriorPrepArgs {
+  const PostItem* items;
+  const int32_t* src;
+  uint8_t* src_delta;   // [A]
+  int32_t* item_src;    // [items]
+  int32_t* overflow;    // [1] set when a step does not fit a byte
+};
+hipError_t launch_posterior_prep(const PosteriorPrepArgs& a, int num_items, hipStream_t stream);
 
 // Tropical twin: the Viterbi costs come from the sweep kernel's TROPICAL instantiation
 // (launch_sweep_tropical: SweepArgs with alpha / beta = the padded forward / backward cost rows,

@@ -66,6 +66,109 @@ __global__ __launch_bounds__(256) void posterior_kernel(PosteriorArgs a) {
   }
 }
 
+// src of every arc as a one-byte step from the arc before it (batch creation, once)
+__global__ __launch_bounds__(256) void posterior_prep_kernel(PosteriorPrepArgs a) {
+  const PostItem item = a.items[blockIdx.x];
+  const int count = item.count & (kPostItemFirst - 1);
+  if (count > 0 && threadIdx.x == 0) a.item_src[blockIdx.x] = a.src[item.arc_begin];
+  bool over = false;
+  for (int t = threadIdx.x; t < count; t += 256) {
+    const int64_t i = item.arc_begin + t;
+    const int step = t == 0 ? 0 : a.src[i] - a.src[i - 1];
+    over |= (unsigned)step > 255u;
+    a.src_delta[i] = (uint8_t)step;
+  }
+  if (__any(over) && (threadIdx.x & 63) == 0) atomicOr(a.overflow, 1);
+}
+
+typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// The same pass with src from the steps: a lane owns FOUR CONSECUTIVE arcs (one 16-byte load per
+// array, two 16-byte stores), a wave 256 consecutive arcs; the sources come from a prefix sum of the
+// steps (shuffles inside the wave, one LDS word per wave across the block).
+template <bool PEN>
+__global__ __launch_bounds__(256) void posterior_delta_kernel(PosteriorArgs a) {
+  __shared__ int wave_steps[4];
+  const PostItem item = a.items[blockIdx.x];
+  const int64_t s0 = a.state_off[item.lattice];
+  const int64_t S = a.state_off[item.lattice + 1] - s0;
+  const int64_t base = padded_state_base(s0, item.lattice);
+  const double* __restrict__ alpha = a.alpha + base;
+  const double* __restrict__ beta = a.beta + base;
+  const double tf = S > 0 ? alpha[S] : 0.0, tb = S > 0 ? beta[0] : 0.0;
+  const double tot = 0.5 * (tb + tf);
+  if ((item.count & kPostItemFirst) && threadIdx.x == 0) {
+    a.tot_fwd[item.lattice] = tf;
+    a.tot_bwd[item.lattice] = tb;
+    a.total[item.lattice] = tot;
+  }
+  const int count = item.count & (kPostItemFirst - 1);
+  if (count == 0) return;  // (workgroup-uniform)
+  const ScaleParams sp = a.sp;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t0 = wave * 256 + lane * 4;
+  const int64_t i0 = item.arc_begin + t0;
+  int d[4], dst[4], il[4] = {0, 0, 0, 0};
+  float g[4], ac[4];
+  if (t0 + 3 < count) {
+    const uint32_t d4 = *reinterpret_cast<const uint32_t __attribute__((aligned(1)))*>(a.src_delta + i0);
+    const int4u dv = *reinterpret_cast<const int4u*>(a.dst + i0);
+    const float4u gv = *reinterpret_cast<const float4u*>(a.graph + i0);
+    const float4u av = *reinterpret_cast<const float4u*>(a.acoustic + i0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = (int)((d4 >> (8 * q)) & 255u), dst[q] = dv[q], g[q] = gv[q], ac[q] = av[q];
+    if (PEN) {
+      const int4u iv = *reinterpret_cast<const int4u*>(a.ilabel + i0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) il[q] = iv[q];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = t0 + q < count;
+      const int64_t i = ok ? i0 + q : item.arc_begin;
+      d[q] = ok ? (int)a.src_delta[i] : 0;
+      dst[q] = a.dst[i];
+      g[q] = a.graph[i];
+      ac[q] = a.acoustic[i];
+      if (PEN) il[q] = a.ilabel[i];
+    }
+  }
+  // sources: inclusive prefix sums of the steps, item-wide
+  int run = d[0] + d[1] + d[2] + d[3];
+  int inc = run;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_steps[wave] = inc;
+  __syncthreads();
+  int src = a.item_src[blockIdx.x] + inc - run;
+  for (int w = 0; w < wave; ++w) src += wave_steps[w];
+  double out[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    src += d[q];
+    const bool ok = t0 + q < count;
+    const double c = arc_cost(g[q], ac[q], PEN ? il[q] != 0 : false, sp);
+    const double through = (ok ? alpha[src] : 0.0) + (ok ? beta[dst[q]] : 0.0) - c;
+    out[q] = (through > -INFINITY) ? through - tot : -INFINITY;
+  }
+  if (t0 + 3 < count) {
+    double2u* o = reinterpret_cast<double2u*>(a.logpost + i0);
+    double2u lo, hi;
+    lo[0] = out[0], lo[1] = out[1], hi[0] = out[2], hi[1] = out[3];
+    o[0] = lo;
+    o[1] = hi;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (t0 + q < count) a.logpost[i0 + q] = out[q];
+  }
+}
+
 // one workgroup per lattice: dense[state_off[u] + s] = padded[state_off[u] + u + s]
 __global__ __launch_bounds__(256) void unpad_kernel(UnpadArgs a) {
   for (int u = blockIdx.x; u < a.num_lattices; u += gridDim.x) {
@@ -96,8 +199,21 @@ hipError_t launch_totals(const TotalsArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+hipError_t launch_posterior_prep(const PosteriorPrepArgs& a, int num_items, hipStream_t stream) {
+  if (num_items <= 0) return hipSuccess;
+  hipLaunchKernelGGL(posterior_prep_kernel, dim3(num_items), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_posterior(const PosteriorArgs& a, int num_items, hipStream_t stream) {
   if (num_items <= 0) return hipSuccess;
+  if (a.src_delta != nullptr) {
+    if (a.sp.penalized)
+      hipLaunchKernelGGL(posterior_delta_kernel<true>, dim3(num_items), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL(posterior_delta_kernel<false>, dim3(num_items), dim3(256), 0, stream, a);
+    return hipGetLastError();
+  }
   if (a.sp.penalized)
     hipLaunchKernelGGL(posterior_kernel<true>, dim3(num_items), dim3(256), 0, stream, a);
   else

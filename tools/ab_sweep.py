@@ -13,5 +13,6 @@ for _ in range(300):
     b.forward_backward(1.0, 0.1, 0.0)
 ctx.sync()
 h = ctx.timing_history(200)
-print("%s: sweep median %.4f ms  min %.4f   step median %.4f ms" % (os.environ.get("KLAT_LIB_OVERRIDE", "tree")[-20:],
-      np.median([t["sweep_ms"] for t in h]), min(t["sweep_ms"] for t in h), np.median([t["total_ms"] for t in h])), flush=True)
+print("%s: sweep median %.4f ms  min %.4f   posterior median %.4f ms   step median %.4f ms" % (os.environ.get("KLAT_LIB_OVERRIDE", "tree")[-20:],
+      np.median([t["sweep_ms"] for t in h]), min(t["sweep_ms"] for t in h), np.median([t["posterior_ms"] for t in h]),
+      np.median([t["total_ms"] for t in h])), flush=True)
