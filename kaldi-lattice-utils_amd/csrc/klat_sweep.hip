@@ -122,6 +122,14 @@ struct __attribute__((aligned(16))) StagedTerm {
 __device__ __forceinline__ void store_staged(StagedTerm* dst, const StagedTerm& t) {
   *reinterpret_cast<int4*>(dst) = make_int4(__double2loint(t.wm), __double2hiint(t.wm), t.k, (int)t.ctl);
 }
+// LAST of a term word as 0 / 1 in one instruction (hipcc turns the C expression, and the bfe builtin,
+// into a shift and an AND)
+static_assert(kLast == 1u << 28, "last_bit() extracts bit 28");
+__device__ __forceinline__ int last_bit(uint32_t w) {
+  int r;
+  asm("v_bfe_u32 %0, %1, 28, 1" : "=v"(r) : "v"(w));
+  return r;
+}
 static constexpr uint32_t kCtlFirst = kFirst;
 static constexpr uint32_t kCtlLast = kLast;
 static constexpr uint32_t kCtlBypass = kBypass;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
         weigh(t, w, g, a);
         t.ctl = w;
         store_staged(dst, t);
-        p += (int)((w / kLast) & 1u);
+        p += last_bit(w);
       };
       // The same for a chunk in which some lane's source is older than the ring (FAR).  The
       // source's natural-log value v is already in alpha / beta -- this very wave stored it, in
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
             const int q = pp - (int)(w & kRelMask);
             const double* srcp = (inside && (w & kFar) != 0) ? &vals[q_off + q_step * q] : sink_row;
             fv[i][r] = __hip_atomic_load(srcp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pp += (int)((w / kLast) & 1u);
+            pp += last_bit(w);
           }
         }
       };
