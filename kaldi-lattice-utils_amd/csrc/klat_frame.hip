@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   // [span_cap]: k0 | k1 << 16 of every arc -- the two passes over all arcs that every tile makes
   // (counts, scatter) read 4 bytes of LDS instead of a 16-byte row of L2 behind a dependent loop
   uint32_t* lspan = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * kFrLdsEntries);
-  __shared__ int tile_max, lab_min, lab_max;
+  __shared__ int tile_max, lab_min, lab_max, span_max, unsorted;
   // Only the frames at which some arc starts or ends (and the tile's first) differ from the frame
   // before them: those CHANGED frames get a bucket, the others repeat their predecessor's records.
   __shared__ uint16_t cidx[kFrTileFrames + 2];    // changed frames before frame k of the tile (cidx[tf] = their number)
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     }                                                                  \
   } while (0)
   // ---- 0. clipped span and x of every arc; the label range of the lattice ----
-  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000;
+  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unsorted = 0;
   __syncthreads();
-  int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000;
+  int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0;
   for (int base = 0; base < nA; base += kFrSpanBatch * kFrThreads) {  // eight arcs per thread at a time: loads batched, no branch around them
     int il[kFrSpanBatch], t0[kFrSpanBatch], t1[kFrSpanBatch];
     float gr[kFrSpanBatch], ac4[kFrSpanBatch];
@@ -394,12 +394,29 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         r.x = (lp[q] > -INFINITY) ? lp[q] + ((double)g + (double)ac) - (double)(g + ac) : lp[q];
       }
       ai[i] = r;
-      if (spans_lds) lspan[i] = (uint32_t)r.k0 | ((uint32_t)r.k1 << 16);
+      if (spans_lds) {
+        // (an empty span is kept as [t, t) at its source's time: in a time-sorted lattice the first
+        // frames of the arcs then ascend with the arc number, which the tiles below make use of)
+        const int t = min(max(t0[q], 0), 65535);
+        lspan[i] = r.k1 > r.k0 ? ((uint32_t)r.k0 | ((uint32_t)r.k1 << 16)) : ((uint32_t)t | ((uint32_t)t << 16));
+        span_max_t = max(span_max_t, r.k1 - r.k0);
+      }
     }
   }
   for (int d = 32; d > 0; d >>= 1) lmin_t = min(lmin_t, __shfl_xor(lmin_t, d, 64)), lmax_t = max(lmax_t, __shfl_xor(lmax_t, d, 64));
-  if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t);
+  for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64));
+  if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t), atomicMax(&span_max, span_max_t);
   __syncthreads();
+  // do the arcs' first frames ascend with the arc number?  Then a tile's arcs are one range of arcs
+  // (two binary searches over the spans in LDS) and its passes need not visit the others.
+  if (spans_lds) {
+    bool desc = false;
+    for (int i = tid + 1; i < nA; i += kFrThreads) desc |= (lspan[i] & 0xFFFFu) < (lspan[i - 1] & 0xFFFFu);
+    if (__any(desc) && (tid & 63) == 0) atomicOr(&unsorted, 1);
+  }
+  __syncthreads();
+  const bool ranged = spans_lds && unsorted == 0;  // workgroup-uniform
+  const int longest = span_max;
   // (label - lab_min) and the arc number fit one 32-bit sort key?  (0xFFFFFFFF stays free for padding)
   int abits = 1;
   while ((1 << abits) < nA) ++abits;
@@ -419,12 +436,28 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     for (int k = tid; k <= tf; k += kFrThreads) lboff[k] = 0, cidx[k] = (k == 0) ? 1 : 0;
     if (tid == 0) big_n = 0;
     __syncthreads();
+    // arcs that can cover a frame of the tile: first frame below the tile's end, and (no arc is
+    // longer than `longest`) above its start less that
+    int arc_lo = 0, arc_hi = nA;
+    if (ranged) {
+      auto first_at_least = [&](int frame) {  // first arc whose first frame is >= frame
+        int l = 0, h = nA;
+        while (l < h) {
+          const int mid = (l + h) >> 1;
+          if ((int)(lspan[mid] & 0xFFFFu) < frame) l = mid + 1;
+          else h = mid;
+        }
+        return l;
+      };
+      arc_lo = first_at_least(f0 - longest + 1);
+      arc_hi = first_at_least(f0 + tf);
+    }
     auto span_of = [&](int i, int& lo, int& hi) {
       const uint32_t sp32 = spans_lds ? lspan[i] : 0u;
       const int k0 = spans_lds ? (int)(sp32 & 0xFFFFu) : ai[i].k0, k1 = spans_lds ? (int)(sp32 >> 16) : ai[i].k1;
       lo = max(k0, f0) - f0, hi = min(k1, f0 + tf) - f0;
     };
-    for (int i = tid; i < nA; i += kFrThreads) {
+    for (int i = arc_lo + tid; i < arc_hi; i += kFrThreads) {
       int lo, hi;
       span_of(i, lo, hi);
       if (hi > lo) {
@@ -483,7 +516,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     FR_LAP(1);
     // ---- 2. every arc drops itself into the buckets of its frames ----
     if (in_lds) {
-      for (int i = tid; i < nA; i += kFrThreads) {
+      for (int i = arc_lo + tid; i < arc_hi; i += kFrThreads) {
         int lo, hi;
         span_of(i, lo, hi);
         if (hi <= lo) continue;
