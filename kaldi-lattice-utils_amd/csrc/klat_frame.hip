@@ -271,6 +271,32 @@ __device__ __forceinline__ void fr_sort32_sizes(uint32_t (&k)[kFrRegs]) {
   if constexpr (SIZE < N) fr_sort32_sizes<N, SIZE * 2>(k);
 }
 
+// The same network over keys that are positive finite doubles as bit patterns (top two bits clear):
+// their order as doubles is their order as integers, and a compare-exchange is v_min_f64 + v_max_f64
+// instead of a 64-bit compare and four selects.  (Bare instructions: fmin / fmax would first quiet
+// signalling NaNs, which these patterns never are.)
+template <int N, int SIZE, int STRIDE>
+__device__ __forceinline__ void fr_sortd_stage(double (&k)[kFrRegs]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int l = i ^ STRIDE;
+    if (l > i) {
+      const bool up = (i & SIZE) == 0;
+      double lo, hi;
+      asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(k[i]), "v"(k[l]));
+      asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(k[i]), "v"(k[l]));
+      k[i] = up ? lo : hi;
+      k[l] = up ? hi : lo;
+    }
+  }
+  if constexpr (STRIDE > 1) fr_sortd_stage<N, SIZE, STRIDE / 2>(k);
+}
+template <int N, int SIZE>
+__device__ __forceinline__ void fr_sortd_sizes(double (&k)[kFrRegs]) {
+  fr_sortd_stage<N, SIZE, SIZE / 2>(k);
+  if constexpr (SIZE < N) fr_sortd_sizes<N, SIZE * 2>(k);
+}
+
 // Sorts a bucket of w entries by (label, arc), folds the runs of one label in arc order, sorts the
 // folded keys (desc(float logp) | label); returns their number.  E(j) is the j-th entry.
 template <class Entry>
@@ -423,6 +449,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   const bool key32 = nA <= 65535 && lab_max >= lab_min &&
                      (uint64_t)((int64_t)lab_max - (int64_t)lab_min) < ((1ull << (32 - abits)) - 1ull);
   const int lab_base = lab_min;
+  const bool dsort = key32 && (int64_t)lab_max - (int64_t)lab_min < ((int64_t)1 << 30);  // folded keys sortable as doubles
 
   FR_LAP(0);
   int nbase = 0;  // expansions of the tiles before this one
@@ -715,10 +742,29 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
           acc = cont ? folded : ex[j];
         }
       }
-      if (narrow)
+      if (dsort) {
+        // (the label range fits 30 bits here: desc(float logp) << 30 | label - lab_base is a positive
+        // finite double, sorted by min / max; the records keep their format)
+        double dk[kFrRegs];
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) {
+          const uint64_t key = ((ek[j] >> 32) << 30) | (uint64_t)(uint32_t)(fr_unbias((uint32_t)ek[j]) - lab_base);
+          dk[j] = __longlong_as_double((long long)(ek[j] == ~0ull ? 0x7FEFFFFFFFFFFFFFull : key));
+        }
+        if (narrow)
+          fr_sortd_sizes<8, 2>(dk);
+        else
+          fr_sortd_sizes<kFrRegs, 2>(dk);
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) {
+          const uint64_t key = (uint64_t)__double_as_longlong(dk[j]);
+          ek[j] = ((key >> 30) << 32) | fr_bias((int32_t)(uint32_t)(key & 0x3FFFFFFFull) + lab_base);
+        }
+      } else if (narrow) {
         fr_sort_regs<8, false>(ek, ex);
-      else
+      } else {
         fr_sort_regs<kFrRegs, false>(ek, ex);
+      }
       const int frame = (k < nc) ? (int)cframe[k] : 0, run = (k < nc) ? (int)cframe[k + 1] - frame : 0;
       int tot, tot_dense;
       const int dst = mbase + fr_block_scan2(mk, mk * run, &tot, &tot_dense, sh).x;
