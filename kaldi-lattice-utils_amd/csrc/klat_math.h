@@ -90,7 +90,15 @@ __device__ __forceinline__ double select64_or_zero(uint64_t mask, double if_set)
 // registers: hipcc otherwise keeps them in VGPRs and emits v_mov_b64 + v_fmac_f64 per step.
 // `live`: lanes whose term counts at all (a lane beyond a job's stored lanes carries its lattice's
 // first term a second time and must weigh nothing)
-__device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& dead, uint64_t live = ~0ull) {
+// `c9v`: the polynomial's leading coefficient in a VECTOR register (arc_weight_c9()): the first fma
+// has two constant operands and only one may come from a scalar register; handed in by the caller so
+// that it is made once per kernel, not once per term
+__device__ __forceinline__ double arc_weight_c9() {
+  double v;
+  asm volatile("v_mov_b64 %0, %1" : "=v"(v) : "s"(1.02059054137655954707e-07));
+  return v;
+}
+__device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& dead, uint64_t live, double c9v) {
   dead = !(c < 1.0e30);
   // NaN -> -1e8; +inf stays (wm is forced to 0 below).  The bare instruction: fmax() first quiets a
   // possible signalling NaN with a second v_max_f64, and c comes out of arithmetic (always quiet)
@@ -101,7 +109,6 @@ __device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& d
   // the instruction saturates (kf is -inf for a dead term); a C++ cast would be undefined there
   asm("v_cvt_i32_f64 %0, %1" : "=v"(k) : "v"(kf));
   double p;
-  const double c9 = 1.02059054137655954707e-07;
   asm("v_fma_f64 %0, %1, %2, %3\n\t"
       "v_fma_f64 %0, %0, %2, %4\n\t"
       "v_fma_f64 %0, %0, %2, %5\n\t"
@@ -112,7 +119,7 @@ __device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& d
       "v_fma_f64 %0, %0, %2, %10\n\t"
       "v_fma_f64 %0, %0, %2, %11"
       : "=&v"(p)
-      : "v"(c9), "v"(f), "s"(1.32596452448871106013e-06), "s"(1.52526729248507371552e-05),
+      : "v"(c9v), "v"(f), "s"(1.32596452448871106013e-06), "s"(1.52526729248507371552e-05),
         "s"(1.54034337512510096551e-04), "s"(1.33335582007945924535e-03),
         "s"(9.61812919393431262072e-03), "s"(5.55041086646516704239e-02),
         "s"(2.40226506956403407234e-01), "s"(6.93147180559946174405e-01),

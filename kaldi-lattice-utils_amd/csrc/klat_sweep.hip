@@ -237,6 +237,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       const int row = AL * LPW;
       const bool stored = sub < AL;
       const uint64_t stored_mask = lane_mask(stored);
+      const double c9v = arc_weight_c9();  // (kept in a vector register for the whole job)
       // (a lane beyond AL reads its lattice's first unit again -- the same cache line, no HBM
       // traffic, and no branch around the prefetch loads -- and ignores it)
       const int unit = (stored ? sub : 0) * LPW + slot;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           t.k = 0;
         } else {
           bool dead;
-          arc_weight(c, t.wm, t.k, dead, stored_mask);
+          arc_weight(c, t.wm, t.k, dead, stored_mask, c9v);
         }
       };
       auto put = [&](StagedTerm* dst, uint32_t w, float g, float a) {
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
           t.k = 0;
         } else {
           bool dead;
-          arc_weight(c, t.wm, t.k, dead, stored_mask);
+          arc_weight(c, t.wm, t.k, dead, stored_mask, c9v);
         }
         t.ctl = ctl;
         store_staged(dst, t);
