@@ -98,7 +98,8 @@ typedef struct {
 typedef struct {
   float sweep_ms;      /* forward+backward lockstep sweep: the fast sweep kernel alone for a batch of one
                           layout class, all classes' launches (fast + exact) otherwise */
-  float totals_ms;     /* exact sweep (its workgroups exit at once unless a job was flagged) + per-lattice totals */
+  float totals_ms;     /* exact sweep (its workgroups exit at once unless a job was flagged); the per-lattice
+                          totals are formed by the posterior pass and count in posterior_ms */
   float posterior_ms;  /* arc posterior kernel */
   float convert_ms;    /* always 0: the sweep writes natural-log alpha/beta itself (kept for ABI stability) */
   float total_ms;      /* first event to last event */
