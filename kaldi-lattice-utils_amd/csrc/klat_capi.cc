@@ -524,14 +524,17 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   if (std::getenv("KLAT_NO_SRC_DELTA") == nullptr && b->A > 0) {  // src as one-byte steps for the posterior pass
     DevBuf<int32_t> over;
     int rc2;
-    if ((rc2 = b->src_delta.alloc((size_t)b->A)) || (rc2 = b->item_src.alloc(P.items.size())) || (rc2 = over.alloc(1))) {
+    if ((rc2 = b->src_delta.alloc((size_t)b->A)) || (rc2 = b->arc_span.alloc((size_t)b->A)) || (rc2 = b->item_src.alloc(P.items.size())) ||
+        (rc2 = over.alloc(1))) {
       klat_batch_destroy(b);
       return rc2;
     }
     PosteriorPrepArgs pp;
     pp.items = b->items.p;
     pp.src = b->src.p;
+    pp.dst = b->dst.p;
     pp.src_delta = b->src_delta.p;
+    pp.span = b->arc_span.p;
     pp.item_src = b->item_src.p;
     pp.overflow = over.p;
     int32_t h_over = 0;
@@ -543,7 +546,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       klat_batch_destroy(b);
       return hip_fail(pe, "posterior preparation");
     }
-    if (h_over) b->src_delta.release(), b->item_src.release();  // a step above 255: the pass reads src itself
+    if (h_over) b->src_delta.release(), b->arc_span.release(), b->item_src.release();  // a step or an arc above 255 states: the pass reads src and dst themselves
   }
   hipError_t e = hipStreamSynchronize(c->stream);  // uploads read pageable host memory of P
   if (e != hipSuccess) {
@@ -646,6 +649,7 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   pa.sp = sp;
   pa.src_delta = b->src_delta.p;
   pa.item_src = b->item_src.p;
+  pa.span = b->arc_span.p;
 
   // sweep_ms of a one-class batch is the fast sweep kernel alone (what rocprofv3 lists under its
   // name): the events sit right around its launch.  The exact sweep's launch after it (all of its

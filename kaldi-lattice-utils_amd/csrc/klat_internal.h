@@ -210,6 +210,7 @@ struct klat_batch {
   klat::DevBuf<klat::LaneInfo> lanes;
   klat::DevBuf<klat::PostItem> items;
   klat::DevBuf<uint8_t> src_delta;   // src as one-byte steps (posterior pass); empty if a step overflowed
+  klat::DevBuf<uint8_t> arc_span;    // dst - src in one byte (the same)
   klat::DevBuf<int32_t> item_src;    // source of the first arc of every posterior item
   // results
   klat::DevBuf<int32_t> job_flags;      // fast sweep -> exact sweep hand-over

@@ -98,12 +98,15 @@ struct PosteriorArgs {
   // some step is above 255 (a run of 255 states without arcs): the pass reads src itself.
   const uint8_t* src_delta;
   const int32_t* item_src;
+  const uint8_t* span;  // dst[i] - src[i] in one byte (same condition: no arc longer than 255 states)
 };
 
 struct PosteriorPrepArgs {
   const PostItem* items;
   const int32_t* src;
+  const int32_t* dst;
   uint8_t* src_delta;   // [A]
+  uint8_t* span;        // [A] dst - src
   int32_t* item_src;    // [items]
   int32_t* overflow;    // [1] set when a step does not fit a byte
 };

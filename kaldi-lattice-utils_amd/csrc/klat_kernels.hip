@@ -74,9 +74,12 @@ __global__ __launch_bounds__(256) void posterior_prep_kernel(PosteriorPrepArgs a
   bool over = false;
   for (int t = threadIdx.x; t < count; t += 256) {
     const int64_t i = item.arc_begin + t;
-    const int step = t == 0 ? 0 : a.src[i] - a.src[i - 1];
-    over |= (unsigned)step > 255u;
+    const int s = a.src[i];
+    const int step = t == 0 ? 0 : s - a.src[i - 1];
+    const int span = a.dst[i] - s;
+    over |= (unsigned)step > 255u || (unsigned)span > 255u;
     a.src_delta[i] = (uint8_t)step;
+    a.span[i] = (uint8_t)span;
   }
   if (__any(over) && (threadIdx.x & 63) == 0) atomicOr(a.overflow, 1);
 }
@@ -85,7 +88,7 @@ typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
 
-// The same pass with src from the steps: a lane owns FOUR CONSECUTIVE arcs (one 16-byte load per
+// The same pass with src from the steps and dst from the arcs' spans (dst - src, one byte): a lane owns FOUR CONSECUTIVE arcs (one 16-byte load per
 // array, two 16-byte stores), a wave 256 consecutive arcs; the sources come from a prefix sum of the
 // steps (shuffles inside the wave, one LDS word per wave across the block).
 template <bool PEN>
@@ -114,11 +117,11 @@ __global__ __launch_bounds__(256) void posterior_delta_kernel(PosteriorArgs a) {
   float g[4], ac[4];
   if (t0 + 3 < count) {
     const uint32_t d4 = *reinterpret_cast<const uint32_t __attribute__((aligned(1)))*>(a.src_delta + i0);
-    const int4u dv = *reinterpret_cast<const int4u*>(a.dst + i0);
+    const uint32_t s4 = *reinterpret_cast<const uint32_t __attribute__((aligned(1)))*>(a.span + i0);
     const float4u gv = *reinterpret_cast<const float4u*>(a.graph + i0);
     const float4u av = *reinterpret_cast<const float4u*>(a.acoustic + i0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) d[q] = (int)((d4 >> (8 * q)) & 255u), dst[q] = dv[q], g[q] = gv[q], ac[q] = av[q];
+    for (int q = 0; q < 4; ++q) d[q] = (int)((d4 >> (8 * q)) & 255u), dst[q] = (int)((s4 >> (8 * q)) & 255u), g[q] = gv[q], ac[q] = av[q];
     if (PEN) {
       const int4u iv = *reinterpret_cast<const int4u*>(a.ilabel + i0);
 #pragma unroll
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void posterior_delta_kernel(PosteriorArgs a) {
       const bool ok = t0 + q < count;
       const int64_t i = ok ? i0 + q : item.arc_begin;
       d[q] = ok ? (int)a.src_delta[i] : 0;
-      dst[q] = a.dst[i];
+      dst[q] = (int)a.span[i];
       g[q] = a.graph[i];
       ac[q] = a.acoustic[i];
       if (PEN) il[q] = a.ilabel[i];
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void posterior_delta_kernel(PosteriorArgs a) {
     src += d[q];
     const bool ok = t0 + q < count;
     const double c = arc_cost(g[q], ac[q], PEN ? il[q] != 0 : false, sp);
-    const double through = (ok ? alpha[src] : 0.0) + (ok ? beta[dst[q]] : 0.0) - c;
+    const double through = (ok ? alpha[src] : 0.0) + (ok ? beta[src + dst[q]] : 0.0) - c;
     out[q] = (through > -INFINITY) ? through - tot : -INFINITY;
   }
   if (t0 + 3 < count) {
