@@ -318,3 +318,34 @@ def test_deep_prefetch_sweep_is_the_same_arithmetic(ctx, monkeypatch):
     monkeypatch.delenv("KLAT_NO_DEEP_PREFETCH", raising=False)
     assert np.array_equal(res[0][0][0], res[1][0][0]) and np.array_equal(res[0][0][1], res[1][0][1])
     assert np.array_equal(res[0][1], res[1][1], equal_nan=True)
+
+
+def test_posterior_pass_from_steps_and_spans_is_the_same_arithmetic(ctx, monkeypatch):
+    """The posterior pass reads src as one-byte steps and dst as one-byte spans when no step or arc is
+    longer than 255 states, the 4-byte arrays otherwise (or with KLAT_NO_SRC_DELTA): the same sums
+    either way, bit for bit; a batch with one long arc takes the second path by itself."""
+    arrays = klat_amd.synth(5, np.array([700, 3, 1, 2500, 64], np.int32), np.array([3, 1, 1, 2, 6], np.int32))
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("KLAT_NO_SRC_DELTA", "1")
+        else:
+            monkeypatch.delenv("KLAT_NO_SRC_DELTA", raising=False)
+        b = klat_amd.Batch(ctx, arrays)
+        b.forward_backward(1.0, 0.3, 0.1)
+        res.append((b.arc_logpost(), b.totals()))
+        b.close()
+    monkeypatch.delenv("KLAT_NO_SRC_DELTA", raising=False)
+    assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
+    for x, y in zip(res[0][1], res[1][1]):
+        assert np.array_equal(x, y, equal_nan=True)
+    long_arc = {k: v.copy() for k, v in arrays.items()}
+    a0 = int(long_arc["arc_off"][3])
+    first = a0 + int(np.argmax(long_arc["src"][a0:] == 0))  # an arc out of the start state of the 2 500-state lattice
+    long_arc["dst"][first] = 2000
+    b = klat_amd.Batch(ctx, long_arc)
+    b.forward_backward(1.0, 0.3, 0.1)
+    post, (total, tf, tb) = b.arc_logpost(), b.totals()
+    b.close()
+    wa, wb, wt, wpost = _oracle_batch(long_arc, 1.0, 0.3, 0.1)
+    _check(total, wt, 1e-8), _check(post, wpost, 1e-8)
