@@ -136,6 +136,19 @@ int klat_batch_create(klat_ctx* ctx, const klat_batch_desc* desc, const klat_pac
 void klat_batch_destroy(klat_batch* batch);
 int klat_batch_get_info(const klat_batch* batch, klat_batch_info* info);
 
+/* Where klat_batch_create spent its time.  The device passes (HIP events on the ctx stream): the count
+ * pass (validation, arcs by destination, rounds per lane count), the level planner, the round prefix
+ * sums, the stream fill, the posterior pass's one-byte source steps; host_ms is the wall time of the
+ * whole call (uploads, the two waits for the device, layout planning on the host).  This is the
+ * reference's untimed preprocessing (kwsbin2/lattice-word-index-segment.cc:41-62,140-141); a caller
+ * that sweeps every batch once pays it per batch, so bench.py reports it (`one_shot`). */
+typedef struct {
+  float count_ms, level_plan_ms, rounds_ms, fill_ms, posterior_prep_ms;
+  float device_ms;  /* sum of the five */
+  float host_ms;
+} klat_pack_timings;
+int klat_batch_get_pack_timings(klat_batch* batch, klat_pack_timings* t);
+
 /* Topological depth of every lattice: the number of states on its longest path (the fewest
  * dependent steps ANY forward-backward needs; the lockstep streams take one round per state or
  * more).  Diagnostic: computed on the host from a copy of the arcs, on demand. */

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -206,6 +207,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
                       klat_batch** out) {
   if (!c || !d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
   klat_pack_options o = {0, 0, 0};
   if (opt) o = *opt;
   // The streams are built on the device from the CSR arrays (klat_pack_device.hip); the host
@@ -277,6 +279,14 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       return rc;                                                     \
     }                                                                \
   } while (0)
+#define KLAT_HIP_B(expr)                                             \
+  do {                                                               \
+    hipError_t _e = (expr);                                          \
+    if (_e != hipSuccess) {                                          \
+      klat_batch_destroy(b);                                         \
+      return hip_fail(_e, #expr);                                    \
+    }                                                                \
+  } while (0)
 #define FAIL(code, msg)                                              \
   do {                                                               \
     klat_batch_destroy(b);                                           \
@@ -299,12 +309,12 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     UP(sa, P.sa.data(), P.sa.size());
   } else {
     // pass 1 on the device: validation, arcs by destination, rounds per lattice for every lane count
-    DevBuf<int32_t> cnt, r0f, r0b, frank, in_arc, status;
+    DevBuf<int32_t> cnt, row, r0f, r0b, frank, in_arc, status;
     DevBuf<LatticeRounds> d_rounds;
     DevBuf<int8_t> d_lat_g;
     DevBuf<PackEntry> d_entries;
     const int32_t status0[4] = {0, -1, 1, 0};
-    if ((rc = cnt.alloc((size_t)(S_tot + 2 * U))) || (rc = r0f.alloc((size_t)(S_tot + 2 * U))) ||
+    if ((rc = cnt.alloc((size_t)(S_tot + 2 * U))) || (rc = row.alloc((size_t)(S_tot + 2 * U))) || (rc = r0f.alloc((size_t)(S_tot + 2 * U))) ||
         (rc = r0b.alloc((size_t)(S_tot + 2 * U))) || (rc = frank.alloc((size_t)S_tot)) || (rc = in_arc.alloc((size_t)A_tot)) ||
         (rc = d_rounds.alloc((size_t)U)) || (rc = status.upload(status0, 4, c->stream))) {
       klat_batch_destroy(b);
@@ -322,6 +332,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pa.final_graph = b->final_graph.p;
     pa.final_acoustic = b->final_acoustic.p;
     pa.cnt = cnt.p;
+    pa.row = row.p;
     pa.r0f = r0f.p;
     pa.r0b = r0b.p;
     pa.frank = frank.p;
@@ -330,7 +341,23 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pa.status = status.p;
     std::vector<LatticeRounds> h_rounds((size_t)U);
     int32_t h_status[4] = {0, -1, 1, 0};
-    hipError_t he = launch_pack_count(pa, (int)U, c->stream);
+    // the count pass keeps a lattice's tables in LDS: the launch of the narrowest class that holds them
+    int class_need[kPackCountClasses] = {0, 0, 0};
+    bool any_global = false;
+    for (int64_t u = 0; u < U; ++u) {
+      const int need = pack_count_lds_bytes(d->state_off[u + 1] - d->state_off[u], d->arc_off[u + 1] - d->arc_off[u]);
+      int k = 0;
+      while (k < kPackCountClasses && need > kPackCountClassLds[k]) ++k;
+      if (k == kPackCountClasses)
+        any_global = true;
+      else
+        class_need[k] = std::max(class_need[k], need);
+    }
+    hipEvent_t* pev = b->pack_ev;
+    for (int i = 0; i < klat_batch::kPackEvents; ++i) KLAT_HIP_B(hipEventCreate(&pev[i]));
+    KLAT_HIP_B(hipEventRecord(pev[0], c->stream));
+    hipError_t he = launch_pack_count(pa, (int)U, class_need, any_global, c->stream);
+    if (he == hipSuccess) he = hipEventRecord(pev[1], c->stream);
     if (he == hipSuccess && U > 0)
       he = hipMemcpyAsync(h_rounds.data(), d_rounds.p, sizeof(LatticeRounds) * h_rounds.size(), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
@@ -348,7 +375,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     // (klat_level.hip) instead of a stream: Kahn's levels on the device, the choice on the host.
     // Only with the automatic layout (a caller that fixes the lanes asks for streams).
     std::vector<uint8_t> on_level((size_t)U, 0);
-    DevBuf<int32_t> order, lvoff, row, depth;  // level planning's tables, until the level streams are written
+    DevBuf<int32_t> order, lvoff, depth;  // level planning's tables, until the level streams are written
     int64_t lv_blocks = 0;
     // KLAT_LEVEL=0 keeps every lattice on the streams, KLAT_LEVEL=1 sends every lattice that qualifies
     // to the level path; by default the level path takes them when they fit the chip in ONE round of
@@ -358,7 +385,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     if (o.lanes_per_lattice == 0 && level_mode != 0 && U > 0) {
       DevBuf<int32_t> counters, records;
       if ((rc = counters.alloc((size_t)(S_tot + 2 * U))) || (rc = order.alloc((size_t)S_tot)) || (rc = lvoff.alloc((size_t)(S_tot + 2 * U))) ||
-          (rc = row.alloc((size_t)(S_tot + 2 * U))) || (rc = depth.alloc((size_t)U)) || (rc = records.alloc((size_t)U))) {
+          (rc = depth.alloc((size_t)U)) || (rc = records.alloc((size_t)U))) {
         klat_batch_destroy(b);
         return rc;
       }
@@ -375,7 +402,10 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       lp.depth = depth.p;
       lp.records = records.p;
       std::vector<int32_t> h_depth((size_t)U), h_records((size_t)U);
-      he = launch_level_plan(lp, (int)U, c->stream);
+      he = hipEventRecord(pev[2], c->stream);
+      if (he == hipSuccess) he = launch_level_plan(lp, (int)U, c->stream);
+      if (he == hipSuccess) he = hipEventRecord(pev[3], c->stream);
+      b->pack_level_timed = true;
       if (he == hipSuccess) he = hipMemcpyAsync(h_depth.data(), depth.p, sizeof(int32_t) * (size_t)U, hipMemcpyDeviceToHost, c->stream);
       if (he == hipSuccess) he = hipMemcpyAsync(h_records.data(), records.p, sizeof(int32_t) * (size_t)U, hipMemcpyDeviceToHost, c->stream);
       if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
@@ -423,16 +453,17 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     if (rc != KLAT_OK) FAIL(rc, err);
     // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, slot)
     std::vector<PackEntry> entries;
-    for (size_t j = 0; j < job_lats.size(); ++j) {
-      const int LPW = 64 / job_lanes(P.jobs[j].tag);
-      for (int k = 0; k < LPW; ++k)
-        entries.push_back(PackEntry{k < (int)job_lats[j].size() ? (int32_t)job_lats[j][(size_t)k] : -1, (int32_t)j, k, 0});
+    for (size_t j = 0; j < P.jobs.size(); ++j) {
+      const int ntiles = P.jobs[j].nchunks * kChunkRounds / kPackTileRounds;
+      for (int t = 0; t < ntiles; t += kPackTilesPerGroup)
+        entries.push_back(PackEntry{(int32_t)j, t, std::min(kPackTilesPerGroup, ntiles - t), 0});
     }
     const size_t nslots = (size_t)chunk_total * kChunkRounds;  // chunk_total counts 16-byte units
     AL(sw, nslots);
     AL(sg, nslots);
     AL(sa, nslots);
     UP(jobs, P.jobs.data(), P.jobs.size());
+    UP(lanes, P.lanes.data(), P.lanes.size());
     if ((rc = d_entries.upload(entries.data(), entries.size(), c->stream)) || (rc = d_lat_g.upload(lat_g.data(), lat_g.size(), c->stream))) {
       klat_batch_destroy(b);
       return rc;
@@ -440,11 +471,15 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pa.lat_g = d_lat_g.p;
     pa.entries = d_entries.p;
     pa.jobs = b->jobs.p;
+    pa.lanes = b->lanes.p;
     pa.sw = b->sw.p;
     pa.sg = b->sg.p;
     pa.sa = b->sa.p;
-    he = launch_pack_rounds(pa, (int)U, c->stream);
+    he = hipEventRecord(pev[4], c->stream);
+    if (he == hipSuccess) he = launch_pack_rounds(pa, (int)U, c->stream);
+    if (he == hipSuccess) he = hipEventRecord(pev[5], c->stream);
     if (he == hipSuccess) he = launch_pack_fill(pa, (int)entries.size(), c->stream);
+    if (he == hipSuccess) he = hipEventRecord(pev[6], c->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);  // scratch and entries go out of scope below
     if (he != hipSuccess) {
@@ -472,7 +507,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       lb.in_arc = in_arc.p;
       lb.order = order.p;
       lb.level_off = lvoff.p;
-      lb.out_begin = row.p;
+      lb.out_begin = row.p;  // (the count pass's row table)
       lb.depth = depth.p;
       lb.stream_off = b->lv_stream_off.p;
       lb.stream = b->lv_stream.p;
@@ -507,8 +542,10 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   b->info.max_rounds = P.max_rounds;
   b->info.num_layouts = (int32_t)P.classes.size();
   b->info.level_lattices = b->num_level;  // lattices on the level-synchronous path
-  if (host_pack) UP(jobs, P.jobs.data(), P.jobs.size());
-  UP(lanes, P.lanes.data(), P.lanes.size());
+  if (host_pack) {
+    UP(jobs, P.jobs.data(), P.jobs.size());
+    UP(lanes, P.lanes.data(), P.lanes.size());
+  }
   UP(items, P.items.data(), P.items.size());
   AL(job_flags, P.jobs.size());
   AL(sink, P.jobs.size() * 64);
@@ -521,6 +558,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
 #undef UP
 #undef AL
 #undef FAIL
+#undef KLAT_HIP_B
   if (std::getenv("KLAT_NO_SRC_DELTA") == nullptr && b->A > 0) {  // src as one-byte steps for the posterior pass
     DevBuf<int32_t> over;
     int rc2;
@@ -539,7 +577,9 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pp.overflow = over.p;
     int32_t h_over = 0;
     hipError_t pe = hipMemsetAsync(over.p, 0, sizeof(int32_t), c->stream);
+    if (pe == hipSuccess && b->pack_ev[7]) pe = hipEventRecord(b->pack_ev[7], c->stream);
     if (pe == hipSuccess) pe = launch_posterior_prep(pp, (int)P.items.size(), c->stream);
+    if (pe == hipSuccess && b->pack_ev[8]) pe = hipEventRecord(b->pack_ev[8], c->stream), b->pack_prep_timed = true;
     if (pe == hipSuccess) pe = hipMemcpyAsync(&h_over, over.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
     if (pe == hipSuccess) pe = hipStreamSynchronize(c->stream);
     if (pe != hipSuccess) {
@@ -553,6 +593,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     klat_batch_destroy(b);
     return hip_fail(e, "upload");
   }
+  b->pack_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   *out = b;
   return KLAT_OK;
 }
@@ -566,6 +607,8 @@ void klat_batch_destroy(klat_batch* b) {
     PoolScope pool_scope(&c->pool);
     for (hipEvent_t e : {b->accum.ev[0], b->accum.ev[1], b->frame.ev[0], b->frame.ev[1]})
       if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->pack_ev)
+      if (e) (void)hipEventDestroy(e);
     delete b;
   }
   ctx_release(c);  // the context itself goes with its last batch if its handle was destroyed first
@@ -574,6 +617,21 @@ void klat_batch_destroy(klat_batch* b) {
 int klat_batch_get_info(const klat_batch* b, klat_batch_info* info) {
   if (!b || !info) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
   *info = b->info;
+  return KLAT_OK;
+}
+
+int klat_batch_get_pack_timings(klat_batch* b, klat_pack_timings* t) {
+  if (!b || !t) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  std::memset(t, 0, sizeof(*t));
+  if (!b->pack_ev[0]) return KLAT_OK;  // KLAT_HOST_PACK=1: nothing ran on the device
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  KLAT_HIP(hipEventElapsedTime(&t->count_ms, b->pack_ev[0], b->pack_ev[1]));
+  if (b->pack_level_timed) KLAT_HIP(hipEventElapsedTime(&t->level_plan_ms, b->pack_ev[2], b->pack_ev[3]));
+  KLAT_HIP(hipEventElapsedTime(&t->rounds_ms, b->pack_ev[4], b->pack_ev[5]));
+  KLAT_HIP(hipEventElapsedTime(&t->fill_ms, b->pack_ev[5], b->pack_ev[6]));
+  if (b->pack_prep_timed) KLAT_HIP(hipEventElapsedTime(&t->posterior_prep_ms, b->pack_ev[7], b->pack_ev[8]));
+  t->device_ms = t->count_ms + t->level_plan_ms + t->rounds_ms + t->fill_ms + t->posterior_prep_ms;
+  t->host_ms = b->pack_host_ms;
   return KLAT_OK;
 }
 

@@ -225,6 +225,11 @@ struct klat_batch {
   // lattices on the level-synchronous path (klat_level.hip): not in any stream job
   int32_t num_level = 0, level_max_states = 0;
   klat::DevBuf<int32_t> lv_lattices, lv_records, lv_stream;
+  // klat_batch_create's device passes: events around count | level plan | rounds | fill | posterior prep
+  static const int kPackEvents = 9;
+  hipEvent_t pack_ev[kPackEvents] = {};
+  bool pack_level_timed = false, pack_prep_timed = false;
+  float pack_host_ms = 0.0f;  // wall time of klat_batch_create (uploads, host planning, waits included)
   klat::DevBuf<int64_t> lv_stream_off;
 };
 

@@ -33,7 +33,7 @@ struct LevelPlanArgs {
   int32_t* counters;    // [S + 2 per lattice] scratch
   int32_t* order;       // [S] states level by level
   int32_t* level_off;   // [S + 2 per lattice] first entry of every level in `order`
-  int32_t* out_begin;   // [S + 2 per lattice] first out-arc of every state
+  const int32_t* out_begin;  // [S + 2 per lattice] first out-arc of every state (the count pass's row table)
   int32_t* depth;       // [U] number of levels, or -1: not for this path
   int32_t* records;     // [U] records per direction (sum over the levels of ceil(states / 64))
 };

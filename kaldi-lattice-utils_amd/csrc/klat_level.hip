@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void level_plan_kernel(LevelPlanArgs a) {
   int32_t* left = a.counters + sb;          // in-arcs not yet visited
   int32_t* order = a.order + s0;            // states, level by level
   int32_t* off = a.level_off + sb;          // first entry of every level in `order`
-  int32_t* row = a.out_begin + sb;          // first out-arc of every state (row[S] = A)
+  const int32_t* row = a.out_begin + sb;    // first out-arc of every state (row[S] = A), from the count pass
   const int32_t* src = a.src + a0;
   const int32_t* dst = a.dst + a0;
   const int max_depth = S / kLevelMinWidth;
@@ -78,27 +78,6 @@ __global__ __launch_bounds__(64) void level_plan_kernel(LevelPlanArgs a) {
     return;
   }
 
-  // row table of the out-arcs (arcs are grouped by source): mark the first arc of every source,
-  // then give the states without arcs the row of the next state that has some (suffix minimum)
-  for (int s = lane; s <= S; s += 64) row[s] = A;
-  __threadfence_block();
-  __syncthreads();
-  for (int i = lane; i < A; i += 64)
-    if (i == 0 || src[i] != src[i - 1]) row[src[i]] = i;
-  __threadfence_block();
-  __syncthreads();
-  int carry = A;
-  for (int base = ((S + 63) / 64 - 1) * 64; base >= 0; base -= 64) {
-    const int s = base + lane;
-    int v = s < S ? row[s] : A;
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_down(v, d, 64);
-      if (lane + d < 64) v = min(v, t);
-    }
-    v = min(v, carry);
-    if (s < S) row[s] = v;
-    carry = __shfl(v, 0, 64);
-  }
   // level 0: the states without in-arcs, in state order
   int tail = 0;
   for (int base = 0; base < S; base += 64) {

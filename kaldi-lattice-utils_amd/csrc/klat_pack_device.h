@@ -8,18 +8,34 @@
 
 namespace klat {
 
-// one workgroup of pack_fill_kernel: lattice `lattice` (or -1: an empty slot) in slot `slot` of job `job`
+// A tile of the fill pass: this many rounds of a job's stored lanes, one contiguous piece of each
+// stream array.  A job's length is a whole number of tiles (kDeepPrefetchChunks chunks of 4 rounds).
+static constexpr int kPackTileRounds = kDeepPrefetchChunks * kChunkRounds;
+static constexpr int kPackTilesPerGroup = 8;  // tiles one workgroup of pack_fill_kernel writes, one after the other
+
+// one workgroup of pack_fill_kernel: tiles [tile_begin, tile_begin + tile_count) of job `job`
 struct PackEntry {
-  int32_t lattice, job, slot, pad;
+  int32_t job, tile_begin, tile_count, pad;
 };
+
+// LDS the count pass needs for a lattice's tables (in- and out-degree prefix: 2 (S + 2) words; arcs
+// by destination as 16-bit arc numbers); above every class for a lattice of 65 536 arcs or more
+static constexpr int kPackCountMaxLds = 150 * 1024;
+static constexpr int kPackCountClasses = 3;
+static constexpr int kPackCountClassLds[kPackCountClasses] = {36 * 1024, 76 * 1024, kPackCountMaxLds};  // 4, 2, 1 workgroups per CU
+__host__ __device__ static inline int pack_count_lds_bytes(int64_t S, int64_t A) {
+  if (A >= 65536 || S >= (1 << 20)) return 0x7FFFFFFF;
+  return (int)(8 * (S + 2) + 2 * ((A + 1) & ~(int64_t)1));
+}
 
 struct PackDevArgs {
   // the CSR batch
   const int64_t* state_off; const int64_t* arc_off;
   const int32_t* src; const int32_t* dst; const int32_t* ilabel;
   const float* graph; const float* acoustic; const float* final_graph; const float* final_acoustic;
-  // scratch: lattice u owns entries [state_off[u] + 2u, +S+2) of cnt / r0f / r0b
-  int32_t* cnt;     // in-degree, then first in-arc of every state (exclusive prefix)
+  // tables: lattice u owns entries [state_off[u] + 2u, +S+2) of cnt / row / r0f / r0b
+  int32_t* cnt;     // first in-arc of every state (exclusive prefix of the in-degrees; [S] = A); [S+1] = number of final states
+  int32_t* row;     // first out-arc of every state ([S] = A)
   int32_t* r0f;     // first forward round of position p = 0..S; [S+1] = number of rounds
   int32_t* r0b;     // first backward round of position p = 0..S-1; [S] = number of rounds
   int32_t* frank;   // [S] rank of a final state among the lattice's final states
@@ -30,10 +46,14 @@ struct PackDevArgs {
   // fill pass
   const PackEntry* entries;
   const SweepJob* jobs;
+  const LaneInfo* lanes;
   int32_t* sw; float* sg; float* sa;
 };
 
-hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, hipStream_t stream);
+// class_need[c]: the largest pack_count_lds_bytes among the lattices of LDS class c (0: none);
+// any_global: some lattice is above the last class
+hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, const int class_need[kPackCountClasses], bool any_global,
+                             hipStream_t stream);
 hipError_t launch_pack_rounds(const PackDevArgs& a, int num_lattices, hipStream_t stream);
 hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, hipStream_t stream);
 

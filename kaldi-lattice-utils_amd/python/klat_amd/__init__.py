@@ -62,6 +62,15 @@ class Timings(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class PackTimings(C.Structure):
+    _fields_ = [("count_ms", C.c_float), ("level_plan_ms", C.c_float), ("rounds_ms", C.c_float),
+                ("fill_ms", C.c_float), ("posterior_prep_ms", C.c_float), ("device_ms", C.c_float),
+                ("host_ms", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class LabelFilter(C.Structure):
     _fields_ = [("include", C.c_void_p), ("num_include", C.c_int32), ("exclude", C.c_void_p),
                 ("num_exclude", C.c_int32)]
@@ -235,6 +244,11 @@ class Batch:
         i = BatchInfo()
         _check(lib().klat_batch_get_info(self.h, C.byref(i)))
         return i.as_dict()
+
+    def pack_timings(self):
+        t = PackTimings()
+        _check(lib().klat_batch_get_pack_timings(self.h, C.byref(t)))
+        return t.as_dict()
 
     def topological_depth(self):
         d = np.zeros(max(self.U, 1), np.int32)
