@@ -309,13 +309,13 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     UP(sa, P.sa.data(), P.sa.size());
   } else {
     // pass 1 on the device: validation, arcs by destination, rounds per lattice for every lane count
-    DevBuf<int32_t> cnt, row, r0f, r0b, frank, in_arc, status;
+    DevBuf<int32_t> cnt, row, r0f, r0b, flist, in_arc, out_arc, status;
     DevBuf<LatticeRounds> d_rounds;
     DevBuf<int8_t> d_lat_g;
     DevBuf<PackEntry> d_entries;
     const int32_t status0[4] = {0, -1, 1, 0};
     if ((rc = cnt.alloc((size_t)(S_tot + 2 * U))) || (rc = row.alloc((size_t)(S_tot + 2 * U))) || (rc = r0f.alloc((size_t)(S_tot + 2 * U))) ||
-        (rc = r0b.alloc((size_t)(S_tot + 2 * U))) || (rc = frank.alloc((size_t)S_tot)) || (rc = in_arc.alloc((size_t)A_tot)) ||
+        (rc = r0b.alloc((size_t)(S_tot + 2 * U))) || (rc = flist.alloc((size_t)S_tot)) || (rc = in_arc.alloc((size_t)A_tot)) || (rc = out_arc.alloc((size_t)A_tot)) ||
         (rc = d_rounds.alloc((size_t)U)) || (rc = status.upload(status0, 4, c->stream))) {
       klat_batch_destroy(b);
       return rc;
@@ -335,7 +335,8 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pa.row = row.p;
     pa.r0f = r0f.p;
     pa.r0b = r0b.p;
-    pa.frank = frank.p;
+    pa.flist = flist.p;
+    pa.out_arc = out_arc.p;
     pa.in_arc = in_arc.p;
     pa.lat_rounds = d_rounds.p;
     pa.status = status.p;
@@ -478,7 +479,9 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     he = hipEventRecord(pev[4], c->stream);
     if (he == hipSuccess) he = launch_pack_rounds(pa, (int)U, c->stream);
     if (he == hipSuccess) he = hipEventRecord(pev[5], c->stream);
-    if (he == hipSuccess) he = launch_pack_fill(pa, (int)entries.size(), c->stream);
+    int max_lpw = 1;
+    for (const LayoutClass& lc : P.classes) max_lpw = std::max(max_lpw, 64 / lc.G);
+    if (he == hipSuccess) he = launch_pack_fill(pa, (int)entries.size(), max_lpw, c->stream);
     if (he == hipSuccess) he = hipEventRecord(pev[6], c->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);  // scratch and entries go out of scope below

@@ -34,12 +34,13 @@ struct PackDevArgs {
   const int32_t* src; const int32_t* dst; const int32_t* ilabel;
   const float* graph; const float* acoustic; const float* final_graph; const float* final_acoustic;
   // tables: lattice u owns entries [state_off[u] + 2u, +S+2) of cnt / row / r0f / r0b
-  int32_t* cnt;     // first in-arc of every state (exclusive prefix of the in-degrees; [S] = A); [S+1] = number of final states
+  int32_t* cnt;     // first in-arc of every state (exclusive prefix of the in-degrees; [S] = A); [S+1] = A + number of final states
   int32_t* row;     // first out-arc of every state ([S] = A)
   int32_t* r0f;     // first forward round of position p = 0..S; [S+1] = number of rounds
-  int32_t* r0b;     // first backward round of position p = 0..S-1; [S] = number of rounds
-  int32_t* frank;   // [S] rank of a final state among the lattice's final states
+  int32_t* r0b;     // first backward round of position p = 0..S-1 (bit 31: its state S-1-p is final); [S] = number of rounds
+  int32_t* flist;   // [S] the lattice's final states in state order (cnt[S+1] - cnt[S] of them)
   int32_t* in_arc;  // [A] arcs sorted by destination (indices local to the lattice)
+  int32_t* out_arc; // [A] the out-arcs of every state in stream order: farthest destination first, equal destinations in arc order
   LatticeRounds* lat_rounds;  // [U] out of the count pass
   const int8_t* lat_g;        // [U] log2(lanes) of every lattice (the plan), in for the later passes
   int32_t* status;  // [4] error code, its lattice, longest span (max_rel), FAR terms
@@ -55,7 +56,8 @@ struct PackDevArgs {
 hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, const int class_need[kPackCountClasses], bool any_global,
                              hipStream_t stream);
 hipError_t launch_pack_rounds(const PackDevArgs& a, int num_lattices, hipStream_t stream);
-hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, hipStream_t stream);
+// max_lpw: the most lattices any job holds (64 / its lanes per lattice)
+hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, int max_lpw, hipStream_t stream);
 
 }  // namespace klat
 #endif

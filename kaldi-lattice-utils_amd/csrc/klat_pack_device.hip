@@ -34,6 +34,7 @@ namespace {
 constexpr int kT = 256;       // pack_rounds_kernel, pack_fill_kernel, pack_count_global_kernel
 constexpr int kTC = 512;      // pack_count_kernel
 
+
 __device__ __forceinline__ bool dev_is_final(const PackDevArgs& a, int64_t gs) {
   return !(a.final_graph[gs] == INFINITY && a.final_acoustic[gs] == INFINITY);
 }
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
     const int ex_f = block_scan<kTC>(f, &tot_f, sh);
     const int ex_o = block_scan<kTC>(od, &tot_o, sh);
     if (s < S) {
-      a.frank[s0 + s] = carry_f + ex_f;
+      if (f) a.flist[s0 + carry_f + ex_f] = s;  // the final states in state order
       const int nb = od + f;
       mtb = max(mtb, nb);
       for (int k = 0; k < kNumLaneChoices; ++k) bsum[k] += (max(nb, 1) + (1 << k) - 1) >> k;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
     }
     carry_c += tot_c;
   }
-  if (tid == 0) a.cnt[sb + S + 1] = nfinal;  // (the spare entry of the row)
+  if (tid == 0) a.cnt[sb + S + 1] = A + nfinal;  // position S holds one term per final state: "in-arcs" A .. A + nfinal - 1
   __syncthreads();
   // stable counting sort of the arcs by destination: scatter (cnt[t] moves from the first entry of
   // bucket t to the first entry of bucket t + 1), then order every bucket by arc number
@@ -191,6 +192,24 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
   }
   __syncthreads();
   for (int i = tid; i < A; i += kTC) a.in_arc[a0 + i] = (int32_t)in_arc[i];
+  __syncthreads();
+  // the out-arcs of every state, farthest destination first, nearest last (the term that depends
+  // on the most recently finished state enters the accumulator last); equal destinations in arc order
+  IA* out_arc = in_arc;  // (the same LDS: the arcs by destination have left)
+  for (int s = tid; s < S; s += kTC) {
+    const int b = row[s], e = row[s + 1];
+    for (int i = b; i < e; ++i) {
+      const int dv = dst[i];
+      int j = i - 1;
+      while (j >= b && dst[out_arc[j]] < dv) {
+        out_arc[j + 1] = out_arc[j];
+        --j;
+      }
+      out_arc[j + 1] = (IA)i;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < A; i += kTC) a.out_arc[a0 + i] = (int32_t)out_arc[i];
   atomicMax(&sh_mtf, mtf);
   atomicMax(&sh_mtb, mtb);
   for (int k = 0; k < kNumLaneChoices; ++k) {
@@ -223,8 +242,9 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
   int32_t* cnt = a.cnt + sb;
   int32_t* row = a.row + sb;
   int32_t* cur = a.r0b + sb;  // (scratch for the counting sort's cursors here)
-  int32_t* frank = a.frank + s0;
+  int32_t* flist = a.flist + s0;
   int32_t* in_arc = a.in_arc + a0;
+  int32_t* out_arc = a.out_arc + a0;
   const int32_t* src = a.src + a0;
   const int32_t* dst = a.dst + a0;
   if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1;
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
     const int f = (s < S && dev_is_final(a, s0 + s)) ? 1 : 0;
     int tot;
     const int ex = block_scan<kT>(f, &tot, sh);
-    if (s < S) frank[s] = carry + ex;
+    if (f) flist[carry + ex] = s;
     carry += tot;
   }
   const int nfinal = carry;
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
     if (p <= S) cnt[p] = carry_c + ex_c;
     carry_c += tot_c;
   }
-  if (tid == 0) cnt[S + 1] = nfinal;
+  if (tid == 0) cnt[S + 1] = A + nfinal;
   __syncthreads();
   for (int s = tid; s < S; s += kT) cur[s] = cnt[s];
   for (int s = tid; s <= S; s += kT) row[s] = lower_bound_src(src, A, s);
@@ -299,6 +319,15 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
     const int nb = row[s + 1] - row[s] + (dev_is_final(a, s0 + s) ? 1 : 0);
     mtb = max(mtb, nb);
     for (int k = 0; k < kNumLaneChoices; ++k) bsum[k] += (max(nb, 1) + (1 << k) - 1) >> k;
+    for (int i = row[s]; i < row[s + 1]; ++i) {  // out-arcs: farthest destination first, equal destinations in arc order
+      const int dv = dst[i];
+      int j = i - 1;
+      while (j >= row[s] && dst[out_arc[j]] < dv) {
+        out_arc[j + 1] = out_arc[j];
+        --j;
+      }
+      out_arc[j + 1] = i;
+    }
   }
   atomicMax(&sh_mtf, mtf);
   atomicMax(&sh_mtb, mtb);
@@ -329,23 +358,23 @@ __global__ __launch_bounds__(kT) void pack_rounds_kernel(PackDevArgs a) {
   const int32_t* row = a.row + sb;
   int32_t* r0f = a.r0f + sb;
   int32_t* r0b = a.r0b + sb;
-  const int nfinal = cnt[S + 1];
   int carry_r = 0, carry_b = 0;
   for (int base = 0; base <= S; base += kT) {
     const int p = base + tid;
-    const int nterm = (p < S) ? cnt[p + 1] - cnt[p] + (p == 0 ? 1 : 0) : nfinal;
+    const int nterm = (p <= S) ? cnt[p + 1] - cnt[p] + (p == 0 ? 1 : 0) : 0;  // (cnt[S + 1] - cnt[S] = the final states)
     const int nr = (p <= S) ? (max(nterm, 1) + (1 << k) - 1) >> k : 0;
-    int nrb = 0;
+    int nrb = 0, fin = 0;
     if (p < S) {
       const int s = S - 1 - p;
-      const int nb = row[s + 1] - row[s] + (dev_is_final(a, s0 + s) ? 1 : 0);
+      fin = dev_is_final(a, s0 + s) ? 1 : 0;
+      const int nb = row[s + 1] - row[s] + fin;
       nrb = (max(nb, 1) + (1 << k) - 1) >> k;
     }
     int tot_r, tot_b;
     const int ex_r = block_scan<kT>(nr, &tot_r, sh);
     const int ex_b = block_scan<kT>(nrb, &tot_b, sh);
     if (p <= S) r0f[p] = carry_r + ex_r;
-    if (p < S) r0b[p] = carry_b + ex_b;
+    if (p < S) r0b[p] = (carry_b + ex_b) | (fin << 31);  // bit 31: the position's state is final (the fill pass reads nothing else for it)
     carry_r += tot_r;
     carry_b += tot_b;
   }
@@ -353,39 +382,94 @@ __global__ __launch_bounds__(kT) void pack_rounds_kernel(PackDevArgs a) {
 }
 
 // ---- fill ----
+#ifndef KLAT_FILL_UNROLL
+#define KLAT_FILL_UNROLL 6
+#endif
+constexpr int kTF = 256;
+constexpr int kFillUnroll = KLAT_FILL_UNROLL;
 constexpr int kTileRounds = kPackTileRounds;     // 32: 8 chunks, what a job's length is a multiple of
-constexpr int kWin = kTileRounds + 2;            // round offsets of the states a tile can hold, per lattice
+constexpr int kWin = kTileRounds + 2;            // window of positions a tile can hold, per lattice (+ one past the end)
+constexpr int kM = 0x7FFFFFFF;
 
-__global__ __launch_bounds__(kT) void pack_fill_kernel(PackDevArgs a) {
+struct TermCtx {
+  int lg, W, LPW, k;  // lg = log2(lanes per lattice): no integer division in this kernel (runtime divisors cost ~40 instructions each)
+};
+// term word of term j of position p (first round r, nr rounds) of the lattice in slot k
+__device__ __forceinline__ uint32_t term_word(const TermCtx& c, int p, int r, int nr, int j, int rel, bool word, bool nil, bool* far) {
+  const uint32_t cell_mask = (uint32_t)(c.W - 1);
+  const uint32_t own_cell = (uint32_t)((p & cell_mask) * c.LPW + c.k);
+  const int rr = r + (j >> c.lg);
+  uint32_t w;
+  *far = false;
+  if (nil) {
+    w = kNil | own_cell;
+  } else if (rel == 0) {
+    w = kOne | own_cell;
+  } else if (rel >= c.W) {
+    w = kFar | (uint32_t)rel;
+    *far = true;
+  } else {
+    w = (uint32_t)(((p - rel) & cell_mask) * c.LPW + c.k);
+    if (rel == 1 && (j >> c.lg) == 0) w |= kBypass;
+  }
+  if (word) w |= kWord;
+  if (!*far) w |= (uint32_t)(c.W * c.LPW + c.k) << kWrShift;  // the lattice's dummy cell unless COMMIT
+  if (rr == r) w |= kFirst;
+  if (rr == r + nr - 1) {
+    w |= kLast;
+    if ((j & ((1 << c.lg) - 1)) == 0 && !*far) w = (w & ~(kCellMask << kWrShift)) | kCommit | (own_cell << kWrShift);
+  }
+  return w;
+}
+
+// One workgroup per (job, run of tiles).  Per tile:
+//   windows   first round (r0f / r0b; backward: bit 31 = final state) and first term (cnt / row) of
+//             the positions that can have a round in the tile: one global round trip;
+//   terms     the lattice in slot k has the threads [k * TPS, (k + 1) * TPS) to itself.  Its terms in
+//             the tile are one run of in_arc (+ flist: position S) / out_arc: a round trip for the arc
+//             numbers, one for the arcs' data, kFillUnroll terms per thread in flight together.  A
+//             forward term sits at the position of its destination, a backward term at that of its
+//             source, its number within the position is its offset from the position's first term:
+//             nothing is searched;
+//   positions one thread per position for what is not an arc: the constant-one terms (alpha[start],
+//             final weights), NIL terms, padding lanes;
+//   store     the tile leaves LDS as whole lines.
+__global__ __launch_bounds__(kTF) void pack_fill_kernel(PackDevArgs a, int max_lpw) {
   __shared__ __attribute__((aligned(16))) uint32_t tw[kTileRounds * 64];
   __shared__ __attribute__((aligned(16))) float tg[kTileRounds * 64];
   __shared__ __attribute__((aligned(16))) float ta[kTileRounds * 64];
-  __shared__ int sh_r[64 * kWin];
-  __shared__ int sh_plo[64], sh_next[64], sh_S[64], sh_lat[64], sh_fin[64];
-  __shared__ int sh_far;
+  extern __shared__ int32_t dyn[];
+  __shared__ int64_t sh_s0[64], sh_a0[64];
+  __shared__ int sh_plo[64], sh_next[64], sh_S[64], sh_lat[64], sh_n[64], sh_A[64];
+  int32_t* win_r = dyn;                    // [LPW][kWin] first round of position plo + o
+  int32_t* win_c = dyn + max_lpw * kWin;   // [LPW][kWin] forward: first in-arc of position plo + o; backward: end of its out-arcs
   const PackEntry e = a.entries[blockIdx.x];
   const SweepJob job = a.jobs[e.job];
-  const int G = job_lanes(job.tag), W = job_ring(job.tag), AL = job_stored_lanes(job.tag), LPW = 64 / G;
+  const int G = job_lanes(job.tag), W = job_ring(job.tag), AL = job_stored_lanes(job.tag);
+  const int lg = 31 - __clz(G), LPW = 64 >> lg, gmask = G - 1;  // G is a power of two
+  const int lg_tps = lg + (31 - __clz(kTF)) - 6;                 // log2 of the threads per lattice: kTF / LPW
   const int tid = threadIdx.x;
   const bool fwd = job.dir == 0;
   const int row_units = AL * LPW;                      // 16-byte units of one chunk row
   const int tile_slots = kTileRounds * row_units;      // stream slots of one tile
   int nfar = 0;
-  if (tid == 0) sh_far = 0;
   // the lattices of the job and, for each, the first position with a round in this run of tiles
   if (tid < LPW) {
     const LaneInfo li = a.lanes[job.lane_tab + tid];
-    int plo = 0, S = 0;
+    int plo = 0, S = 0, A = 0;
+    int64_t s0 = 0, a0 = 0;
     if (li.lattice >= 0) {
       S = li.num_states;
-      const int64_t sb = li.state_base + 2 * (int64_t)li.lattice;
-      const int32_t* r0 = (fwd ? a.r0f : a.r0b) + sb;
+      s0 = li.state_base;
+      a0 = a.arc_off[li.lattice];
+      A = (int)(a.arc_off[li.lattice + 1] - a0);
+      const int32_t* r0 = (fwd ? a.r0f : a.r0b) + s0 + 2 * (int64_t)li.lattice;
       const int P = fwd ? S + 1 : S;  // positions; r0[P] = the lattice's rounds
       const int R0 = e.tile_begin * kTileRounds;
       int lo = 0, hi = P;             // first p with r0[p + 1] > R0 (P if none)
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (r0[mid + 1] > R0)
+        if ((r0[mid + 1] & kM) > R0)
           hi = mid;
         else
           lo = mid + 1;
@@ -394,30 +478,51 @@ __global__ __launch_bounds__(kT) void pack_fill_kernel(PackDevArgs a) {
     }
     sh_lat[tid] = li.lattice;
     sh_S[tid] = S;
+    sh_A[tid] = A;
     sh_plo[tid] = plo;
+    sh_s0[tid] = s0;
+    sh_a0[tid] = a0;
   }
   __syncthreads();
   for (int t = 0; t < e.tile_count; ++t) {
     const int R0 = (e.tile_begin + t) * kTileRounds, R1 = R0 + kTileRounds;
-    // padding everywhere: zero-weight terms that park their (unused) result in the lattice's dummy
-    // cell behind the ring
-    for (int i = tid; i < tile_slots; i += kT) {
-      const int slot = ((i >> 2) % row_units) % LPW;
-      tw[i] = kNil | ((uint32_t)(W * LPW + slot) << kWrShift);
-      tg[i] = INFINITY;
-      ta[i] = 0.0f;
+    // ---- padding everywhere (zero-weight terms that park their unused result in the lattice's
+    // dummy cell behind the ring) and the windows
+    for (int i = tid; i < (tile_slots >> 2); i += kTF) {  // one 16-byte unit (4 rounds of a lane) per store
+      const int slot = i & (LPW - 1);  // unit = lane * LPW + slot, a row is a whole number of lanes
+      const uint32_t w = kNil | ((uint32_t)(W * LPW + slot) << kWrShift);
+      reinterpret_cast<uint4*>(tw)[i] = make_uint4(w, w, w, w);
+      reinterpret_cast<float4*>(tg)[i] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+      reinterpret_cast<float4*>(ta)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    for (int i = tid; i < LPW * kWin; i += kT) {
+    for (int i = tid; i < LPW * kWin; i += kTF) {
       const int k = i / kWin, o = i - k * kWin;
-      int v = 0x7FFFFFFF;
+      int vr = kM, vc = 0;
       const int u = sh_lat[k];
       if (u >= 0) {
         const int S = sh_S[k], P = fwd ? S + 1 : S;
         const int p = sh_plo[k] + o;
-        if (p <= P) v = ((fwd ? a.r0f : a.r0b) + a.state_off[u] + 2 * (int64_t)u)[p];
-        if (o == 0) sh_next[k] = P, sh_fin[k] = 0;
+        const int64_t sb = sh_s0[k] + 2 * (int64_t)u;
+        if (p <= P) vr = ((fwd ? a.r0f : a.r0b) + sb)[p];
+        vc = fwd ? a.cnt[sb + min(p, S + 1)] : a.row[sb + max(S - p, 0)];
+        if (o == 0) sh_next[k] = P;
       }
-      sh_r[i] = v;
+      if (o == 0) sh_n[k] = 0;
+      win_r[i] = vr;
+      win_c[i] = vc;
+    }
+    __syncthreads();
+    // ---- which positions have a round in the tile; the first position of the next tile
+    for (int i = tid; i < LPW * (kTileRounds + 1); i += kTF) {
+      const int k = i / (kTileRounds + 1), o = i - k * (kTileRounds + 1);
+      if (sh_lat[k] < 0) continue;
+      const int P = fwd ? sh_S[k] + 1 : sh_S[k];
+      const int p = sh_plo[k] + o;
+      if (p >= P) continue;
+      const int r = win_r[k * kWin + o] & kM, rn = win_r[k * kWin + o + 1] & kM;
+      if (r <= R1 && rn > R1) sh_next[k] = p;
+      if (r >= R1 || rn <= R0) continue;
+      atomicMax(&sh_n[k], o + 1);
     }
     __syncthreads();
     auto put = [&](int k, int rr, int sub, uint32_t w, float g, float ac) {
@@ -426,185 +531,109 @@ __global__ __launch_bounds__(kT) void pack_fill_kernel(PackDevArgs a) {
       tg[i] = g;
       ta[i] = ac;
     };
-    for (int i = tid; i < LPW * (kTileRounds + 1); i += kT) {
-      const int k = i / (kTileRounds + 1), o = i - k * (kTileRounds + 1);
-      const int u = sh_lat[k];
-      if (u < 0) continue;
-      const int S = sh_S[k], P = fwd ? S + 1 : S;
-      const int p = sh_plo[k] + o;
-      const int r = sh_r[k * kWin + o], rn = sh_r[k * kWin + o + 1];
-      if (p >= P) continue;
-      if (r <= R1 && rn > R1) sh_next[k] = p;  // the first position of the next tile
-      if (r >= R1 || rn <= R0) continue;
-      const int nr = rn - r;
-      if (fwd && p == S) {  // one term per final state: by the whole workgroup, below
-        sh_fin[k] = 1;
-        continue;
-      }
-      const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
-      const int64_t sb = s0 + 2 * (int64_t)u;
-      const uint32_t cell_mask = (uint32_t)(W - 1);
-      const uint32_t own_cell = (uint32_t)((p & cell_mask) * LPW + k);
-      const uint32_t dummy = (uint32_t)(W * LPW + k) << kWrShift;
-      // term j of the position sits in round r + j / G on lane j % G of the lattice
-      const int jlo = max(0, (R0 - r) * G), jhi = min(nr * G, (R1 - r) * G);
-      int j = 0, nterm = 0;
-      auto emit = [&](int rel, bool word, float g, float ac, bool nil) {
-        if (j >= jlo && j < jhi && (j % G) < AL) {
-          const int rr = r + j / G;
-          uint32_t w;
-          bool far = false;
-          if (nil) {
-            w = kNil | own_cell;
-          } else if (rel == 0) {
-            w = kOne | own_cell;
-          } else if (rel >= W) {
-            w = kFar | (uint32_t)rel;
-            far = true;
-            nfar++;
+    // ---- one thread per arc term
+    {
+      const int k = tid >> lg_tps, gl = tid & ((1 << lg_tps) - 1);
+      const int n = sh_n[k];
+      const int32_t* wc = win_c + k * kWin;
+      const int32_t* wr = win_r + k * kWin;
+      const int nterms = n > 0 ? (fwd ? wc[n] - wc[0] : wc[0] - wc[n]) : 0;
+      const int first = n > 0 ? (fwd ? wc[0] : wc[n]) : 0;  // the lattice's first term here: in-arc number / out-arc number
+      const int plo = sh_plo[k], S = sh_S[k], A = sh_A[k];
+      const int64_t a0 = sh_a0[k], s0 = sh_s0[k];
+      const int32_t* ia = (fwd ? a.in_arc : a.out_arc) + a0;
+      const TermCtx tc = {lg, W, LPW, k};
+      for (int tb = gl; tb < nterms; tb += kFillUnroll << lg_tps) {
+        int tx[kFillUnroll], arc[kFillUnroll];
+#pragma unroll
+        for (int u = 0; u < kFillUnroll; ++u) {
+          tx[u] = first + min(tb + (u << lg_tps), nterms - 1);  // (a lane without a term repeats the last one and drops it)
+          arc[u] = tx[u] < A ? ia[tx[u]] : a.flist[s0 + tx[u] - A];  // (forward, position S: one term per final state)
+        }
+        int vs[kFillUnroll], vd[kFillUnroll], il[kFillUnroll];
+        float gg[kFillUnroll], aa[kFillUnroll];
+#pragma unroll
+        for (int u = 0; u < kFillUnroll; ++u) {
+          if (tx[u] < A) {
+            const int64_t x = a0 + arc[u];
+            vs[u] = a.src[x];
+            vd[u] = a.dst[x];
+            il[u] = a.ilabel[x];
+            gg[u] = a.graph[x];
+            aa[u] = a.acoustic[x];
           } else {
-            w = (uint32_t)(((p - rel) & cell_mask) * LPW + k);
-            if (rel == 1 && j < G) w |= kBypass;
+            vs[u] = arc[u], vd[u] = S, il[u] = 0;
+            gg[u] = a.final_graph[s0 + arc[u]];
+            aa[u] = a.final_acoustic[s0 + arc[u]];
           }
-          if (word) w |= kWord;
-          if (!far) w |= dummy;
-          if (rr == r) w |= kFirst;
-          if (rr == r + nr - 1) {
-            w |= kLast;
-            if (j % G == 0 && !far) w = (w & ~(kCellMask << kWrShift)) | kCommit | (own_cell << kWrShift);
-          }
-          put(k, rr, j % G, w, nil ? INFINITY : g, ac);
         }
-        ++j;  // (every term sits on a stored lane: AL = min(G, the most terms of one position))
-      };
-      if (fwd) {
-        const int32_t* cnt = a.cnt + sb;
-        const int32_t* in_arc = a.in_arc + a0;
-        const int q0 = cnt[p], q1 = cnt[p + 1];
-        nterm = q1 - q0 + (p == 0 ? 1 : 0);
-        if (p == 0) emit(0, false, 0.0f, 0.0f, false);  // alpha[start] = 0
-        // skip the in-arcs whose rounds lie before the tile
-        int q = q0;
-        if (j < jlo) {
-          const int skip = min(q1 - q0, jlo - j);
-          q += skip;
-          j += skip;
+#pragma unroll
+        for (int u = 0; u < kFillUnroll; ++u) {
+          const int p = fwd ? vd[u] : S - 1 - vs[u];
+          const int o = p - plo;
+          const int r = wr[o] & kM, nr = (wr[o + 1] & kM) - r;
+          // the term's number within its position: its offset from the position's first term, behind the constant-one term
+          const int j = fwd ? tx[u] - wc[o] + (p == 0 ? 1 : 0) : tx[u] - wc[o + 1] + (int)((uint32_t)wr[o] >> 31);
+          const int rr = r + (j >> lg);
+          if (tb + (u << lg_tps) >= nterms || rr < R0 || rr >= R1) continue;
+          bool far;
+          const uint32_t w = term_word(tc, p, r, nr, j, vd[u] - vs[u], il[u] != 0, false, &far);
+          nfar += far ? 1 : 0;
+          put(k, rr, j & gmask, w, gg[u], aa[u]);
         }
-        for (; q < q1 && j < jhi; ++q) {
-          const int64_t i2 = a0 + in_arc[q];
-          emit(p - a.src[i2], a.ilabel[i2] != 0, a.graph[i2], a.acoustic[i2], false);
-        }
-        if (nterm == 0) emit(0, false, 0.0f, 0.0f, true);
-      } else {
-        const int s = S - 1 - p;
-        const int32_t* row = a.row + sb;
-        const int32_t* dst = a.dst + a0;
-        const int lo = row[s], hi = row[s + 1];
-        const bool fin = dev_is_final(a, s0 + s);
-        nterm = hi - lo + (fin ? 1 : 0);
-        if (fin) emit(0, false, a.final_graph[s0 + s], a.final_acoustic[s0 + s], false);
-        // farthest destination first, nearest last; arcs with the same destination in arc order
-        int last_dst = 0x7FFFFFFF, last_idx = -1;
-        for (int n = lo; n < hi && j < jhi; ++n) {
-          int best = -1, best_dst = -1;
-          for (int i2 = lo; i2 < hi; ++i2) {
-            const int d = dst[i2];
-            const bool after = d < last_dst || (d == last_dst && i2 > last_idx);
-            if (after && (d > best_dst)) {
-              best = i2;
-              best_dst = d;
-            }
-          }
-          last_dst = best_dst;
-          last_idx = best;
-          if (j >= jlo)
-            emit(best_dst - s, a.ilabel[a0 + best] != 0, a.graph[a0 + best], a.acoustic[a0 + best], false);
-          else
-            ++j;
-        }
-        if (nterm == 0) emit(0, false, 0.0f, 0.0f, true);
+      }
+    }
+    // ---- one thread per position: what is not an arc
+    for (int i = tid; i < LPW * (kTileRounds + 1); i += kTF) {
+      const int k = i / (kTileRounds + 1), o = i - k * (kTileRounds + 1);
+      if (o >= sh_n[k]) continue;
+      const int S = sh_S[k];
+      const int p = sh_plo[k] + o;
+      const int r = win_r[k * kWin + o] & kM, nr = (win_r[k * kWin + o + 1] & kM) - r;
+      const int jlo = max(0, (R0 - r) << lg), jhi = min(nr << lg, (R1 - r) << lg);
+      const int deg = fwd ? win_c[k * kWin + o + 1] - win_c[k * kWin + o] : win_c[k * kWin + o] - win_c[k * kWin + o + 1];
+      const bool lead = fwd ? p == 0 : ((uint32_t)win_r[k * kWin + o] >> 31) != 0;  // alpha[start] = 0; a final state's weight
+      const int nterm = deg + (lead ? 1 : 0);
+      const TermCtx tc = {lg, W, LPW, k};
+      bool far;
+      if (jlo == 0 && (lead || nterm == 0)) {
+        float g = 0.0f, ac = 0.0f;
+        if (lead && !fwd) g = a.final_graph[sh_s0[k] + S - 1 - p], ac = a.final_acoustic[sh_s0[k] + S - 1 - p];
+        const uint32_t w = term_word(tc, p, r, nr, 0, 0, false, !lead, &far);
+        put(k, r, 0, w, lead ? g : INFINITY, ac);
       }
       // lanes of the position's rounds that carry no term
+      const uint32_t dummy = (uint32_t)(W * LPW + k) << kWrShift;
       for (int jj = max(max(nterm, 1), jlo); jj < jhi; ++jj) {
-        if (jj % G >= AL) continue;
-        const int rr = r + jj / G;
+        if ((jj & gmask) >= AL) continue;
+        const int rr = r + (jj >> lg);
         uint32_t w = kNil | dummy;
         if (rr == r) w |= kFirst;
         if (rr == r + nr - 1) w |= kLast;
-        put(k, rr, jj % G, w, INFINITY, 0.0f);
+        put(k, rr, jj & gmask, w, INFINITY, 0.0f);
       }
     }
     __syncthreads();
-    if (fwd) {  // position S of the lattices that have it in this tile
-      for (int k = 0; k < LPW; ++k) {
-        if (!sh_fin[k]) continue;
-        const int u = sh_lat[k], S = sh_S[k];
-        const int64_t s0 = a.state_off[u];
-        const int64_t sb = s0 + 2 * (int64_t)u;
-        const int r = a.r0f[sb + S], nr = a.r0f[sb + S + 1] - r;
-        const int nfinal = a.cnt[sb + S + 1];
-        const int jlo = max(0, (R0 - r) * G), jhi = min(nr * G, (R1 - r) * G);
-        const uint32_t own_cell = (uint32_t)((S & (W - 1)) * LPW + k);
-        const uint32_t dummy = (uint32_t)(W * LPW + k) << kWrShift;
-        for (int s = tid; s < S; s += kT) {
-          if (!dev_is_final(a, s0 + s)) continue;
-          const int j = a.frank[s0 + s];
-          if (j < jlo || j >= jhi || j % G >= AL) continue;
-          const int rr = r + j / G, rel = S - s;
-          uint32_t w;
-          bool far = false;
-          if (rel >= W) {
-            w = kFar | (uint32_t)rel;
-            far = true;
-            nfar++;
-          } else {
-            w = (uint32_t)(((S - rel) & (W - 1)) * LPW + k);
-            if (rel == 1 && j < G) w |= kBypass;
-          }
-          if (!far) w |= dummy;
-          if (rr == r) w |= kFirst;
-          if (rr == r + nr - 1) {
-            w |= kLast;
-            if (j % G == 0 && !far) w = (w & ~(kCellMask << kWrShift)) | kCommit | (own_cell << kWrShift);
-          }
-          put(k, rr, j % G, w, a.final_graph[s0 + s], a.final_acoustic[s0 + s]);
-        }
-        // no final state: one NIL term; then the lanes without a term
-        for (int jj = max(nfinal, jlo) + tid; jj < jhi; jj += kT) {
-          if (jj % G >= AL) continue;
-          const int rr = r + jj / G;
-          uint32_t w = kNil | (jj == 0 ? own_cell : 0u) | dummy;  // jj == 0: no final state, one NIL term
-          if (rr == r) w |= kFirst;
-          if (rr == r + nr - 1) {
-            w |= kLast;
-            if (jj == 0) w = (w & ~(kCellMask << kWrShift)) | kCommit | (own_cell << kWrShift);
-          }
-          put(k, rr, jj % G, w, INFINITY, 0.0f);
-        }
-      }
-      __syncthreads();
-    }
-    // the tile leaves as whole lines
+    // ---- the tile leaves as whole lines
     {
       const int64_t base = (job.chunk_off + (int64_t)(R0 >> 2) * row_units) << 2;  // first slot of the tile
       uint4* gw = reinterpret_cast<uint4*>(a.sw + base);
       float4* gg = reinterpret_cast<float4*>(a.sg + base);
       float4* ga = reinterpret_cast<float4*>(a.sa + base);
       const uint4* lw = reinterpret_cast<const uint4*>(tw);
-      const float4* lg = reinterpret_cast<const float4*>(tg);
+      const float4* lg4 = reinterpret_cast<const float4*>(tg);
       const float4* la = reinterpret_cast<const float4*>(ta);
-      for (int i = tid; i < (tile_slots >> 2); i += kT) {
+      for (int i = tid; i < (tile_slots >> 2); i += kTF) {
         gw[i] = lw[i];
-        gg[i] = lg[i];
+        gg[i] = lg4[i];
         ga[i] = la[i];
       }
     }
     if (tid < LPW) sh_plo[tid] = sh_next[tid];
     __syncthreads();
   }
-  if (nfar) atomicAdd(&sh_far, nfar);
-  __syncthreads();
-  if (tid == 0 && sh_far) atomicAdd(&a.status[3], sh_far);
+  for (int d = 32; d > 0; d >>= 1) nfar += __shfl_xor(nfar, d, 64);
+  if ((tid & 63) == 0 && nfar) atomicAdd(&a.status[3], nfar);
 }
 
 }  // namespace
@@ -633,9 +662,10 @@ hipError_t launch_pack_rounds(const PackDevArgs& a, int num_lattices, hipStream_
   return hipGetLastError();
 }
 
-hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, hipStream_t stream) {
+hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, int max_lpw, hipStream_t stream) {
   if (num_entries <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_fill_kernel, dim3(num_entries), dim3(kT), 0, stream, a);
+  const size_t lds = (size_t)max_lpw * kWin * 2 * sizeof(int32_t);
+  hipLaunchKernelGGL(pack_fill_kernel, dim3(num_entries), dim3(kTF), lds, stream, a, max_lpw);
   return hipGetLastError();
 }
 
