@@ -354,6 +354,15 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       else
         class_need[k] = std::max(class_need[k], need);
     }
+    DevBuf<unsigned long long> d_prof;
+    if (std::getenv("KLAT_PACK_PROFILE") != nullptr) {
+      if ((rc = d_prof.alloc(8))) {
+        klat_batch_destroy(b);
+        return rc;
+      }
+      KLAT_HIP_B(hipMemsetAsync(d_prof.p, 0, 8 * sizeof(unsigned long long), c->stream));
+      pa.prof = d_prof.p;
+    }
     hipEvent_t* pev = b->pack_ev;
     for (int i = 0; i < klat_batch::kPackEvents; ++i) KLAT_HIP_B(hipEventCreate(&pev[i]));
     KLAT_HIP_B(hipEventRecord(pev[0], c->stream));
@@ -366,6 +375,13 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     if (he != hipSuccess) {
       klat_batch_destroy(b);
       return hip_fail(he, "stream packing (count pass)");
+    }
+    if (pa.prof) {
+      unsigned long long h[8];
+      KLAT_HIP_B(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));
+      const double n = (double)std::max<int64_t>(U, 1);
+      std::fprintf(stderr, "klat pack_count phases, cycles per lattice: clear %.0f  arcs %.0f  states %.0f  scatter %.0f  buckets %.0f  in_arc out %.0f  out-arcs %.0f  tail %.0f\n",
+                   h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7] / n);
     }
     if (h_status[0] != 0)
       FAIL(h_status[0] == 2 ? KLAT_ERR_BAD_TOPOLOGY : KLAT_ERR_INVALID_ARG,

@@ -49,6 +49,7 @@ struct PackDevArgs {
   const SweepJob* jobs;
   const LaneInfo* lanes;
   int32_t* sw; float* sg; float* sa;
+  unsigned long long* prof;  // [8] or null: phase cycles of the count pass (KLAT_PACK_PROFILE=1)
 };
 
 // class_need[c]: the largest pack_count_lds_bytes among the lattices of LDS class c (0: none);

@@ -76,12 +76,49 @@ __device__ __forceinline__ void report_bad(const PackDevArgs& a, int code, int u
   if (atomicCAS(&a.status[0], 0, code) == 0) a.status[1] = u;
 }
 
+// exclusive prefix sums of three ints per thread with one pair of barriers
+template <int T>
+__device__ void block_scan3(const int v[3], int ex[3], int tot[3], int* sh /* [3 * T/64] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl[3] = {v[0], v[1], v[2]};
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int t = __shfl_up(incl[c], d, 64);
+      if (lane >= d) incl[c] += t;
+    }
+  }
+  __syncthreads();  // sh may still be read from a previous call
+  if (lane == 63) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sh[c * (T / 64) + wave] = incl[c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int off = 0, t = 0;
+    for (int w = 0; w < T / 64; ++w) {
+      const int x = sh[c * (T / 64) + w];
+      if (w < wave) off += x;
+      t += x;
+    }
+    tot[c] = t;
+    ex[c] = off + incl[c] - v[c];
+  }
+}
+
 // The lattice's tables in LDS; arc numbers as 16-bit words (a lattice of 65 536 arcs or more takes
-// the global kernel: pack_count_lds_bytes puts it above every class).
+// the global kernel: pack_count_lds_bytes puts it above every class).  The passes over the arcs
+// keep kCountUnroll loads per thread in flight (one after the other, twelve dependent round trips
+// per pass were most of the kernel).
 typedef uint16_t IA;
+#ifndef KLAT_COUNT_UNROLL
+#define KLAT_COUNT_UNROLL 4
+#endif
+constexpr int kCountUnroll = KLAT_COUNT_UNROLL;
 __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_lo, int lds_hi) {
   extern __shared__ int32_t lds[];
-  __shared__ int sh[kTC / 64];
+  __shared__ int sh[3 * (kTC / 64)];
   __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
   const int u = blockIdx.x, tid = threadIdx.x;
@@ -101,85 +138,127 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
   const int64_t sb = s0 + 2 * (int64_t)u;
   const int32_t* src = a.src + a0;
   const int32_t* dst = a.dst + a0;
+  // diagnostic (KLAT_PACK_PROFILE=1): shader cycles of thread 0 per phase, summed over the workgroups
+  unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = a.prof ? __builtin_readcyclecounter() : 0;
+  auto stamp = [&](int phase) {
+    if (a.prof) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      pc[phase] += now - pt;
+      pt = now;
+    }
+  };
   if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
   for (int s = tid; s < 2 * (S + 2); s += kTC) lds[s] = 0;
   __syncthreads();
+  stamp(0);
   // degrees + validation (the host packer's checks: ids in range, arcs grouped by source, every
   // arc goes to a higher state)
   int mr = 1;
-  for (int i = tid; i < A; i += kTC) {
-    const int s = src[i], t = dst[i];
-    const int prev = i > 0 ? src[i - 1] : 0;
-    if (s < 0 || s >= S || s < prev) {
-      atomicMax(&sh_bad, 2);  // malformed CSR
-    } else if (t <= s || t >= S) {
-      atomicMax(&sh_bad, 1);  // not topologically sorted
-    } else {
-      atomicAdd(&cnt[t], 1);
-      atomicAdd(&row[s], 1);
-      mr = max(mr, t - s);
+  for (int ib = tid; ib < A; ib += kTC * kCountUnroll) {
+    int vs[kCountUnroll], vt[kCountUnroll], vp[kCountUnroll];
+#pragma unroll
+    for (int x = 0; x < kCountUnroll; ++x) {
+      const int i = min(ib + x * kTC, A - 1);
+      vs[x] = src[i], vt[x] = dst[i], vp[x] = i > 0 ? src[i - 1] : 0;
+    }
+#pragma unroll
+    for (int x = 0; x < kCountUnroll; ++x) {
+      if (ib + x * kTC >= A) continue;
+      const int s = vs[x], t = vt[x];
+      if (s < 0 || s >= S || s < vp[x]) {
+        atomicMax(&sh_bad, 2);  // malformed CSR
+      } else if (t <= s || t >= S) {
+        atomicMax(&sh_bad, 1);  // not topologically sorted
+      } else {
+        atomicAdd(&cnt[t], 1);
+        atomicAdd(&row[s], 1);
+        mr = max(mr, t - s);
+      }
     }
   }
-  for (int s = tid; s < S; s += kTC)
-    if (dev_is_final(a, s0 + s)) mr = max(mr, S - s);
-  atomicMax(&sh_mr, mr);
   __syncthreads();
+  stamp(1);
   if (sh_bad) {
     if (tid == 0) report_bad(a, sh_bad == 2 ? 1 /* INVALID_ARG */ : 2 /* BAD_TOPOLOGY */, u);
     return;
   }
-  if (tid == 0) atomicMax(&a.status[2], sh_mr);
-  // rank of every final state among the finals (terms of the forward stream's last position),
-  // backward rounds (position p = S-1-s holds the out-arcs of s + its final weight), row table
+  // per state: rank among the final states (the terms of the forward stream's last position), first
+  // out-arc (row table), first in-arc; the rounds of every position for every number of lanes --
+  // forward position p holds the in-arcs of state p (+ the constant-one term of the start state),
+  // backward position S-1-s the out-arcs of s (+ its final weight)
   int fsum[kNumLaneChoices] = {0}, bsum[kNumLaneChoices] = {0};
-  int carry_f = 0, carry_o = 0, mtf = 1, mtb = 1;
+  int carry[3] = {0, 0, 0}, mtf = 1, mtb = 1;
   for (int base = 0; base <= S; base += kTC) {
     const int s = base + tid;
-    const int f = (s < S && dev_is_final(a, s0 + s)) ? 1 : 0;
-    const int od = s < S ? row[s] : 0;
-    int tot_f, tot_o;
-    const int ex_f = block_scan<kTC>(f, &tot_f, sh);
-    const int ex_o = block_scan<kTC>(od, &tot_o, sh);
+    int v[3] = {0, 0, 0}, ex[3], tot[3];
     if (s < S) {
-      if (f) a.flist[s0 + carry_f + ex_f] = s;  // the final states in state order
-      const int nb = od + f;
+      const float fg = a.final_graph[s0 + s], fa = a.final_acoustic[s0 + s];
+      v[0] = !(fg == INFINITY && fa == INFINITY) ? 1 : 0;
+      v[1] = row[s];
+      v[2] = cnt[s];
+    }
+    block_scan3<kTC>(v, ex, tot, sh);
+    if (s < S) {
+      if (v[0]) {
+        a.flist[s0 + carry[0] + ex[0]] = s;  // the final states in state order
+        mr = max(mr, S - s);
+      }
+      const int nb = v[1] + v[0], nf = v[2] + (s == 0 ? 1 : 0);
       mtb = max(mtb, nb);
-      for (int k = 0; k < kNumLaneChoices; ++k) bsum[k] += (max(nb, 1) + (1 << k) - 1) >> k;
+      mtf = max(mtf, nf);
+      for (int k = 0; k < kNumLaneChoices; ++k) {
+        bsum[k] += (max(nb, 1) + (1 << k) - 1) >> k;
+        fsum[k] += (max(nf, 1) + (1 << k) - 1) >> k;
+      }
     }
-    if (s <= S) row[s] = carry_o + ex_o;
-    carry_f += tot_f;
-    carry_o += tot_o;
+    if (s <= S) {
+      row[s] = carry[1] + ex[1];
+      cnt[s] = carry[2] + ex[2];
+      a.row[sb + s] = carry[1] + ex[1];
+      a.cnt[sb + s] = carry[2] + ex[2];
+    }
+    carry[0] += tot[0], carry[1] += tot[1], carry[2] += tot[2];
   }
-  const int nfinal = carry_f;
-  // forward: rounds of every position p = 0..S (S = the virtual super-final state) for every
-  // number of lanes; in-degrees -> exclusive prefix in place (cnt[p] = first in-arc of p, cnt[S] = A)
-  int carry_c = 0;
-  for (int base = 0; base <= S; base += kTC) {
-    const int p = base + tid;
-    const int c = (p < S) ? cnt[p] : 0;
-    const int nterm = (p < S) ? c + (p == 0 ? 1 : 0) : nfinal;
-    if (p <= S) {
-      mtf = max(mtf, nterm);
-      for (int k = 0; k < kNumLaneChoices; ++k) fsum[k] += (max(nterm, 1) + (1 << k) - 1) >> k;
-    }
-    int tot_c;
-    const int ex_c = block_scan<kTC>(c, &tot_c, sh);
-    if (p <= S) {
-      cnt[p] = carry_c + ex_c;
-      a.cnt[sb + p] = carry_c + ex_c;
-      a.row[sb + p] = row[p];
-    }
-    carry_c += tot_c;
+  const int nfinal = carry[0];
+  if (tid == 0) {
+    a.cnt[sb + S + 1] = A + nfinal;  // position S holds one term per final state: "in-arcs" A .. A + nfinal - 1
+    mtf = max(mtf, nfinal);
+    for (int k = 0; k < kNumLaneChoices; ++k) fsum[k] += (max(nfinal, 1) + (1 << k) - 1) >> k;
   }
-  if (tid == 0) a.cnt[sb + S + 1] = A + nfinal;  // position S holds one term per final state: "in-arcs" A .. A + nfinal - 1
+  for (int d = 32; d > 0; d >>= 1) mr = max(mr, __shfl_xor(mr, d, 64));
+  if ((tid & 63) == 0) atomicMax(&sh_mr, mr);
   __syncthreads();
+  stamp(2);
   // stable counting sort of the arcs by destination: scatter (cnt[t] moves from the first entry of
   // bucket t to the first entry of bucket t + 1), then order every bucket by arc number
-  for (int i = tid; i < A; i += kTC) in_arc[atomicAdd(&cnt[dst[i]], 1)] = (IA)i;
+  for (int ib = tid; ib < A; ib += kTC * kCountUnroll) {
+    int vt[kCountUnroll];
+#pragma unroll
+    for (int x = 0; x < kCountUnroll; ++x) vt[x] = dst[min(ib + x * kTC, A - 1)];
+#pragma unroll
+    for (int x = 0; x < kCountUnroll; ++x)
+      if (ib + x * kTC < A) in_arc[atomicAdd(&cnt[vt[x]], 1)] = (IA)(ib + x * kTC);
+  }
   __syncthreads();
+  stamp(3);
   for (int s = tid; s < S; s += kTC) {
-    const int b = s > 0 ? cnt[s - 1] : 0, e = cnt[s];
+    const int b = s > 0 ? cnt[s - 1] : 0, e = cnt[s], n = e - b;
+    if (n <= 1) continue;
+    if (n <= 4) {  // in registers: a sorting network on up to four arc numbers
+      int v[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) v[x] = x < n ? (int)in_arc[b + x] : 0x10000 + x;
+      auto cswap = [&](int x, int y) {
+        const int lo = min(v[x], v[y]), hi = max(v[x], v[y]);
+        v[x] = lo, v[y] = hi;
+      };
+      cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (x < n) in_arc[b + x] = (IA)v[x];
+      continue;
+    }
     for (int i = b + 1; i < e; ++i) {
       const IA v = in_arc[i];
       int j = i - 1;
@@ -191,37 +270,73 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
     }
   }
   __syncthreads();
+  stamp(4);
   for (int i = tid; i < A; i += kTC) a.in_arc[a0 + i] = (int32_t)in_arc[i];
-  __syncthreads();
-  // the out-arcs of every state, farthest destination first, nearest last (the term that depends
-  // on the most recently finished state enters the accumulator last); equal destinations in arc order
-  IA* out_arc = in_arc;  // (the same LDS: the arcs by destination have left)
+  stamp(5);
+  // the out-arcs of every state in stream order: farthest destination first, nearest last (the term
+  // that depends on the most recently finished state enters the accumulator last), equal
+  // destinations in arc order.  Up to four arcs in registers; more through the table in HBM.
   for (int s = tid; s < S; s += kTC) {
-    const int b = row[s], e = row[s + 1];
-    for (int i = b; i < e; ++i) {
-      const int dv = dst[i];
-      int j = i - 1;
-      while (j >= b && dst[out_arc[j]] < dv) {
-        out_arc[j + 1] = out_arc[j];
-        --j;
+    const int b = row[s], e = row[s + 1], deg = e - b;
+    if (deg <= 0) continue;
+    if (deg <= 4) {
+      int d[4], id[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        id[x] = b + x;
+        d[x] = x < deg ? dst[b + x] : -1 - x;  // (the slots behind the last arc sort to the end, in order)
       }
-      out_arc[j + 1] = (IA)i;
+      // sorting network on (destination descending, arc ascending)
+      auto cswap = [&](int x, int y) {
+        if (d[x] < d[y] || (d[x] == d[y] && id[x] > id[y])) {
+          const int td = d[x], ti = id[x];
+          d[x] = d[y], id[x] = id[y];
+          d[y] = td, id[y] = ti;
+        }
+      };
+      cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (x < deg) a.out_arc[a0 + b + x] = id[x];
+    } else {
+      int32_t* out_arc = a.out_arc + a0;
+      for (int i = b; i < e; ++i) {
+        const int dv = dst[i];
+        int j = i - 1;
+        while (j >= b && dst[out_arc[j]] < dv) {
+          out_arc[j + 1] = out_arc[j];
+          --j;
+        }
+        out_arc[j + 1] = i;
+      }
     }
   }
-  __syncthreads();
-  for (int i = tid; i < A; i += kTC) a.out_arc[a0 + i] = (int32_t)out_arc[i];
-  atomicMax(&sh_mtf, mtf);
-  atomicMax(&sh_mtb, mtb);
-  for (int k = 0; k < kNumLaneChoices; ++k) {
-    if (fsum[k]) atomicAdd(&sh_rounds[k], fsum[k]);
-    if (bsum[k]) atomicAdd(&sh_rounds[kNumLaneChoices + k], bsum[k]);
+  stamp(6);
+  // (reduced per wave first: 512 threads adding to the same 14 words one after the other were half the kernel)
+  for (int d = 32; d > 0; d >>= 1) {
+    mtf = max(mtf, __shfl_xor(mtf, d, 64));
+    mtb = max(mtb, __shfl_xor(mtb, d, 64));
+#pragma unroll
+    for (int k = 0; k < kNumLaneChoices; ++k) fsum[k] += __shfl_xor(fsum[k], d, 64), bsum[k] += __shfl_xor(bsum[k], d, 64);
+  }
+  if ((tid & 63) == 0) {
+    atomicMax(&sh_mtf, mtf);
+    atomicMax(&sh_mtb, mtb);
+    for (int k = 0; k < kNumLaneChoices; ++k) {
+      atomicAdd(&sh_rounds[k], fsum[k]);
+      atomicAdd(&sh_rounds[kNumLaneChoices + k], bsum[k]);
+    }
   }
   __syncthreads();
   if (tid < kNumLaneChoices) {
     a.lat_rounds[u].fwd[tid] = sh_rounds[tid];
     a.lat_rounds[u].bwd[tid] = sh_rounds[kNumLaneChoices + tid];
   }
+  stamp(7);
+  if (a.prof && tid == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.prof[i], pc[i]);
   if (tid == 0) {
+    atomicMax(&a.status[2], sh_mr);
     a.lat_rounds[u].max_rel = sh_mr;
     a.lat_rounds[u].max_terms = min(sh_mtf, 64) | (min(sh_mtb, 64) << 16);
   }
