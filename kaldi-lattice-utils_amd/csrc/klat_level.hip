@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void level_plan_kernel(LevelPlanArgs a) {
   __shared__ int tail_sh;
   const int u = blockIdx.x, lane = threadIdx.x;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
-  const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
+  const int S = (int)(a.state_off[u + 1] - s0);
   if (S < kLevelMinStates || S > kLevelMaxStates) {
     if (lane == 0) a.depth[u] = -1;
     return;
@@ -56,23 +56,14 @@ __global__ __launch_bounds__(64) void level_plan_kernel(LevelPlanArgs a) {
   int32_t* order = a.order + s0;            // states, level by level
   int32_t* off = a.level_off + sb;          // first entry of every level in `order`
   const int32_t* row = a.out_begin + sb;    // first out-arc of every state (row[S] = A), from the count pass
-  const int32_t* src = a.src + a0;
   const int32_t* dst = a.dst + a0;
   const int max_depth = S / kLevelMinWidth;
 
   // A time-ordered chain (nearly every state linked to its successor) is as deep as it is long:
   // tell it from one pass over the arcs instead of from max_depth steps of Kahn's algorithm.
   // With g states lacking the link, some run of linked states is at least (S - g) / (g + 1) long.
-  for (int s = lane; s < S; s += 64) left[s] = 0;
-  __threadfence_block();
-  __syncthreads();
-  for (int i = lane; i < A; i += 64)
-    if (dst[i] == src[i] + 1) left[src[i]] = 1;
-  __threadfence_block();
-  __syncthreads();
-  int linked = 0;
-  for (int s = lane; s < S; s += 64) linked += left[s];
-  for (int d = 32; d > 0; d >>= 1) linked += __shfl_xor(linked, d, 64);
+  // (the count pass of the stream packer counted the linked states: the spare entry of the row table)
+  const int linked = row[S + 1];
   if (linked > (S - linked + 1) * max_depth) {
     if (lane == 0) a.depth[u] = -1;
     return;

@@ -119,7 +119,7 @@ constexpr int kCountUnroll = KLAT_COUNT_UNROLL;
 __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_lo, int lds_hi) {
   extern __shared__ int32_t lds[];
   __shared__ int sh[3 * (kTC / 64)];
-  __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb;
+  __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb, sh_linked;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
       pt = now;
     }
   };
-  if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1;
+  if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
   for (int s = tid; s < 2 * (S + 2); s += kTC) lds[s] = 0;
   __syncthreads();
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
   // the out-arcs of every state in stream order: farthest destination first, nearest last (the term
   // that depends on the most recently finished state enters the accumulator last), equal
   // destinations in arc order.  Up to four arcs in registers; more through the table in HBM.
+  int linked = 0;  // states with an arc to their successor (the level planner's test for a time-ordered chain)
   for (int s = tid; s < S; s += kTC) {
     const int b = row[s], e = row[s + 1], deg = e - b;
     if (deg <= 0) continue;
@@ -295,13 +296,18 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
         }
       };
       cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+      int nearest = d[0];
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
-        if (x < deg) a.out_arc[a0 + b + x] = id[x];
+      for (int x = 0; x < 4; ++x) {
+        if (x < deg) a.out_arc[a0 + b + x] = id[x], nearest = d[x];
+      }
+      linked += nearest == s + 1 ? 1 : 0;
     } else {
       int32_t* out_arc = a.out_arc + a0;
+      int nearest = S;
       for (int i = b; i < e; ++i) {
         const int dv = dst[i];
+        nearest = min(nearest, dv);
         int j = i - 1;
         while (j >= b && dst[out_arc[j]] < dv) {
           out_arc[j + 1] = out_arc[j];
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
         }
         out_arc[j + 1] = i;
       }
+      linked += nearest == s + 1 ? 1 : 0;
     }
   }
   stamp(6);
@@ -319,9 +326,11 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
 #pragma unroll
     for (int k = 0; k < kNumLaneChoices; ++k) fsum[k] += __shfl_xor(fsum[k], d, 64), bsum[k] += __shfl_xor(bsum[k], d, 64);
   }
+  for (int d = 32; d > 0; d >>= 1) linked += __shfl_xor(linked, d, 64);
   if ((tid & 63) == 0) {
     atomicMax(&sh_mtf, mtf);
     atomicMax(&sh_mtb, mtb);
+    atomicAdd(&sh_linked, linked);
     for (int k = 0; k < kNumLaneChoices; ++k) {
       atomicAdd(&sh_rounds[k], fsum[k]);
       atomicAdd(&sh_rounds[kNumLaneChoices + k], bsum[k]);
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
   if (a.prof && tid == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&a.prof[i], pc[i]);
   if (tid == 0) {
+    a.row[sb + S + 1] = sh_linked;  // (the spare entry of the row table)
     atomicMax(&a.status[2], sh_mr);
     a.lat_rounds[u].max_rel = sh_mr;
     a.lat_rounds[u].max_terms = min(sh_mtf, 64) | (min(sh_mtb, 64) << 16);
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
 // above `lds_hi` bytes of tables.
 __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, int lds_hi) {
   __shared__ int sh[kT / 64];
-  __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb;
+  __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb, sh_linked;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
   int32_t* out_arc = a.out_arc + a0;
   const int32_t* src = a.src + a0;
   const int32_t* dst = a.dst + a0;
-  if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1;
+  if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
   for (int s = tid; s < S + 2; s += kT) cnt[s] = 0;
   __syncthreads();
@@ -434,8 +444,10 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
     const int nb = row[s + 1] - row[s] + (dev_is_final(a, s0 + s) ? 1 : 0);
     mtb = max(mtb, nb);
     for (int k = 0; k < kNumLaneChoices; ++k) bsum[k] += (max(nb, 1) + (1 << k) - 1) >> k;
+    int nearest = S;
     for (int i = row[s]; i < row[s + 1]; ++i) {  // out-arcs: farthest destination first, equal destinations in arc order
       const int dv = dst[i];
+      nearest = min(nearest, dv);
       int j = i - 1;
       while (j >= row[s] && dst[out_arc[j]] < dv) {
         out_arc[j + 1] = out_arc[j];
@@ -443,6 +455,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
       }
       out_arc[j + 1] = i;
     }
+    if (nearest == s + 1) atomicAdd(&sh_linked, 1);
   }
   atomicMax(&sh_mtf, mtf);
   atomicMax(&sh_mtb, mtb);
@@ -456,6 +469,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
     a.lat_rounds[u].bwd[tid] = sh_rounds[kNumLaneChoices + tid];
   }
   if (tid == 0) {
+    row[S + 1] = sh_linked;  // (the spare entry of the row table: the level planner's chain test)
     a.lat_rounds[u].max_rel = sh_mr;
     a.lat_rounds[u].max_terms = min(sh_mtf, 64) | (min(sh_mtb, 64) << 16);
   }
