@@ -16,6 +16,8 @@ Beside the headline the line carries:
   shapes       sweep / step time and roofline fractions on the shard one GPU of an 8-GPU node would
                hold of BASELINE configs[3] (C4/8: 12 500 x 5 000 states) and configs[4] (C5/8: the
                skewed mix), and on a wide shape whose topological depth is far below its states;
+  one_shot     stream packing + one forward-backward (+ segment index) on a FRESH C2 batch whose arrays
+               are on the device: what a tool pays per batch (every caller sweeps a batch once);
   accumulate   device time of the segment-index and frame-posterior kernels on the C2 batch;
   index_gather (N > 1) klat_segment_index on every rank's shard + the gather of the 24-byte
                records to rank 0 over RCCL from device buffers (include/klat_dist.h), timed.
@@ -228,6 +230,51 @@ def accumulate_leg(klat_amd, batch, arrays, A):
                                     fr_bytes / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fr_ms > 0 else 1e9))}
 
 
+def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
+    """What every caller of the tools runs ONCE per batch: klat_batch_create's device passes (the stream
+    packer: the reference's untimed preprocessing, kwsbin2/lattice-word-index-segment.cc:41-62,140-141)
+    + one klat_forward_backward + the segment index, on a FRESH batch whose CSR arrays are already on
+    the device.  Device milliseconds (HIP events) and the wall time of the three calls; medians."""
+    import ctypes as C
+    L = klat_amd.lib()
+    dev, keep = dict(arrays), []
+    for name in ("src", "dst", "ilabel", "olabel", "graph", "acoustic", "final_graph", "final_acoustic", "state_time"):
+        t = torch.from_numpy(np.ascontiguousarray(arrays[name])).cuda()
+        keep.append(t)
+        dev[name] = int(t.data_ptr())
+    torch.cuda.synchronize()
+    f, fkeep = klat_amd.Batch._filter(None, None)
+    rows = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        b = klat_amd.Batch(ctx, dev)
+        t1 = time.perf_counter()
+        b.forward_backward(*SCALES)
+        ctx.sync()
+        t2 = time.perf_counter()
+        off = np.zeros(b.U + 1, np.int64)
+        n, ims = C.c_int64(0), C.c_float(0)
+        klat_amd._check(L.klat_segment_index(b.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
+        t3 = time.perf_counter()
+        klat_amd._check(L.klat_get_accum_timings(b.h, C.byref(ims), None))
+        pt, ft = b.pack_timings(), b.timings()
+        rows.append((pt, ft["total_ms"], ims.value, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+        b.close()
+    rows = rows[1:]  # (the first call also allocates)
+    med = lambda xs: median(list(xs))
+    pack = {k: med(r[0][k] for r in rows) for k in ("count_ms", "level_plan_ms", "rounds_ms", "fill_ms", "posterior_prep_ms", "device_ms")}
+    fb, seg = med(r[1] for r in rows), med(r[2] for r in rows)
+    wall = [med(r[3] for r in rows), med(r[4] for r in rows), med(r[5] for r in rows)]
+    del keep
+    return {"what": "fresh C2 batch, CSR arrays resident on the device: stream packing + one forward-backward (+ segment index); "
+                    "device time by HIP events, wall time of the calls",
+            "pack_device_ms": pack, "forward_backward_device_ms": fb, "segment_index_device_ms": seg,
+            "device_ms": pack["device_ms"] + fb, "arcs_per_s": A / ((pack["device_ms"] + fb) * 1e-3),
+            "device_ms_with_index": pack["device_ms"] + fb + seg, "arcs_per_s_with_index": A / ((pack["device_ms"] + fb + seg) * 1e-3),
+            "wall_ms": {"batch_create": wall[0], "forward_backward": wall[1], "segment_index": wall[2], "total": sum(wall)},
+            "arcs_per_s_wall": A / (sum(wall[:2]) * 1e-3), "arcs_per_s_wall_with_index": A / (sum(wall) * 1e-3)}
+
+
 def dry_run(args, rank, world):
     """CPU rehearsal of the N-rank plumbing (launch, rendezvous, sharding, C++ gather over the host
     transport).  No kernel runs and nothing is measured: `value` is null."""
@@ -281,6 +328,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true")
     ap.add_argument("--no-accumulate", action="store_true")
+    ap.add_argument("--no-one-shot", action="store_true")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -441,6 +489,13 @@ def main():
                            "arcs_per_s": A / sec, "h2d_bytes": int(sum(v.nbytes for v in arrays.values())),
                            "d2h_bytes": int(post.nbytes + ab[0].nbytes + ab[1].nbytes)}
         del post, ab
+
+    # ---- the one-shot path of the tools: pack + sweep (+ index) on a fresh batch, device-resident input
+    if rank == 0 and not args.no_one_shot:
+        try:
+            out["one_shot"] = one_shot_leg(klat_amd, torch, ctx, arrays, A)
+        except Exception as e:  # must not take the headline with it
+            out["one_shot"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     # ---- accumulate stage on the resident C2 batch (all ranks: the gather leg needs every shard's index)
     if not args.no_accumulate:
