@@ -101,7 +101,6 @@ typedef struct {
   float totals_ms;     /* exact sweep (its workgroups exit at once unless a job was flagged); the per-lattice
                           totals are formed by the posterior pass and count in posterior_ms */
   float posterior_ms;  /* arc posterior kernel */
-  float convert_ms;    /* always 0: the sweep writes natural-log alpha/beta itself (kept for ABI stability) */
   float total_ms;      /* first event to last event */
 } klat_timings;
 
@@ -117,6 +116,13 @@ void klat_ctx_retain(klat_ctx* ctx);  /* one more owner (libklat_dist's communic
 int klat_ctx_sync(klat_ctx* ctx);
 /* the ctx's hipStream_t, for callers that enqueue their own work or events behind it */
 void* klat_ctx_stream(klat_ctx* ctx);
+/* A context recycles the device blocks of its destroyed batches (hipFree synchronises the whole
+ * device); it keeps at most a quarter of the device's memory that way.  klat_ctx_trim waits for the
+ * context's stream and hands the cached blocks back to the runtime -- for hosts that share the GPU
+ * with another allocator (PyTorch's, RCCL's): call it between phases, or when that allocator reports
+ * out-of-memory.  The library itself empties the pools of all its contexts before it reports
+ * KLAT_ERR_OOM.  released_bytes may be NULL. */
+int klat_ctx_trim(klat_ctx* ctx, int64_t* released_bytes);
 
 /* Page-locked host memory for the arrays of klat_batch_desc and for the result buffers of the
  * fetch calls: copies from / to it run at the full PCIe rate and asynchronously to the host

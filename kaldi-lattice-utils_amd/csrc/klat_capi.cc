@@ -35,6 +35,7 @@ DevPool*& current_pool() {
 }
 
 int hip_fail(hipError_t e, const char* what) {
+  if (current_pool()) current_pool()->failing = true;  // the rest of this call frees instead of recycling (DevPool)
   return set_error(e == hipErrorOutOfMemory ? KLAT_ERR_OOM : KLAT_ERR_HIP,
                    std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -96,7 +97,6 @@ static int read_timings(klat_ctx* c, int64_t step, klat_timings* t) {
   KLAT_HIP(hipEventElapsedTime(&t->sweep_ms, ev[0], ev[1]));
   KLAT_HIP(hipEventElapsedTime(&t->totals_ms, ev[1], ev[2]));
   KLAT_HIP(hipEventElapsedTime(&t->posterior_ms, ev[2], ev[3]));
-  t->convert_ms = 0.0f;  // the sweep's producer wave writes natural-log alpha/beta itself
   KLAT_HIP(hipEventElapsedTime(&t->total_ms, ev[0], ev[3]));
   return KLAT_OK;
 }
@@ -147,6 +147,10 @@ int klat_ctx_create(int device, klat_ctx** out) {
   klat_ctx* c = new (std::nothrow) klat_ctx();
   if (!c) return set_error(KLAT_ERR_OOM, "host allocation failed");
   c->device = device;
+  {  // what the context's pool may keep: a quarter of the device's memory
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) c->pool.max_bytes = std::min(DevPool::kMaxBytes, total_b / 4);
+  }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -202,6 +206,15 @@ int klat_ctx_sync(klat_ctx* c) {
 }
 
 void* klat_ctx_stream(klat_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int klat_ctx_trim(klat_ctx* c, int64_t* released_bytes) {
+  if (!c) return set_error(KLAT_ERR_INVALID_ARG, "ctx is null");
+  KLAT_HIP(hipSetDevice(c->device));
+  KLAT_HIP(hipStreamSynchronize(c->stream));
+  if (released_bytes) *released_bytes = (int64_t)c->pool.cached;
+  c->pool.clear();
+  return KLAT_OK;
+}
 
 int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_options* opt,
                       klat_batch** out) {

@@ -155,8 +155,8 @@ extern "C" {
 
 int klat_partition_by_arcs(const int64_t* arc_counts, int64_t n, int32_t world, int64_t* bounds) {
   if (n < 0 || world < 1 || !bounds || (n > 0 && !arc_counts)) return set_error(KLAT_ERR_INVALID_ARG, "klat_partition_by_arcs: bad argument");
-  // prefix sums of (arcs + 1): rank r starts at the first utterance whose prefix reaches r/world of
-  // the total, so the ranges are contiguous, ordered and never overlap
+  // prefix sums of (arcs + 1): rank r starts at the utterance boundary nearest r/world of the total,
+  // so the ranges are contiguous, ordered and never overlap
   std::vector<int64_t> csum((size_t)n + 1, 0);
   for (int64_t u = 0; u < n; ++u) {
     if (arc_counts[u] < 0) return set_error(KLAT_ERR_INVALID_ARG, "klat_partition_by_arcs: negative arc count");
@@ -173,6 +173,10 @@ int klat_partition_by_arcs(const int64_t* arc_counts, int64_t n, int32_t world, 
       else hi = mid;
     }
     int64_t b = lo;
+    // the utterance that straddles the target goes to whichever side leaves the boundary nearer the
+    // target (always taking the first prefix >= target put it in the lower rank: [50,50,50,50,400] over
+    // two ranks gave the second one nothing)
+    if (b > 0 && b <= n && target - csum[(size_t)b - 1] < csum[(size_t)b] - target) b -= 1;
     if (b < bounds[r - 1]) b = bounds[r - 1];
     if (b > n) b = n;
     bounds[r] = b;
@@ -241,6 +245,7 @@ int klat_comm_info(const klat_comm* c, int32_t* rank, int32_t* world, int32_t* t
   if (transport_ranks) {
     *transport_ranks = c->world;
     if (c->rccl) {
+      if (!c->nccl) return set_error(KLAT_ERR_COMM, "klat_comm_info: the communicator was aborted after an earlier failure");
       int n = 0;
       D_NCCL(ncclCommCount(c->nccl, &n));
       *transport_ranks = n;
@@ -261,72 +266,114 @@ void klat_comm_destroy(klat_comm* c) {
   if (ctx) klat_ctx_destroy(ctx);
 }
 
+// A failure that only this rank sees must not leave the others inside the exchange: everything a
+// rank can check or allocate on its own happens BEFORE a size all-gather that carries a status word,
+// the root's allocation (which needs the sizes) is confirmed by a second one-word all-gather, so all
+// ranks leave together; an error between group_begin and group_end still closes the group, and an
+// RCCL communicator that failed inside the exchange is aborted (its peers then fail instead of
+// waiting) and refuses further use.
+static int abort_comm(klat_comm* c, int rc) {
+  if (c->rccl && c->nccl) {
+    const std::string msg = klat_last_error();  // (keep the first error's text)
+    (void)ncclCommAbort(c->nccl);
+    c->nccl = nullptr;
+    return set_error(rc, msg + " (communicator aborted)");
+  }
+  return rc;
+}
+
 int klat_gather_records(klat_comm* c, const void* records, int32_t record_bytes, const int64_t* record_off,
                         int64_t num_utts, int32_t root, int64_t* total_utts, int64_t* total_records) {
   if (!c || record_bytes <= 0 || num_utts < 0 || (num_utts > 0 && !record_off) || root < 0 || root >= c->world)
     return set_error(KLAT_ERR_INVALID_ARG, "klat_gather_records: bad argument");
-  const int64_t num_records = num_utts > 0 ? record_off[num_utts] - record_off[0] : 0;
-  if (num_records < 0 || (num_records > 0 && !records)) return set_error(KLAT_ERR_INVALID_ARG, "klat_gather_records: bad records");
+  if (c->rccl && !c->nccl) return set_error(KLAT_ERR_COMM, "klat_gather_records: the communicator was aborted after an earlier failure");
   if (c->rccl) D_HIP(hipSetDevice(c->device));
   c->have_result = false;
   const bool is_root = c->rank == root;
   const auto t0 = std::chrono::steady_clock::now();
 
-  // 1. sizes of every rank
-  const int64_t mine[3] = {num_records, num_utts, (int64_t)record_bytes};
-  std::vector<int64_t> sizes((size_t)c->world * 3);
-  int rc = all_gather_i64(c, mine, sizes.data(), 3);
-  if (rc != KLAT_OK) return rc;
-  int64_t tot_rec = 0, tot_utt = 0;
-  for (int32_t r = 0; r < c->world; ++r) {
-    if (sizes[(size_t)r * 3 + 2] != record_bytes) return set_error(KLAT_ERR_INVALID_ARG, "klat_gather_records: ranks disagree on the record size");
-    if (sizes[(size_t)r * 3] < 0 || sizes[(size_t)r * 3 + 1] < 0) return set_error(KLAT_ERR_COMM, "klat_gather_records: negative size from a rank");
-    tot_rec += sizes[(size_t)r * 3];
-    tot_utt += sizes[(size_t)r * 3 + 1];
-  }
-
-  // 2. per-utterance record counts of this rank, in transport memory
+  // 1. everything local: validation, the per-utterance record counts in transport memory
+  int local_rc = KLAT_OK;
+  std::string local_msg;
+  const int64_t num_records = num_utts > 0 ? record_off[num_utts] - record_off[0] : 0;
+  if (num_records < 0 || (num_records > 0 && !records)) local_rc = set_error(KLAT_ERR_INVALID_ARG, "klat_gather_records: bad records");
   std::vector<int64_t> cnt((size_t)num_utts);
-  for (int64_t u = 0; u < num_utts; ++u) {
+  for (int64_t u = 0; u < num_utts && local_rc == KLAT_OK; ++u) {
     cnt[(size_t)u] = record_off[u + 1] - record_off[u];
-    if (cnt[(size_t)u] < 0) return set_error(KLAT_ERR_INVALID_ARG, "klat_gather_records: record_off decreases");
+    if (cnt[(size_t)u] < 0) local_rc = set_error(KLAT_ERR_INVALID_ARG, "klat_gather_records: record_off decreases");
   }
   const void* cnt_src = cnt.data();
-  if (c->rccl && !is_root) {
-    if ((rc = c->send_counts.reserve(sizeof(int64_t) * (size_t)num_utts))) return rc;
-    if ((rc = copy_in(c, c->send_counts.p, cnt.data(), sizeof(int64_t) * (size_t)num_utts, true))) return rc;
-    D_HIP(hipStreamSynchronize(c->stream));  // `cnt` is pageable host memory
+  if (local_rc == KLAT_OK && c->rccl && !is_root) {
+    if ((local_rc = c->send_counts.reserve(sizeof(int64_t) * (size_t)num_utts)) == KLAT_OK &&
+        (local_rc = copy_in(c, c->send_counts.p, cnt.data(), sizeof(int64_t) * (size_t)num_utts, true)) == KLAT_OK) {
+      const hipError_t e = hipStreamSynchronize(c->stream);  // `cnt` is pageable host memory
+      if (e != hipSuccess) local_rc = hip_err(e, "hipStreamSynchronize");
+    }
     cnt_src = c->send_counts.p;
   }
+  if (local_rc != KLAT_OK) local_msg = klat_last_error();
 
-  // 3. payload: every peer straight to the root, at its offset in rank order
+  // 2. sizes and status of every rank
+  const int64_t mine[4] = {local_rc == KLAT_OK ? num_records : 0, local_rc == KLAT_OK ? num_utts : 0, (int64_t)record_bytes, (int64_t)local_rc};
+  std::vector<int64_t> sizes((size_t)c->world * 4);
+  int rc = all_gather_i64(c, mine, sizes.data(), 4);
+  if (rc != KLAT_OK) return abort_comm(c, rc);
+  if (local_rc != KLAT_OK) return set_error(local_rc, local_msg);
+  int64_t tot_rec = 0, tot_utt = 0;
+  for (int32_t r = 0; r < c->world; ++r) {  // (every rank sees the same table: they all return here or none does)
+    if (sizes[(size_t)r * 4 + 3] != 0)
+      return set_error(KLAT_ERR_COMM, "klat_gather_records: rank " + std::to_string(r) + " failed before the exchange (code " + std::to_string(sizes[(size_t)r * 4 + 3]) + ")");
+    if (sizes[(size_t)r * 4 + 2] != record_bytes) return set_error(KLAT_ERR_INVALID_ARG, "klat_gather_records: ranks disagree on the record size");
+    if (sizes[(size_t)r * 4] < 0 || sizes[(size_t)r * 4 + 1] < 0) return set_error(KLAT_ERR_COMM, "klat_gather_records: negative size from a rank");
+    tot_rec += sizes[(size_t)r * 4];
+    tot_utt += sizes[(size_t)r * 4 + 1];
+  }
+
+  // 3. the root's buffers need the sizes: a second status word before anything is posted
+  int64_t ready = 0;
+  std::string ready_msg;
   if (is_root) {
-    if ((rc = c->records.reserve((size_t)tot_rec * (size_t)record_bytes))) return rc;
-    if ((rc = c->counts.reserve(sizeof(int64_t) * (size_t)tot_utt))) return rc;
-    if ((rc = group_begin(c))) return rc;
+    int arc = c->records.reserve((size_t)tot_rec * (size_t)record_bytes);
+    if (arc == KLAT_OK) arc = c->counts.reserve(sizeof(int64_t) * (size_t)tot_utt);
+    if (arc != KLAT_OK) ready = arc, ready_msg = klat_last_error();
+  }
+  std::vector<int64_t> readies((size_t)c->world);
+  rc = all_gather_i64(c, &ready, readies.data(), 1);
+  if (rc != KLAT_OK) return abort_comm(c, rc);
+  if (readies[(size_t)root] != 0)
+    return is_root ? set_error((int)ready, ready_msg) : set_error(KLAT_ERR_COMM, "klat_gather_records: the root could not allocate the gathered records");
+
+  // 4. payload: every peer straight to the root, at its offset in rank order
+  if ((rc = group_begin(c))) return abort_comm(c, rc);
+  if (is_root) {
     int64_t ro = 0, uo = 0;
-    for (int32_t r = 0; r < c->world; ++r) {
-      const int64_t nr = sizes[(size_t)r * 3], nu = sizes[(size_t)r * 3 + 1];
+    for (int32_t r = 0; r < c->world && rc == KLAT_OK; ++r) {
+      const int64_t nr = sizes[(size_t)r * 4], nu = sizes[(size_t)r * 4 + 1];
       unsigned char* rdst = c->records.p + (size_t)ro * (size_t)record_bytes;
       unsigned char* cdst = c->counts.p + sizeof(int64_t) * (size_t)uo;
       if (r == root) {
-        if ((rc = copy_in(c, rdst, records, (size_t)nr * (size_t)record_bytes, false))) return rc;
-        if ((rc = copy_in(c, cdst, cnt.data(), sizeof(int64_t) * (size_t)nu, true))) return rc;
+        if ((rc = copy_in(c, rdst, records, (size_t)nr * (size_t)record_bytes, false)) == KLAT_OK)
+          rc = copy_in(c, cdst, cnt.data(), sizeof(int64_t) * (size_t)nu, true);
       } else {
-        if ((rc = p2p(c, false, rdst, nr * record_bytes, r))) return rc;
-        if ((rc = p2p(c, false, cdst, (int64_t)sizeof(int64_t) * nu, r))) return rc;
+        if ((rc = p2p(c, false, rdst, nr * record_bytes, r)) == KLAT_OK) rc = p2p(c, false, cdst, (int64_t)sizeof(int64_t) * nu, r);
       }
       ro += nr;
       uo += nu;
     }
-    if ((rc = group_end(c))) return rc;
   } else {
-    if ((rc = group_begin(c))) return rc;
-    if ((rc = p2p(c, true, const_cast<void*>(records), num_records * record_bytes, root))) return rc;
-    if ((rc = p2p(c, true, const_cast<void*>(cnt_src), (int64_t)sizeof(int64_t) * num_utts, root))) return rc;
-    if ((rc = group_end(c))) return rc;
+    if ((rc = p2p(c, true, const_cast<void*>(records), num_records * record_bytes, root)) == KLAT_OK)
+      rc = p2p(c, true, const_cast<void*>(cnt_src), (int64_t)sizeof(int64_t) * num_utts, root);
   }
-  if (c->rccl) D_HIP(hipStreamSynchronize(c->stream));
+  {
+    std::string first = rc != KLAT_OK ? klat_last_error() : "";
+    const int erc = group_end(c);  // (always paired with group_begin)
+    if (rc != KLAT_OK) return abort_comm(c, set_error(rc, first));
+    if (erc != KLAT_OK) return abort_comm(c, erc);
+  }
+  if (c->rccl) {
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return abort_comm(c, hip_err(e, "hipStreamSynchronize"));
+  }
   c->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   c->last_payload = is_root ? (tot_rec - num_records) * record_bytes + (int64_t)sizeof(int64_t) * (tot_utt - num_utts) : 0;
   c->record_bytes = record_bytes;

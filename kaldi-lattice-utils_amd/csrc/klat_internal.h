@@ -32,12 +32,22 @@ int hip_fail(hipError_t e, const char* what);
 // context's sweep stalls behind it) and hipMalloc + hipFree of a batch's ~20 arrays cost tens of
 // milliseconds, several times the sweep they serve.  A freed block goes to its context's pool and
 // is handed out again for a request of at most the same size and at least half of it (batches of
-// one shape recur); the pool is emptied when the context is destroyed or holds more than kMaxBytes.
+// one shape recur).  What the pool keeps is bounded -- a quarter of the device's memory at most
+// (max_bytes, set when the context is created) -- and can be given back: klat_ctx_trim, the
+// destruction of the context, and an out-of-memory hipMalloc anywhere in the library, which empties
+// the pools of EVERY context of the process before it tries again (the registry below).  While a
+// call is failing (`failing`, set by hip_fail, cleared when the call returns) its temporaries go
+// back through hipFree, which waits for the device: kernels of the failed call may still be running
+// on them, and a recycled block would be handed to the next call at once.
 struct DevPool {
   static constexpr size_t kMaxBytes = (size_t)96 << 30;
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks;
   size_t cached = 0;
+  size_t max_bytes = kMaxBytes;
+  bool failing = false;
+  DevPool() { registry(this, true); }
+  ~DevPool() { registry(this, false); }
   void* take(size_t bytes, size_t* got) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = free_blocks.lower_bound(bytes);
@@ -50,7 +60,7 @@ struct DevPool {
   }
   bool give(void* p, size_t bytes) {
     std::lock_guard<std::mutex> lock(mu);
-    if (cached + bytes > kMaxBytes) return false;
+    if (failing || cached + bytes > max_bytes) return false;
     free_blocks.emplace(bytes, p);
     cached += bytes;
     return true;
@@ -61,13 +71,37 @@ struct DevPool {
     free_blocks.clear();
     cached = 0;
   }
+  // every pool of the process (contexts of all devices: a block cached for one GPU is of no use to an
+  // allocation on another, but telling them apart is not worth a device query per block)
+  static void registry(DevPool* p, bool add) {
+    static std::mutex rmu;
+    static std::vector<DevPool*>* all = new std::vector<DevPool*>();  // never destroyed: contexts may outlive static destruction
+    std::lock_guard<std::mutex> lock(rmu);
+    if (p) {
+      if (add) {
+        all->push_back(p);
+      } else {
+        for (size_t i = 0; i < all->size(); ++i)
+          if ((*all)[i] == p) {
+            all->erase(all->begin() + (long)i);
+            break;
+          }
+      }
+      return;
+    }
+    for (DevPool* q : *all) q->clear();  // p == nullptr: empty them all
+  }
+  static void clear_all() { registry(nullptr, false); }
 };
 // the pool the calling thread's current API call allocates from (set by PoolScope)
 DevPool*& current_pool();
 struct PoolScope {
   DevPool* saved;
   explicit PoolScope(DevPool* p) : saved(current_pool()) { current_pool() = p; }
-  ~PoolScope() { current_pool() = saved; }
+  ~PoolScope() {  // (the call's locals are gone by now: a failing call has returned its temporaries through hipFree)
+    if (current_pool()) current_pool()->failing = false;
+    current_pool() = saved;
+  }
 };
 
 template <class T>
@@ -102,9 +136,9 @@ struct DevBuf {
       return KLAT_OK;
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
-    if (e == hipErrorOutOfMemory && pool) {  // give the cached blocks back and try once more
+    if (e == hipErrorOutOfMemory) {  // give the cached blocks of every context back and try once more
       (void)hipGetLastError();
-      pool->clear();
+      DevPool::clear_all();
       e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
     }
     if (e != hipSuccess) {

@@ -19,9 +19,11 @@ int main(int argc, char* argv[]) {
     const char* usage =
         "Forward-backward of every lattice through ComputeLatticeAlphasAndBetas, from several threads.\n"
         "\n"
-        "Usage: klat-alphas-betas [--num-threads=N] [--device=D] <lattice-rspecifier>\n";
+        "Usage: klat-alphas-betas [--num-threads=N] [--device=D] [--viterbi] <lattice-rspecifier>\n";
     ParseOptions po(usage);
     int32_t num_threads = 1, device = 0;
+    bool viterbi = false;
+    po.Register("viterbi", &viterbi, "Best-path (max) instead of sum: the routine's viterbi argument.");
     po.Register("num-threads", &num_threads, "Worker threads, one lattice each at a time.");
     po.Register("device", &device, "GPU device index.");
     po.Read(argc, argv);
@@ -51,7 +53,7 @@ int main(int argc, char* argv[]) {
           try {
             std::vector<double> alpha, beta;
             Result& r = results[i];
-            r.total = ComputeLatticeAlphasAndBetas(lats[i], false, &alpha, &beta);
+            r.total = ComputeLatticeAlphasAndBetas(lats[i], viterbi, &alpha, &beta);
             r.alpha_last = alpha.back();
             r.beta0 = beta.front();
             for (double v : alpha)

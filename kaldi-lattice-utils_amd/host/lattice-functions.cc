@@ -437,13 +437,25 @@ void SetDefaultDevice(int device) {
 
 double ComputeLatticeAlphasAndBetas(const CompactLattice& clat, bool viterbi, std::vector<double>* alpha,
                                     std::vector<double>* beta) {
-  if (viterbi) KLAT_ERR("ComputeLatticeAlphasAndBetas: viterbi=true is not on the accelerated path");
   if (clat.NumStates() == 0 || clat.Start() != 0) KLAT_ERR("ComputeLatticeAlphasAndBetas: lattice must be top-sorted with start state 0");
   static thread_local ContextLease lease;  // one HIP stream per calling thread (re-entrant, B2 contract)
   Context& ctx = *lease.ctx;
   LatticeBatch lb;
   lb.Add(clat, nullptr);
   DeviceBatch db(ctx, lb);
+  if (viterbi) {
+    // LogAddOrMax(viterbi = true, ...) of upstream's routine: alpha / beta are the best partial paths'
+    // log-likelihoods = minus the Viterbi costs of the sweep's (min,+) twin (klat_viterbi)
+    const klat_scales unit = {1.0f, 1.0f, 0.0f};
+    Check(klat_viterbi(db.get(), &unit), "klat_viterbi");
+    alpha->assign(clat.NumStates(), 0.0);
+    beta->assign(clat.NumStates(), 0.0);
+    double best = 0.0;
+    Check(klat_get_viterbi(db.get(), alpha->data(), beta->data(), &best), "klat_get_viterbi");
+    for (double& v : *alpha) v = -v;  // (+inf cost: unreachable -> log-zero)
+    for (double& v : *beta) v = -v;
+    return -best;  // tot_forward = tot_backward = the best complete path
+  }
   db.ForwardBackward(1.0f, 1.0f, 0.0f);
   alpha->assign(clat.NumStates(), 0.0);
   beta->assign(clat.NumStates(), 0.0);

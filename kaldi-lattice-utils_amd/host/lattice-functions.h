@@ -111,8 +111,8 @@ void PruneLatticesOnDevice(Context& ctx, float beam, float graph_scale, float ac
                            std::vector<CompactLattice>* lats);
 
 // ComputeLatticeAlphasAndBetas (latbin/lattice-to-word-frame-post.cc:88-90): same signature and
-// return value (0.5*(tot_forward+tot_backward)); viterbi must be false (every call site of the
-// reference passes false).  Runs the lattice as a one-element batch on the calling thread's GPU
+// return value (0.5*(tot_forward+tot_backward)); viterbi = true (no call site of the reference
+// passes it) runs the (min,+) twin of the sweep.  Runs the lattice as a one-element batch on the calling thread's GPU
 // context; batch callers should use LatticeBatch/DeviceBatch directly.
 double ComputeLatticeAlphasAndBetas(const CompactLattice& clat, bool viterbi, std::vector<double>* alpha,
                                     std::vector<double>* beta);

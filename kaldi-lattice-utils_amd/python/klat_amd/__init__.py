@@ -56,7 +56,7 @@ class BatchInfo(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("sweep_ms", C.c_float), ("totals_ms", C.c_float), ("posterior_ms", C.c_float),
-                ("convert_ms", C.c_float), ("total_ms", C.c_float)]
+                ("total_ms", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -207,6 +207,12 @@ class Ctx:
         arr = (Timings * count)()
         _check(lib().klat_ctx_timing_history(self.h, C.c_int32(count), arr))
         return [t.as_dict() for t in arr]
+
+    def trim(self):
+        """hands the context's recycled device blocks back to the runtime; returns the bytes released"""
+        n = C.c_int64(0)
+        _check(lib().klat_ctx_trim(self.h, C.byref(n)))
+        return n.value
 
     def sync(self):
         _check(lib().klat_ctx_sync(self.h))

@@ -25,7 +25,10 @@ def _partition_numpy(arc_counts, world_size):
     total = csum[-1]
     bounds = [0]
     for r in range(1, world_size):
-        b = int(np.searchsorted(csum, total * r // world_size, side="left"))
+        target = int(total) * r // world_size
+        b = int(np.searchsorted(csum, target, side="left"))
+        if 0 < b <= n and target - int(csum[b - 1]) < int(csum[b]) - target:  # the boundary nearer the target
+            b -= 1
         bounds.append(min(max(b, bounds[-1]), n))
     bounds.append(n)
     return np.array(bounds, dtype=np.int64)
@@ -55,6 +58,11 @@ def test_partition_by_arcs_balances_and_keeps_order():
         assert b[0] == 0 and b[-1] == len(arcs) and np.all(np.diff(b) >= 0) and len(b) == world + 1
         loads = np.array([arcs[b[r]:b[r + 1]].sum() for r in range(world)])
         assert loads.max() <= arcs.sum() / world + arcs.max() + 1
+    # a heavy trailing utterance must not starve the ranks behind it of everything before it (the
+    # boundary is the prefix NEAREST the target, not the first one at or above it)
+    assert kdist.partition_by_arcs([50, 50, 50, 50, 400], 2).tolist() == [0, 4, 5]
+    b = kdist.partition_by_arcs([10, 10, 10, 1000], 4)
+    assert b.tolist() == [0, 3, 3, 3, 4] or b[1] < 4, b.tolist()
     # more ranks than utterances, and empty lattices
     b = kdist.partition_by_arcs([5, 0, 0], 8)
     assert b[0] == 0 and b[-1] == 3 and np.all(np.diff(b) >= 0)

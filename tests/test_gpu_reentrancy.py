@@ -152,6 +152,61 @@ def test_b2_mirror_from_worker_threads(tmp_path, golden_dir):
         assert abs(float(f[3]) - wb[arrays["state_off"][u]]) <= 1e-8 * max(1.0, abs(wt[u]))
 
 
+def test_ctx_trim_releases_the_recycled_blocks():
+    """A context keeps the device blocks of its destroyed batches for the next batch (hipFree stalls the
+    whole device); klat_ctx_trim hands them back -- for hosts that share the GPU with another allocator
+    -- and the context goes on working."""
+    ns = np.full(200, 300, np.int32)
+    fo = np.full(200, 3, np.int32)
+    a = klat_amd.synth(11, ns, fo)
+    ctx = klat_amd.Ctx(0)
+    b = klat_amd.Batch(ctx, a)
+    b.forward_backward(1.0, 0.1, 0.0)
+    want = b.totals()[0]
+    b.close()
+    released = ctx.trim()
+    assert released > a["src"].nbytes * 4, released  # the batch's arrays, streams and results were cached
+    assert ctx.trim() == 0
+    b = klat_amd.Batch(ctx, a)
+    b.forward_backward(1.0, 0.1, 0.0)
+    assert np.array_equal(b.totals()[0], want)
+    b.close()
+    ctx.close()
+
+
+def test_b2_mirror_viterbi(tmp_path):
+    """ComputeLatticeAlphasAndBetas(clat, viterbi = true, ...): LogAddOrMax takes the maximum, so the
+    return value is minus the cost of the best path and beta[start] equals it (upstream's routine behind
+    latbin/lattice-to-word-frame-post.cc:88-90; no call site of the reference passes true).  Checked
+    against a plain dynamic programme over the arcs."""
+    rng = np.random.RandomState(9)
+    ns = rng.randint(2, 90, size=12).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4], size=12).astype(np.int32)
+    arrays = klat_amd.synth(4242, ns, fo)
+    ark = tmp_path / "lats.ark.txt"
+    from test_host_tools import _write_text_archive
+    _write_text_archive(str(ark), arrays, ns)
+    p = subprocess.run([os.path.join(BIN, "klat-alphas-betas"), "--viterbi", "--num-threads=2", "ark:%s" % ark],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == len(ns)
+    for u, line in enumerate(lines):
+        s0, s1 = int(arrays["state_off"][u]), int(arrays["state_off"][u + 1])
+        a0, a1 = int(arrays["arc_off"][u]), int(arrays["arc_off"][u + 1])
+        cost = np.full(s1 - s0, np.inf)
+        cost[0] = 0.0
+        for i in range(a0, a1):  # arcs are grouped by source and go to higher states
+            c = cost[arrays["src"][i]] + float(arrays["graph"][i]) + float(arrays["acoustic"][i])
+            cost[arrays["dst"][i]] = min(cost[arrays["dst"][i]], c)
+        fin = arrays["final_graph"][s0:s1].astype(np.float64) + arrays["final_acoustic"][s0:s1].astype(np.float64)
+        best = float(np.min(cost + fin))
+        f = line.split()
+        assert abs(float(f[1]) + best) <= 1e-9 * max(1.0, abs(best)), (u, f[1], best)      # return value
+        assert abs(float(f[3]) + best) <= 1e-9 * max(1.0, abs(best))                        # beta[start]
+        assert abs(float(f[2]) + cost[-1]) <= 1e-9 * max(1.0, abs(cost[-1])) or not np.isfinite(cost[-1])  # alpha[S-1]
+
+
 OUTLIVE = textwrap.dedent("""
     import os, sys
     import numpy as np
