@@ -23,11 +23,16 @@
 
 #include "../lattice-functions.h"
 #include "../table-writers.h"
+#include "sharded-index.h"
 #include "tool-common.h"
 
+// --devices=0-7 (not in the reference; BASELINE configs[2] shards this tool over the node's GPUs): one
+// process per GPU, each takes a contiguous share of the archive and writes its own tables (JOB in the
+// wspecifiers); see sharded-index.h.
 int main(int argc, char* argv[]) {
+  using namespace klat;
+  std::unique_ptr<DeviceRanks> ranks;
   try {
-    using namespace klat;
     const char* usage =
         "Generate especial 1-best path through lattices, which minimizes a different loss-function "
         "other than the 0-1 error on the sequence: the number of position-wise errors, an upper "
@@ -41,6 +46,8 @@ int main(int argc, char* argv[]) {
     co.Register(&po);
     int32_t nbest = 1;
     po.Register("nbest", &nbest, "Number of best paths per utterance (1 = the reference's output; up to 128).");
+    DevicesOption dopt;
+    dopt.Register(&po);
     po.Read(argc, argv);
     if (po.NumArgs() < 1 || po.NumArgs() > 3) {
       po.PrintUsage();
@@ -49,9 +56,11 @@ int main(int argc, char* argv[]) {
     if (nbest < 1 || nbest > KLAT_NBEST_MAX) KLAT_ERR("--nbest must be in [1, " << KLAT_NBEST_MAX << "]");
     std::unique_ptr<Int32VectorWriter> transcriptions_writer;
     std::unique_ptr<BaseFloatWriter> costs_writer;
-    if (po.NumArgs() > 1) transcriptions_writer.reset(new Int32VectorWriter(po.GetArg(2)));
-    if (po.NumArgs() > 2) costs_writer.reset(new BaseFloatWriter(po.GetArg(3)));
-    Context ctx(co.device);
+    ranks.reset(new DeviceRanks(dopt.devices, co.device, "host"));  // forks: nothing before this line touches HIP
+    const int32_t rank = ranks->rank(), world = ranks->world();
+    if (po.NumArgs() > 1) transcriptions_writer.reset(new Int32VectorWriter(JobSpecifier(po.GetArg(2), rank, world)));
+    if (po.NumArgs() > 2) costs_writer.reset(new BaseFloatWriter(JobSpecifier(po.GetArg(3), rank, world)));
+    Context ctx(ranks->device());
     klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
 
     double total_cost = 0.0;
@@ -137,7 +146,8 @@ int main(int argc, char* argv[]) {
       batch.Clear();
     };
 
-    for (SequentialCompactLatticeReader reader(po.GetArg(1)); !reader.Done(); reader.Next()) {
+    RankArchiveReader reader(po.GetArg(1), rank, world);
+    for (; !reader.Done(); reader.Next()) {
       CompactLattice clat;
       std::vector<int32_t> state_input_length;
       int32_t lattice_frames = 0;
@@ -171,9 +181,14 @@ int main(int argc, char* argv[]) {
     if (costs_writer) costs_writer->Close();
     KLAT_LOG("Overall cost per frame is " << (total_frames ? total_cost / total_frames : 0.0) << " over " << total_frames
                                           << " frames.");
-    return 0;
+    if (world > 1) KLAT_VLOG(1, "Rank " << rank << "/" << world << ": parsed " << reader.parsed() << " of " << reader.total() << " lattices");
+    return ranks->Finish(0);
   } catch (const std::exception& e) {
     std::cerr << e.what();
+    if (ranks) {
+      ranks->Abort();
+      return ranks->Finish(-1);
+    }
     return -1;
   }
 }

@@ -5,11 +5,15 @@
 
 #include "../lattice-functions.h"
 #include "../table-writers.h"
+#include "sharded-index.h"
 #include "tool-common.h"
 
+// --devices=0-7 (not in the reference): one process per GPU, each takes a contiguous share of the
+// archive and writes its own Posterior table (JOB in the wspecifier); see sharded-index.h.
 int main(int argc, char* argv[]) {
+  using namespace klat;
+  std::unique_ptr<DeviceRanks> ranks;
   try {
-    using namespace klat;
     const char* usage =
         "Compute the posterior log-probability of each word for each given utterance frame. That is, "
         "we compute log P(a_i = v | x), for all possible utterance frames i and words v.\n"
@@ -20,13 +24,17 @@ int main(int argc, char* argv[]) {
     ParseOptions po(usage);
     CommonOptions co;
     co.Register(&po);
+    DevicesOption dopt;
+    dopt.Register(&po);
     po.Read(argc, argv);
     if (po.NumArgs() != 2) {
       po.PrintUsage();
       exit(1);
     }
-    PosteriorWriter posterior_writer(po.GetArg(2));
-    Context ctx(co.device);
+    ranks.reset(new DeviceRanks(dopt.devices, co.device, "host"));  // forks: nothing before this line touches HIP
+    const int32_t rank = ranks->rank(), world = ranks->world();
+    PosteriorWriter posterior_writer(JobSpecifier(po.GetArg(2), rank, world));
+    Context ctx(ranks->device());
     klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
 
     std::vector<std::string> keys;
@@ -40,7 +48,8 @@ int main(int argc, char* argv[]) {
       batch.Clear();
     };
 
-    for (SequentialCompactLatticeReader reader(po.GetArg(1)); !reader.Done(); reader.Next()) {
+    RankArchiveReader reader(po.GetArg(1), rank, world);
+    for (; !reader.Done(); reader.Next()) {
       CompactLattice& clat = reader.Value();
       std::vector<int32_t> times;
       int32_t total_frames = 0;
@@ -64,9 +73,14 @@ int main(int argc, char* argv[]) {
     }
     flush();
     posterior_writer.Close();
-    return 0;
+    if (world > 1) KLAT_VLOG(1, "Rank " << rank << "/" << world << ": parsed " << reader.parsed() << " of " << reader.total() << " lattices");
+    return ranks->Finish(0);
   } catch (const std::exception& e) {
     std::cerr << e.what();
+    if (ranks) {
+      ranks->Abort();
+      return ranks->Finish(-1);
+    }
     return -1;
   }
 }

@@ -21,9 +21,15 @@
 
 #include <atomic>
 #include <cerrno>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <exception>
+#include <mutex>
+#include <thread>
 
 #include "../../../include/klat_dist.h"
+#include "../archive-index.h"
 #include "tool-common.h"
 
 namespace klat {
@@ -78,6 +84,7 @@ class DeviceRanks {
     host_gather_ = gather == "host";
     if (gather != "rccl" && gather != "host") KLAT_ERR("--gather must be rccl or host");
     if (world_ == 1) return;
+    if (world_ > 64) KLAT_ERR("--devices: at most 64 GPUs");
     shared_ = static_cast<Shared*>(mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0));
     if (shared_ == MAP_FAILED) KLAT_ERR("mmap: " << std::strerror(errno));
     new (shared_) Shared();
@@ -90,7 +97,6 @@ class DeviceRanks {
         socks_[(size_t)r] = sv[0];
         child_end[(size_t)r] = sv[1];
       }
-    if (world_ > 64) KLAT_ERR("--devices: at most 64 GPUs");
     const pid_t parent = getpid();
     struct sigaction sa;
     std::memset(&sa, 0, sizeof(sa));
@@ -154,7 +160,10 @@ class DeviceRanks {
   // Rank 0: waits for the workers; returns 0 if all of them succeeded.  Workers do not return.
   int Finish(int my_status) {
     if (world_ == 1) return my_status;
-    if (comm_) klat_comm_destroy(comm_), comm_ = nullptr;
+    // the orderly teardown of the communicator is for the success path: after a failure the other
+    // ranks may sit inside the gather, and ncclCommDestroy could wait for them for ever
+    if (comm_ && my_status == 0) klat_comm_destroy(comm_);
+    comm_ = nullptr;
     if (rank_ != 0) {
       std::cout.flush();
       std::cerr.flush();
@@ -245,7 +254,150 @@ struct ShardOptions {
   }
 };
 
+// ---- tools whose output needs no gather (lattice-to-word-frame-post, lattice-best-path2): with
+// --devices every rank takes one contiguous range of the WHOLE archive (by bytes) and writes its own
+// table, the wspecifier's "JOB" replaced by rank + 1 as Kaldi's parallel scripts name their pieces;
+// the pieces concatenated in job order are the single-GPU output, entry for entry.  The loops are
+// per-utterance independent in the reference, too (latbin/lattice-to-word-frame-post.cc:68,
+// latbin/lattice-best-path2.cc:78). ----
+inline std::string JobSpecifier(const std::string& wspecifier, int32_t rank, int32_t world) {
+  const size_t at = wspecifier.find("JOB");
+  if (at == std::string::npos) {
+    if (world > 1)
+      KLAT_ERR("--devices with more than one GPU writes one table per rank: put JOB into the wspecifier (e.g. ark:post.JOB.ark), "
+               "it is replaced by 1.." << world);
+    return wspecifier;
+  }
+  std::string out = wspecifier;
+  out.replace(at, 3, std::to_string(rank + 1));
+  return out;
+}
+
+// SequentialCompactLatticeReader look-alike over this rank's share of the archive.
+class RankArchiveReader {
+ public:
+  RankArchiveReader(const std::string& rspecifier, int32_t rank, int32_t world) {
+    if (world == 1) {
+      stream_.reset(new SequentialCompactLatticeReader(rspecifier));
+      return;
+    }
+    if (!MappedArchive::Mappable(rspecifier))
+      KLAT_ERR("--devices with more than one GPU needs a plain archive file (every rank scans it for the entry boundaries), not "
+               << rspecifier);
+    archive_.reset(new MappedArchive(rspecifier));
+    std::vector<int64_t> bytes;
+    while (!archive_->Done()) {
+      entries_.emplace_back();
+      archive_->ScanNext(&entries_.back());
+      bytes.push_back((int64_t)(entries_.back().end - entries_.back().begin));
+    }
+    std::vector<int64_t> bounds((size_t)world + 1);
+    Check(klat_partition_by_arcs(bytes.data(), (int64_t)bytes.size(), world, bounds.data()), "klat_partition_by_arcs");
+    pos_ = (size_t)bounds[(size_t)rank];
+    end_ = (size_t)bounds[(size_t)rank + 1];
+    total_ = entries_.size();
+    Load();
+  }
+  bool Done() const { return stream_ ? stream_->Done() : pos_ >= end_; }
+  const std::string& Key() const { return stream_ ? stream_->Key() : entries_[pos_].key; }
+  CompactLattice& Value() { return stream_ ? stream_->Value() : value_; }
+  void FreeCurrent() {
+    if (stream_) stream_->FreeCurrent();
+    else value_.DeleteStates();
+  }
+  void Next() {
+    if (stream_) {
+      stream_->Next();
+      return;
+    }
+    ++pos_;
+    Load();
+  }
+  size_t parsed() const { return parsed_; }
+  size_t total() const { return total_; }
+
+ private:
+  void Load() {
+    if (pos_ < end_) archive_->Read(entries_[pos_], &value_), ++parsed_;
+  }
+  std::unique_ptr<SequentialCompactLatticeReader> stream_;
+  std::unique_ptr<MappedArchive> archive_;
+  std::vector<ArchiveEntry> entries_;
+  size_t pos_ = 0, end_ = 0, parsed_ = 0, total_ = 0;
+  CompactLattice value_;
+};
+
+// A queue of at most `depth` items between two stages of the tools' pipeline (read | GPU | write).
+template <class T>
+class StageQueue {
+ public:
+  explicit StageQueue(size_t depth) : depth_(depth) {}
+  void Push(T&& v) {
+    std::unique_lock<std::mutex> lock(mu_);
+    not_full_.wait(lock, [&] { return q_.size() < depth_; });
+    q_.push_back(std::move(v));
+    not_empty_.notify_one();
+  }
+  T Pop() {
+    std::unique_lock<std::mutex> lock(mu_);
+    not_empty_.wait(lock, [&] { return !q_.empty(); });
+    T v = std::move(q_.front());
+    q_.pop_front();
+    not_full_.notify_one();
+    return v;
+  }
+
+ private:
+  size_t depth_;
+  std::mutex mu_;
+  std::condition_variable not_full_, not_empty_;
+  std::deque<T> q_;
+};
+
+// The lattices of a super-batch that this rank owns, ready for klat_batch_create.
+template <bool POSITION>
+inline void FlattenForIndex(std::vector<CompactLattice>* mine, LatticeBatch* batch, std::vector<int32_t>* state_len_all) {
+  for (auto& clat : *mine) {
+    std::vector<int32_t> times, state_len;
+    if (POSITION) {
+      CompactLattice dlat;
+      if (clat.Start() != CompactLattice::kNoStateId) {
+        TopSortCompactLatticeIfNeeded(&clat);
+        DisambiguateStateInputSequenceLength(clat, &dlat, &state_len, false);  // kwsbin2/lattice-word-index-position.cc:64-65
+        CompactLatticeStateTimes(dlat, &times);
+      }
+      batch->Add(dlat, &times);
+      state_len_all->insert(state_len_all->end(), state_len.begin(), state_len.end());
+    } else {
+      if (clat.Start() != CompactLattice::kNoStateId) {
+        TopSortCompactLatticeIfNeeded(&clat);
+        CompactLatticeStateTimes(clat, &times);
+      }
+      batch->Add(clat, &times);
+    }
+    clat.DeleteStates();
+  }
+}
+
+struct DevicesOption {
+  std::string devices;
+  void Register(ParseOptions* po) {
+    po->Register("devices", &devices,
+                 "GPUs to shard the lattices over, one process each (e.g. 0-7 or 0,2,5), every rank writing its own table "
+                 "(JOB in the wspecifier = rank + 1); empty = --device only.");
+  }
+};
+
 // POSITION = false: lattice-word-index-segment; true: lattice-word-index-position.
+//
+// Three stages run side by side in every rank: a reader thread (scan the next super-batch of the
+// archive, parse THIS RANK'S entries only, prune / top-sort / state times / flatten), the calling
+// thread (the GPU: stream packing, sweep, index, gather to rank 0) and, on rank 0, a writer thread
+// (the records of the super-batch before).  A plain file is mapped and scanned (archive-index.h):
+// the ranks agree on the entries' byte ranges without parsing them, deal them out by bytes, and
+// each parses its own share -- the reference reads every lattice once
+// (kwsbin2/lattice-word-index-segment.cc:261-274), and so does the node.  Standard input or a
+// command cannot be scanned ahead: every rank then parses everything, as before.
 template <bool POSITION, class Writer, class Record>
 int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOptions& so, const std::string& rspecifier,
                  const std::string& wspecifier) {
@@ -258,87 +410,153 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
   if (world > 1 && ParseSpecifier(rspecifier, false).filename == "-")
     KLAT_ERR("--devices with more than one GPU needs an input every rank can read (a file or a command), not standard input");
   int status = 0;
+  struct SuperBatch {
+    std::vector<std::string> keys;      // all entries of the super-batch, in input order
+    int64_t lo = 0, hi = 0;             // this rank's range
+    std::vector<CompactLattice> mine;   // --device-prune: still to be pruned and flattened by the GPU stage
+    LatticeBatch batch;
+    std::vector<int32_t> state_len_all;
+    bool end = false;
+    std::exception_ptr error;
+  };
+  struct WriteJob {
+    std::vector<std::string> keys;
+    std::vector<Record> rec;
+    std::vector<int64_t> off;
+    bool end = false;
+  };
+  StageQueue<std::unique_ptr<SuperBatch>> read_q(2);
+  StageQueue<std::unique_ptr<WriteJob>> write_q(2);
+  std::thread reader_thread, writer_thread;
+  std::atomic<bool> stop{false};
+  std::exception_ptr writer_error;
   try {
     std::unique_ptr<Writer> writer;
     if (rank == 0) writer.reset(new Writer(wspecifier));  // only the writing rank opens (and truncates) the output
     Context ctx(ranks.device());
     ranks.InitComm(ctx);
     klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
-    SequentialCompactLatticeReader reader(rspecifier);
+    const bool mapped = MappedArchive::Mappable(rspecifier);
+    int64_t parsed_lattices = 0, parsed_arcs = 0, seen_lattices = 0;
+
+    reader_thread = std::thread([&]() {
+      try {
+        std::unique_ptr<MappedArchive> archive;
+        std::unique_ptr<SequentialCompactLatticeReader> reader;
+        if (mapped) archive.reset(new MappedArchive(rspecifier));
+        else reader.reset(new SequentialCompactLatticeReader(rspecifier));
+        auto done = [&]() { return mapped ? archive->Done() : reader->Done(); };
+        while (!done() && !stop.load()) {
+          // one super-batch: what `world` GPUs take in one go
+          std::unique_ptr<SuperBatch> sb(new SuperBatch());
+          std::vector<int64_t> weight;  // what the entries are dealt out by: bytes (scanned) or arcs (parsed)
+          std::vector<ArchiveEntry> entries;
+          std::vector<CompactLattice> lats;
+          int64_t total = 0;
+          // (a scanned entry's arcs are not known: 24 bytes is less than any arc takes in either format)
+          const int64_t budget = (int64_t)co.max_batch_arcs * world * (mapped ? 24 : 1);
+          while (!done() && (int64_t)sb->keys.size() < (int64_t)co.batch_size * world && total < budget) {
+            if (mapped) {
+              entries.emplace_back();
+              archive->ScanNext(&entries.back());
+              sb->keys.push_back(entries.back().key);
+              weight.push_back((int64_t)(entries.back().end - entries.back().begin));
+            } else {
+              sb->keys.push_back(reader->Key());
+              weight.push_back(reader->Value().NumArcs());
+              lats.push_back(std::move(reader->Value()));
+              reader->FreeCurrent();
+              reader->Next();
+            }
+            total += weight.back();
+          }
+          const int64_t n = (int64_t)sb->keys.size();
+          std::vector<int64_t> bounds((size_t)world + 1);
+          Check(klat_partition_by_arcs(weight.data(), n, world, bounds.data()), "klat_partition_by_arcs");
+          sb->lo = bounds[(size_t)rank], sb->hi = bounds[(size_t)rank + 1];
+          std::vector<CompactLattice> mine;
+          if (mapped) {
+            mine.resize((size_t)(sb->hi - sb->lo));
+            for (int64_t u = sb->lo; u < sb->hi; ++u) archive->Read(entries[(size_t)u], &mine[(size_t)(u - sb->lo)]);
+          } else {
+            mine.assign(std::make_move_iterator(lats.begin() + sb->lo), std::make_move_iterator(lats.begin() + sb->hi));
+            lats.clear();  // other ranks' lattices: only their arc counts mattered
+          }
+          seen_lattices += n;
+          parsed_lattices += mapped ? sb->hi - sb->lo : n;
+          if (mapped)
+            for (const auto& clat : mine) parsed_arcs += clat.NumArcs();
+          else
+            parsed_arcs += total;
+          if (io.Prunes() && io.device_prune) {
+            sb->mine = std::move(mine);  // the GPU stage takes the pruning decisions of the whole batch
+          } else {
+            if (io.Prunes())  // PruneLattice(beam, &clat), kwsbin2/lattice-word-index-segment.cc:49-51
+              for (auto& clat : mine)
+                if (clat.Start() != CompactLattice::kNoStateId)
+                  PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &clat);
+            FlattenForIndex<POSITION>(&mine, &sb->batch, &sb->state_len_all);
+          }
+          read_q.Push(std::move(sb));
+        }
+        std::unique_ptr<SuperBatch> last(new SuperBatch());
+        last->end = true;
+        read_q.Push(std::move(last));
+      } catch (...) {
+        std::unique_ptr<SuperBatch> last(new SuperBatch());
+        last->end = true;
+        last->error = std::current_exception();
+        read_q.Push(std::move(last));
+      }
+    });
+    if (rank == 0)
+      writer_thread = std::thread([&]() {
+        try {
+          for (;;) {
+            std::unique_ptr<WriteJob> job = write_q.Pop();
+            if (job->end) break;
+            if (writer_error) continue;
+            for (size_t u = 0; u < job->keys.size(); ++u)
+              writer->Write(job->keys[u], job->rec.data() + job->off[u], job->off[u + 1] - job->off[u]);
+          }
+        } catch (...) {
+          writer_error = std::current_exception();
+          for (;;)  // keep draining: the GPU stage must never block on a dead writer
+            if (write_q.Pop()->end) break;
+        }
+      });
+
     int64_t num_lattices = 0;
-    while (!reader.Done()) {
-      // one super-batch: what `world` GPUs take in one go
-      std::vector<std::string> keys;
-      std::vector<CompactLattice> lats;
-      std::vector<int64_t> arc_counts;
-      int64_t arcs = 0;
-      for (; !reader.Done() && (int64_t)keys.size() < (int64_t)co.batch_size * world && arcs < (int64_t)co.max_batch_arcs * world;
-           reader.Next()) {
-        keys.push_back(reader.Key());
-        arc_counts.push_back(reader.Value().NumArcs());
-        arcs += arc_counts.back();
-        lats.push_back(std::move(reader.Value()));
-        reader.FreeCurrent();
-      }
-      const int64_t n = (int64_t)keys.size();
+    for (;;) {
+      std::unique_ptr<SuperBatch> sb = read_q.Pop();
+      if (sb->error) std::rethrow_exception(sb->error);
+      if (sb->end) break;
+      if (writer_error) std::rethrow_exception(writer_error);
+      const int64_t n = (int64_t)sb->keys.size(), lo = sb->lo, hi = sb->hi;
       num_lattices += n;
-      std::vector<int64_t> bounds((size_t)world + 1);
-      Check(klat_partition_by_arcs(arc_counts.data(), n, world, bounds.data()), "klat_partition_by_arcs");
-      const int64_t lo = bounds[(size_t)rank], hi = bounds[(size_t)rank + 1];
-      for (int64_t u = 0; u < n; ++u)
-        if (u < lo || u >= hi) lats[(size_t)u].DeleteStates();  // other ranks' lattices: only their arc counts mattered
-      std::vector<CompactLattice> mine(std::make_move_iterator(lats.begin() + lo), std::make_move_iterator(lats.begin() + hi));
-      lats.clear();
-      if (io.Prunes() && !mine.empty()) {  // PruneLattice(beam, &clat), kwsbin2/lattice-word-index-segment.cc:49-51
-        if (io.device_prune) {
-          PruneLatticesOnDevice(ctx, io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &mine);
-        } else {
-          for (auto& clat : mine)
-            if (clat.Start() != CompactLattice::kNoStateId)
-              PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &clat);
-        }
-      }
-      LatticeBatch batch;
-      std::vector<int32_t> state_len_all;
-      for (auto& clat : mine) {
-        std::vector<int32_t> times, state_len;
-        if (POSITION) {
-          CompactLattice dlat;
-          if (clat.Start() != CompactLattice::kNoStateId) {
-            TopSortCompactLatticeIfNeeded(&clat);
-            DisambiguateStateInputSequenceLength(clat, &dlat, &state_len, false);  // kwsbin2/lattice-word-index-position.cc:64-65
-            CompactLatticeStateTimes(dlat, &times);
-          }
-          batch.Add(dlat, &times);
-          state_len_all.insert(state_len_all.end(), state_len.begin(), state_len.end());
-        } else {
-          if (clat.Start() != CompactLattice::kNoStateId) {
-            TopSortCompactLatticeIfNeeded(&clat);
-            CompactLatticeStateTimes(clat, &times);
-          }
-          batch.Add(clat, &times);
-        }
-        clat.DeleteStates();
+      if (!sb->mine.empty()) {
+        PruneLatticesOnDevice(ctx, io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &sb->mine);
+        FlattenForIndex<POSITION>(&sb->mine, &sb->batch, &sb->state_len_all);
       }
       // this rank's range on its GPU
       std::unique_ptr<DeviceBatch> db;
       std::vector<int64_t> off((size_t)(hi - lo) + 1, 0);
       int64_t nrec = 0;
       if (hi > lo) {
-        db.reset(new DeviceBatch(ctx, batch, &popt));
+        db.reset(new DeviceBatch(ctx, sb->batch, &popt));
         db->ForwardBackward(co.graph_scale, co.acoustic_scale, co.insertion_penalty);
         if (POSITION)
-          Check(klat_position_index(db->get(), state_len_all.data(), &filter, off.data(), nullptr, 0, &nrec), "klat_position_index");
+          Check(klat_position_index(db->get(), sb->state_len_all.data(), &filter, off.data(), nullptr, 0, &nrec), "klat_position_index");
         else
           Check(klat_segment_index(db->get(), &filter, off.data(), nullptr, 0, &nrec), "klat_segment_index");
       }
-      std::vector<Record> rec;
-      std::vector<int64_t> all_off;
+      std::unique_ptr<WriteJob> job(new WriteJob());
+      std::vector<Record>& rec = job->rec;
       auto fetch_mine = [&]() {
         rec.resize((size_t)std::max<int64_t>(nrec, 1));
         if (hi <= lo) return;
         if (POSITION)
-          Check(klat_position_index(db->get(), state_len_all.data(), &filter, off.data(),
+          Check(klat_position_index(db->get(), sb->state_len_all.data(), &filter, off.data(),
                                     reinterpret_cast<klat_position_record*>(rec.data()), (int64_t)rec.size(), &nrec),
                 "klat_position_index");
         else
@@ -348,7 +566,7 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
       };
       if (world == 1) {
         fetch_mine();
-        all_off = off;
+        job->off = off;
       } else {
         int64_t tu = 0, tr = 0;
         if (ranks.host_gather()) {
@@ -361,24 +579,51 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
         }
         if (rank == 0) {
           if (tu != n) KLAT_ERR("gathered " << tu << " utterances, expected " << n);
-          all_off.assign((size_t)n + 1, 0);
+          job->off.assign((size_t)n + 1, 0);
           rec.resize((size_t)std::max<int64_t>(tr, 1));
-          Check(klat_gather_fetch(ranks.comm(), all_off.data(), rec.data(), (int64_t)rec.size()), "klat_gather_fetch");
+          Check(klat_gather_fetch(ranks.comm(), job->off.data(), rec.data(), (int64_t)rec.size()), "klat_gather_fetch");
         }
       }
-      if (rank == 0)
-        for (int64_t u = 0; u < n; ++u)
-          writer->Write(keys[(size_t)u], rec.data() + all_off[(size_t)u], all_off[(size_t)u + 1] - all_off[(size_t)u]);
       KLAT_VLOG(1, "Rank " << rank << "/" << world << ": lattices [" << lo << ", " << hi << ") of a super-batch of " << n
-                           << ", " << batch.NumArcs() << " arcs, " << nrec << " records");
+                           << ", " << sb->batch.NumArcs() << " arcs, " << nrec << " records");
+      if (rank == 0) {
+        job->keys = std::move(sb->keys);
+        write_q.Push(std::move(job));
+      }
+    }
+    reader_thread.join();
+    if (rank == 0) {
+      std::unique_ptr<WriteJob> last(new WriteJob());
+      last->end = true;
+      write_q.Push(std::move(last));
+      writer_thread.join();
+      if (writer_error) std::rethrow_exception(writer_error);
     }
     if (writer) writer->Close();
+    KLAT_VLOG(1, "Rank " << rank << "/" << world << ": parsed " << parsed_lattices << " of " << seen_lattices << " lattices ("
+                         << parsed_arcs << " arcs)" << (mapped ? ", archive scanned in place" : ", archive read as a stream"));
     KLAT_VLOG(1, "Done " << num_lattices << " lattices.");
   } catch (const std::exception& e) {
     if (world > 1) std::cerr << "rank " << rank << ": ";
     std::cerr << e.what();
     status = -1;
     ranks.Abort();
+    // the stages must not outlive this frame: unblock and join them
+    stop.store(true);
+    if (reader_thread.joinable()) {
+      std::thread drain([&]() {
+        for (;;)
+          if (read_q.Pop()->end) break;
+      });
+      reader_thread.join();
+      drain.join();
+    }
+    if (writer_thread.joinable()) {
+      std::unique_ptr<WriteJob> last(new WriteJob());
+      last->end = true;
+      write_q.Push(std::move(last));
+      writer_thread.join();
+    }
   }
   return ranks.Finish(status);
 }

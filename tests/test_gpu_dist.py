@@ -114,3 +114,85 @@ def test_tool_devices_mode_reports_a_failing_rank(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert "device index out of range" in p.stderr or "worker rank failed" in p.stderr
+
+
+def _archives(tmp_path, n=60, seed=12):
+    rng = np.random.RandomState(seed)
+    ns = rng.randint(2, 200, size=n).astype(np.int32)
+    fo = rng.choice([1, 2, 3], size=n).astype(np.int32)
+    arrays = klat_amd.synth(77, ns, fo)
+    txt = tmp_path / "lats.ark.txt"
+    from test_host_tools import _write_text_archive
+    _write_text_archive(str(txt), arrays, ns)
+    binary = tmp_path / "lats.ark"
+    p = subprocess.run([os.path.join(BIN, "klat-lattice-copy"), "ark:%s" % txt, "ark:%s" % binary], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return arrays, ns, str(txt), str(binary)
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_devices_mode_each_rank_parses_only_its_share(tmp_path, binary):
+    """The reference reads every lattice once (kwsbin2/lattice-word-index-segment.cc:261-274).  With three
+    ranks on a plain file each rank scans the entry boundaries and PARSES a third of the arcs -- not the
+    whole archive, seven eighths of which it would throw away on an 8-GPU node -- and the records are what
+    the single-GPU run writes."""
+    import re
+    arrays, ns, txt, bin_ = _archives(tmp_path)
+    ark = bin_ if binary else txt
+    one = subprocess.run([os.path.join(BIN, "lattice-word-index-segment"), "--acoustic-scale=0.1", "ark:%s" % ark, "ark,t:-"],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    p = subprocess.run([os.path.join(BIN, "lattice-word-index-segment"), "--acoustic-scale=0.1", "--verbose=1", "--devices=0,0,0", "--gather=host",
+                        "--batch-size=7", "ark:%s" % ark, "ark,t:-"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert [l.split()[0] for l in p.stdout.splitlines()] == [l.split()[0] for l in one.stdout.splitlines()]
+    assert len(p.stdout) == len(one.stdout)
+    total_arcs = int(arrays["arc_off"][-1])
+    got = {}
+    for m in re.finditer(r"Rank (\d)/3: parsed (\d+) of (\d+) lattices \((\d+) arcs\), archive scanned in place", p.stderr):
+        got[int(m.group(1))] = (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+    assert sorted(got) == [0, 1, 2], p.stderr[-3000:]
+    assert all(v[1] == len(ns) for v in got.values())
+    assert sum(v[0] for v in got.values()) == len(ns) and sum(v[2] for v in got.values()) == total_arcs
+    for r, (_, _, arcs) in got.items():
+        assert 0.2 * total_arcs <= arcs <= 0.47 * total_arcs, (r, arcs, total_arcs)
+    # a command instead of a file cannot be scanned ahead: every rank parses everything, same records
+    q = subprocess.run([os.path.join(BIN, "lattice-word-index-segment"), "--acoustic-scale=0.1", "--verbose=1", "--devices=0,0", "--gather=host",
+                        "--batch-size=16", "ark:cat %s|" % ark, "ark,t:-"], capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr[-3000:]
+    assert [l.split()[0] for l in q.stdout.splitlines()] == [l.split()[0] for l in one.stdout.splitlines()]
+    assert "archive read as a stream" in q.stderr
+
+
+@pytest.mark.parametrize("tool,args", [("lattice-to-word-frame-post", ["--acoustic-scale=0.1"]),
+                                       ("lattice-best-path2", ["--acoustic-scale=0.1", "--nbest=3"])])
+def test_job_tools_devices_mode_pieces_concatenate_to_the_single_gpu_output(tmp_path, tool, args):
+    """lattice-to-word-frame-post (entry point #1) and lattice-best-path2 (BASELINE configs[2]) with
+    --devices: every rank takes a contiguous share of the archive and writes table JOB; the pieces in
+    job order are the single-GPU output, key for key (per-utterance independent loops,
+    latbin/lattice-to-word-frame-post.cc:68, latbin/lattice-best-path2.cc:78)."""
+    arrays, ns, txt, bin_ = _archives(tmp_path, n=23, seed=4)
+    one = subprocess.run([os.path.join(BIN, tool)] + args + ["ark:%s" % bin_, "ark,t:%s" % (tmp_path / "one.txt")],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    p = subprocess.run([os.path.join(BIN, tool)] + args + ["--devices=0,0,0", "--batch-size=4", "ark:%s" % bin_, "ark,t:%s" % (tmp_path / "piece.JOB.txt")],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    pieces = [open(tmp_path / ("piece.%d.txt" % j)).read() for j in (1, 2, 3)]
+    assert all(pieces), "every rank writes a piece"
+    want = open(tmp_path / "one.txt").read()
+    got = "".join(pieces)
+    wl, gl = want.splitlines(), got.splitlines()
+    assert [l.split()[0] for l in gl] == [l.split()[0] for l in wl]
+    if tool == "lattice-best-path2":
+        assert got == want  # integer transcripts
+    else:  # posteriors: the layout of a lattice's sweep depends on the batch it shares -- last bits may differ
+        for a, b in zip(gl, wl):
+            ta, tb = a.split(), b.split()
+            assert len(ta) == len(tb)
+            for x, y in zip(ta[1:], tb[1:]):
+                assert x == y or abs(float(x) - float(y)) <= 1e-4 * max(1.0, abs(float(y)))
+    # no JOB in the wspecifier: refused before any rank starts work
+    r = subprocess.run([os.path.join(BIN, tool)] + args + ["--devices=0,0", "ark:%s" % bin_, "ark,t:%s" % (tmp_path / "x.txt")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "JOB" in r.stderr
