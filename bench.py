@@ -20,7 +20,10 @@ Beside the headline the line carries:
                are on the device: what a tool pays per batch (every caller sweeps a batch once);
   accumulate   device time of the segment-index and frame-posterior kernels on the C2 batch;
   index_gather (N > 1) klat_segment_index on every rank's shard + the gather of the 24-byte
-               records to rank 0 over RCCL from device buffers (include/klat_dist.h), timed.
+               records to rank 0 over RCCL from device buffers (include/klat_dist.h), timed;
+  strong_c4    STRONG scaling on north_star's target shape: BASELINE configs[3] whole (100 000 x 5 000
+               states), the same list at every N, each rank sweeping its klat_partition_by_arcs range:
+               forward-backward + segment index + gather to rank 0, node arcs/s.
 KLAT_BENCH_DRYRUN=1: no GPU work at all -- the ranks rendezvous over gloo and run the launch,
 sharding and gather plumbing on the host transport (the CPU test of the N > 1 path)."""
 import argparse
@@ -275,6 +278,122 @@ def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
             "arcs_per_s_wall": A / (sum(wall[:2]) * 1e-3), "arcs_per_s_wall_with_index": A / (sum(wall) * 1e-3)}
 
 
+C4 = {"lattices": 100000, "states": 5000, "fanout": 3, "seed": 20260003}  # BASELINE configs[3], north_star's scaling target
+STRONG_REFERENCE = os.path.join("profiles", "r03_strong_c4_1gpu.json")   # this leg at N = 1, taken on a box of the same pool
+
+
+def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, barrier, lattices, reps=3):
+    """north_star's own scaling claim: the SAME list of lattices (BASELINE configs[3]: 100 000 x 5 000 states x
+    fanout 3) at every N, strong scaling -- the reference's parallel model is TaskSequencer over one fixed archive
+    (kwsbin2/lattice-word-index-segment.cc:260-275).  Every rank takes its klat_partition_by_arcs range (it
+    generates only that range: first_utt = its first utterance), then, timed between barriers on all ranks:
+    klat_forward_backward + klat_segment_index + klat_gather_index to rank 0 (device buffers over RCCL).
+    Node rate = the list's arcs / the slowest rank's time."""
+    import ctypes as C
+    from klat_amd import dist as kdist
+    L = klat_amd.lib()
+    weights = np.full(lattices, C4["states"] * C4["fanout"], np.int64)
+    bounds = kdist.partition_by_arcs(weights, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    # the rank's range, generated and uploaded in slices (host peak: one slice), concatenated on the device
+    fields = ("src", "dst", "ilabel", "olabel", "graph", "acoustic", "final_graph", "final_acoustic", "state_time")
+    parts = {f: [] for f in fields}
+    state_off, arc_off = [np.zeros(1, np.int64)], [np.zeros(1, np.int64)]
+    t_gen = time.perf_counter()
+    for a0 in range(lo, hi, 12500):
+        n = min(12500, hi - a0)
+        sl = klat_amd.synth(C4["seed"], np.full(n, C4["states"], np.int32), np.full(n, C4["fanout"], np.int32), first_utt=a0,
+                            host_threads=host_threads)
+        for f in fields:
+            parts[f].append(torch.from_numpy(np.ascontiguousarray(sl[f])).cuda())
+        state_off.append(sl["state_off"][1:] + state_off[-1][-1])
+        arc_off.append(sl["arc_off"][1:] + arc_off[-1][-1])
+        del sl
+    dev = {"state_off": np.concatenate(state_off), "arc_off": np.concatenate(arc_off)}
+    keep = []
+    for f in fields:
+        t = torch.cat(parts[f]) if len(parts[f]) > 1 else parts[f][0]
+        parts[f] = None
+        keep.append(t)
+        dev[f] = int(t.data_ptr())
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t_gen
+    t0 = time.perf_counter()
+    b = klat_amd.Batch(ctx, dev, host_threads=host_threads)
+    create_s = time.perf_counter() - t0
+    A = b.A
+    for _ in range(3):
+        b.forward_backward(*SCALES)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        b.forward_backward(*SCALES)
+    barrier()
+    step_s = (time.perf_counter() - t0) / 5
+    f, fkeep = klat_amd.Batch._filter(None, None)
+    off = np.zeros(b.U + 1, np.int64)
+    n = C.c_int64(0)
+    times, err = [], None
+    tu = tr = 0
+    try:
+        for it in range(reps + 1):  # (the first pass allocates: not counted)
+            barrier()
+            t0 = time.perf_counter()
+            b.forward_backward(*SCALES)
+            klat_amd._check(L.klat_segment_index(b.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
+            if comm is not None:
+                tu, tr = comm.gather_index(b, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)
+            barrier()
+            if it:
+                times.append(time.perf_counter() - t0)
+    except Exception as e:  # (the whole list with its index on ONE GPU is the tightest fit)
+        err = "%s: %s" % (type(e).__name__, str(e)[:200])
+    tot = torch.tensor([float(A), float(n.value), step_s, median(times) if times else 0.0, 1.0 if err else 0.0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        sums = tot.clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+        total_arcs, total_records, failed = float(sums[0]), float(sums[1]), float(tot[4]) > 0
+    else:
+        total_arcs, total_records, failed = float(A), float(n.value), err is not None
+    step_max, pipe_max = float(tot[2]), float(tot[3])
+    out = None
+    if rank == 0:
+        ref = None
+        try:
+            ref = json.load(open(os.path.join(ROOT, STRONG_REFERENCE)))
+        except Exception:
+            pass
+        out = {"workload": "BASELINE configs[3] WHOLE: %d lattices x %d states x fanout %d (seed %d), the same list at every N; "
+                           "rank r sweeps its klat_partition_by_arcs range" % (lattices, C4["states"], C4["fanout"], C4["seed"]),
+               "scaling": "strong", "ranks": world, "total_arcs": total_arcs, "rank0_lattices": hi - lo, "rank0_arcs": A,
+               "rank0_generate_seconds": gen_s, "rank0_batch_create_seconds": create_s,
+               "step_seconds": step_max, "node_arcs_per_s_step": total_arcs / step_max if step_max > 0 else None,
+               "pipeline": "klat_forward_backward + klat_segment_index" + (" + klat_gather_index to rank 0 (RCCL, device buffers)" if comm is not None else ""),
+               "pipeline_seconds": pipe_max if not failed else None,
+               "node_arcs_per_s": total_arcs / pipe_max if (pipe_max > 0 and not failed) else None,
+               "index_records": total_records, "error": err}
+        if comm is not None and not failed:
+            st = comm.stats()
+            out["gather"] = {"utterances": int(tu), "records": int(tr), "payload_bytes_into_rank0": st["payload_bytes"], "seconds": st["seconds"],
+                             "GB_per_s_into_rank0": st["payload_bytes"] / st["seconds"] / 1e9 if st["seconds"] > 0 else None}
+        if world == 1:
+            out["speedup_vs_1gpu"] = 1.0
+        elif ref and ref.get("total_arcs") == total_arcs and ref.get("node_arcs_per_s") and out["node_arcs_per_s"]:
+            out["one_gpu_reference"] = {"node_arcs_per_s": ref["node_arcs_per_s"], "node_arcs_per_s_step": ref.get("node_arcs_per_s_step"),
+                                        "source": STRONG_REFERENCE + " (this leg at N = 1 on a box of the same pool)"}
+            out["speedup_vs_1gpu"] = out["node_arcs_per_s"] / ref["node_arcs_per_s"]
+            if ref.get("node_arcs_per_s_step"):
+                out["speedup_vs_1gpu_step"] = out["node_arcs_per_s_step"] / ref["node_arcs_per_s_step"]
+        else:
+            out["speedup_vs_1gpu"] = None  # (no 1-GPU record of this list size: compare the per-N lines of the scaling run)
+    b.close()
+    del keep
+    torch.cuda.empty_cache()
+    ctx.trim()
+    return out
+
+
 def dry_run(args, rank, world):
     """CPU rehearsal of the N-rank plumbing (launch, rendezvous, sharding, C++ gather over the host
     transport).  No kernel runs and nothing is measured: `value` is null."""
@@ -306,11 +425,36 @@ def dry_run(args, rank, world):
             assert all_off.tolist() == arrays["arc_off"].tolist() and all_rec["label"].tolist() == list(range(len(all_rec)))
             gathered = {"ranks": nranks, "records": int(len(all_rec)), "order_restored": True}
         dist.barrier()
-        dist.destroy_process_group()
+    # the strong-scaling leg's plumbing: ONE list (a small stand-in for configs[3]), every rank generates only its
+    # klat_partition_by_arcs range with first_utt = its first utterance; the ranges must tile the list exactly
+    strong = None
+    L = min(args.strong_lattices, 96)
+    sb = kdist.partition_by_arcs(np.full(L, 40 * 3, np.int64), world)
+    slo, shi = int(sb[rank]), int(sb[rank + 1])
+    mine = klat_amd.synth(C4["seed"], np.full(shi - slo, 40, np.int32), np.full(shi - slo, 3, np.int32), first_utt=slo)
+    whole = klat_amd.synth(C4["seed"], np.full(L, 40, np.int32), np.full(L, 3, np.int32)) if rank == 0 else None
+    counts = np.array([shi - slo, int(mine["arc_off"][-1])], np.int64)
+    if world > 1:
+        import torch
+        import torch.distributed as dist2
+        dist2.init_process_group("gloo") if not dist2.is_initialized() else None
+        t = torch.from_numpy(counts.copy())
+        allc = [torch.zeros_like(t) for _ in range(world)]
+        dist2.all_gather(allc, t)
+        tot = np.sum([c.numpy() for c in allc], axis=0)
+        dist2.barrier()
+        dist2.destroy_process_group()
+    else:
+        tot = counts
+    if rank == 0:
+        a0, a1 = int(whole["arc_off"][slo]), int(whole["arc_off"][shi])
+        assert np.array_equal(mine["dst"], whole["dst"][a0:a1]) and np.array_equal(mine["graph"], whole["graph"][a0:a1]), "a rank's range must be the list's own lattices"
+        assert int(tot[0]) == L and int(tot[1]) == int(whole["arc_off"][-1]), (tot, L)
+        strong = {"scaling": "strong", "ranks": world, "lattices": L, "total_arcs": int(tot[1]), "ranges_tile_the_list": True}
     if rank == 0:
         print(json.dumps({"metric": "lattice-arcs/sec (whole node) on forward-backward + arc posteriors", "value": None,
                           "unit": "lattice-arcs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "dry_run": True, "index_gather": gathered}))
+                          "dry_run": True, "index_gather": gathered, "strong_c4": strong}))
 
 
 def main():
@@ -329,6 +473,8 @@ def main():
     ap.add_argument("--no-shapes", action="store_true")
     ap.add_argument("--no-accumulate", action="store_true")
     ap.add_argument("--no-one-shot", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg on BASELINE configs[3]")
+    ap.add_argument("--strong-lattices", type=int, default=C4["lattices"], help="lattices of the strong-scaling list (default: configs[3] whole)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -504,6 +650,7 @@ def main():
             out["accumulate"] = acc
 
     # ---- N > 1: segment index of every shard gathered to rank 0 over RCCL, from device buffers
+    comm = None
     if world > 1:
         try:  # (a failure of this leg must not take the headline line with it)
             from klat_amd import dist as kdist
@@ -536,10 +683,23 @@ def main():
                                        "seconds": sec, "GB_per_s_into_rank0": st["payload_bytes"] / sec / 1e9 if sec > 0 else None,
                                        "order": "rank order = input order (checked)"}
                 del rec, roff
-            comm.close()
         except Exception as e:
             if rank == 0:
                 out["index_gather"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+    # ---- strong scaling on BASELINE configs[3] whole: north_star's own target shape, the same list at every N
+    batch.close()
+    ctx.trim()
+    if not args.no_strong:
+        try:
+            strong = strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, barrier, args.strong_lattices)
+            if rank == 0:
+                out["strong_c4"] = strong
+        except Exception as e:
+            if rank == 0:
+                out["strong_c4"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if comm is not None:
+        comm.close()
 
     # ---- other BASELINE shapes, on rank 0 (the others wait at the barrier below)
     if rank == 0 and not args.no_shapes:
@@ -563,7 +723,7 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:  # (at every N: the same host cores, the same sample)
             out["cpu_baseline"] = cpu_baseline(ns, fo, args.seed, SCALES)
         print(json.dumps(out))
     batch.close()

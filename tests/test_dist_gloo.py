@@ -157,6 +157,9 @@ def test_bench_gpus_flag_starts_the_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True
     assert out["index_gather"] == {"ranks": 2, "records": out["index_gather"]["records"], "order_restored": True}
+    # the strong-scaling leg (north_star's claim: the SAME configs[3] list at every N): the two ranks' ranges tile one list
+    assert out["strong_c4"]["scaling"] == "strong" and out["strong_c4"]["ranks"] == 2 and out["strong_c4"]["ranges_tile_the_list"]
+    assert out["strong_c4"]["lattices"] == 96 and out["strong_c4"]["total_arcs"] > 0
 
 
 def test_bench_refuses_a_world_that_disagrees_with_gpus():
