@@ -252,7 +252,7 @@ def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
         t0 = time.perf_counter()
         b = klat_amd.Batch(ctx, dev)
         t1 = time.perf_counter()
-        b.forward_backward(*SCALES)
+        b.forward_backward(*SCALES, arc_posteriors=False)  # what the tools call: sweep + totals, no per-arc pass
         ctx.sync()
         t2 = time.perf_counter()
         off = np.zeros(b.U + 1, np.int64)
@@ -269,8 +269,9 @@ def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
     fb, seg = med(r[1] for r in rows), med(r[2] for r in rows)
     wall = [med(r[3] for r in rows), med(r[4] for r in rows), med(r[5] for r in rows)]
     del keep
-    return {"what": "fresh C2 batch, CSR arrays resident on the device: stream packing + one forward-backward (+ segment index); "
-                    "device time by HIP events, wall time of the calls",
+    return {"what": "fresh C2 batch, CSR arrays resident on the device: stream packing + one forward-backward without the per-arc "
+                    "posterior pass (KLAT_FB_NO_ARC_POSTERIORS, the tools' call) + segment index; device time by HIP events, "
+                    "wall time of the calls",
             "pack_device_ms": pack, "forward_backward_device_ms": fb, "segment_index_device_ms": seg,
             "device_ms": pack["device_ms"] + fb, "arcs_per_s": A / ((pack["device_ms"] + fb) * 1e-3),
             "device_ms_with_index": pack["device_ms"] + fb + seg, "arcs_per_s_with_index": A / ((pack["device_ms"] + fb + seg) * 1e-3),

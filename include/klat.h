@@ -100,7 +100,7 @@ typedef struct {
                           layout class, all classes' launches (fast + exact) otherwise */
   float totals_ms;     /* exact sweep (its workgroups exit at once unless a job was flagged); the per-lattice
                           totals are formed by the posterior pass and count in posterior_ms */
-  float posterior_ms;  /* arc posterior kernel */
+  float posterior_ms;  /* arc posterior kernel (KLAT_FB_NO_ARC_POSTERIORS: the totals kernel in its place) */
   float total_ms;      /* first event to last event */
 } klat_timings;
 
@@ -165,6 +165,13 @@ int klat_batch_topological_depth(klat_batch* batch, int32_t* depth /* [num_latti
  * alpha[src] - cost + beta[dst] - total, alpha/beta in natural log.  Asynchronous on the
  * ctx stream; results stay on the device until fetched. */
 int klat_forward_backward(klat_batch* batch, const klat_scales* scales);
+/* The same with flags.  KLAT_FB_NO_ARC_POSTERIORS: sweep and totals only -- no per-arc posterior pass
+ * (8 B per arc written, 18 read).  The accumulators below do not need it: like the reference's loops
+ * (kwsbin2/lattice-word-index-segment.cc:160-163,98-108) they form fw[src] + arc_lkh + bw[dst] from
+ * alpha / beta themselves and subtract the total when a record is final.  klat_get_arc_logpost still
+ * works afterwards (the pass then runs on demand). */
+#define KLAT_FB_NO_ARC_POSTERIORS 1u
+int klat_forward_backward_ex(klat_batch* batch, const klat_scales* scales, uint32_t flags);
 int klat_get_timings(const klat_batch* batch, klat_timings* t);
 /* Kernel times of the last `count` (<= 512) calls of klat_forward_backward on this context, oldest
  * first: a caller may enqueue many steps without waiting and read their times afterwards (waits for

@@ -18,7 +18,17 @@ struct AccumArgs {
   const int32_t* olabel;
   const int32_t* state_time;
   const int32_t* state_len;  // position index only
-  const double* logpost;
+  // what forms an arc's log-likelihood of all paths through it, fw[src] + arc_lkh + bw[dst]
+  // (kwsbin2/lattice-word-index-segment.cc:160-163): the accumulators read alpha / beta themselves --
+  // the 8 B per arc they spent on the posterior pass's `logpost` now go to the arc's two costs -- and
+  // subtract the lattice's total when a record is final (:98-108), as the reference does
+  const double* alpha;   // padded (klat_kernels.h)
+  const double* beta;
+  const double* total;   // [U]
+  const int32_t* ilabel; // read only when an insertion penalty applies
+  const float* graph;
+  const float* acoustic;
+  ScaleParams sp;
   const int32_t* include;
   int32_t num_include;
   const int32_t* exclude;
@@ -31,6 +41,26 @@ struct AccumArgs {
   int32_t min_arcs, max_arcs;  // a launch takes the lattices with min_arcs < arcs <= max_arcs
   long long* phase_clock;      // [U][8] or null: s_memtime stamps of the hash kernel's phases (KLAT_ACCUM_PROFILE)
 };
+
+}  // namespace klat
+#if defined(__HIPCC__)
+#include "klat_math.h"
+namespace klat {
+// alpha[src] + beta[dst] - cost of arc i (a0: the lattice's first arc, pb: its padded state base): the
+// expression of the posterior pass (klat_kernels.hip), so the values are the same bits
+__device__ __forceinline__ double accum_through(const AccumArgs& a, int64_t a0, int64_t pb, int i, int src, int dst) {
+  const bool word = a.sp.penalized ? a.ilabel[a0 + i] != 0 : false;
+  const double c = arc_cost(a.graph[a0 + i], a.acoustic[a0 + i], word, a.sp);
+  return a.alpha[pb + src] + a.beta[pb + dst] - c;
+}
+__device__ __forceinline__ double accum_through(const AccumArgs& a, int64_t a0, int64_t pb, int i) {
+  return accum_through(a, a0, pb, i, a.src[a0 + i], a.dst[a0 + i]);
+}
+// a record's value once its arcs are folded: log-zero stays log-zero (also when the lattice has no path: total = -inf)
+__device__ __forceinline__ double accum_normalise(double through, double total) { return through > -INFINITY ? through - total : -INFINITY; }
+}  // namespace klat
+#endif
+namespace klat {
 
 struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)
   int32_t f0, f1, f2, f3;
@@ -108,7 +138,8 @@ struct FrameArgs {
   const int32_t* state_time;
   const int32_t* num_frames;  // [U]
   FrameArc* arc_info;         // [A] scratch: clipped span and x of every arc
-  const double* logpost;
+  const double* alpha;        // padded
+  const double* beta;
   const double* total;
   void* key_scratch;  // 16 B per slot
   void* rec_scratch;  // 16 B per slot

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
   const int tid = threadIdx.x;
   const int64_t a0 = a.arc_off[u], a1 = a.arc_off[u + 1];
   const int64_t s0 = a.state_off[u];
+  const int64_t pb = padded_state_base(s0, u);
   const int nA = (int)(a1 - a0);
   if (nA <= a.min_arcs || nA > a.max_arcs) return;  // the radix kernel's lattice (workgroup-uniform)
   Key* keys = reinterpret_cast<Key*>(a.key_scratch) + a.scratch_off[u];
@@ -243,21 +244,21 @@ __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
       }
       if (head) {
         int arc = (int)(uint32_t)ki.b;
-        double acc = a.logpost[a0 + arc];
+        double acc = accum_through(a, a0, pb, arc);
         double best = acc;
         int best_arc = arc;
         for (int j = i + 1; j < n; ++j) {
           const Key kj = keys[j];
           if (kj.a != ki.a || ((kj.b & group_mask_b) != (ki.b & group_mask_b))) break;
           arc = (int)(uint32_t)kj.b;
-          const double x = a.logpost[a0 + arc];
+          const double x = accum_through(a, a0, pb, arc);
           acc = log_add(acc, x);
           if (x > best) {  // strict: the first maximum in arc order wins
             best = x;
             best_arc = arc;
           }
         }
-        rec.k0 = desc_key(acc);
+        rec.k0 = desc_key(accum_normalise(acc, a.total[u]));  // lkh - total_lkh_, kwsbin2/lattice-word-index-segment.cc:107
         if (POSITION) {
           const int32_t label = unbias((uint32_t)(ki.a >> 32));
           const int32_t pos = unbias((uint32_t)ki.a) + 1;  // 1-based on output

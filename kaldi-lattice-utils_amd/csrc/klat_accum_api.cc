@@ -88,7 +88,17 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
   a.dst = b->dst.p;
   a.olabel = b->olabel.p;
   a.state_time = b->state_time.p;
-  a.logpost = b->logpost.p;
+  a.alpha = b->alpha.p;
+  a.beta = b->beta.p;
+  a.total = b->total.p;
+  a.ilabel = b->ilabel.p;
+  a.graph = b->graph.p;
+  a.acoustic = b->acoustic.p;
+  a.sp.gs_f = b->scales.graph_scale;
+  a.sp.as_f = b->scales.acoustic_scale;
+  a.sp.pen = b->scales.insertion_penalty;
+  a.sp.scaled = (b->scales.acoustic_scale != 1.0f || b->scales.graph_scale != 1.0f) ? 1 : 0;
+  a.sp.penalized = (b->scales.insertion_penalty != 0.0f) ? 1 : 0;
   a.key_scratch = st.key_scratch.p;
   a.rec_scratch = st.rec_scratch.p;
   a.val_scratch = st.val_scratch.p;
@@ -328,7 +338,8 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
   a.graph = b->graph.p;
   a.acoustic = b->acoustic.p;
   a.state_time = b->state_time.p;
-  a.logpost = b->logpost.p;
+  a.alpha = b->alpha.p;
+  a.beta = b->beta.p;
   a.total = b->total.p;
   a.sp.gs_f = b->scales.graph_scale;
   a.sp.as_f = b->scales.acoustic_scale;

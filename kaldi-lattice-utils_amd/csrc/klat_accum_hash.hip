@@ -169,13 +169,12 @@ __device__ __forceinline__ void block_sort_any(V* v, int c, Less less) {
   }
 }
 
-// value (full double image) and key of the record that arc `i` stands for: a unique arc's own, or
-// -- for the first arc of a repeated key -- the folded value staged in the lattice's scratch row
+// value (full double image) and key of the record that arc `i` stands for: `vals` holds every arc's
+// normalised through-likelihood, the folded sum in place of a repeated key's first arc
 template <bool POSITION>
-__device__ __forceinline__ void record_of(const AccumArgs& a, const RadixPack& pk, int64_t a0, int64_t s0, const uint32_t* headbit,
-                                          const double* staged, int i, uint64_t* dkey, uint64_t* key) {
-  const double v = (headbit[i >> 5] & (1u << (i & 31))) ? staged[i] : a.logpost[a0 + i];
-  *dkey = hdesc_key(v);
+__device__ __forceinline__ void record_of(const AccumArgs& a, const RadixPack& pk, int64_t a0, int64_t s0, const double* vals, int i,
+                                          uint64_t* dkey, uint64_t* key) {
+  *dkey = hdesc_key(vals[i]);
   (void)arc_key<POSITION>(a, pk, a0, s0, i, key);
 }
 
@@ -198,6 +197,10 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
   uint32_t* marked = reinterpret_cast<uint32_t*>(smem + (size_t)H * 4);      // [H / 32] slots with a repeated key
   uint32_t* headbit = marked;                                    // [MAXN / 32] later: first arcs of repeated keys
   uint32_t* bcnt = marked + H / 32;                              // [B / 2] packed 16-bit counters -> inclusive scan
+  // every arc's value alpha[src] - cost + beta[dst] - total, formed once while its ends are in registers
+  // (phase 1) and read by the later phases: in LDS behind the other arrays where the CU has room for it
+  // (up to 8 192 arcs: 64 KiB), else in the lattice's scratch row (L2)
+  constexpr bool kValsInLds = LOGH <= 14;
   __shared__ int sh[T / 64];
   __shared__ unsigned long long sh_dmin, sh_dmax;
   __shared__ double sh_vmin, sh_vmax;
@@ -205,10 +208,12 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
 
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t a0 = a.arc_off[u], s0 = a.state_off[u];
+  const int64_t pb = padded_state_base(s0, u);
   const int n = (int)(a.arc_off[u + 1] - a0);
   if (n <= a.min_arcs || n > a.max_arcs) return;  // another launch's lattice (workgroup-uniform)
+  const double tot = a.total[u];
+  double* vals = kValsInLds ? reinterpret_cast<double*>(smem + (size_t)H * 4 + H / 8 + (size_t)B * 2) : a.val_scratch + a.scratch_off[u];
   Payload* payload = reinterpret_cast<Payload*>(a.key_scratch) + a.scratch_off[u];  // by first arc, repeated keys only
-  double* staged = a.val_scratch + a.scratch_off[u];                                // the same
   Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + a.scratch_off[u];
 #define KLAT_STAMP(k)                                                                 \
   do {                                                                                \
@@ -229,15 +234,24 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     int32_t lab[kPerThread / 2], t0[kPerThread / 2], t1[kPerThread / 2];
+    float gr[kPerThread / 2], ac[kPerThread / 2];
+    bool word[kPerThread / 2];
+    double thr[kPerThread / 2];
 #pragma unroll
     for (int q = 0; q < kPerThread / 2; ++q) {
       const int i = min((half * (kPerThread / 2) + q) * T + tid, n - 1);
       lab[q] = a.olabel[a0 + i];
       t0[q] = a.src[a0 + i];
       t1[q] = a.dst[a0 + i];
+      gr[q] = a.graph[a0 + i];
+      ac[q] = a.acoustic[a0 + i];
+      word[q] = a.sp.penalized ? a.ilabel[a0 + i] != 0 : false;
     }
 #pragma unroll
     for (int q = 0; q < kPerThread / 2; ++q) {
+      // fw[src] + bw[dst] - cost (kwsbin2/lattice-word-index-segment.cc:160-163), the posterior pass's
+      // expression: the accumulator needs no per-arc posteriors from anybody
+      thr[q] = a.alpha[pb + t0[q]] + a.beta[pb + t1[q]] - arc_cost(gr[q], ac[q], word[q], a.sp);
       t0[q] = POSITION ? a.state_len[s0 + t0[q]] : a.state_time[s0 + t0[q]];
       if (!POSITION) t1[q] = a.state_time[s0 + t1[q]];
     }
@@ -245,6 +259,7 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
     for (int q = 0; q < kPerThread / 2; ++q) {
       const int j = half * (kPerThread / 2) + q;
       const int i = j * T + tid;
+      if (i < n) vals[i] = accum_normalise(thr[q], tot);
       bool ok = i < n && lab[q] != 0;
       if (filtered && ok)
         ok = a.num_include > 0 ? hin_sorted(a.include, a.num_include, lab[q]) : !hin_sorted(a.exclude, a.num_exclude, lab[q]);
@@ -254,7 +269,9 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
       if (ok) valid |= 1u << j;
     }
   }
+  if (!kValsInLds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (vals in the scratch row: read by other threads below)
   __syncthreads();
+  if (!kValsInLds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   KLAT_STAMP(1);
   // optimistic insert of every key at its home slot, all compare-and-swaps in flight at once
   uint32_t slot[kPerThread], seen[kPerThread];
@@ -332,18 +349,18 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
       if (!(p == 0 || (dups[p - 1] >> 14) != (w >> 14))) continue;
       int arc = (int)(w & 0x3FFFu);
       const int first_arc = arc;
-      double acc = a.logpost[a0 + arc], best = acc;
+      double acc = vals[arc], best = acc;
       int best_arc = arc;
       for (int q = p + 1; q < tot_dup && (dups[q] >> 14) == (w >> 14); ++q) {
         arc = (int)(dups[q] & 0x3FFFu);
-        const double x = a.logpost[a0 + arc];
+        const double x = vals[arc];
         acc = hlog_add(acc, x);
         if (x > best) {  // strict: the first maximum in arc order wins
           best = x;
           best_arc = arc;
         }
       }
-      staged[first_arc] = acc;
+      vals[first_arc] = acc;  // (runs are disjoint: nobody else reads this arc's own value any more)
       if (POSITION) {
         uint64_t k = 0;
         (void)arc_key<POSITION>(a, pk, a0, s0, first_arc, &k);
@@ -372,12 +389,7 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
   // ---- 3. order by (logp desc, key) ----
   double val[kPerThread];
 #pragma unroll
-  for (int j = 0; j < kPerThread; ++j) val[j] = a.logpost[a0 + min(j * T + tid, n - 1)];  // batched
-  if (tot_dup > 0) {
-#pragma unroll
-    for (int j = 0; j < kPerThread; ++j)
-      if (recmask & dupmask & (1u << j)) val[j] = staged[j * T + tid];
-  }
+  for (int j = 0; j < kPerThread; ++j) val[j] = vals[min(j * T + tid, n - 1)];  // (a repeated key's first arc holds the folded sum)
   int m;
   {
     unsigned long long dlo = ~0ull, dhi = 0ull;
@@ -480,8 +492,8 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
   auto less = [&](uint64_t x, uint64_t y) -> bool {
     if ((x >> RB) != (y >> RB)) return x < y;
     uint64_t dx, kx, dy, ky;
-    record_of<POSITION>(a, pk, a0, s0, headbit, staged, (int)(x & idmask), &dx, &kx);
-    record_of<POSITION>(a, pk, a0, s0, headbit, staged, (int)(y & idmask), &dy, &ky);
+    record_of<POSITION>(a, pk, a0, s0, vals, (int)(x & idmask), &dx, &kx);
+    record_of<POSITION>(a, pk, a0, s0, vals, (int)(y & idmask), &dy, &ky);
     return dx != dy ? dx < dy : kx < ky;
   };
   // crowded buckets (clustered or tied values) are sorted by the whole workgroup, in place
@@ -565,7 +577,7 @@ hipError_t launch_hash_one(const AccumArgs& a, const RadixPack& pk, int num_latt
   constexpr int T = 1024;
   constexpr int H = 1 << LOGH;
   constexpr int B = H / 4;
-  const size_t lds = (size_t)H * 4 + H / 8 + (size_t)B * 2;
+  const size_t lds = (size_t)H * 4 + H / 8 + (size_t)B * 2 + (LOGH <= 14 ? (size_t)(H / 2) * sizeof(double) : 0);  // + the arcs' values
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_hash_kernel<POSITION, LOGH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

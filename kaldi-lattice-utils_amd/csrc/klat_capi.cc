@@ -586,40 +586,10 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   AL(tot_bwd, b->U);
   AL(alpha, b->S + b->U);
   AL(beta, b->S + b->U);
-  AL(logpost, b->A);
 #undef UP
 #undef AL
 #undef FAIL
 #undef KLAT_HIP_B
-  if (std::getenv("KLAT_NO_SRC_DELTA") == nullptr && b->A > 0) {  // src as one-byte steps for the posterior pass
-    DevBuf<int32_t> over;
-    int rc2;
-    if ((rc2 = b->src_delta.alloc((size_t)b->A)) || (rc2 = b->arc_span.alloc((size_t)b->A)) || (rc2 = b->item_src.alloc(P.items.size())) ||
-        (rc2 = over.alloc(1))) {
-      klat_batch_destroy(b);
-      return rc2;
-    }
-    PosteriorPrepArgs pp;
-    pp.items = b->items.p;
-    pp.src = b->src.p;
-    pp.dst = b->dst.p;
-    pp.src_delta = b->src_delta.p;
-    pp.span = b->arc_span.p;
-    pp.item_src = b->item_src.p;
-    pp.overflow = over.p;
-    int32_t h_over = 0;
-    hipError_t pe = hipMemsetAsync(over.p, 0, sizeof(int32_t), c->stream);
-    if (pe == hipSuccess && b->pack_ev[7]) pe = hipEventRecord(b->pack_ev[7], c->stream);
-    if (pe == hipSuccess) pe = launch_posterior_prep(pp, (int)P.items.size(), c->stream);
-    if (pe == hipSuccess && b->pack_ev[8]) pe = hipEventRecord(b->pack_ev[8], c->stream), b->pack_prep_timed = true;
-    if (pe == hipSuccess) pe = hipMemcpyAsync(&h_over, over.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-    if (pe == hipSuccess) pe = hipStreamSynchronize(c->stream);
-    if (pe != hipSuccess) {
-      klat_batch_destroy(b);
-      return hip_fail(pe, "posterior preparation");
-    }
-    if (h_over) b->src_delta.release(), b->arc_span.release(), b->item_src.release();  // a step or an arc above 255 states: the pass reads src and dst themselves
-  }
   hipError_t e = hipStreamSynchronize(c->stream);  // uploads read pageable host memory of P
   if (e != hipSuccess) {
     klat_batch_destroy(b);
@@ -691,7 +661,67 @@ int klat_batch_topological_depth(klat_batch* b, int32_t* depth) {
   return KLAT_OK;
 }
 
-int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
+static ScaleParams make_scale_params(const klat_scales& s);
+
+// The arc posteriors are made when somebody asks for them: klat_forward_backward without
+// KLAT_FB_NO_ARC_POSTERIORS, or klat_get_arc_logpost after a sweep that left them out.  The first pass
+// over a batch allocates `logpost` and builds the one-byte source steps and arc spans of the arcs.
+static int ensure_posterior_tables(klat_batch* b) {
+  klat_ctx* c = b->ctx;
+  int rc;
+  if (b->logpost.n < (size_t)b->A && (rc = b->logpost.alloc((size_t)b->A))) return rc;
+  if (b->post_prepared) return KLAT_OK;
+  b->post_prepared = true;
+  if (std::getenv("KLAT_NO_SRC_DELTA") != nullptr || b->A == 0) return KLAT_OK;
+  DevBuf<int32_t> over;
+  if ((rc = b->src_delta.alloc((size_t)b->A)) || (rc = b->arc_span.alloc((size_t)b->A)) || (rc = b->item_src.alloc((size_t)b->num_items)) ||
+      (rc = over.alloc(1)))
+    return rc;
+  PosteriorPrepArgs pp;
+  pp.items = b->items.p;
+  pp.src = b->src.p;
+  pp.dst = b->dst.p;
+  pp.src_delta = b->src_delta.p;
+  pp.span = b->arc_span.p;
+  pp.item_src = b->item_src.p;
+  pp.overflow = over.p;
+  int32_t h_over = 0;
+  KLAT_HIP(hipMemsetAsync(over.p, 0, sizeof(int32_t), c->stream));
+  if (b->pack_ev[7]) KLAT_HIP(hipEventRecord(b->pack_ev[7], c->stream));
+  KLAT_HIP(launch_posterior_prep(pp, b->num_items, c->stream));
+  if (b->pack_ev[8]) {
+    KLAT_HIP(hipEventRecord(b->pack_ev[8], c->stream));
+    b->pack_prep_timed = true;
+  }
+  KLAT_HIP(hipMemcpyAsync(&h_over, over.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipStreamSynchronize(c->stream));
+  if (h_over) b->src_delta.release(), b->arc_span.release(), b->item_src.release();  // a step or an arc above 255 states: the pass reads src and dst themselves
+  return KLAT_OK;
+}
+
+static void fill_posterior_args(klat_batch* b, const ScaleParams& sp, PosteriorArgs* pa) {
+  pa->items = b->items.p;
+  pa->state_off = b->state_off.p;
+  pa->src = b->src.p;
+  pa->dst = b->dst.p;
+  pa->ilabel = b->ilabel.p;
+  pa->graph = b->graph.p;
+  pa->acoustic = b->acoustic.p;
+  pa->alpha = b->alpha.p;
+  pa->beta = b->beta.p;
+  pa->total = b->total.p;
+  pa->tot_fwd = b->tot_fwd.p;
+  pa->tot_bwd = b->tot_bwd.p;
+  pa->logpost = b->logpost.p;
+  pa->sp = sp;
+  pa->src_delta = b->src_delta.p;
+  pa->item_src = b->item_src.p;
+  pa->span = b->arc_span.p;
+}
+
+int klat_forward_backward(klat_batch* b, const klat_scales* sc) { return klat_forward_backward_ex(b, sc, 0); }
+
+int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flags) {
   if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
   klat_scales s = {1.0f, 1.0f, 0.0f};
   if (sc) s = *sc;
@@ -722,24 +752,14 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   sa.ring_slots = 0;  // per layout class below
   sa.far_prefetch = 0;
 
+  const bool want_post = (flags & KLAT_FB_NO_ARC_POSTERIORS) == 0;
+  if (flags & ~(uint32_t)KLAT_FB_NO_ARC_POSTERIORS) return set_error(KLAT_ERR_INVALID_ARG, "klat_forward_backward_ex: unknown flag");
+  if (want_post) {
+    const int rc = ensure_posterior_tables(b);
+    if (rc != KLAT_OK) return rc;
+  }
   PosteriorArgs pa;
-  pa.items = b->items.p;
-  pa.state_off = b->state_off.p;
-  pa.src = b->src.p;
-  pa.dst = b->dst.p;
-  pa.ilabel = b->ilabel.p;
-  pa.graph = b->graph.p;
-  pa.acoustic = b->acoustic.p;
-  pa.alpha = b->alpha.p;
-  pa.beta = b->beta.p;
-  pa.total = b->total.p;
-  pa.tot_fwd = b->tot_fwd.p;
-  pa.tot_bwd = b->tot_bwd.p;
-  pa.logpost = b->logpost.p;
-  pa.sp = sp;
-  pa.src_delta = b->src_delta.p;
-  pa.item_src = b->item_src.p;
-  pa.span = b->arc_span.p;
+  fill_posterior_args(b, sp, &pa);
 
   // sweep_ms of a one-class batch is the fast sweep kernel alone (what rocprofv3 lists under its
   // name): the events sit right around its launch.  The exact sweep's launch after it (all of its
@@ -771,7 +791,20 @@ int klat_forward_backward(klat_batch* b, const klat_scales* sc) {
   // (the totals are formed by the posterior kernel's first item of every lattice; totals_ms of the
   // timings is what is left between the two events: the exact sweep's launch)
   KLAT_HIP(hipEventRecord(ev[2], c->stream));
-  KLAT_HIP(launch_posterior(pa, b->num_items, c->stream));
+  if (want_post) {
+    KLAT_HIP(launch_posterior(pa, b->num_items, c->stream));
+  } else {  // the lattices' totals alone (the accumulators form the arcs' posteriors from alpha / beta themselves)
+    TotalsArgs ta;
+    ta.num_lattices = (int32_t)b->U;
+    ta.state_off = b->state_off.p;
+    ta.alpha = b->alpha.p;
+    ta.beta = b->beta.p;
+    ta.total = b->total.p;
+    ta.tot_fwd = b->tot_fwd.p;
+    ta.tot_bwd = b->tot_bwd.p;
+    KLAT_HIP(launch_totals(ta, c->stream));
+  }
+  b->have_logpost = want_post;
   KLAT_HIP(hipEventRecord(ev[3], c->stream));
   b->timing_step = c->steps++;
   b->swept = true;
@@ -1000,6 +1033,13 @@ int klat_get_arc_logpost(klat_batch* b, double* logpost) {
   KLAT_HIP(hipSetDevice(b->ctx->device));
   PoolScope pool_scope(&b->ctx->pool);
   int rc;
+  if (!b->have_logpost) {  // the sweep ran with KLAT_FB_NO_ARC_POSTERIORS: the pass runs now
+    if ((rc = ensure_posterior_tables(b))) return rc;
+    PosteriorArgs pa;
+    fill_posterior_args(b, make_scale_params(b->scales), &pa);
+    KLAT_HIP(launch_posterior(pa, b->num_items, b->ctx->stream));
+    b->have_logpost = true;
+  }
   if ((rc = fetch(b, logpost, b->logpost.p, sizeof(double) * (size_t)b->A))) return rc;
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   return KLAT_OK;

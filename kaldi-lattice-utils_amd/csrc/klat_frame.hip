@@ -356,6 +356,8 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   const int64_t a0 = a.arc_off[u];
   const int nA = (int)(a.arc_off[u + 1] - a0);
   const int64_t s0 = a.state_off[u];
+  const int64_t pb = padded_state_base(s0, u);
+  const double tot = a.total[u];
   const int T = a.num_frames[u];
   FKey* keys = reinterpret_cast<FKey*>(a.key_scratch) + a.scratch_off[u];
   FKey* recs = reinterpret_cast<FKey*>(a.rec_scratch) + a.scratch_off[u];
@@ -393,10 +395,13 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
       t1[q] = a.dst[a0 + i];
       gr[q] = a.graph[a0 + i];
       ac4[q] = a.acoustic[a0 + i];
-      lp[q] = a.logpost[a0 + i];
     }
 #pragma unroll
     for (int q = 0; q < kFrSpanBatch; ++q) {
+      // fw[u] + bw[nextstate] - cost - total (latbin/lattice-to-word-frame-post.cc:102-104,122), formed
+      // here from alpha / beta: no posterior pass has to run before this kernel
+      const double through = a.alpha[pb + t0[q]] + a.beta[pb + t1[q]] - arc_cost(gr[q], ac4[q], il[q] != 0, sp);
+      lp[q] = (through > -INFINITY) ? through - tot : -INFINITY;
       t0[q] = a.state_time[s0 + t0[q]];
       t1[q] = a.state_time[s0 + t1[q]];
     }
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         r.k0 = lo;
         r.k1 = hi;
         lmin_t = min(lmin_t, il[q]), lmax_t = max(lmax_t, il[q]);
-        // logpost holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
+        // lp holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
         // cost here as a float sum, so swap the double sum for the float one
         float g, ac;
         arc_cost_parts(gr[q], ac4[q], true, sp, g, ac);

@@ -229,6 +229,8 @@ struct klat_batch {
   std::vector<klat::LayoutClass> classes;
   int32_t deep_prefetch = 0;  // SweepArgs.deep_prefetch of this batch
   bool swept = false;
+  bool have_logpost = false;   // the last sweep (or a later klat_get_arc_logpost) ran the arc-posterior pass
+  bool post_prepared = false;  // the posterior pass's one-byte tables were built (first pass over the batch)
   int64_t timing_step = -1;  // the context's step counter at this batch's last klat_forward_backward
   klat_scales scales = {1.f, 1.f, 0.f};
   klat_batch_info info = {};

@@ -389,7 +389,8 @@ DeviceBatch::DeviceBatch(Context& ctx, const LatticeBatch& batch, const klat_pac
 DeviceBatch::~DeviceBatch() { klat_batch_destroy(b_); }
 void DeviceBatch::ForwardBackward(float graph_scale, float acoustic_scale, float insertion_penalty) {
   const klat_scales s = {graph_scale, acoustic_scale, insertion_penalty};
-  Check(klat_forward_backward(b_, &s), "klat_forward_backward");
+  // none of the tools reads per-arc posteriors: the accumulators form them from alpha / beta
+  Check(klat_forward_backward_ex(b_, &s, KLAT_FB_NO_ARC_POSTERIORS), "klat_forward_backward");
 }
 
 namespace {

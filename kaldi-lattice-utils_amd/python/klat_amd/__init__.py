@@ -261,9 +261,12 @@ class Batch:
         _check(lib().klat_batch_topological_depth(self.h, _p(d)))
         return d[:self.U]
 
-    def forward_backward(self, graph_scale=1.0, acoustic_scale=1.0, insertion_penalty=0.0):
+    def forward_backward(self, graph_scale=1.0, acoustic_scale=1.0, insertion_penalty=0.0, arc_posteriors=True):
         s = Scales(graph_scale, acoustic_scale, insertion_penalty)
-        _check(lib().klat_forward_backward(self.h, C.byref(s)))
+        if arc_posteriors:
+            _check(lib().klat_forward_backward(self.h, C.byref(s)))
+        else:  # KLAT_FB_NO_ARC_POSTERIORS: what the tools run (the accumulators read alpha / beta)
+            _check(lib().klat_forward_backward_ex(self.h, C.byref(s), C.c_uint32(1)))
 
     def timings(self):
         t = Timings()

@@ -417,3 +417,92 @@ def test_frame_post_beyond_the_lds_spans(ctx, case):
         _check_frames(off, labels, logps, fb, want)
         fb += nframes[u]
     assert off[-1] == len(labels)
+
+
+def test_accumulators_need_no_posterior_pass(ctx):
+    """The tools sweep with KLAT_FB_NO_ARC_POSTERIORS: the accumulators form fw[src] + arc_lkh + bw[dst]
+    from alpha / beta themselves (kwsbin2/lattice-word-index-segment.cc:160-163) and subtract the total at
+    record time (:98-108).  Same records, bit for bit, as after a sweep with the posterior pass; and
+    klat_get_arc_logpost still answers afterwards (the pass runs on demand)."""
+    rng = np.random.RandomState(21)
+    ns = rng.randint(2, 300, size=30).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 5], size=30).astype(np.int32)
+    arrays = klat_amd.synth(99, ns, fo)
+    nf = arrays["state_time"][arrays["state_off"][1:] - 1].astype(np.int32)
+    out = []
+    for arc_posteriors in (True, False):
+        b = klat_amd.Batch(ctx, arrays)
+        b.forward_backward(1.0, 0.1, 0.5, arc_posteriors=arc_posteriors)
+        off, rec = b.segment_index()
+        foff, lab, lp = b.frame_post(nf)
+        post = b.arc_logpost()
+        tot = b.totals()
+        out.append((off, rec.tobytes(), foff, lab, lp.tobytes(), post, tot))
+        b.close()
+    (o0, r0, f0, l0, p0, a0, t0), (o1, r1, f1, l1, p1, a1, t1) = out
+    assert np.array_equal(o0, o1) and r0 == r1
+    assert np.array_equal(f0, f1) and np.array_equal(l0, l1) and p0 == p1
+    assert np.array_equal(a0, a1) and all(np.array_equal(x, y) for x, y in zip(t0, t1))
+
+
+def _log_add(x, y):
+    if x < y:
+        x, y = y, x
+    d = y - x
+    return x + np.log1p(np.exp(d)) if d >= np.log(np.finfo(np.float64).eps) else x
+
+
+@pytest.mark.parametrize("source", ["egs", "synthetic"])
+def test_frame_post_is_the_segment_index_summed_over_frames(ctx, golden_dir, source):
+    """lattice-to-word-frame-post has no known-answer vector in the reference; the segment index has
+    (kwsbin2/README.md:75).  The two accumulate the same quantity: an arc (w, t0, t1) adds its likelihood
+    to every frame t0 <= k < t1 (latbin/lattice-to-word-frame-post.cc:110-116) and to the record (w, t0, t1)
+    (kwsbin2/lattice-word-index-segment.cc:165-171).  So the frame posterior of (k, w) must be the LogAdd
+    of the segment records (w, t0, t1) with t0 <= k < t1, narrowed to float -- the unpinned output checked
+    against the family of outputs the README pins.  (The frame tool forms the arc cost as a float sum and
+    LogAdds in arc order, the index as doubles per segment: a few float32 ulps.)"""
+    if source == "egs":  # every shipped example lattice, the README's among them
+        lats, times = [], []
+        for name in sorted(os.listdir(golden_dir)):
+            if not name.startswith("egs_") or not name.endswith(".txt"):
+                continue
+            for lat in latfmt.read_text_archive(os.path.join(golden_dir, name)):
+                lat = latfmt.prepare(lat)
+                try:
+                    t = orc.state_times(lat)[0]
+                except RuntimeError:  # (the character lattices carry no consistent frame times: not inputs of these tools)
+                    continue
+                lats.append(lat)
+                times.append(t)
+        assert len(lats) >= 2
+        arrays = klat_amd.concat_lattices(lats, times)
+    else:
+        rng = np.random.RandomState(33)
+        ns = rng.randint(2, 120, size=20).astype(np.int32)
+        fo = rng.choice([1, 2, 3, 4], size=20).astype(np.int32)
+        arrays = klat_amd.synth(1234, ns, fo)
+    U = len(arrays["state_off"]) - 1
+    nf = arrays["state_time"][arrays["state_off"][1:] - 1].astype(np.int32)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.25, 0.0, arc_posteriors=False)
+    off, rec = b.segment_index()
+    foff, lab, lp = b.frame_post(nf)
+    b.close()
+    fb = np.concatenate([[0], np.cumsum(nf)])
+    checked = 0
+    for u in range(U):
+        want = [dict() for _ in range(int(nf[u]))]
+        for r in rec[off[u]:off[u + 1]]:
+            for k in range(max(int(r["t0"]), 0), min(int(r["t1"]), int(nf[u]))):
+                w = int(r["label"])
+                want[k][w] = _log_add(want[k][w], float(r["logp"])) if w in want[k] else float(r["logp"])
+        for k in range(int(nf[u])):
+            e0, e1 = int(foff[fb[u] + k]), int(foff[fb[u] + k + 1])
+            got = {int(lab[i]): float(lp[i]) for i in range(e0, e1)}
+            assert sorted(got) == sorted(want[k]), (u, k)
+            for w, v in got.items():
+                assert abs(v - want[k][w]) <= 2e-5 * max(1.0, abs(v)), (u, k, w, v, want[k][w])
+                checked += 1
+            vals = [float(lp[i]) for i in range(e0, e1)]
+            assert all(vals[i] >= vals[i + 1] for i in range(len(vals) - 1))
+    assert checked > 0
