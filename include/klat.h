@@ -68,6 +68,25 @@ typedef struct {
   const int32_t* state_time;    /* [S]  CompactLatticeStateTimes; may be NULL if no accumulator is used */
 } klat_batch_desc;
 
+/* The same batch without what a CompactLattice does not hold: it is an acceptor (ilabel == olabel: one
+ * label array), the source of an arc is implied by the arcs' grouping (out_degree per state), and the arc's
+ * span dst - src fits a byte on every shape of BASELINE.json.  13 B per arc + 16 B per state cross PCIe
+ * instead of 28 + 12; src / dst / olabel are rebuilt on the device.  A batch with a longer arc, or with
+ * ilabel != olabel (the padded lattices of lattice-best-path2), takes klat_batch_desc. */
+typedef struct {
+  int32_t num_lattices;
+  const int64_t* state_off;     /* [num_lattices+1] host */
+  const int64_t* arc_off;       /* [num_lattices+1] host */
+  const int32_t* out_degree;    /* [S] arcs leaving every state; the arcs follow in state order */
+  const uint8_t* span;          /* [A] dst - src, 1 .. 255 */
+  const int32_t* label;         /* [A] ilabel == olabel */
+  const float* graph;           /* [A] */
+  const float* acoustic;        /* [A] */
+  const float* final_graph;     /* [S] */
+  const float* final_acoustic;  /* [S] */
+  const int32_t* state_time;    /* [S] or NULL */
+} klat_batch_desc_compact;
+
 /* Options of the three tools that reach the sweep. */
 typedef struct {
   float graph_scale;        /* --graph-scale       default 1.0 */
@@ -139,6 +158,10 @@ void klat_host_free(void* ptr);
  * preprocessing time", kwsbin2/lattice-word-index-segment.cc:140-141). */
 int klat_batch_create(klat_ctx* ctx, const klat_batch_desc* desc, const klat_pack_options* opt,
                       klat_batch** out);
+/* The same from the compact descriptor (host or device pointers); KLAT_ERR_INVALID_ARG if the out-degrees
+ * of a lattice do not add up to its arcs. */
+int klat_batch_create_compact(klat_ctx* ctx, const klat_batch_desc_compact* desc, const klat_pack_options* opt,
+                              klat_batch** out);
 void klat_batch_destroy(klat_batch* batch);
 int klat_batch_get_info(const klat_batch* batch, klat_batch_info* info);
 

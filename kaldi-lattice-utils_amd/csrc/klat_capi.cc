@@ -600,6 +600,62 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   return KLAT_OK;
 }
 
+int klat_batch_create_compact(klat_ctx* c, const klat_batch_desc_compact* d, const klat_pack_options* opt, klat_batch** out) {
+  if (!c || !d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  const int64_t U = d->num_lattices;
+  if (U < 0 || (U > 0 && (!d->state_off || !d->arc_off))) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: null offsets");
+  const int64_t S = U ? d->state_off[U] : 0, A = U ? d->arc_off[U] : 0;
+  if (A > 0 && (!d->span || !d->label || !d->graph || !d->acoustic)) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: null arc arrays");
+  if (S > 0 && (!d->out_degree || !d->final_graph || !d->final_acoustic)) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: null state arrays");
+  KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);
+  // the compact arrays go up, src / dst are rebuilt on the device, and the full descriptor -- device
+  // pointers -- takes the ordinary path (its copies are device to device)
+  DevBuf<int32_t> deg, label, src, dst, status, time;
+  DevBuf<uint8_t> span;
+  DevBuf<float> graph, acoustic, fg, fa;
+  const int32_t zero = 0;
+  int rc;
+  if ((rc = deg.upload(d->out_degree, (size_t)S, c->stream)) || (rc = span.upload(d->span, (size_t)A, c->stream)) ||
+      (rc = label.upload(d->label, (size_t)A, c->stream)) || (rc = graph.upload(d->graph, (size_t)A, c->stream)) ||
+      (rc = acoustic.upload(d->acoustic, (size_t)A, c->stream)) || (rc = fg.upload(d->final_graph, (size_t)S, c->stream)) ||
+      (rc = fa.upload(d->final_acoustic, (size_t)S, c->stream)) || (rc = src.alloc((size_t)A)) || (rc = dst.alloc((size_t)A)) ||
+      (rc = status.upload(&zero, 1, c->stream)) || (d->state_time && (rc = time.upload(d->state_time, (size_t)S, c->stream))))
+    return rc;
+  DevBuf<int64_t> so, ao;
+  if ((rc = so.upload(d->state_off, (size_t)U + 1, c->stream)) || (rc = ao.upload(d->arc_off, (size_t)U + 1, c->stream))) return rc;
+  ExpandArgs ea;
+  ea.state_off = so.p;
+  ea.arc_off = ao.p;
+  ea.out_degree = deg.p;
+  ea.span = span.p;
+  ea.src = src.p;
+  ea.dst = dst.p;
+  ea.status = status.p;
+  KLAT_HIP(launch_expand_compact(ea, (int)U, c->stream));
+  int32_t h_status = 0;
+  KLAT_HIP(hipMemcpyAsync(&h_status, status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipStreamSynchronize(c->stream));
+  if (h_status != 0)
+    return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: the out-degrees of lattice " + std::to_string(h_status - 1) + " do not add up to its arcs");
+  klat_batch_desc full;
+  std::memset(&full, 0, sizeof(full));
+  full.num_lattices = d->num_lattices;
+  full.state_off = d->state_off;
+  full.arc_off = d->arc_off;
+  full.src = src.p;
+  full.dst = dst.p;
+  full.ilabel = label.p;
+  full.olabel = label.p;
+  full.graph = graph.p;
+  full.acoustic = acoustic.p;
+  full.final_graph = fg.p;
+  full.final_acoustic = fa.p;
+  full.state_time = d->state_time ? time.p : nullptr;
+  return klat_batch_create(c, &full, opt, out);
+}
+
 void klat_batch_destroy(klat_batch* b) {
   if (!b) return;
   klat_ctx* c = b->ctx;

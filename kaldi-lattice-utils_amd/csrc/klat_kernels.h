@@ -110,6 +110,15 @@ struct PosteriorPrepArgs {
   int32_t* item_src;    // [items]
   int32_t* overflow;    // [1] set when a step does not fit a byte
 };
+// klat_batch_desc_compact -> src / dst of every arc (one workgroup per lattice); status[0] = 1 + the first
+// lattice whose out-degrees do not add up to its arcs
+struct ExpandArgs {
+  const int64_t* state_off; const int64_t* arc_off;
+  const int32_t* out_degree; const uint8_t* span;
+  int32_t* src; int32_t* dst;
+  int32_t* status;
+};
+hipError_t launch_expand_compact(const ExpandArgs& a, int num_lattices, hipStream_t stream);
 hipError_t launch_posterior_prep(const PosteriorPrepArgs& a, int num_items, hipStream_t stream);
 
 // Tropical twin: the Viterbi costs come from the sweep kernel's TROPICAL instantiation

@@ -196,6 +196,50 @@ void fill_ln_table(LnTabEntry* t) {
   }
 }
 
+// The arcs of a compact descriptor: state s owns the arcs [row[s], row[s + 1]), row = prefix sums of the
+// out-degrees; src = s, dst = s + span.
+__global__ __launch_bounds__(256) void expand_compact_kernel(ExpandArgs a) {
+  __shared__ int sh[4];
+  __shared__ int carry_sh;
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
+  const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
+  int carry = 0;
+  for (int base = 0; base < S; base += 256) {
+    const int s = base + tid;
+    const int deg = s < S ? a.out_degree[s0 + s] : 0;
+    int incl = deg;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    int off = carry, tot = 0;
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) off += sh[w];
+      tot += sh[w];
+    }
+    const int first = off + incl - deg;
+    if (s < S && deg >= 0 && first + deg <= A)
+      for (int i = first; i < first + deg; ++i) {
+        a.src[a0 + i] = s;
+        a.dst[a0 + i] = s + (int)a.span[a0 + i];
+      }
+    carry += tot;
+  }
+  if (tid == 0) carry_sh = carry;
+  __syncthreads();
+  if (tid == 0 && carry_sh != A) atomicCAS(&a.status[0], 0, u + 1);
+}
+
+hipError_t launch_expand_compact(const ExpandArgs& a, int num_lattices, hipStream_t stream) {
+  if (num_lattices <= 0) return hipSuccess;
+  hipLaunchKernelGGL(expand_compact_kernel, dim3(num_lattices), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_totals(const TotalsArgs& a, hipStream_t stream) {
   if (a.num_lattices <= 0) return hipSuccess;
   hipLaunchKernelGGL(totals_kernel, dim3((a.num_lattices + 255) / 256), dim3(256), 0, stream, a);

@@ -33,6 +33,34 @@ class BatchDesc(C.Structure):
                 ("state_time", C.c_void_p)]
 
 
+class BatchDescCompact(C.Structure):
+    _fields_ = [("num_lattices", C.c_int32), ("state_off", C.c_void_p), ("arc_off", C.c_void_p),
+                ("out_degree", C.c_void_p), ("span", C.c_void_p), ("label", C.c_void_p),
+                ("graph", C.c_void_p), ("acoustic", C.c_void_p), ("final_graph", C.c_void_p),
+                ("final_acoustic", C.c_void_p), ("state_time", C.c_void_p)]
+
+
+COMPACT_FIELDS = [("state_off", np.int64), ("arc_off", np.int64), ("out_degree", np.int32), ("span", np.uint8),
+                  ("label", np.int32), ("graph", np.float32), ("acoustic", np.float32), ("final_graph", np.float32),
+                  ("final_acoustic", np.float32), ("state_time", np.int32)]
+
+
+def compact_arrays(arrays):
+    """klat_batch_desc arrays -> klat_batch_desc_compact arrays (an acceptor whose arcs span at most 255
+    states), or None if the batch does not fit that form."""
+    span = arrays["dst"].astype(np.int64) - arrays["src"].astype(np.int64)
+    if len(span) and (span.min() < 1 or span.max() > 255 or not np.array_equal(arrays["ilabel"], arrays["olabel"])):
+        return None
+    S = int(arrays["state_off"][-1])
+    gsrc = arrays["src"].astype(np.int64) + np.repeat(arrays["state_off"][:-1], np.diff(arrays["arc_off"]))
+    out = {"state_off": arrays["state_off"], "arc_off": arrays["arc_off"], "out_degree": np.bincount(gsrc, minlength=S).astype(np.int32),
+           "span": span.astype(np.uint8), "label": arrays["ilabel"], "graph": arrays["graph"], "acoustic": arrays["acoustic"],
+           "final_graph": arrays["final_graph"], "final_acoustic": arrays["final_acoustic"]}
+    if arrays.get("state_time") is not None:
+        out["state_time"] = arrays["state_time"]
+    return out
+
+
 class Scales(C.Structure):
     _fields_ = [("graph_scale", C.c_float), ("acoustic_scale", C.c_float),
                 ("insertion_penalty", C.c_float)]
@@ -245,6 +273,31 @@ class Batch:
         opt = PackOptions(lanes_per_lattice, ring_slots, host_threads)
         self.h = C.c_void_p()
         _check(lib().klat_batch_create(ctx.h, C.byref(self.desc), C.byref(opt), C.byref(self.h)))
+
+    @classmethod
+    def from_compact(cls, ctx, compact, lanes_per_lattice=0, ring_slots=0, host_threads=0):
+        """klat_batch_create_compact: `compact` as compact_arrays() returns it."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _live.add(self)
+        d, keep = BatchDescCompact(), {}
+        d.num_lattices = len(compact["state_off"]) - 1
+        for name, dt in COMPACT_FIELDS:
+            a = compact.get(name)
+            if a is None:
+                setattr(d, name, None)
+                continue
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep[name] = a
+            setattr(d, name, a.ctypes.data)
+        self.desc, self._keep = d, keep
+        self.U = d.num_lattices
+        self.S = int(keep["state_off"][-1]) if self.U else 0
+        self.A = int(keep["arc_off"][-1]) if self.U else 0
+        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads)
+        _check(lib().klat_batch_create_compact(ctx.h, C.byref(d), C.byref(opt), C.byref(self.h)))
+        return self
 
     def info(self):
         i = BatchInfo()
