@@ -48,7 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_hbm_traffic.json")  # PMC passes of this round's kernels
+TRAFFIC_PROFILE = os.path.join("profiles", "r03_hbm_traffic.json")  # PMC passes of this round's kernels
 SCALES = (1.0, 0.1, 0.0)
 
 
