@@ -137,7 +137,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     int64_t n_small = 0, n_medium = 0, n_large = 0;
     for (int64_t u = 0; u < b->U; ++u) {
       const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
-      (arcs <= kHashMaxArcs / 2 ? n_small : arcs <= kHashMaxArcs ? n_medium : n_large)++;
+      (arcs <= kHashMaxArcs / 2 ? n_small : arcs < kHashMaxArcs ? n_medium : n_large)++;  // (16 384 arcs exactly: a table entry {fingerprint all ones, arc 16 383} would equal the empty marker)
     }
     radix = radix && n_small + n_medium > 0 && b->A > 0;
     st.cached_mode = st.dense_mode = 0;
@@ -182,11 +182,11 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
         KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 14, c->stream));
       }
       if (n_medium > 0) {
-        a.min_arcs = kHashMaxArcs / 2, a.max_arcs = kHashMaxArcs;
+        a.min_arcs = kHashMaxArcs / 2, a.max_arcs = kHashMaxArcs - 1;
         KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 15, c->stream));
       }
       if (n_large > 0) {
-        a.min_arcs = kHashMaxArcs, a.max_arcs = 0x7FFFFFFF;
+        a.min_arcs = kHashMaxArcs - 1, a.max_arcs = 0x7FFFFFFF;
         KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
       }
       a.min_arcs = -1, a.max_arcs = 0x7FFFFFFF;
@@ -525,7 +525,8 @@ int klat_nbest(klat_batch* b, const float* arc_cost, int32_t k, int32_t max_labe
   int64_t max_states = 1;
   for (int64_t u = 0; u < b->U; ++u) {
     max_states = std::max(max_states, b->h_state_off[u + 1] - b->h_state_off[u]);
-    if (b->h_arc_off[u + 1] - b->h_arc_off[u] >= (int64_t)1 << 25 || b->h_state_off[u + 1] - b->h_state_off[u] >= (int64_t)1 << 25)
+    // (arc 2^25 - 1 with rank 127 would be the back pointer's "none")
+    if (b->h_arc_off[u + 1] - b->h_arc_off[u] >= ((int64_t)1 << 25) - 1 || b->h_state_off[u + 1] - b->h_state_off[u] >= (int64_t)1 << 25)
       return set_error(KLAT_ERR_INVALID_ARG, "klat_nbest: lattice too large for the 25-bit back pointers");
   }
   // persistent one-wave workgroups, each with [max_states][128] keys of scratch; at most 8 GiB of it
