@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 TRAFFIC_PROFILE = os.path.join("profiles", "r03_hbm_traffic.json")  # PMC passes of this round's kernels
 SCALES = (1.0, 0.1, 0.0)
+FUSE = SCALES  # klat_pack_options.fuse_scales of every batch of the run (--no-fuse: None): 10-byte stream slots
 
 
 def cpu_model():
@@ -161,7 +162,7 @@ def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=1
     of few lattices that are far wider than deep runs on the level path (klat_level.hip); for such
     a batch the time through the streams (lanes fixed by the caller) is reported beside it."""
     arrays = klat_amd.synth(seed, ns, fo, host_threads=host_threads, wide=wide)
-    b = klat_amd.Batch(ctx, arrays, host_threads=host_threads, lanes_per_lattice=lanes)
+    b = klat_amd.Batch(ctx, arrays, host_threads=host_threads, lanes_per_lattice=lanes, fuse_scales=FUSE)
     info = b.info()
     depth = b.topological_depth()
     for _ in range(warm):
@@ -250,7 +251,7 @@ def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
     rows = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        b = klat_amd.Batch(ctx, dev)
+        b = klat_amd.Batch(ctx, dev, fuse_scales=FUSE)
         t1 = time.perf_counter()
         b.forward_backward(*SCALES, arc_posteriors=False)  # what the tools call: sweep + totals, no per-arc pass
         ctx.sync()
@@ -320,7 +321,7 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t_gen
     t0 = time.perf_counter()
-    b = klat_amd.Batch(ctx, dev, host_threads=host_threads)
+    b = klat_amd.Batch(ctx, dev, host_threads=host_threads, fuse_scales=FUSE)
     create_s = time.perf_counter() - t0
     A = b.A
     for _ in range(3):
@@ -474,10 +475,14 @@ def main():
     ap.add_argument("--no-shapes", action="store_true")
     ap.add_argument("--no-accumulate", action="store_true")
     ap.add_argument("--no-one-shot", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="generic 12-byte stream slots (the scales stay kernel arguments)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg on BASELINE configs[3]")
     ap.add_argument("--strong-lattices", type=int, default=C4["lattices"], help="lattices of the strong-scaling list (default: configs[3] whole)")
     args = ap.parse_args()
 
+    global FUSE
+    if args.no_fuse:
+        FUSE = None
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -511,7 +516,7 @@ def main():
     ctx = klat_amd.Ctx(local_rank)
     t0 = time.perf_counter()
     batch = klat_amd.Batch(ctx, arrays, lanes_per_lattice=args.lanes_per_lattice, ring_slots=args.ring_slots,
-                           host_threads=host_threads)
+                           host_threads=host_threads, fuse_scales=FUSE)
     pack_s = time.perf_counter() - t0
     info = batch.info()
     A, S = info["num_arcs"], info["num_states"]
@@ -582,6 +587,8 @@ def main():
         value = world * A * args.steps / elapsed
         sweep_med = median(sweep_ms)
         # algorithmic bytes of the sweep launch (SURVEY.md 8d "fb-only"): 32 B/arc + 32 B/state
+        # (with fused scales the stream slot is 10 bytes, not 12: the ALGORITHMIC figure of SURVEY.md 8d stays the
+        # denominator-independent 32 B per arc, so a faster launch shows as a higher fraction)
         sweep_bytes = 32.0 * A + 32.0 * S
         achieved = sweep_bytes / (sweep_med * 1e-3) / 1e9
         step_bytes = 56.0 * A + 48.0 * S  # fb + arc posterior: 72 B/arc at fanout 3
@@ -597,7 +604,8 @@ def main():
                        "lattices_per_gpu": U, "states": args.states, "fanout": args.fanout,
                        "arcs_per_gpu": A, "lanes_per_lattice": info["lanes_per_lattice"],
                        "ring_slots": info["ring_slots"], "sweep_waves": info["num_jobs"],
-                       "topological_depth": args.states, "sharding": "utterances across ranks, no data-path collective"},
+                       "topological_depth": args.states, "sharding": "utterances across ranks, no data-path collective",
+                       "fused_scales": FUSE is not None, "stream_slot_bytes": 10 if FUSE is not None else 12},
             "roofline": {"bound": "hbm", "kernel": "klat::sweep_kernel (forward+backward lockstep sweep)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -635,7 +643,7 @@ def main():
 
         post = np.empty(A, np.float64)
         ab = (np.empty(S, np.float64), np.empty(S, np.float64))
-        sec = boundary(lambda: klat_amd.Batch(ctx, arrays, host_threads=host_threads), post, ab)
+        sec = boundary(lambda: klat_amd.Batch(ctx, arrays, host_threads=host_threads, fuse_scales=FUSE), post, ab)
         out["boundary"] = {"what": "host CSR arrays in, host alpha/beta/arc posteriors out, one batch after the other "
                                    "(H2D + packing + sweep + D2H; PCIe-bound)", "seconds_per_batch": sec,
                            "arcs_per_s": A / sec, "h2d_bytes": int(sum(v.nbytes for v in arrays.values())),

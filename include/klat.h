@@ -100,6 +100,12 @@ typedef struct {
                                 fanout and length (lattices of equal G form one layout class) */
   int32_t ring_slots;        /* W, power of two in [8,1024] with W * (64/G) <= 4032; 0 = choose from the batch */
   int32_t host_threads;      /* threads used by the host packer; 0 = hardware concurrency */
+  /* NULL, or the scales every sweep of this batch will use: the packer then applies ScaleLattice /
+   * AddWordInsPen itself (the same float roundings) and stores a term's cost as a float and a 16-bit
+   * residual -- 10 bytes per stream slot instead of 12, one sixth less for the sweep to read, the cost exact
+   * to 2^-40 of the batch's largest.  klat_forward_backward / klat_viterbi with other scales then return
+   * KLAT_ERR_STATE.  The tools know their scales before they read a lattice and set this. */
+  const klat_scales* fuse_scales;
 } klat_pack_options;
 
 typedef struct {

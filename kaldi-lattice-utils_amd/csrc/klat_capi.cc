@@ -103,6 +103,8 @@ static int read_timings(klat_ctx* c, int64_t step, klat_timings* t) {
 
 extern "C" {
 
+static ScaleParams make_scale_params(const klat_scales& s);
+
 const char* klat_last_error(void) { return g_last_error.c_str(); }
 const char* klat_version(void) { return "klat 0.1 (gfx950)"; }
 
@@ -221,7 +223,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   if (!c || !d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
-  klat_pack_options o = {0, 0, 0};
+  klat_pack_options o = {0, 0, 0, nullptr};
   if (opt) o = *opt;
   // The streams are built on the device from the CSR arrays (klat_pack_device.hip); the host
   // packer (same streams, bit for bit) remains behind klat_pack_host and KLAT_HOST_PACK=1.
@@ -237,6 +239,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     if (d->state_off[u + 1] < d->state_off[u] || d->arc_off[u + 1] < d->arc_off[u])
       return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc: offsets of lattice " + std::to_string(u) + " decrease");
   const int64_t S_tot = U ? d->state_off[U] : 0, A_tot = U ? d->arc_off[U] : 0;
+  if (host_pack) o.fuse_scales = nullptr;
   if (host_pack) {
     // the host packer reads the arc and state arrays on the host
     for (const void* ptr : {(const void*)d->src, (const void*)d->dst, (const void*)d->ilabel, (const void*)d->graph,
@@ -376,9 +379,27 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       KLAT_HIP_B(hipMemsetAsync(d_prof.p, 0, 8 * sizeof(unsigned long long), c->stream));
       pa.prof = d_prof.p;
     }
+    // fused costs: the batch's largest finite cost decides the unit of the 16-bit residuals
+    DevBuf<unsigned long long> d_maxcost;
+    unsigned long long h_maxcost = 0;
+    if (o.fuse_scales) {
+      b->fused = true;
+      b->fuse_scales = *o.fuse_scales;
+      pa.fused = 1;
+      pa.fsp = make_scale_params(b->fuse_scales);
+      if ((rc = d_maxcost.upload(&h_maxcost, 1, c->stream))) {
+        klat_batch_destroy(b);
+        return rc;
+      }
+      pa.maxcost = d_maxcost.p;
+    }
     hipEvent_t* pev = b->pack_ev;
     for (int i = 0; i < klat_batch::kPackEvents; ++i) KLAT_HIP_B(hipEventCreate(&pev[i]));
     KLAT_HIP_B(hipEventRecord(pev[0], c->stream));
+    if (b->fused) {
+      KLAT_HIP_B(launch_pack_maxcost(pa, A_tot, S_tot, c->stream));
+      KLAT_HIP_B(hipMemcpyAsync(&h_maxcost, d_maxcost.p, sizeof(h_maxcost), hipMemcpyDeviceToHost, c->stream));
+    }
     hipError_t he = launch_pack_count(pa, (int)U, class_need, any_global, c->stream);
     if (he == hipSuccess) he = hipEventRecord(pev[1], c->stream);
     if (he == hipSuccess && U > 0)
@@ -491,7 +512,20 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     const size_t nslots = (size_t)chunk_total * kChunkRounds;  // chunk_total counts 16-byte units
     AL(sw, nslots);
     AL(sg, nslots);
-    AL(sa, nslots);
+    if (b->fused) {
+      AL(sl, nslots);
+      // a cost below 2^E is a float (24 bits: an ulp of at most 2^(E-24)) plus a residual of at most half
+      // an ulp, kept as a 16-bit integer in units of 2^(E-40)
+      double maxc;
+      std::memcpy(&maxc, &h_maxcost, sizeof(maxc));
+      int e = 0;
+      (void)std::frexp(std::max(maxc, 1.0), &e);
+      b->lo_unit = std::ldexp(1.0, e - 40);
+      pa.sl = b->sl.p;
+      pa.lo_inv_unit = 1.0 / b->lo_unit;
+    } else {
+      AL(sa, nslots);
+    }
     UP(jobs, P.jobs.data(), P.jobs.size());
     UP(lanes, P.lanes.data(), P.lanes.size());
     if ((rc = d_entries.upload(entries.data(), entries.size(), c->stream)) || (rc = d_lat_g.upload(lat_g.data(), lat_g.size(), c->stream))) {
@@ -717,8 +751,6 @@ int klat_batch_topological_depth(klat_batch* b, int32_t* depth) {
   return KLAT_OK;
 }
 
-static ScaleParams make_scale_params(const klat_scales& s);
-
 // The arc posteriors are made when somebody asks for them: klat_forward_backward without
 // KLAT_FB_NO_ARC_POSTERIORS, or klat_get_arc_logpost after a sweep that left them out.  The first pass
 // over a batch allocates `logpost` and builds the one-byte source steps and arc spans of the arcs.
@@ -807,6 +839,14 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
   sa.sc = make_stream_cost(sp);
   sa.ring_slots = 0;  // per layout class below
   sa.far_prefetch = 0;
+  if (b->fused) {
+    if (s.graph_scale != b->fuse_scales.graph_scale || s.acoustic_scale != b->fuse_scales.acoustic_scale ||
+        s.insertion_penalty != b->fuse_scales.insertion_penalty)
+      return set_error(KLAT_ERR_STATE, "this batch was created with klat_pack_options.fuse_scales: its streams hold the costs under those scales only");
+    sa.sl = b->sl.p;
+    sa.lo_unit = b->lo_unit;
+    sa.fused = 1;
+  }
 
   const bool want_post = (flags & KLAT_FB_NO_ARC_POSTERIORS) == 0;
   if (flags & ~(uint32_t)KLAT_FB_NO_ARC_POSTERIORS) return set_error(KLAT_ERR_INVALID_ARG, "klat_forward_backward_ex: unknown flag");
@@ -905,6 +945,14 @@ int klat_viterbi(klat_batch* b, const klat_scales* sc) {
   va.sc = make_stream_cost(va.sp);
   va.ring_slots = 0;
   va.far_prefetch = 0;
+  if (b->fused) {
+    if (s.graph_scale != b->fuse_scales.graph_scale || s.acoustic_scale != b->fuse_scales.acoustic_scale ||
+        s.insertion_penalty != b->fuse_scales.insertion_penalty)
+      return set_error(KLAT_ERR_STATE, "this batch was created with klat_pack_options.fuse_scales: its streams hold the costs under those scales only");
+    va.sl = b->sl.p;
+    va.lo_unit = b->lo_unit;
+    va.fused = 1;
+  }
   if (b->num_level > 0) KLAT_HIP(launch_level(b, b->fwd_cost.p, b->bwd_cost.p, va.sp, true));
   rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
     SweepArgs ca = va;
@@ -994,6 +1042,7 @@ int klat_batch_get_streams(klat_batch* b, int32_t* sw, float* sg, float* sa) {
   PoolScope pool_scope(&b->ctx->pool);
   const size_t n = (size_t)(b->info.fwd_slots + b->info.bwd_slots);
   if (n == 0) return KLAT_OK;
+  if (b->fused && sa) return set_error(KLAT_ERR_STATE, "a batch with fused costs has no acoustic stream");
   if (sw) KLAT_HIP(hipMemcpyAsync(sw, b->sw.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
   if (sg) KLAT_HIP(hipMemcpyAsync(sg, b->sg.p, n * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
   if (sa) KLAT_HIP(hipMemcpyAsync(sa, b->sa.p, n * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
@@ -1111,8 +1160,9 @@ struct klat_packed {
 int klat_pack_host(const klat_batch_desc* d, const klat_pack_options* opt, klat_packed** out) {
   if (!d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
-  klat_pack_options o = {0, 0, 0};
+  klat_pack_options o = {0, 0, 0, nullptr};
   if (opt) o = *opt;
+  o.fuse_scales = nullptr;  // (the host packer defines the generic stream format)
   klat_packed* p = new (std::nothrow) klat_packed();
   if (!p) return set_error(KLAT_ERR_OOM, "host allocation failed");
   std::string err;

@@ -242,6 +242,11 @@ struct klat_batch {
   // lockstep streams
   klat::DevBuf<int32_t> sw;
   klat::DevBuf<float> sg, sa;
+  // fused costs (klat_pack_options.fuse_scales): sg = (float)cost, sl = the residual in units of lo_unit, no sa
+  bool fused = false;
+  klat_scales fuse_scales = {1.f, 1.f, 0.f};
+  double lo_unit = 0.0;
+  klat::DevBuf<int16_t> sl;
   klat::DevBuf<klat::SweepJob> jobs;
   klat::DevBuf<klat::LaneInfo> lanes;
   klat::DevBuf<klat::PostItem> items;

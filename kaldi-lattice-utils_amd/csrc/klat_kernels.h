@@ -66,6 +66,10 @@ struct SweepArgs {
   int32_t ring_slots;
   int32_t far_prefetch;  // the jobs hold sources older than the ring: prefetch their values (W >= 32)
   int32_t deep_prefetch = 0;  // the batch's workgroups fit six per CU: the fast sweep may hold 8 chunks per lane in registers
+  // fused costs (klat_pack_options.fuse_scales): sg = (float)cost, sl = its residual in units of lo_unit, sa unused
+  const int16_t* sl = nullptr;
+  double lo_unit = 0.0;
+  int32_t fused = 0;
 };
 
 struct TotalsArgs {

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "klat_device.h"
+#include "klat_kernels.h"
 
 namespace klat {
 
@@ -49,6 +50,12 @@ struct PackDevArgs {
   const SweepJob* jobs;
   const LaneInfo* lanes;
   int32_t* sw; float* sg; float* sa;
+  // fused costs (klat_pack_options.fuse_scales): sg holds (float)cost, sl the residual in units of lo_unit
+  int16_t* sl;
+  int32_t fused;
+  ScaleParams fsp;
+  double lo_inv_unit;
+  unsigned long long* maxcost;  // [1] bits of the largest finite |cost| of the batch (pack_maxcost_kernel)
   unsigned long long* prof;  // [8] or null: phase cycles of the count pass (KLAT_PACK_PROFILE=1)
 };
 
@@ -56,6 +63,8 @@ struct PackDevArgs {
 // any_global: some lattice is above the last class
 hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, const int class_need[kPackCountClasses], bool any_global,
                              hipStream_t stream);
+// the largest finite cost of the batch under a.fsp (arcs and final weights)
+hipError_t launch_pack_maxcost(const PackDevArgs& a, int64_t num_arcs, int64_t num_states, hipStream_t stream);
 hipError_t launch_pack_rounds(const PackDevArgs& a, int num_lattices, hipStream_t stream);
 // max_lpw: the most lattices any job holds (64 / its lanes per lattice)
 hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, int max_lpw, hipStream_t stream);

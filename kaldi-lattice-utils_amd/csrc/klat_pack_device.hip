@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "klat_device.h"
+#include "klat_math.h"
 #include "klat_pack_device.h"
 
 namespace klat {
@@ -475,6 +476,22 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
   }
 }
 
+// Fused costs: the largest finite cost of the batch (the residuals' unit follows from it).  Positive doubles
+// order like their bit patterns.
+__global__ __launch_bounds__(kT) void pack_maxcost_kernel(PackDevArgs a, int64_t num_arcs, int64_t num_states) {
+  double m = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < num_arcs; i += (int64_t)gridDim.x * kT) {
+    const double c = fabs(arc_cost(a.graph[i], a.acoustic[i], a.fsp.penalized ? a.ilabel[i] != 0 : false, a.fsp));
+    if (c < 1.0e30) m = fmax(m, c);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < num_states; i += (int64_t)gridDim.x * kT) {
+    const double c = fabs(arc_cost(a.final_graph[i], a.final_acoustic[i], false, a.fsp));
+    if (c < 1.0e30) m = fmax(m, c);
+  }
+  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(a.maxcost, (unsigned long long)__double_as_longlong(m));
+}
+
 __global__ __launch_bounds__(kT) void pack_rounds_kernel(PackDevArgs a) {
   __shared__ int sh[kT / 64];
   const int u = blockIdx.x, tid = threadIdx.x;
@@ -657,8 +674,19 @@ __global__ __launch_bounds__(kTF) void pack_fill_kernel(PackDevArgs a, int max_l
     auto put = [&](int k, int rr, int sub, uint32_t w, float g, float ac) {
       const int i = ((((rr - R0) >> 2) * row_units + sub * LPW + k) << 2) + ((rr - R0) & 3);
       tw[i] = w;
-      tg[i] = g;
-      ta[i] = ac;
+      if (a.fused) {
+        // the cost as the reference forms it (ScaleLattice, AddWordInsPen, ConvertToCost), kept as a float and
+        // a 16-bit residual in units of the batch's lo_unit
+        const double c = arc_cost(g, ac, (w & kWord) != 0, a.fsp);
+        const float hi = (float)c;
+        int n = 0;
+        if (c < 1.0e30 && c > -1.0e30) n = max(-32767, min(32767, (int)rint((c - (double)hi) * a.lo_inv_unit)));
+        tg[i] = hi;
+        ta[i] = __int_as_float(n);
+      } else {
+        tg[i] = g;
+        ta[i] = ac;
+      }
     };
     // ---- one thread per arc term
     {
@@ -748,14 +776,25 @@ __global__ __launch_bounds__(kTF) void pack_fill_kernel(PackDevArgs a, int max_l
       const int64_t base = (job.chunk_off + (int64_t)(R0 >> 2) * row_units) << 2;  // first slot of the tile
       uint4* gw = reinterpret_cast<uint4*>(a.sw + base);
       float4* gg = reinterpret_cast<float4*>(a.sg + base);
-      float4* ga = reinterpret_cast<float4*>(a.sa + base);
       const uint4* lw = reinterpret_cast<const uint4*>(tw);
       const float4* lg4 = reinterpret_cast<const float4*>(tg);
       const float4* la = reinterpret_cast<const float4*>(ta);
-      for (int i = tid; i < (tile_slots >> 2); i += kTF) {
-        gw[i] = lw[i];
-        gg[i] = lg4[i];
-        ga[i] = la[i];
+      if (a.fused) {  // the residuals as four 16-bit words per unit
+        int2* gl = reinterpret_cast<int2*>(a.sl + base);
+        for (int i = tid; i < (tile_slots >> 2); i += kTF) {
+          gw[i] = lw[i];
+          gg[i] = lg4[i];
+          const float4 r = la[i];
+          const int n0 = __float_as_int(r.x), n1 = __float_as_int(r.y), n2 = __float_as_int(r.z), n3 = __float_as_int(r.w);
+          gl[i] = make_int2((n0 & 0xFFFF) | (n1 << 16), (n2 & 0xFFFF) | (n3 << 16));
+        }
+      } else {
+        float4* ga = reinterpret_cast<float4*>(a.sa + base);
+        for (int i = tid; i < (tile_slots >> 2); i += kTF) {
+          gw[i] = lw[i];
+          gg[i] = lg4[i];
+          ga[i] = la[i];
+        }
       }
     }
     if (tid < LPW) sh_plo[tid] = sh_next[tid];
@@ -782,6 +821,11 @@ hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, const int c
       hipLaunchKernelGGL(pack_count_kernel, dim3(num_lattices), dim3(kTC), (size_t)class_need[c], stream, a,
                          c == 0 ? -1 : kPackCountClassLds[c - 1], kPackCountClassLds[c]);
   if (any_global) hipLaunchKernelGGL(pack_count_global_kernel, dim3(num_lattices), dim3(kT), 0, stream, a, kPackCountMaxLds);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_maxcost(const PackDevArgs& a, int64_t num_arcs, int64_t num_states, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_maxcost_kernel, dim3(2048), dim3(kT), 0, stream, a, num_arcs, num_states);
   return hipGetLastError();
 }
 

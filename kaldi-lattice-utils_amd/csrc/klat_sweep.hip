@@ -224,10 +224,13 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
 
     // cost_mode: 0 = stream_cost(), 1 = arc_cost() (StreamCost::general), 2 = graph scale 1 and no
     // insertion penalty (StreamCost::plain: the usual --acoustic-scale-only call): the graph cost is
-    // the stored float itself, three instructions per term less
+    // the stored float itself, three instructions per term less; 3 = FUSED: the packer applied the scales
+    // (klat_pack_options.fuse_scales), a slot holds (float)cost and a 16-bit residual -- 10 bytes instead of 12
     auto run = [&](auto cost_mode) {
       constexpr bool GENERAL = decltype(cost_mode)::value == 1;
       constexpr bool PLAIN = decltype(cost_mode)::value == 2;
+      constexpr bool FUSED = decltype(cost_mode)::value == 3;
+      const double lo_unit = args.lo_unit;
       const ScaleParams sp = args.sp;
       const StreamCost sc = args.sc;
       // The stream stores the units (16 B = 4 rounds) of the first AL lanes of every lattice only
@@ -244,12 +247,19 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       const int4* __restrict__ sw = reinterpret_cast<const int4*>(args.sw) + job.chunk_off + unit;
       const float4* __restrict__ sg = reinterpret_cast<const float4*>(args.sg) + job.chunk_off + unit;
       const float4* __restrict__ sa = reinterpret_cast<const float4*>(args.sa) + job.chunk_off + unit;
+      const int2* __restrict__ sl = reinterpret_cast<const int2*>(args.sl) + job.chunk_off + unit;
       int4 wb[D];
       float4 gb[D], ab[D];
       auto load_chunk = [&](int j, int64_t cn) {
         wb[j] = sw[cn * row];
         gb[j] = sg[cn * row];
-        ab[j] = sa[cn * row];
+        if (FUSED) {  // four residuals in 8 bytes; handed on as the bit patterns of their integers
+          const int2 l = sl[cn * row];
+          ab[j] = make_float4(__int_as_float((int)(short)(l.x & 0xFFFF)), __int_as_float(l.x >> 16),
+                              __int_as_float((int)(short)(l.y & 0xFFFF)), __int_as_float(l.y >> 16));
+        } else {
+          ab[j] = sa[cn * row];
+        }
       };
 #pragma unroll
       for (int j = 0; j < D; ++j) load_chunk(j, min(j, nchunks - 1));
@@ -260,7 +270,10 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       int out_p0 = 0, out_n = 0, pend_p0 = 0, pend_n = 0;
 
       auto weigh = [&](StagedTerm& t, uint32_t w, float g, float a) {
-        const double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : PLAIN ? (double)g + (double)(sc.as * a) : stream_cost(w, g, a, sc);
+        const double c = FUSED     ? fma((double)__float_as_int(a), lo_unit, (double)g)
+                         : GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp)
+                         : PLAIN   ? (double)g + (double)(sc.as * a)
+                                   : stream_cost(w, g, a, sc);
         if (TROPICAL) {
           t.wm = (c < 1.0e30 && stored) ? c : INFINITY;  // Zero weights, NaN, padding
           t.k = 0;
@@ -284,7 +297,10 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       // v = the source's value when the term is FAR (ignored otherwise)
       auto put_far_v = [&](StagedTerm* dst, uint32_t w, float g, float a, double v) {
         StagedTerm t;
-        double c = GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp) : PLAIN ? (double)g + (double)(sc.as * a) : stream_cost(w, g, a, sc);
+        double c = FUSED     ? fma((double)__float_as_int(a), lo_unit, (double)g)
+                   : GENERAL ? arc_cost(g, a, (w & kWord) != 0, sp)
+                   : PLAIN   ? (double)g + (double)(sc.as * a)
+                             : stream_cost(w, g, a, sc);
         const bool last = (w & kLast) != 0;
         uint32_t ctl = w;
         if (w & kFar) {
@@ -451,7 +467,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
       copy_table();
       copy_store();
     };
-    if (args.sc.general)
+    if (args.fused)
+      run(std::integral_constant<int, 3>());
+    else if (args.sc.general)
       run(std::integral_constant<int, 1>());
     else if (args.sc.plain)
       run(std::integral_constant<int, 2>());

@@ -61,7 +61,7 @@ int main(int argc, char* argv[]) {
     if (po.NumArgs() > 1) transcriptions_writer.reset(new Int32VectorWriter(JobSpecifier(po.GetArg(2), rank, world)));
     if (po.NumArgs() > 2) costs_writer.reset(new BaseFloatWriter(JobSpecifier(po.GetArg(3), rank, world)));
     Context ctx(ranks->device());
-    klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
+    klat_pack_options popt = co.PackOptions();
 
     double total_cost = 0.0;
     int64_t total_frames = 0;

@@ -44,7 +44,7 @@ int main(int argc, char* argv[]) {
     if (beam_ratio <= 0.0f || beam_ratio >= 1.0f) KLAT_ERR("--beam_ratio must be in the open range (0.0, 1.0).");
     CompactLatticeWriter lattice_writer(po.GetArg(2));
     Context ctx(co.device);
-    klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
+    klat_pack_options popt = co.PackOptions();
     const double inf = std::numeric_limits<double>::infinity();
 
     std::vector<std::string> keys;

@@ -51,7 +51,7 @@ int main(int argc, char* argv[]) {
     }
     PosteriorWriter posterior_writer(po.GetArg(2));
     Context ctx(co.device);
-    klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
+    klat_pack_options popt = co.PackOptions();
     const bool scaled = co.acoustic_scale != 1.0f || co.graph_scale != 1.0f;
 
     struct Final {

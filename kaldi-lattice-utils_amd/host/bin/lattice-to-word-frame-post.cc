@@ -35,7 +35,7 @@ int main(int argc, char* argv[]) {
     const int32_t rank = ranks->rank(), world = ranks->world();
     PosteriorWriter posterior_writer(JobSpecifier(po.GetArg(2), rank, world));
     Context ctx(ranks->device());
-    klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
+    klat_pack_options popt = co.PackOptions();
 
     std::vector<std::string> keys;
     std::vector<int32_t> num_frames;

@@ -42,7 +42,7 @@ int main(int argc, char* argv[]) {
 
     UtteranceScoreWriter score_writer(po.GetArg(2));
     Context ctx(co.device);
-    klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
+    klat_pack_options popt = co.PackOptions();
 
     std::vector<std::string> keys;
     std::vector<int64_t> word_off(1, 0);

@@ -435,7 +435,7 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
     if (rank == 0) writer.reset(new Writer(wspecifier));  // only the writing rank opens (and truncates) the output
     Context ctx(ranks.device());
     ranks.InitComm(ctx);
-    klat_pack_options popt = {co.lanes_per_lattice, 0, 0};
+    klat_pack_options popt = co.PackOptions();
     const bool mapped = MappedArchive::Mappable(rspecifier);
     int64_t parsed_lattices = 0, parsed_arcs = 0, seen_lattices = 0;
 

@@ -15,6 +15,7 @@
 namespace klat {
 
 struct CommonOptions {
+ public:
   float acoustic_scale = 1.0f, graph_scale = 1.0f, insertion_penalty = 0.0f;
   int32_t batch_size = 4096;      // lattices per GPU batch
   int32_t max_batch_arcs = 64 << 20;
@@ -30,6 +31,16 @@ struct CommonOptions {
     po->Register("device", &device, "GPU device index.");
     po->Register("lanes-per-lattice", &lanes_per_lattice, "Lanes per lattice of the sweep kernel (0 = choose from the batch).");
   }
+  // The tools know their scales before they read a lattice: the stream packer applies them
+  // (klat_pack_options.fuse_scales: 10-byte stream slots instead of 12).  Valid while this object lives.
+  klat_pack_options PackOptions() const {
+    fuse_ = {graph_scale, acoustic_scale, insertion_penalty};
+    klat_pack_options o = {lanes_per_lattice, 0, 0, &fuse_};
+    return o;
+  }
+
+ private:
+  mutable klat_scales fuse_ = {1.0f, 1.0f, 0.0f};
 };
 
 struct IndexOptions {

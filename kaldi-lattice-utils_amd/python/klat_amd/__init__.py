@@ -68,7 +68,7 @@ class Scales(C.Structure):
 
 class PackOptions(C.Structure):
     _fields_ = [("lanes_per_lattice", C.c_int32), ("ring_slots", C.c_int32),
-                ("host_threads", C.c_int32)]
+                ("host_threads", C.c_int32), ("fuse_scales", C.c_void_p)]
 
 
 class BatchInfo(C.Structure):
@@ -262,7 +262,9 @@ class Ctx:
 
 
 class Batch:
-    def __init__(self, ctx, arrays, lanes_per_lattice=0, ring_slots=0, host_threads=0):
+    def __init__(self, ctx, arrays, lanes_per_lattice=0, ring_slots=0, host_threads=0, fuse_scales=None):
+        """fuse_scales: (graph_scale, acoustic_scale, insertion_penalty) every sweep of the batch will use
+        (klat_pack_options.fuse_scales: 10-byte stream slots), or None."""
         self.ctx = ctx
         self.h = C.c_void_p()
         _live.add(self)
@@ -270,7 +272,8 @@ class Batch:
         self.U = self.desc.num_lattices
         self.S = int(self._keep["state_off"][-1]) if self.U else 0
         self.A = int(self._keep["arc_off"][-1]) if self.U else 0
-        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads)
+        fs = Scales(*fuse_scales) if fuse_scales is not None else None
+        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads, C.addressof(fs) if fs is not None else None)
         self.h = C.c_void_p()
         _check(lib().klat_batch_create(ctx.h, C.byref(self.desc), C.byref(opt), C.byref(self.h)))
 
@@ -295,7 +298,7 @@ class Batch:
         self.U = d.num_lattices
         self.S = int(keep["state_off"][-1]) if self.U else 0
         self.A = int(keep["arc_off"][-1]) if self.U else 0
-        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads)
+        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads, None)
         _check(lib().klat_batch_create_compact(ctx.h, C.byref(d), C.byref(opt), C.byref(self.h)))
         return self
 

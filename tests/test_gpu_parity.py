@@ -378,3 +378,43 @@ def test_compact_descriptor_gives_the_same_batch(ctx):
     with pytest.raises(klat_amd.KlatError) as e:
         klat_amd.Batch.from_compact(ctx, bad)
     assert e.value.code == klat_amd.ERR_INVALID_ARG and "lattice 3" in str(e.value)
+
+
+def test_fused_scales_streams_match_the_generic_ones(ctx):
+    """klat_pack_options.fuse_scales: the packer applies ScaleLattice / AddWordInsPen and the stream holds a
+    term's cost as a float plus a 16-bit residual (10-byte slots, a sixth less for the sweep to read).  The
+    cost is exact to 2^-40 of the batch's largest: alpha / beta / posteriors agree with the generic streams to
+    1e-9, the Viterbi twin likewise, and a sweep under other scales is refused."""
+    rng = np.random.RandomState(5)
+    ns = np.concatenate([[1, 2], rng.randint(2, 500, size=40)]).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4, 6], size=len(ns)).astype(np.int32)
+    arrays = klat_amd.synth(8128, ns, fo)
+    arrays["graph"][::17] = np.inf  # dead arcs stay dead
+    for scales in ((1.0, 0.1, 0.0), (0.7, 0.3, 0.5), (1.0, 1.0, 0.0)):
+        res = []
+        for fuse in (None, scales):
+            b = klat_amd.Batch(ctx, arrays, fuse_scales=fuse)
+            b.forward_backward(*scales)
+            ab, post, tot = b.alpha_beta(), b.arc_logpost(), b.totals()
+            b.viterbi(*scales)
+            res.append((ab, post, tot, b.viterbi_costs(), b.info()))
+            if fuse is not None:
+                with pytest.raises(klat_amd.KlatError) as e:
+                    b.forward_backward(scales[0], scales[1] * 0.5, scales[2])
+                assert e.value.code == klat_amd.ERR_STATE
+                assert b.info()["fwd_slots"] == res[0][4]["fwd_slots"]
+            b.close()
+        (ab0, p0, t0, v0, _), (ab1, p1, t1, v1, _) = res
+        for x, y in ((ab0[0], ab1[0]), (ab0[1], ab1[1]), (p0, p1), (t0[0], t1[0]), (v0[0], v1[0]), (v0[1], v1[1])):
+            fin = np.isfinite(x)
+            assert np.array_equal(fin, np.isfinite(y))
+            assert np.all(np.abs(x[fin] - y[fin]) <= 1e-9 * np.maximum(1.0, np.abs(x[fin])))
+    wa, wb, wt, wthr = _oracle_batch(arrays, 0.7, 0.3, 0.5)
+    b = klat_amd.Batch(ctx, arrays, fuse_scales=(0.7, 0.3, 0.5))
+    b.forward_backward(0.7, 0.3, 0.5)
+    a, be = b.alpha_beta()
+    b.close()
+    fin = np.isfinite(wa)
+    assert np.all(np.abs(a[fin] - wa[fin]) <= 1e-8 * np.maximum(1.0, np.abs(wa[fin])))
+    fin = np.isfinite(wb)
+    assert np.all(np.abs(be[fin] - wb[fin]) <= 1e-8 * np.maximum(1.0, np.abs(wb[fin])))
