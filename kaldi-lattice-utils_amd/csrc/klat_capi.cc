@@ -223,6 +223,17 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   if (!c || !d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
+  const bool host_prof = std::getenv("KLAT_PACK_PROFILE") != nullptr;
+  auto t_last = t_begin;
+  std::string host_stages;
+  auto lap = [&](const char* what) {
+    if (!host_prof) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), " %s %.3f", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    host_stages += buf;
+    t_last = now;
+  };
   klat_pack_options o = {0, 0, 0, nullptr};
   if (opt) o = *opt;
   // The streams are built on the device from the CSR arrays (klat_pack_device.hip); the host
@@ -410,6 +421,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       klat_batch_destroy(b);
       return hip_fail(he, "stream packing (count pass)");
     }
+    lap("uploads+count+wait");
     if (pa.prof) {
       unsigned long long h[8];
       KLAT_HIP_B(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -500,8 +512,10 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     plan_layout(U, d->state_off, d->arc_off, h_rounds.data(), o, &lat_g, on_level.data());
     std::vector<std::vector<int64_t>> job_lats;
     int64_t chunk_total = 0;
+    lap("level");
     rc = build_jobs(U, d->state_off, h_rounds.data(), lat_g, o, &P, &job_lats, &chunk_total, &err);
     if (rc != KLAT_OK) FAIL(rc, err);
+    lap("plan+jobs");
     // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, slot)
     std::vector<PackEntry> entries;
     for (size_t j = 0; j < P.jobs.size(); ++j) {
@@ -552,6 +566,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       klat_batch_destroy(b);
       return hip_fail(he, "stream packing (fill pass)");
     }
+    lap("entries+rounds+fill+wait");
     P.far_terms = h_status[3];
     if (b->num_level > 0) {  // the level streams: the arcs as the level sweep consumes them
       if ((rc = b->lv_stream.alloc((size_t)lv_blocks * kLevelBlockDwords))) {
@@ -629,6 +644,8 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     klat_batch_destroy(b);
     return hip_fail(e, "upload");
   }
+  lap("tail");
+  if (host_prof) std::fprintf(stderr, "klat_batch_create host stages (ms):%s\n", host_stages.c_str());
   b->pack_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   *out = b;
   return KLAT_OK;

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
 import klat_amd
 ctx = klat_amd.Ctx(0)
 a = klat_amd.synth(20260001, np.full(10000, 2000, np.int32), np.full(10000, 3, np.int32), host_threads=16)
-b = klat_amd.Batch(ctx, a, host_threads=16)
+b = klat_amd.Batch(ctx, a, host_threads=16, fuse_scales=(1.0, 0.1, 0.0) if os.environ.get("KLAT_AB_FUSE", "1") == "1" else None)
 for _ in range(300):
     b.forward_backward(1.0, 0.1, 0.0)
 ctx.sync()
