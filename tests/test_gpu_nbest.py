@@ -107,11 +107,11 @@ def test_two_thousand_state_lattices_against_the_oracle_dp(ctx):
 
 def test_config2_shard_nbest_properties(ctx):
     """BASELINE configs[2] is lattice-best-path2 with n-best = 100 on 50 000 lattices of 2 000 states:
-    a quarter of the shard one GPU of eight holds (1 500 lattices, same generator and seed), checked
+    the WHOLE shard one GPU of eight holds (6 250 lattices, same generator and seed; 5.1 GB of paths), checked
     through what does not need the oracle at that size -- 100 paths per lattice, costs in order, the
     best cost equal to the tropical sweep's best cost over the same arc costs, every path's label
     count within the lattice's depth -- and against the oracle's k-best DP on a sample."""
-    U = 1500
+    U = 6250
     arrays = klat_amd.synth(20260002, np.full(U, 2000, np.int32), np.full(U, 3, np.int32), host_threads=8)
     rng = np.random.RandomState(2)
     A = int(arrays["arc_off"][-1])
