@@ -1,0 +1,46 @@
+// klat-archive-scan -- lists the entries of a lattice archive as the --devices tools see them: the
+// archive is mapped and scanned for the entry boundaries without building a lattice
+// (archive-index.h), then every entry is parsed from its byte range.  Prints per entry
+//   key  begin  end  t|b  states  arcs
+// Not one of the reference's tools: test plumbing for the scanner every rank of a multi-GPU run
+// relies on to agree on the entries it does not parse.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../archive-index.h"
+#include "../kaldi-io.h"
+
+int main(int argc, char* argv[]) {
+  try {
+    using namespace klat;
+    ParseOptions po("List the entries of a lattice archive (mapped and scanned in place).\nUsage: klat-archive-scan <lattice-rspecifier>\n");
+    bool parse = true;
+    po.Register("parse", &parse, "Also parse every entry from its byte range and print its states and arcs.");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 1) {
+      po.PrintUsage();
+      exit(1);
+    }
+    if (!MappedArchive::Mappable(po.GetArg(1))) KLAT_ERR("not a plain file: " << po.GetArg(1));
+    MappedArchive archive(po.GetArg(1));
+    int64_t n = 0;
+    while (!archive.Done()) {
+      ArchiveEntry e;
+      archive.ScanNext(&e);
+      long long states = -1, arcs = -1;
+      if (parse) {
+        CompactLattice clat;
+        archive.Read(e, &clat);
+        states = clat.NumStates();
+        arcs = clat.NumArcs();
+      }
+      std::printf("%s %zu %zu %c %lld %lld\n", e.key.c_str(), e.begin, e.end, e.binary ? 'b' : 't', states, arcs);
+      ++n;
+    }
+    KLAT_LOG("Scanned " << n << " entries of " << archive.size() << " bytes.");
+    return 0;
+  } catch (const std::exception& e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}
