@@ -146,7 +146,7 @@ int main(int argc, char* argv[]) {
       batch.Clear();
     };
 
-    RankArchiveReader reader(po.GetArg(1), rank, world);
+    RankArchiveReader reader(po.GetArg(1), rank, world, co.HostThreads(world));
     for (; !reader.Done(); reader.Next()) {
       CompactLattice clat;
       std::vector<int32_t> state_input_length;

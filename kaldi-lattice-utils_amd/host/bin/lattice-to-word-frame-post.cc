@@ -48,7 +48,7 @@ int main(int argc, char* argv[]) {
       batch.Clear();
     };
 
-    RankArchiveReader reader(po.GetArg(1), rank, world);
+    RankArchiveReader reader(po.GetArg(1), rank, world, co.HostThreads(world));
     for (; !reader.Done(); reader.Next()) {
       CompactLattice& clat = reader.Value();
       std::vector<int32_t> times;

@@ -21,6 +21,7 @@
 
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -273,17 +274,19 @@ inline std::string JobSpecifier(const std::string& wspecifier, int32_t rank, int
   return out;
 }
 
-// SequentialCompactLatticeReader look-alike over this rank's share of the archive.
+// SequentialCompactLatticeReader look-alike over this rank's share of the archive.  A plain file is
+// mapped and scanned (also on one GPU); the rank's entries are parsed kChunk at a time on `threads`
+// threads, a chunk ahead of the caller's loop.
 class RankArchiveReader {
  public:
-  RankArchiveReader(const std::string& rspecifier, int32_t rank, int32_t world) {
-    if (world == 1) {
+  RankArchiveReader(const std::string& rspecifier, int32_t rank, int32_t world, int threads = 1) : threads_(threads) {
+    if (!MappedArchive::Mappable(rspecifier)) {
+      if (world > 1)
+        KLAT_ERR("--devices with more than one GPU needs a plain archive file (every rank scans it for the entry boundaries), not "
+                 << rspecifier);
       stream_.reset(new SequentialCompactLatticeReader(rspecifier));
       return;
     }
-    if (!MappedArchive::Mappable(rspecifier))
-      KLAT_ERR("--devices with more than one GPU needs a plain archive file (every rank scans it for the entry boundaries), not "
-               << rspecifier);
     archive_.reset(new MappedArchive(rspecifier));
     std::vector<int64_t> bytes;
     while (!archive_->Done()) {
@@ -296,14 +299,15 @@ class RankArchiveReader {
     pos_ = (size_t)bounds[(size_t)rank];
     end_ = (size_t)bounds[(size_t)rank + 1];
     total_ = entries_.size();
+    chunk_begin_ = chunk_end_ = pos_;
     Load();
   }
   bool Done() const { return stream_ ? stream_->Done() : pos_ >= end_; }
   const std::string& Key() const { return stream_ ? stream_->Key() : entries_[pos_].key; }
-  CompactLattice& Value() { return stream_ ? stream_->Value() : value_; }
+  CompactLattice& Value() { return stream_ ? stream_->Value() : chunk_[pos_ - chunk_begin_]; }
   void FreeCurrent() {
     if (stream_) stream_->FreeCurrent();
-    else value_.DeleteStates();
+    else chunk_[pos_ - chunk_begin_].DeleteStates();
   }
   void Next() {
     if (stream_) {
@@ -317,14 +321,22 @@ class RankArchiveReader {
   size_t total() const { return total_; }
 
  private:
+  static constexpr size_t kChunk = 512;
   void Load() {
-    if (pos_ < end_) archive_->Read(entries_[pos_], &value_), ++parsed_;
+    if (pos_ < chunk_end_ || pos_ >= end_) return;
+    chunk_begin_ = pos_;
+    chunk_end_ = std::min(end_, pos_ + kChunk);
+    chunk_.clear();
+    chunk_.resize(chunk_end_ - chunk_begin_);
+    ParallelFor((int64_t)chunk_.size(), threads_, [&](int64_t i) { archive_->Read(entries_[chunk_begin_ + (size_t)i], &chunk_[(size_t)i]); });
+    parsed_ += chunk_.size();
   }
   std::unique_ptr<SequentialCompactLatticeReader> stream_;
   std::unique_ptr<MappedArchive> archive_;
   std::vector<ArchiveEntry> entries_;
-  size_t pos_ = 0, end_ = 0, parsed_ = 0, total_ = 0;
-  CompactLattice value_;
+  std::vector<CompactLattice> chunk_;
+  size_t pos_ = 0, end_ = 0, parsed_ = 0, total_ = 0, chunk_begin_ = 0, chunk_end_ = 0;
+  int threads_ = 1;
 };
 
 // A queue of at most `depth` items between two stages of the tools' pipeline (read | GPU | write).
@@ -354,29 +366,39 @@ class StageQueue {
   std::deque<T> q_;
 };
 
-// The lattices of a super-batch that this rank owns, ready for klat_batch_create.
+// The lattices of a super-batch that this rank owns, ready for klat_batch_create: top-sort, [length
+// disambiguation], state times per lattice on `threads` threads, then appended in input order.
 template <bool POSITION>
-inline void FlattenForIndex(std::vector<CompactLattice>* mine, LatticeBatch* batch, std::vector<int32_t>* state_len_all) {
-  for (auto& clat : *mine) {
+inline void FlattenForIndex(std::vector<CompactLattice>* mine, LatticeBatch* batch, std::vector<int32_t>* state_len_all, int threads) {
+  struct Prepared {
+    CompactLattice dlat;
     std::vector<int32_t> times, state_len;
+  };
+  std::vector<Prepared> prep(mine->size());
+  ParallelFor((int64_t)mine->size(), threads, [&](int64_t i) {
+    CompactLattice& clat = (*mine)[(size_t)i];
+    Prepared& p = prep[(size_t)i];
     if (POSITION) {
-      CompactLattice dlat;
       if (clat.Start() != CompactLattice::kNoStateId) {
         TopSortCompactLatticeIfNeeded(&clat);
-        DisambiguateStateInputSequenceLength(clat, &dlat, &state_len, false);  // kwsbin2/lattice-word-index-position.cc:64-65
-        CompactLatticeStateTimes(dlat, &times);
+        DisambiguateStateInputSequenceLength(clat, &p.dlat, &p.state_len, false);  // kwsbin2/lattice-word-index-position.cc:64-65
+        CompactLatticeStateTimes(p.dlat, &p.times);
       }
-      batch->Add(dlat, &times);
-      state_len_all->insert(state_len_all->end(), state_len.begin(), state_len.end());
-    } else {
-      if (clat.Start() != CompactLattice::kNoStateId) {
-        TopSortCompactLatticeIfNeeded(&clat);
-        CompactLatticeStateTimes(clat, &times);
-      }
-      batch->Add(clat, &times);
+      clat.DeleteStates();
+    } else if (clat.Start() != CompactLattice::kNoStateId) {
+      TopSortCompactLatticeIfNeeded(&clat);
+      CompactLatticeStateTimes(clat, &p.times);
     }
-    clat.DeleteStates();
+  });
+  std::vector<const CompactLattice*> lats(mine->size());
+  std::vector<const std::vector<int32_t>*> times(mine->size());
+  for (size_t i = 0; i < mine->size(); ++i) {
+    lats[i] = POSITION ? &prep[i].dlat : &(*mine)[i];
+    times[i] = &prep[i].times;
+    if (POSITION) state_len_all->insert(state_len_all->end(), prep[i].state_len.begin(), prep[i].state_len.end());
   }
+  batch->AddMany(lats, times, threads);
+  for (size_t i = 0; i < mine->size(); ++i) (*mine)[i].DeleteStates();
 }
 
 struct DevicesOption {
@@ -437,7 +459,11 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
     ranks.InitComm(ctx);
     klat_pack_options popt = co.PackOptions();
     const bool mapped = MappedArchive::Mappable(rspecifier);
+    const int host_threads = co.HostThreads(world);
     int64_t parsed_lattices = 0, parsed_arcs = 0, seen_lattices = 0;
+    double t_scan = 0, t_parse = 0, t_prep = 0, t_gpu = 0, t_write = 0;  // seconds per stage (--verbose=1)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
 
     reader_thread = std::thread([&]() {
       try {
@@ -455,6 +481,7 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
           int64_t total = 0;
           // (a scanned entry's arcs are not known: 24 bytes is less than any arc takes in either format)
           const int64_t budget = (int64_t)co.max_batch_arcs * world * (mapped ? 24 : 1);
+          auto t0 = now();
           while (!done() && (int64_t)sb->keys.size() < (int64_t)co.batch_size * world && total < budget) {
             if (mapped) {
               entries.emplace_back();
@@ -470,6 +497,8 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
             }
             total += weight.back();
           }
+          t_scan += since(t0);
+          t0 = now();
           const int64_t n = (int64_t)sb->keys.size();
           std::vector<int64_t> bounds((size_t)world + 1);
           Check(klat_partition_by_arcs(weight.data(), n, world, bounds.data()), "klat_partition_by_arcs");
@@ -477,11 +506,13 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
           std::vector<CompactLattice> mine;
           if (mapped) {
             mine.resize((size_t)(sb->hi - sb->lo));
-            for (int64_t u = sb->lo; u < sb->hi; ++u) archive->Read(entries[(size_t)u], &mine[(size_t)(u - sb->lo)]);
+            ParallelFor(sb->hi - sb->lo, host_threads, [&](int64_t i) { archive->Read(entries[(size_t)(sb->lo + i)], &mine[(size_t)i]); });
           } else {
             mine.assign(std::make_move_iterator(lats.begin() + sb->lo), std::make_move_iterator(lats.begin() + sb->hi));
             lats.clear();  // other ranks' lattices: only their arc counts mattered
           }
+          t_parse += since(t0);
+          t0 = now();
           seen_lattices += n;
           parsed_lattices += mapped ? sb->hi - sb->lo : n;
           if (mapped)
@@ -492,11 +523,13 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
             sb->mine = std::move(mine);  // the GPU stage takes the pruning decisions of the whole batch
           } else {
             if (io.Prunes())  // PruneLattice(beam, &clat), kwsbin2/lattice-word-index-segment.cc:49-51
-              for (auto& clat : mine)
-                if (clat.Start() != CompactLattice::kNoStateId)
-                  PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &clat);
-            FlattenForIndex<POSITION>(&mine, &sb->batch, &sb->state_len_all);
+              ParallelFor((int64_t)mine.size(), host_threads, [&](int64_t i) {
+                if (mine[(size_t)i].Start() != CompactLattice::kNoStateId)
+                  PruneLattice(io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &mine[(size_t)i]);
+              });
+            FlattenForIndex<POSITION>(&mine, &sb->batch, &sb->state_len_all, host_threads);
           }
+          t_prep += since(t0);
           read_q.Push(std::move(sb));
         }
         std::unique_ptr<SuperBatch> last(new SuperBatch());
@@ -516,8 +549,13 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
             std::unique_ptr<WriteJob> job = write_q.Pop();
             if (job->end) break;
             if (writer_error) continue;
-            for (size_t u = 0; u < job->keys.size(); ++u)
-              writer->Write(job->keys[u], job->rec.data() + job->off[u], job->off[u + 1] - job->off[u]);
+            const auto t0 = now();
+            std::vector<std::string> values(job->keys.size());  // formatted on the host threads, written in input order
+            ParallelFor((int64_t)values.size(), host_threads, [&](int64_t u) {
+              Writer::Format(writer->binary(), job->rec.data() + job->off[(size_t)u], job->off[(size_t)u + 1] - job->off[(size_t)u], &values[(size_t)u]);
+            });
+            for (size_t u = 0; u < job->keys.size(); ++u) writer->WriteFormatted(job->keys[u], values[u]);
+            t_write += since(t0);
           }
         } catch (...) {
           writer_error = std::current_exception();
@@ -532,11 +570,12 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
       if (sb->error) std::rethrow_exception(sb->error);
       if (sb->end) break;
       if (writer_error) std::rethrow_exception(writer_error);
+      const auto t_gpu0 = now();
       const int64_t n = (int64_t)sb->keys.size(), lo = sb->lo, hi = sb->hi;
       num_lattices += n;
       if (!sb->mine.empty()) {
         PruneLatticesOnDevice(ctx, io.beam, co.graph_scale, co.acoustic_scale, co.insertion_penalty, &sb->mine);
-        FlattenForIndex<POSITION>(&sb->mine, &sb->batch, &sb->state_len_all);
+        FlattenForIndex<POSITION>(&sb->mine, &sb->batch, &sb->state_len_all, host_threads);
       }
       // this rank's range on its GPU
       std::unique_ptr<DeviceBatch> db;
@@ -586,6 +625,7 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
       }
       KLAT_VLOG(1, "Rank " << rank << "/" << world << ": lattices [" << lo << ", " << hi << ") of a super-batch of " << n
                            << ", " << sb->batch.NumArcs() << " arcs, " << nrec << " records");
+      t_gpu += since(t_gpu0);
       if (rank == 0) {
         job->keys = std::move(sb->keys);
         write_q.Push(std::move(job));
@@ -602,6 +642,8 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
     if (writer) writer->Close();
     KLAT_VLOG(1, "Rank " << rank << "/" << world << ": parsed " << parsed_lattices << " of " << seen_lattices << " lattices ("
                          << parsed_arcs << " arcs)" << (mapped ? ", archive scanned in place" : ", archive read as a stream"));
+    KLAT_VLOG(1, "Rank " << rank << "/" << world << " stages (s, they overlap): scan " << t_scan << "  parse " << t_parse << "  prepare " << t_prep
+                         << "  GPU + gather " << t_gpu << "  write " << t_write << "  (" << host_threads << " host threads)");
     KLAT_VLOG(1, "Done " << num_lattices << " lattices.");
   } catch (const std::exception& e) {
     if (world > 1) std::cerr << "rank " << rank << ": ";

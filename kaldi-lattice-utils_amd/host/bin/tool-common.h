@@ -2,8 +2,12 @@
 // the two knobs this implementation adds (--batch-size lattices per GPU batch, --device).
 #ifndef KLAT_HOST_TOOL_COMMON_H_
 #define KLAT_HOST_TOOL_COMMON_H_
+#include <atomic>
+#include <exception>
 #include <limits>
+#include <mutex>
 #include <set>
+#include <thread>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -14,6 +18,46 @@
 
 namespace klat {
 
+// Host threads a rank spends on parsing and preparing its lattices (the archive entries are
+// independent byte ranges; the GPU side of a C2-sized batch takes milliseconds, its parsing on one
+// thread a third of a second): the machine's cores over the ranks, sixteen at most.
+inline int DefaultHostThreads(int world) {
+  const unsigned hc = std::thread::hardware_concurrency();
+  const int t = hc ? (int)hc / std::max(1, world) : 1;
+  return std::max(1, std::min(t, 16));
+}
+
+// f(i) for i in [0, n) on `threads` threads (dynamic schedule); the first exception is rethrown here.
+template <class F>
+inline void ParallelFor(int64_t n, int threads, F f) {
+  if (threads <= 1 || n < 2) {
+    for (int64_t i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::atomic<int64_t> next(0);
+  std::exception_ptr error;
+  std::mutex mu;
+  auto worker = [&]() {
+    try {
+      for (;;) {
+        const int64_t i = next.fetch_add(1);
+        if (i >= n) break;
+        f(i);
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!error) error = std::current_exception();
+      next.store(n);
+    }
+  };
+  std::vector<std::thread> pool;
+  const int nt = (int)std::min<int64_t>(threads, n);
+  for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  if (error) std::rethrow_exception(error);
+}
+
 struct CommonOptions {
  public:
   float acoustic_scale = 1.0f, graph_scale = 1.0f, insertion_penalty = 0.0f;
@@ -21,6 +65,7 @@ struct CommonOptions {
   int32_t max_batch_arcs = 64 << 20;
   int32_t device = 0;
   int32_t lanes_per_lattice = 0;  // 0 = automatic
+  int32_t host_threads = 0;       // 0 = DefaultHostThreads()
   void Register(ParseOptions* po) {
     po->Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic likelihoods in the lattices.");
     po->Register("graph-scale", &graph_scale, "Scaling factor for graph probabilities in the lattices.");
@@ -30,7 +75,9 @@ struct CommonOptions {
     po->Register("max-batch-arcs", &max_batch_arcs, "Upper bound on arcs per GPU batch.");
     po->Register("device", &device, "GPU device index.");
     po->Register("lanes-per-lattice", &lanes_per_lattice, "Lanes per lattice of the sweep kernel (0 = choose from the batch).");
+    po->Register("host-threads", &host_threads, "Threads that parse and prepare the lattices of a batch (0 = the machine's cores over the ranks, 16 at most).");
   }
+  int HostThreads(int world) const { return host_threads > 0 ? host_threads : DefaultHostThreads(world); }
   // The tools know their scales before they read a lattice: the stream packer applies them
   // (klat_pack_options.fuse_scales: 10-byte stream slots instead of 12).  Valid while this object lives.
   klat_pack_options PackOptions() const {
@@ -84,11 +131,14 @@ inline void WritePosteriors(Context& ctx, const LatticeBatch& batch, const klat_
   Check(klat_frame_post(db.get(), num_frames.data(), frame_off.data(), labels.data(), logps.data(),
                         (int64_t)labels.size(), &n),
         "klat_frame_post");
-  int64_t fb = 0;
-  for (size_t u = 0; u < keys.size(); ++u) {
-    writer->WriteFlat(keys[u], num_frames[u], frame_off.data() + fb, labels.data(), logps.data());
-    fb += num_frames[u];
-  }
+  // formatted on the host threads (a text Posterior table is mostly number formatting), written in input order
+  std::vector<int64_t> fb(keys.size() + 1, 0);
+  for (size_t u = 0; u < keys.size(); ++u) fb[u + 1] = fb[u] + num_frames[u];
+  std::vector<std::string> values(keys.size());
+  ParallelFor((int64_t)keys.size(), co.HostThreads(1), [&](int64_t u) {
+    PosteriorWriter::FormatFlat(writer->binary(), num_frames[(size_t)u], frame_off.data() + fb[(size_t)u], labels.data(), logps.data(), &values[(size_t)u]);
+  });
+  for (size_t u = 0; u < keys.size(); ++u) writer->WriteFormatted(keys[u], values[u]);
 }
 
 // SequentialCompactLatticeReader with the reference's PruneLattice step applied

@@ -4,6 +4,8 @@
 #include <mutex>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <map>
 #include <queue>
 #include <tuple>
@@ -360,6 +362,58 @@ void LatticeBatch::Add(const CompactLattice& clat, const std::vector<int32_t>* t
   }
   state_off_.push_back((int64_t)final_graph_.size());
   arc_off_.push_back((int64_t)src_.size());
+}
+
+void LatticeBatch::AddMany(const std::vector<const CompactLattice*>& lats, const std::vector<const std::vector<int32_t>*>& times, int threads) {
+  const size_t n = lats.size();
+  std::vector<int64_t> so(n + 1), ao(n + 1);
+  so[0] = state_off_.back(), ao[0] = arc_off_.back();
+  bool all_times = true;
+  for (size_t i = 0; i < n; ++i) {
+    const CompactLattice& clat = *lats[i];
+    const int32_t S = clat.Start() == CompactLattice::kNoStateId ? 0 : clat.NumStates();
+    if (S > 0 && clat.Start() != 0) KLAT_ERR("LatticeBatch::Add: lattice must be top-sorted with start state 0");
+    so[i + 1] = so[i] + S;
+    ao[i + 1] = ao[i] + (S > 0 ? clat.NumArcs() : 0);
+    if (!times[i]) all_times = false;
+  }
+  if (!all_times) has_times_ = false;
+  final_graph_.resize((size_t)so[n]);
+  final_acoustic_.resize((size_t)so[n]);
+  if (has_times_) state_time_.resize((size_t)so[n]);
+  for (std::vector<int32_t>* v : {&src_, &dst_, &ilabel_, &olabel_}) v->resize((size_t)ao[n]);
+  graph_.resize((size_t)ao[n]);
+  acoustic_.resize((size_t)ao[n]);
+  std::atomic<size_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) break;
+      const CompactLattice& clat = *lats[i];
+      const int32_t S = (int32_t)(so[i + 1] - so[i]);
+      int64_t a = ao[i];
+      for (int32_t s = 0; s < S; ++s) {
+        const CompactLatticeState& st = clat.State(s);
+        final_graph_[(size_t)(so[i] + s)] = st.final_graph;
+        final_acoustic_[(size_t)(so[i] + s)] = st.final_acoustic;
+        if (has_times_) state_time_[(size_t)(so[i] + s)] = (*times[i])[(size_t)s];
+        for (const auto& arc : st.arcs) {
+          src_[(size_t)a] = s;
+          dst_[(size_t)a] = arc.nextstate;
+          ilabel_[(size_t)a] = arc.ilabel;
+          olabel_[(size_t)a] = arc.olabel;
+          graph_[(size_t)a] = arc.graph;
+          acoustic_[(size_t)a] = arc.acoustic;
+          ++a;
+        }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < std::min<int>(threads, (int)n); ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  for (size_t i = 0; i < n; ++i) state_off_.push_back(so[i + 1]), arc_off_.push_back(ao[i + 1]);
 }
 
 klat_batch_desc LatticeBatch::Desc() const {

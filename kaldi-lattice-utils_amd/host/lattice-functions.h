@@ -67,6 +67,9 @@ class LatticeBatch {
   void Clear();
   // appends clat (must be top-sorted with Start()==0, or empty); times may be null
   void Add(const CompactLattice& clat, const std::vector<int32_t>* times);
+  // the same for many lattices at once, their arrays filled on `threads` threads (a push_back per field and
+  // arc flattened 30 M arcs/s; the arcs of a C2-sized batch are 60 M)
+  void AddMany(const std::vector<const CompactLattice*>& lats, const std::vector<const std::vector<int32_t>*>& times, int threads);
   int32_t NumLattices() const { return (int32_t)state_off_.size() - 1; }
   int64_t NumArcs() const { return arc_off_.back(); }
   int64_t NumStates() const { return state_off_.back(); }

@@ -7,6 +7,7 @@
 #ifndef KLAT_HOST_TABLE_WRITERS_H_
 #define KLAT_HOST_TABLE_WRITERS_H_
 #include <cstdint>
+#include <sstream>
 #include <string>
 #include <utility>
 #include <vector>
@@ -21,6 +22,16 @@ class ArchiveWriter {
  public:
   explicit ArchiveWriter(const std::string& wspecifier) : spec_(ParseSpecifier(wspecifier, true)), out_(spec_.filename) {}
   void Close() { out_.Close(); }
+  bool binary() const { return !spec_.text; }
+  // "key " and a value some Format() made for this writer's mode (formatting is the expensive part of a
+  // text table and is done on several threads; the writes stay in input order)
+  void WriteFormatted(const std::string& key, const std::string& value) {
+    std::ostream& os = out_.Stream();
+    os << key << ' ';
+    if (binary()) os.write("\0B", 2);
+    os.write(value.data(), (std::streamsize)value.size());
+    End();
+  }
 
  protected:
   std::ostream& Begin(const std::string& key) {
@@ -29,7 +40,6 @@ class ArchiveWriter {
     InitKaldiOutputStream(os, !spec_.text);
     return os;
   }
-  bool binary() const { return !spec_.text; }
   // Binary records are assembled in one buffer and written with one call: a value is Kaldi's
   // 1-byte size tag + the little-endian bytes (WriteBasicType), and a stream call per value is what
   // the tools' time went into.
@@ -53,30 +63,35 @@ class PosteriorWriter : public ArchiveWriter {
   using ArchiveWriter::ArchiveWriter;
   // the same record straight from klat_frame_post's flat arrays: frames [0, num_frames) of one
   // utterance, entries of frame k at [frame_off[k], frame_off[k + 1])
-  void WriteFlat(const std::string& key, int32_t num_frames, const int64_t* frame_off, const int32_t* labels,
-                 const float* logps) {
-    std::ostream& os = Begin(key);
-    if (binary()) {
-      buf_.clear();
-      buf_.reserve((size_t)(frame_off[num_frames] - frame_off[0]) * 10 + (size_t)num_frames * 5 + 16);
-      Put(&buf_, num_frames);
+  static void FormatFlat(bool binary, int32_t num_frames, const int64_t* frame_off, const int32_t* labels, const float* logps,
+                         std::string* out) {
+    out->clear();
+    if (binary) {
+      out->reserve((size_t)(frame_off[num_frames] - frame_off[0]) * 10 + (size_t)num_frames * 5 + 16);
+      Put(out, num_frames);
       for (int32_t k = 0; k < num_frames; ++k) {
-        Put(&buf_, (int32_t)(frame_off[k + 1] - frame_off[k]));
+        Put(out, (int32_t)(frame_off[k + 1] - frame_off[k]));
         for (int64_t i = frame_off[k]; i < frame_off[k + 1]; ++i) {
-          Put(&buf_, labels[i]);
-          Put(&buf_, logps[i]);
+          Put(out, labels[i]);
+          Put(out, logps[i]);
         }
       }
-      os.write(buf_.data(), (std::streamsize)buf_.size());
     } else {
+      std::ostringstream os;
+      InitKaldiOutputStream(os, false);
       for (int32_t k = 0; k < num_frames; ++k) {
         os << "[ ";
         for (int64_t i = frame_off[k]; i < frame_off[k + 1]; ++i) os << labels[i] << ' ' << logps[i] << ' ';
         os << "] ";
       }
       os << '\n';
+      *out = os.str();
     }
-    End();
+  }
+  void WriteFlat(const std::string& key, int32_t num_frames, const int64_t* frame_off, const int32_t* labels,
+                 const float* logps) {
+    FormatFlat(binary(), num_frames, frame_off, labels, logps, &buf_);
+    WriteFormatted(key, buf_);
   }
   void Write(const std::string& key, const T& post) {
     std::ostream& os = Begin(key);
@@ -175,17 +190,16 @@ class UtteranceScoreWriter : public ArchiveWriter {
 class SegmentScoreWriter : public ArchiveWriter {
  public:
   using ArchiveWriter::ArchiveWriter;
-  void Write(const std::string& key, const klat_segment_record* rec, int64_t n) {
-    std::ostream& os = Begin(key);
-    if (binary()) {
-      buf_.clear();
-      buf_.reserve((size_t)n * 24 + 8);
-      Put(&buf_, (int32_t)n);
-      for (int64_t i = 0; i < n; ++i) Put(&buf_, rec[i].label), Put(&buf_, rec[i].t0), Put(&buf_, rec[i].t1), Put(&buf_, rec[i].logp);
-      os.write(buf_.data(), (std::streamsize)buf_.size());
-      End();
+  static void Format(bool binary, const klat_segment_record* rec, int64_t n, std::string* out) {
+    out->clear();
+    if (binary) {
+      out->reserve((size_t)n * 24 + 8);
+      Put(out, (int32_t)n);
+      for (int64_t i = 0; i < n; ++i) Put(out, rec[i].label), Put(out, rec[i].t0), Put(out, rec[i].t1), Put(out, rec[i].logp);
       return;
     }
+    std::ostringstream os;
+    InitKaldiOutputStream(os, false);
     for (int64_t i = 0; i < n; ++i) {
       WriteBasicType(os, false, rec[i].label);
       WriteBasicType(os, false, rec[i].t0);
@@ -194,7 +208,11 @@ class SegmentScoreWriter : public ArchiveWriter {
       if (i + 1 < n) os << "; ";
     }
     os << '\n';
-    End();
+    *out = os.str();
+  }
+  void Write(const std::string& key, const klat_segment_record* rec, int64_t n) {
+    Format(binary(), rec, n, &buf_);
+    WriteFormatted(key, buf_);
   }
 
  private:
@@ -205,18 +223,17 @@ class SegmentScoreWriter : public ArchiveWriter {
 class PositionScoreWriter : public ArchiveWriter {
  public:
   using ArchiveWriter::ArchiveWriter;
-  void Write(const std::string& key, const klat_position_record* rec, int64_t n) {
-    std::ostream& os = Begin(key);
-    if (binary()) {
-      buf_.clear();
-      buf_.reserve((size_t)n * 29 + 8);
-      Put(&buf_, (int32_t)n);
+  static void Format(bool binary, const klat_position_record* rec, int64_t n, std::string* out) {
+    out->clear();
+    if (binary) {
+      out->reserve((size_t)n * 29 + 8);
+      Put(out, (int32_t)n);
       for (int64_t i = 0; i < n; ++i)
-        Put(&buf_, rec[i].label), Put(&buf_, rec[i].pos), Put(&buf_, rec[i].t0), Put(&buf_, rec[i].t1), Put(&buf_, rec[i].logp);
-      os.write(buf_.data(), (std::streamsize)buf_.size());
-      End();
+        Put(out, rec[i].label), Put(out, rec[i].pos), Put(out, rec[i].t0), Put(out, rec[i].t1), Put(out, rec[i].logp);
       return;
     }
+    std::ostringstream os;
+    InitKaldiOutputStream(os, false);
     for (int64_t i = 0; i < n; ++i) {
       WriteBasicType(os, false, rec[i].label);
       WriteBasicType(os, false, rec[i].pos);
@@ -226,7 +243,11 @@ class PositionScoreWriter : public ArchiveWriter {
       if (i + 1 < n) os << "; ";
     }
     os << '\n';
-    End();
+    *out = os.str();
+  }
+  void Write(const std::string& key, const klat_position_record* rec, int64_t n) {
+    Format(binary(), rec, n, &buf_);
+    WriteFormatted(key, buf_);
   }
 
  private:
