@@ -337,19 +337,26 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
     n = C.c_int64(0)
     times, err = [], None
     tu = tr = 0
-    try:
-        for it in range(reps + 1):  # (the first pass allocates: not counted)
-            barrier()
-            t0 = time.perf_counter()
+    for it in range(reps + 1):  # (the first pass allocates: not counted)
+        barrier()
+        t0 = time.perf_counter()
+        try:
             b.forward_backward(*SCALES)
             klat_amd._check(L.klat_segment_index(b.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
-            if comm is not None:
-                tu, tr = comm.gather_index(b, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)
-            barrier()
-            if it:
-                times.append(time.perf_counter() - t0)
-    except Exception as e:  # (the whole list with its index on ONE GPU is the tightest fit)
-        err = "%s: %s" % (type(e).__name__, str(e)[:200])
+        except Exception as e:  # (the whole list with its index on ONE GPU is the tightest fit)
+            err = "%s: %s" % (type(e).__name__, str(e)[:200])
+        if world > 1:  # a rank that failed must not leave the others inside the gather: they all learn of it first
+            ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok[0]) == 0.0 and not err:
+                err = "another rank failed before the gather"
+        if err:
+            break
+        if comm is not None:
+            tu, tr = comm.gather_index(b, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)
+        barrier()
+        if it:
+            times.append(time.perf_counter() - t0)
     tot = torch.tensor([float(A), float(n.value), step_s, median(times) if times else 0.0, 1.0 if err else 0.0], dtype=torch.float64, device="cuda")
     if world > 1:
         sums = tot.clone()
