@@ -695,7 +695,15 @@ def main():
             f, keep = klat_amd.Batch._filter(None, None)
             off = np.zeros(batch.U + 1, np.int64)
             n = C.c_int64(0)
-            klat_amd._check(klat_amd.lib().klat_segment_index(batch.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
+            local_err = None
+            try:
+                klat_amd._check(klat_amd.lib().klat_segment_index(batch.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
+            except Exception as e:
+                local_err = e
+            ok = torch.tensor([0.0 if local_err else 1.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # (every rank enters the gather, or none does)
+            if float(ok[0]) == 0.0:
+                raise local_err or RuntimeError("another rank failed before the gather")
             comm.gather_index(batch, klat_amd.SEGMENT_DTYPE, root=0, fetch=False)  # warm-up: buffers, RCCL channels
             times = []
             for _ in range(3):
