@@ -381,7 +381,7 @@ void LatticeBatch::AddMany(const std::vector<const CompactLattice*>& lats, const
   final_graph_.resize((size_t)so[n]);
   final_acoustic_.resize((size_t)so[n]);
   if (has_times_) state_time_.resize((size_t)so[n]);
-  for (std::vector<int32_t>* v : {&src_, &dst_, &ilabel_, &olabel_}) v->resize((size_t)ao[n]);
+  for (PodVec<int32_t>* v : {&src_, &dst_, &ilabel_, &olabel_}) v->resize((size_t)ao[n]);
   graph_.resize((size_t)ao[n]);
   acoustic_.resize((size_t)ao[n]);
   std::atomic<size_t> next(0);

@@ -5,6 +5,8 @@
 #ifndef KLAT_HOST_LATTICE_FUNCTIONS_H_
 #define KLAT_HOST_LATTICE_FUNCTIONS_H_
 #include <cstdint>
+#include <cstdlib>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -62,6 +64,53 @@ double ScaledCost(float graph, float acoustic, bool word, float graph_scale, flo
 bool ConnectKeeping(const std::vector<std::vector<uint8_t>>& keep, CompactLattice* clat);
 
 // A batch of top-sorted lattices flattened to the CSR/SoA layout of klat_batch_desc.
+// A growable array of plain values whose resize() leaves the new elements unset: the arrays of a batch are
+// hundreds of megabytes that AddMany's threads overwrite at once, and std::vector would zero them on one
+// thread first.
+template <class T>
+class PodVec {
+ public:
+  PodVec() = default;
+  PodVec(const PodVec&) = delete;
+  PodVec& operator=(const PodVec&) = delete;
+  PodVec(PodVec&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr, o.n_ = o.cap_ = 0; }
+  PodVec& operator=(PodVec&& o) noexcept {
+    if (this != &o) {
+      std::free(p_);
+      p_ = o.p_, n_ = o.n_, cap_ = o.cap_;
+      o.p_ = nullptr, o.n_ = o.cap_ = 0;
+    }
+    return *this;
+  }
+  ~PodVec() { std::free(p_); }
+  void clear() { n_ = 0; }
+  size_t size() const { return n_; }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  T& operator[](size_t i) { return p_[i]; }
+  const T& operator[](size_t i) const { return p_[i]; }
+  void resize(size_t n) {  // new elements are NOT initialised
+    if (n > cap_) grow(n);
+    n_ = n;
+  }
+  void push_back(T v) {
+    if (n_ == cap_) grow(n_ + 1);
+    p_[n_++] = v;
+  }
+
+ private:
+  void grow(size_t need) {
+    size_t c = cap_ ? cap_ * 2 : 1024;
+    if (c < need) c = need;
+    T* q = static_cast<T*>(std::realloc(p_, c * sizeof(T)));
+    if (!q) throw std::bad_alloc();
+    p_ = q;
+    cap_ = c;
+  }
+  T* p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+};
+
 class LatticeBatch {
  public:
   void Clear();
@@ -79,8 +128,8 @@ class LatticeBatch {
 
  private:
   std::vector<int64_t> state_off_{0}, arc_off_{0};
-  std::vector<int32_t> src_, dst_, ilabel_, olabel_, state_time_;
-  std::vector<float> graph_, acoustic_, final_graph_, final_acoustic_;
+  PodVec<int32_t> src_, dst_, ilabel_, olabel_, state_time_;
+  PodVec<float> graph_, acoustic_, final_graph_, final_acoustic_;
   bool has_times_ = true;
 };
 
