@@ -33,6 +33,22 @@ int main(int argc, char* argv[]) {
         archive.Read(e, &clat);
         states = clat.NumStates();
         arcs = clat.NumArcs();
+        // a binary entry read straight into arrays must be the object form flattened
+        FlatLattice direct, via_object;
+        if (archive.ReadFlat(e, &direct)) {
+          ToFlat(clat, &via_object);
+          if (direct.start != via_object.start || direct.row != via_object.row || direct.dst != via_object.dst ||
+              direct.ilabel != via_object.ilabel || direct.olabel != via_object.olabel || direct.len != via_object.len ||
+              direct.graph != via_object.graph || direct.acoustic != via_object.acoustic || direct.final_graph != via_object.final_graph ||
+              direct.final_acoustic != via_object.final_acoustic || direct.final_len != via_object.final_len)
+            KLAT_ERR("entry " << e.key << ": the flat reader and the object reader disagree");
+          if (IsTopSortedFromZero(direct)) {
+            std::vector<int32_t> t;
+            (void)FlatLatticeStateTimes(direct, &t);
+          }
+        } else if (e.binary) {
+          KLAT_ERR("entry " << e.key << ": not a binary CompactLattice");
+        }
       }
       std::printf("%s %zu %zu %c %lld %lld\n", e.key.c_str(), e.begin, e.end, e.binary ? 'b' : 't', states, arcs);
       ++n;

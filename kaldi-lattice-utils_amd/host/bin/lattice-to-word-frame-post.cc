@@ -49,6 +49,32 @@ int main(int argc, char* argv[]) {
     };
 
     RankArchiveReader reader(po.GetArg(1), rank, world, co.HostThreads(world));
+    if (reader.mapped()) {
+      // a mapped archive: a batch's entries straight into arrays on the host threads (no object per state)
+      std::vector<FlatLattice> flats;
+      std::vector<std::vector<int32_t>> times;
+      while (reader.ReadFlatChunk((size_t)co.batch_size, co.max_batch_arcs, &keys, &flats)) {
+        times.assign(flats.size(), std::vector<int32_t>());
+        num_frames.assign(flats.size(), 0);
+        std::vector<uint8_t> misaligned(flats.size(), 0);
+        ParallelFor((int64_t)flats.size(), co.HostThreads(world), [&](int64_t i) {
+          const FlatLattice& fl = flats[(size_t)i];
+          if (fl.NumStates() == 0) return;
+          num_frames[(size_t)i] = FlatLatticeStateTimes(fl, &times[(size_t)i]);
+          const std::vector<int32_t>& t = times[(size_t)i];
+          for (int32_t s = 0; s < fl.NumStates() && !misaligned[(size_t)i]; ++s)
+            for (int32_t k = fl.row[(size_t)s]; k < fl.row[(size_t)s + 1]; ++k)
+              if (fl.ilabel[(size_t)k] != 0 && t[(size_t)s] >= t[(size_t)fl.dst[(size_t)k]]) {
+                misaligned[(size_t)i] = 1;
+                break;
+              }
+        });
+        for (size_t i = 0; i < flats.size(); ++i)
+          if (misaligned[i]) KLAT_WARN("Lattice " << keys[i] << " is misaligned, a word with zero duration was found!");
+        batch.AddManyFlat(flats, times, co.HostThreads(world));
+        flush();
+      }
+    }
     for (; !reader.Done(); reader.Next()) {
       CompactLattice& clat = reader.Value();
       std::vector<int32_t> times;

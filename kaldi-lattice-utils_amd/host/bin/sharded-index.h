@@ -300,14 +300,17 @@ class RankArchiveReader {
     end_ = (size_t)bounds[(size_t)rank + 1];
     total_ = entries_.size();
     chunk_begin_ = chunk_end_ = pos_;
-    Load();
   }
   bool Done() const { return stream_ ? stream_->Done() : pos_ >= end_; }
   const std::string& Key() const { return stream_ ? stream_->Key() : entries_[pos_].key; }
-  CompactLattice& Value() { return stream_ ? stream_->Value() : chunk_[pos_ - chunk_begin_]; }
+  CompactLattice& Value() {
+    if (stream_) return stream_->Value();
+    Load();  // (parses the chunk around pos_ when the caller first asks for a value of it)
+    return chunk_[pos_ - chunk_begin_];
+  }
   void FreeCurrent() {
     if (stream_) stream_->FreeCurrent();
-    else chunk_[pos_ - chunk_begin_].DeleteStates();
+    else if (pos_ >= chunk_begin_ && pos_ < chunk_end_) chunk_[pos_ - chunk_begin_].DeleteStates();
   }
   void Next() {
     if (stream_) {
@@ -315,10 +318,39 @@ class RankArchiveReader {
       return;
     }
     ++pos_;
-    Load();
   }
   size_t parsed() const { return parsed_; }
   size_t total() const { return total_; }
+  // Mapped archives only (false otherwise: the caller walks Key() / Value()): the next up to `max` entries of
+  // this rank as flat lattices, top-sorted from state 0 -- a binary entry straight from its bytes, any other
+  // through the object form -- parsed on the reader's threads.  Call instead of, not mixed with, Next().
+  bool mapped() const { return !stream_; }
+  bool ReadFlatChunk(size_t max, int64_t max_arcs, std::vector<std::string>* keys, std::vector<FlatLattice>* flats) {
+    keys->clear();
+    flats->clear();
+    if (stream_ || pos_ >= end_) return false;
+    size_t n = 0;
+    const size_t first = pos_;
+    // (an entry's arcs are not known before it is parsed: 24 bytes is less than any arc takes in either format)
+    for (int64_t bytes = 0; n < max && first + n < end_ && (n == 0 || bytes < max_arcs * 24); ++n)
+      bytes += (int64_t)(entries_[first + n].end - entries_[first + n].begin);
+    flats->resize(n);
+    for (size_t i = 0; i < n; ++i) keys->push_back(entries_[first + i].key);
+    ParallelFor((int64_t)n, threads_, [&](int64_t i) {
+      FlatLattice& fl = (*flats)[(size_t)i];
+      if (!archive_->ReadFlat(entries_[first + (size_t)i], &fl) || !IsTopSortedFromZero(fl)) {
+        CompactLattice clat;
+        archive_->Read(entries_[first + (size_t)i], &clat);
+        if (clat.Start() != CompactLattice::kNoStateId) TopSortCompactLatticeIfNeeded(&clat);
+        ToFlat(clat, &fl);
+      }
+    });
+    pos_ += n;
+    parsed_ += n;
+    chunk_.clear();
+    chunk_begin_ = chunk_end_ = pos_;
+    return true;
+  }
 
  private:
   static constexpr size_t kChunk = 512;
@@ -557,6 +589,34 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
           Check(klat_partition_by_arcs(weight.data(), n, world, bounds.data()), "klat_partition_by_arcs");
           sb->lo = bounds[(size_t)rank], sb->hi = bounds[(size_t)rank + 1];
           std::vector<CompactLattice> mine;
+          // The segment index without --beam needs nothing of a lattice but its arrays: a binary entry is read
+          // straight into them (FlatLattice), no object per state; any other entry, and a lattice that is not
+          // top-sorted yet, goes through the object form and is flattened afterwards.
+          const bool flat_path = mapped && !POSITION && !io.Prunes();
+          if (flat_path) {
+            const int64_t m = sb->hi - sb->lo;
+            std::vector<FlatLattice> flats((size_t)m);
+            std::vector<std::vector<int32_t>> ftimes((size_t)m);
+            ParallelFor(m, host_threads, [&](int64_t i) {
+              FlatLattice& fl = flats[(size_t)i];
+              if (!archive->ReadFlat(entries[(size_t)(sb->lo + i)], &fl) || !IsTopSortedFromZero(fl)) {
+                CompactLattice clat;
+                archive->Read(entries[(size_t)(sb->lo + i)], &clat);
+                if (clat.Start() != CompactLattice::kNoStateId) TopSortCompactLatticeIfNeeded(&clat);
+                ToFlat(clat, &fl);
+              }
+              if (fl.NumStates() > 0) FlatLatticeStateTimes(fl, &ftimes[(size_t)i]);
+            });
+            t_parse += since(t0);
+            t0 = now();
+            for (const auto& fl : flats) parsed_arcs += fl.NumArcs();
+            seen_lattices += n;
+            parsed_lattices += m;
+            sb->batch.AddManyFlat(flats, ftimes, host_threads);
+            t_prep += since(t0);
+            read_q.Push(std::move(sb));
+            continue;
+          }
           if (mapped) {
             mine.resize((size_t)(sb->hi - sb->lo));
             ParallelFor(sb->hi - sb->lo, host_threads, [&](int64_t i) { archive->Read(entries[(size_t)(sb->lo + i)], &mine[(size_t)i]); });

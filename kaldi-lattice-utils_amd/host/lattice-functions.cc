@@ -4,6 +4,7 @@
 #include <mutex>
 
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <thread>
 #include <map>
@@ -406,6 +407,52 @@ void LatticeBatch::AddMany(const std::vector<const CompactLattice*>& lats, const
           acoustic_[(size_t)a] = arc.acoustic;
           ++a;
         }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < std::min<int>(threads, (int)n); ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  for (size_t i = 0; i < n; ++i) state_off_.push_back(so[i + 1]), arc_off_.push_back(ao[i + 1]);
+}
+
+void LatticeBatch::AddManyFlat(const std::vector<FlatLattice>& lats, const std::vector<std::vector<int32_t>>& times, int threads) {
+  const size_t n = lats.size();
+  std::vector<int64_t> so(n + 1), ao(n + 1);
+  so[0] = state_off_.back(), ao[0] = arc_off_.back();
+  for (size_t i = 0; i < n; ++i) {
+    if (!IsTopSortedFromZero(lats[i])) KLAT_ERR("LatticeBatch::Add: lattice must be top-sorted with start state 0");
+    so[i + 1] = so[i] + lats[i].NumStates();
+    ao[i + 1] = ao[i] + lats[i].NumArcs();
+  }
+  final_graph_.resize((size_t)so[n]);
+  final_acoustic_.resize((size_t)so[n]);
+  if (has_times_) state_time_.resize((size_t)so[n]);
+  for (PodVec<int32_t>* v : {&src_, &dst_, &ilabel_, &olabel_}) v->resize((size_t)ao[n]);
+  graph_.resize((size_t)ao[n]);
+  acoustic_.resize((size_t)ao[n]);
+  std::atomic<size_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) break;
+      const FlatLattice& lat = lats[i];
+      const int32_t S = lat.NumStates();
+      const size_t A = (size_t)lat.NumArcs();
+      if (S > 0) {
+        std::memcpy(final_graph_.data() + so[i], lat.final_graph.data(), sizeof(float) * (size_t)S);
+        std::memcpy(final_acoustic_.data() + so[i], lat.final_acoustic.data(), sizeof(float) * (size_t)S);
+        if (has_times_) std::memcpy(state_time_.data() + so[i], times[i].data(), sizeof(int32_t) * (size_t)S);
+      }
+      if (A > 0) {
+        std::memcpy(dst_.data() + ao[i], lat.dst.data(), sizeof(int32_t) * A);
+        std::memcpy(ilabel_.data() + ao[i], lat.ilabel.data(), sizeof(int32_t) * A);
+        std::memcpy(olabel_.data() + ao[i], lat.olabel.data(), sizeof(int32_t) * A);
+        std::memcpy(graph_.data() + ao[i], lat.graph.data(), sizeof(float) * A);
+        std::memcpy(acoustic_.data() + ao[i], lat.acoustic.data(), sizeof(float) * A);
+        for (int32_t s = 0; s < S; ++s)
+          for (int32_t k = lat.row[(size_t)s]; k < lat.row[(size_t)s + 1]; ++k) src_[(size_t)(ao[i] + k)] = s;
       }
     }
   };

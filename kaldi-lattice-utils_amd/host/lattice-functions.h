@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/klat.h"
+#include "archive-index.h"
 #include "compact-lattice.h"
 
 namespace klat {
@@ -119,6 +120,8 @@ class LatticeBatch {
   // the same for many lattices at once, their arrays filled on `threads` threads (a push_back per field and
   // arc flattened 30 M arcs/s; the arcs of a C2-sized batch are 60 M)
   void AddMany(const std::vector<const CompactLattice*>& lats, const std::vector<const std::vector<int32_t>*>& times, int threads);
+  // the same from the flat form (archive-index.h); every lattice top-sorted from state 0
+  void AddManyFlat(const std::vector<FlatLattice>& lats, const std::vector<std::vector<int32_t>>& times, int threads);
   int32_t NumLattices() const { return (int32_t)state_off_.size() - 1; }
   int64_t NumArcs() const { return arc_off_.back(); }
   int64_t NumStates() const { return state_off_.back(); }
