@@ -130,6 +130,7 @@ void MappedArchive::ScanNext(ArchiveEntry* e) {
       const int64_t narcs = i64();
       if (narcs < 0) bad();
       if (!compact) {  // a Lattice arc is 20 bytes
+        if (narcs > (int64_t)((size_ - p) / 20)) bad();
         need((size_t)narcs * 20);
         p += (size_t)narcs * 20;
       } else {
