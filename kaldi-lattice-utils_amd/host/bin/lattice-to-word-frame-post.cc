@@ -40,9 +40,10 @@ int main(int argc, char* argv[]) {
     std::vector<std::string> keys;
     std::vector<int32_t> num_frames;
     LatticeBatch batch;
+    PinnedPool pool;  // (declared after ctx: released while the HIP runtime is up)
     auto flush = [&]() {
       if (keys.empty()) return;
-      WritePosteriors(ctx, batch, popt, co, keys, num_frames, &posterior_writer);
+      WritePosteriors(ctx, batch, popt, co, keys, num_frames, &posterior_writer, &pool);
       keys.clear();
       num_frames.clear();
       batch.Clear();

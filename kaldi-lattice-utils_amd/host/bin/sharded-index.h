@@ -398,44 +398,6 @@ class StageQueue {
   std::deque<T> q_;
 };
 
-// Page-locked buffers (klat_host_alloc) for the records on their way from the GPU to the writer, recycled
-// between the two stages: into fresh pageable memory 264 MB of records came back at 4 GB/s.
-class PinnedPool {
- public:
-  ~PinnedPool() {
-    for (auto& b : free_) klat_host_free(b.first);
-  }
-  void* Acquire(size_t bytes, size_t* cap) {
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      for (size_t i = 0; i < free_.size(); ++i)
-        if (free_[i].second >= bytes) {
-          void* p = free_[i].first;
-          *cap = free_[i].second;
-          free_.erase(free_.begin() + (long)i);
-          return p;
-        }
-      if (!free_.empty()) {  // too small: let it go
-        klat_host_free(free_.back().first);
-        free_.pop_back();
-      }
-    }
-    void* p = nullptr;
-    *cap = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
-    Check(klat_host_alloc(&p, *cap), "klat_host_alloc");
-    return p;
-  }
-  void Release(void* p, size_t cap) {
-    if (!p) return;
-    std::lock_guard<std::mutex> lock(mu_);
-    free_.emplace_back(p, cap);
-  }
-
- private:
-  std::mutex mu_;
-  std::vector<std::pair<void*, size_t>> free_;
-};
-
 // The lattices of a super-batch that this rank owns, ready for klat_batch_create: top-sort, [length
 // disambiguation], state times per lattice on `threads` threads, then appended in input order.
 template <bool POSITION>

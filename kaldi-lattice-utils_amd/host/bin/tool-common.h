@@ -112,32 +112,82 @@ struct IndexOptions {
   }
 };
 
+// Page-locked buffers (klat_host_alloc) for results on their way from the GPU to the writer, recycled
+// between batches: into fresh pageable memory 264 MB of records came back at 4 GB/s.
+class PinnedPool {
+ public:
+  ~PinnedPool() {
+    for (auto& b : free_) klat_host_free(b.first);
+  }
+  void* Acquire(size_t bytes, size_t* cap) {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      size_t best = free_.size();
+      for (size_t i = 0; i < free_.size(); ++i)  // the smallest buffer that is large enough
+        if (free_[i].second >= bytes && (best == free_.size() || free_[i].second < free_[best].second)) best = i;
+      if (best < free_.size()) {
+        void* p = free_[best].first;
+        *cap = free_[best].second;
+        free_.erase(free_.begin() + (long)best);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    *cap = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+    Check(klat_host_alloc(&p, *cap), "klat_host_alloc");
+    return p;
+  }
+  void Release(void* p, size_t cap) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(mu_);
+    free_.emplace_back(p, cap);
+    if (free_.size() > 8) {  // keep the larger ones
+      size_t smallest = 0;
+      for (size_t i = 1; i < free_.size(); ++i)
+        if (free_[i].second < free_[smallest].second) smallest = i;
+      klat_host_free(free_[smallest].first);
+      free_.erase(free_.begin() + (long)smallest);
+    }
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<std::pair<void*, size_t>> free_;
+};
+
 // Forward-backward over one batch, then the per-frame word posteriors of every lattice written
 // as Posterior entries (latbin/lattice-to-word-frame-post.cc:93-139).  "Frames" are whatever the
 // batch carries as state times: frames for lattice-to-word-frame-post, word positions for
 // lattice-to-word-position-post.
 inline void WritePosteriors(Context& ctx, const LatticeBatch& batch, const klat_pack_options& popt,
                             const CommonOptions& co, const std::vector<std::string>& keys,
-                            const std::vector<int32_t>& num_frames, PosteriorWriter* writer) {
+                            const std::vector<int32_t>& num_frames, PosteriorWriter* writer, PinnedPool* pool = nullptr) {
   DeviceBatch db(ctx, batch, &popt);
   db.ForwardBackward(co.graph_scale, co.acoustic_scale, co.insertion_penalty);
   int64_t T = 0;
   for (int32_t f : num_frames) T += f;
-  std::vector<int64_t> frame_off((size_t)T + 1, 0);
+  // results in page-locked buffers that the next batch reuses (or plain unset memory): a gigabyte of
+  // posteriors into zeroed std::vectors cost more than the kernels that made them
+  PinnedPool local;
+  if (!pool) pool = &local;
+  size_t cap_off = 0, cap_lab = 0, cap_lp = 0;
+  int64_t* frame_off = static_cast<int64_t*>(pool->Acquire(sizeof(int64_t) * (size_t)(T + 1), &cap_off));
   int64_t n = 0;
-  Check(klat_frame_post(db.get(), num_frames.data(), frame_off.data(), nullptr, nullptr, 0, &n), "klat_frame_post");
-  std::vector<int32_t> labels((size_t)std::max<int64_t>(n, 1));
-  std::vector<float> logps((size_t)std::max<int64_t>(n, 1));
-  Check(klat_frame_post(db.get(), num_frames.data(), frame_off.data(), labels.data(), logps.data(),
-                        (int64_t)labels.size(), &n),
-        "klat_frame_post");
+  Check(klat_frame_post(db.get(), num_frames.data(), frame_off, nullptr, nullptr, 0, &n), "klat_frame_post");
+  const int64_t cap = std::max<int64_t>(n, 1);
+  int32_t* labels = static_cast<int32_t*>(pool->Acquire(sizeof(int32_t) * (size_t)cap, &cap_lab));
+  float* logps = static_cast<float*>(pool->Acquire(sizeof(float) * (size_t)cap, &cap_lp));
+  Check(klat_frame_post(db.get(), num_frames.data(), frame_off, labels, logps, cap, &n), "klat_frame_post");
   // formatted on the host threads (a text Posterior table is mostly number formatting), written in input order
   std::vector<int64_t> fb(keys.size() + 1, 0);
   for (size_t u = 0; u < keys.size(); ++u) fb[u + 1] = fb[u] + num_frames[u];
   std::vector<std::string> values(keys.size());
   ParallelFor((int64_t)keys.size(), co.HostThreads(1), [&](int64_t u) {
-    PosteriorWriter::FormatFlat(writer->binary(), num_frames[(size_t)u], frame_off.data() + fb[(size_t)u], labels.data(), logps.data(), &values[(size_t)u]);
+    PosteriorWriter::FormatFlat(writer->binary(), num_frames[(size_t)u], frame_off + fb[(size_t)u], labels, logps, &values[(size_t)u]);
   });
+  pool->Release(frame_off, cap_off);
+  pool->Release(labels, cap_lab);
+  pool->Release(logps, cap_lp);
   for (size_t u = 0; u < keys.size(); ++u) writer->WriteFormatted(keys[u], values[u]);
 }
 
