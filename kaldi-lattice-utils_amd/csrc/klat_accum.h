@@ -85,7 +85,8 @@ struct RangeArgs {
   int32_t* out;              // [4]: label min, label max, time max, length max
 };
 hipError_t launch_range(const RangeArgs& a, hipStream_t stream);
-hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots,
+// max_arcs: the most arcs of a lattice this launch takes (its workgroups are as wide as that lattice needs)
+hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots, int max_arcs,
                              hipStream_t stream);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
                                OutRecord* out, hipStream_t stream);

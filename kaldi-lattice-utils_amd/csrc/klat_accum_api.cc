@@ -134,9 +134,11 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     // table of 2^14 slots up to 8192 arcs, 2^15 above), the others the general kernel
     bool radix = std::getenv("KLAT_INDEX_BITONIC") == nullptr;  // (test hook: force the general kernel)
     RadixPack pk = {0, 0, 0, 0};
-    int64_t n_small = 0, n_medium = 0, n_large = 0;
+    int64_t n_small = 0, n_medium = 0, n_large = 0, most_small = 0, most_medium = 0;
     for (int64_t u = 0; u < b->U; ++u) {
       const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
+      if (arcs <= kHashMaxArcs / 2) most_small = std::max(most_small, arcs);
+      else if (arcs < kHashMaxArcs) most_medium = std::max(most_medium, arcs);
       (arcs <= kHashMaxArcs / 2 ? n_small : arcs < kHashMaxArcs ? n_medium : n_large)++;  // (16 384 arcs exactly: a table entry {fingerprint all ones, arc 16 383} would equal the empty marker)
     }
     radix = radix && n_small + n_medium > 0 && b->A > 0;
@@ -179,11 +181,11 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     if (radix) {
       if (n_small > 0) {
         a.min_arcs = -1, a.max_arcs = kHashMaxArcs / 2;
-        KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 14, c->stream));
+        KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 14, (int)most_small, c->stream));
       }
       if (n_medium > 0) {
         a.min_arcs = kHashMaxArcs / 2, a.max_arcs = kHashMaxArcs - 1;
-        KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 15, c->stream));
+        KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 15, (int)most_medium, c->stream));
       }
       if (n_large > 0) {
         a.min_arcs = kHashMaxArcs - 1, a.max_arcs = 0x7FFFFFFF;

@@ -30,6 +30,7 @@
 // of LDS; LOGH = 15: up to 16 384 arcs, 16 per thread, 150 KiB.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "klat_accum.h"
@@ -78,8 +79,7 @@ struct Rec {  // 24 B: what index_gather_kernel reads
 };
 
 // exclusive prefix sum of one int per thread over the block; *total = block sum
-template <int T>
-__device__ __forceinline__ int block_excl_sum(int v, int* total, int* sh /* [T/64] */) {
+__device__ __forceinline__ int block_excl_sum(int T, int v, int* total, int* sh /* [T/64] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int incl = v;
 #pragma unroll
@@ -91,7 +91,6 @@ __device__ __forceinline__ int block_excl_sum(int v, int* total, int* sh /* [T/6
   if (lane == 63) sh[wave] = incl;
   __syncthreads();
   int off = 0, tot = 0;
-#pragma unroll
   for (int w = 0; w < T / 64; ++w) {
     const int s = sh[w];
     if (w < wave) off += s;
@@ -143,8 +142,8 @@ __device__ __forceinline__ Payload make_payload(const AccumArgs& a, const RadixP
 
 // Sorting network for ANY length c (bitonic with mirrored first step: all comparators ascending, so
 // skipping the comparators that reach past c equals padding with +infinity), by the whole workgroup.
-template <int T, class V, class Less>
-__device__ __forceinline__ void block_sort_any(V* v, int c, Less less) {
+template <class V, class Less>
+__device__ __forceinline__ void block_sort_any(int T, V* v, int c, Less less) {
   int P = 1;
   while (P < c) P <<= 1;
   for (int k = 2; k <= P; k <<= 1) {
@@ -178,15 +177,22 @@ __device__ __forceinline__ void record_of(const AccumArgs& a, const RadixPack& p
   (void)arc_key<POSITION>(a, pk, a0, s0, i, key);
 }
 
-template <bool POSITION, int LOGH>
-__global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack pk) {
+// TWO: the instantiation for launches whose lattices fit 768 threads (C2: 6 000 arcs): at most 80 VGPRs and the
+// arcs' values in the scratch row instead of LDS, so that TWO workgroups share a CU and one's barriers and LDS
+// round trips hide behind the other's work (the phases are chains of dependent LDS / L2 round trips: one
+// workgroup per CU left the CU waiting most of the time).
+template <bool POSITION, int LOGH, bool TWO>
+__global__ __launch_bounds__(TWO ? 768 : 1024) __attribute__((amdgpu_waves_per_eu(TWO ? 6 : 4, TWO ? 6 : 4)))
+void index_hash_kernel(AccumArgs a, RadixPack pk) {
   // The phases are bound by LDS / L2 latency, not by arithmetic, and 16 waves per CU is what the
   // register budget allows either way: one workgroup of 16 waves measured the same as two of 8
   // (2.5 ms on C2) and keeps the per-thread arrays short.
-  constexpr int T = 1024;
+  // The workgroup is as wide as the launch's largest lattice needs (512 .. 1 024 threads in whole waves, kPerThread
+  // arcs each): C2's 6 000 arcs take 12 waves, not 16 -- a quarter of the instructions and of every barrier gone.
+  const int T = (int)blockDim.x;
   constexpr int H = 1 << LOGH;
   constexpr int MAXN = H / 2;
-  constexpr int kPerThread = MAXN / T;  // arcs (and records) per thread: 8 or 16
+  constexpr int kPerThread = MAXN / 1024;  // arcs (and records) per thread: 8 or 16
   constexpr int RB = LOGH - 1;          // bits of an arc index (= record id)
   constexpr int B = MAXN / 2;           // value buckets
   static_assert(MAXN * 2 == H, "load factor 0.5");
@@ -200,8 +206,8 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
   // every arc's value alpha[src] - cost + beta[dst] - total, formed once while its ends are in registers
   // (phase 1) and read by the later phases: in LDS behind the other arrays where the CU has room for it
   // (up to 8 192 arcs: 64 KiB), else in the lattice's scratch row (L2)
-  constexpr bool kValsInLds = LOGH <= 14;
-  __shared__ int sh[T / 64];
+  constexpr bool kValsInLds = LOGH <= 14 && !TWO;
+  __shared__ int sh[1024 / 64];
   __shared__ unsigned long long sh_dmin, sh_dmax;
   __shared__ double sh_vmin, sh_vmax;
   __shared__ int sh_nbig, sh_big[MAXN / kSerialMax + 1];
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
   for (int j = 0; j < kPerThread; ++j)
     if ((valid & (1u << j)) && (marked[slot[j] >> 5] & (1u << (slot[j] & 31)))) dupmask |= 1u << j, ++ndup;
   int tot_dup;
-  int dpos = block_excl_sum<T>(ndup, &tot_dup, sh);
+  int dpos = block_excl_sum(T, ndup, &tot_dup, sh);
   __syncthreads();  // every thread has read `marked` and the table: the regions become `headbit` and `dups`
   for (int i = tid; i < MAXN / 32; i += T) headbit[i] = 0;
   uint32_t recmask = valid & ~dupmask;  // the arcs that stand for a record: unique keys, plus first arcs of repeated keys
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
     for (int j = 0; j < kPerThread; ++j)
       if (dupmask & (1u << j)) dups[dpos++] = (slot[j] << 14) | (uint32_t)(j * T + tid);
     __syncthreads();
-    block_sort_any<T>(dups, tot_dup, [](uint32_t x, uint32_t y) { return x < y; });
+    block_sort_any(T, dups, tot_dup, [](uint32_t x, uint32_t y) { return x < y; });
     for (int p = tid; p < tot_dup; p += T) {
       const uint32_t w = dups[p];
       if (!(p == 0 || (dups[p - 1] >> 14) != (w >> 14))) continue;
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
         }
       }
     }
-    (void)block_excl_sum<T>(__popc(recmask), &m, sh);  // (its barriers also publish the minima / maxima)
+    (void)block_excl_sum(T, __popc(recmask), &m, sh);  // (its barriers also publish the minima / maxima)
   }
   __syncthreads();
   const uint64_t dmin = m > 0 ? sh_dmin : 0ull;
@@ -453,24 +459,25 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
     }
   }
   __syncthreads();
-  {  // in-place inclusive scan of the B 16-bit counters: B / T consecutive ones per thread
-    constexpr int PER = B / T;  // 4 or 8
+  {  // in-place inclusive scan of the B 16-bit counters: PER consecutive ones per thread, by the first B / PER threads
+    constexpr int PER = B / 512;  // 8 or 16 (a workgroup has at least 512 threads)
     static_assert(PER % 2 == 0, "");
     uint32_t w[PER / 2];
     int sum = 0;
+    const bool scans = tid < B / PER;
 #pragma unroll
     for (int q = 0; q < PER / 2; ++q) {
-      w[q] = bcnt[tid * (PER / 2) + q];
+      w[q] = scans ? bcnt[tid * (PER / 2) + q] : 0u;
       sum += (int)(w[q] & 0xFFFFu) + (int)(w[q] >> 16);
     }
     int total;
-    int run = block_excl_sum<T>(sum, &total, sh);
+    int run = block_excl_sum(T, sum, &total, sh);
 #pragma unroll
     for (int q = 0; q < PER / 2; ++q) {
       const int lo = run + (int)(w[q] & 0xFFFFu);
       const int hi = lo + (int)(w[q] >> 16);
       run = hi;
-      bcnt[tid * (PER / 2) + q] = (uint32_t)lo | ((uint32_t)hi << 16);
+      if (scans) bcnt[tid * (PER / 2) + q] = (uint32_t)lo | ((uint32_t)hi << 16);
     }
   }
   __syncthreads();
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
   for (int g = 0; g < nbig; ++g) {
     const int b = sh_big[g];
     const int lo = b ? (int)bend[b - 1] : 0, hi = (int)bend[b];
-    block_sort_any<T>(order + lo, hi - lo, less);
+    block_sort_any(T, order + lo, hi - lo, less);
   }
   // every record finds its final position inside its bucket: by counting the smaller entries of a
   // small bucket (independent LDS reads, no dependent chain), by binary search in a sorted crowded one
@@ -573,27 +580,40 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(AccumArgs a, RadixPack
 }
 
 template <bool POSITION, int LOGH>
-hipError_t launch_hash_one(const AccumArgs& a, const RadixPack& pk, int num_lattices, hipStream_t stream) {
-  constexpr int T = 1024;
+hipError_t launch_hash_one(const AccumArgs& a, const RadixPack& pk, int num_lattices, int max_arcs, hipStream_t stream) {
   constexpr int H = 1 << LOGH;
   constexpr int B = H / 4;
-  const size_t lds = (size_t)H * 4 + H / 8 + (size_t)B * 2 + (LOGH <= 14 ? (size_t)(H / 2) * sizeof(double) : 0);  // + the arcs' values
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_hash_kernel<POSITION, LOGH>),
+  constexpr int kPerThread = (H / 2) / 1024;
+  // whole waves for the launch's largest lattice, 512 threads at least (the counters' scan), 1 024 at most
+  int T = ((max_arcs + kPerThread - 1) / kPerThread + 63) / 64 * 64;
+  T = T < 512 ? 512 : T > 1024 ? 1024 : T;
+  const bool two = LOGH <= 14 && T <= 768 && std::getenv("KLAT_INDEX_ONE_PER_CU") == nullptr;
+  const size_t lds = (size_t)H * 4 + H / 8 + (size_t)B * 2 + (LOGH <= 14 && !two ? (size_t)(H / 2) * sizeof(double) : 0);  // + the arcs' values
+  if (two) {
+    if constexpr (LOGH <= 14) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_hash_kernel<POSITION, LOGH, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((index_hash_kernel<POSITION, LOGH, true>), dim3(num_lattices), dim3(T), lds, stream, a, pk);
+    }
+    return hipGetLastError();
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_hash_kernel<POSITION, LOGH, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((index_hash_kernel<POSITION, LOGH>), dim3(num_lattices), dim3(T), lds, stream, a, pk);
+  hipLaunchKernelGGL((index_hash_kernel<POSITION, LOGH, false>), dim3(num_lattices), dim3(T), lds, stream, a, pk);
   return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots,
+hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots, int max_arcs,
                              hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
   if (log_slots == 14)
-    return position ? launch_hash_one<true, 14>(a, pk, num_lattices, stream) : launch_hash_one<false, 14>(a, pk, num_lattices, stream);
+    return position ? launch_hash_one<true, 14>(a, pk, num_lattices, max_arcs, stream) : launch_hash_one<false, 14>(a, pk, num_lattices, max_arcs, stream);
   if (log_slots == 15)
-    return position ? launch_hash_one<true, 15>(a, pk, num_lattices, stream) : launch_hash_one<false, 15>(a, pk, num_lattices, stream);
+    return position ? launch_hash_one<true, 15>(a, pk, num_lattices, max_arcs, stream) : launch_hash_one<false, 15>(a, pk, num_lattices, max_arcs, stream);
   return hipErrorInvalidValue;
 }
 
