@@ -117,6 +117,8 @@ typedef struct {
   int32_t max_rounds;                 /* longest lockstep stream, in rounds */
   int32_t num_layouts;                /* layout classes (distinct lanes_per_lattice) = sweep launches */
   int32_t level_lattices;             /* lattices on the level-synchronous path (wide lattices; no stream job) */
+  int32_t chain_lattices;             /* long lattices the log-semiring sweep cuts into segments (klat_chain.hip) */
+  int32_t chain_segments;             /* ... and the segments they were cut into */
 } klat_batch_info;
 
 /* Per-kernel device times of the last klat_forward_backward (HIP events on the ctx stream). */
@@ -179,10 +181,16 @@ int klat_batch_get_info(const klat_batch* batch, klat_batch_info* info);
  * that sweeps every batch once pays it per batch, so bench.py reports it (`one_shot`). */
 typedef struct {
   float count_ms, level_plan_ms, rounds_ms, fill_ms, posterior_prep_ms;
-  float device_ms;  /* sum of the five */
+  float device_ms;  /* sum of the device passes (the five above and chain_prep_ms) */
   float host_ms;
+  float chain_prep_ms;  /* the arc records of the lattices swept in segments */
 } klat_pack_timings;
 int klat_batch_get_pack_timings(klat_batch* batch, klat_pack_timings* t);
+
+/* Long lattices of a batch that waits for them are swept in segments (klat_batch_info.chain_lattices; DESIGN.md
+ * 5).  Values that do not fit that path's arithmetic make the lockstep streams, which those lattices keep,
+ * sweep them again inside the same klat_forward_backward.  *raised = 1 if the batch's last sweep did so. */
+int klat_batch_chain_fallback(klat_batch* batch, int32_t* raised);
 
 /* Topological depth of every lattice: the number of states on its longest path (the fewest
  * dependent steps ANY forward-backward needs; the lockstep streams take one round per state or

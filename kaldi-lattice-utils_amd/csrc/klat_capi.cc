@@ -11,6 +11,7 @@
 #include <limits>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -44,15 +45,15 @@ int hip_fail(hipError_t e, const char* what) {
 
 using namespace klat;
 
-// Runs launch(layout class, stream) for every layout class of the batch: the first class (longest
-// chain) on the context's stream, the others on side streams that fork from it and join it again,
-// so that the few long workgroups of a skewed batch run beside the many short ones.
-template <class F>
-static int for_each_class(klat_batch* b, F launch) {
-  klat_ctx* c = b->ctx;
-  const size_t n = b->classes.size();
+// Runs the pieces of one sweep side by side: the first on the context's stream, the others on side
+// streams that fork from it and join it again, so that the few long workgroups of a skewed batch run
+// beside the many short ones.  The pieces are the layout classes (the class with the longest chain
+// first) and, before them, the lattices swept in segments (klat_chain.hip).
+typedef std::function<hipError_t(hipStream_t)> SweepPiece;
+static int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
+  const size_t n = work.size();
   if (n <= 1) {
-    if (n == 1) KLAT_HIP(launch(b->classes[0], c->stream));
+    if (n == 1) KLAT_HIP(work[0](c->stream));
     return KLAT_OK;
   }
   if (!c->fork_ev) {
@@ -65,12 +66,122 @@ static int for_each_class(klat_batch* b, F launch) {
   KLAT_HIP(hipEventRecord(c->fork_ev, c->stream));
   const int used = (int)std::min<size_t>(n - 1, klat_ctx::kSideStreams);
   for (int i = 0; i < used; ++i) KLAT_HIP(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
-  for (size_t k = 0; k < n; ++k) KLAT_HIP(launch(b->classes[k], k == 0 ? c->stream : c->side[(k - 1) % klat_ctx::kSideStreams]));
+  for (size_t k = 0; k < n; ++k) KLAT_HIP(work[k](k == 0 ? c->stream : c->side[(k - 1) % klat_ctx::kSideStreams]));
   for (int i = 0; i < used; ++i) {
     KLAT_HIP(hipEventRecord(c->join_ev[i], c->side[i]));
     KLAT_HIP(hipStreamWaitEvent(c->stream, c->join_ev[i], 0));
   }
   return KLAT_OK;
+}
+
+template <class F>
+static int for_each_class(klat_batch* b, F launch) {
+  std::vector<SweepPiece> work;
+  for (const LayoutClass& lc : b->classes) {
+    const LayoutClass* lcp = &lc;
+    work.push_back([&launch, lcp](hipStream_t s) { return launch(*lcp, s); });
+  }
+  return run_side_by_side(b->ctx, work);
+}
+
+// Which lattices are swept in segments (klat_chain.hip).  Candidates: at least two segments long, no arc longer
+// than kChainMaxSpan states, not on the level path.  A batch the chip is busy with anyway keeps its streams: the segment path walks every
+// arc (c + 2) / 2 times as often as a stream does.  Otherwise the planner's own model of the streams
+// (plan_cycles) is weighed against a model of the segment path for a few size thresholds -- everything at or
+// above the threshold goes -- and the cheapest choice is taken if it beats the streams by a quarter.
+// KLAT_CHAIN=0 / =1: never / every candidate; KLAT_CHAIN_SEG: states per segment (256).
+static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* lr,
+                                  const klat_pack_options& o, const uint8_t* on_level, std::vector<uint8_t>* on_chain,
+                                  std::vector<ChainLattice>* out, int* seg_len_out, int* c_out, size_t* num_records) {
+  const char* env = std::getenv("KLAT_CHAIN");
+  const int mode = env ? std::atoi(env) : -1;
+  out->clear();
+  if (mode == 0 || U <= 0) return;
+  const char* seg_env = std::getenv("KLAT_CHAIN_SEG");
+  int seg_len = seg_env ? std::atoi(seg_env) : 256;
+  seg_len = std::max(2 * kChainMaxSpan, std::min(seg_len, 1 << 20));
+  std::vector<int64_t> cand;
+  double sum_states = 0, longest = 0;
+  for (int64_t u = 0; u < U; ++u) {
+    const int64_t S = state_off[u + 1] - state_off[u];
+    if (on_level[u] || S <= 0) continue;
+    sum_states += (double)S;
+    longest = std::max(longest, (double)S);
+    if (S >= 2 * (int64_t)seg_len && lr[u].max_span <= kChainMaxSpan) cand.push_back(u);
+  }
+  if (cand.empty()) return;
+  std::sort(cand.begin(), cand.end(), [&](int64_t x, int64_t y) {
+    const int64_t sx = state_off[x + 1] - state_off[x], sy = state_off[y + 1] - state_off[y];
+    return sx != sy ? sx > sy : x < y;
+  });
+  size_t take = cand.size();
+  if (mode < 0) {
+    // cycles: a stream round of a lone workgroup ~320, a state of a full chip ~60 SIMD-cycles over 1024 SIMDs
+    if (longest * 320.0 < 1.3 * sum_states * 60.0 / 1024.0) return;
+    const double base = plan_cycles(U, state_off, arc_off, lr, o, on_level);
+    std::vector<uint8_t> skip(on_level, on_level + U);
+    double best = 0.75 * base;
+    size_t best_take = 0, n = 0;
+    double arcs = 0, work_c = 2;
+    int64_t thr = state_off[cand[0] + 1] - state_off[cand[0]];
+    for (int it = 0; it < 16 && n < cand.size(); ++it) {
+      thr = std::max<int64_t>(2 * (int64_t)seg_len, (int64_t)((double)thr * 0.7));
+      double fan_max = 1, segs_max = 1;
+      while (n < cand.size() && state_off[cand[n] + 1] - state_off[cand[n]] >= thr) {
+        const int64_t u = cand[n++];
+        skip[(size_t)u] = 1;
+        arcs += (double)(arc_off[u + 1] - arc_off[u]);
+        work_c = std::max(work_c, (double)lr[u].max_span);
+      }
+      for (size_t i = 0; i < n; ++i) {
+        const int64_t u = cand[i], S = state_off[u + 1] - state_off[u];
+        fan_max = std::max(fan_max, (double)(arc_off[u + 1] - arc_off[u]) / (double)S + 1.0);
+        segs_max = std::max(segs_max, (double)(S / seg_len));
+      }
+      int cc = 2;
+      while (cc < work_c) cc *= 2;
+      // two walks of a segment (transfer, sweep) at ~250 cycles a record, the serial combine at ~2500 a segment,
+      // four launches; the walks' work: 2.2 SIMD-cycles per record and lane, c lanes for the transfer, 2 for the sweep
+      const double latency = 2.0 * (double)seg_len * 1.5 * fan_max * 250.0 + segs_max * 2500.0 + 60000.0;
+      const double work = arcs * (cc + 2) * 2.2 / 1024.0;
+      const double total = std::max(plan_cycles(U, state_off, arc_off, lr, o, skip.data()), latency) + work;
+      if (total < best) best = total, best_take = n;
+      if (thr == 2 * (int64_t)seg_len) break;
+    }
+    take = best_take;
+  }
+  if (take == 0) return;
+  int cc = 2;
+  for (size_t i = 0; i < take; ++i)
+    while (cc < lr[cand[i]].max_span) cc *= 2;
+  seg_len = std::max(seg_len, 2 * cc);
+  std::vector<int64_t> chosen(cand.begin(), cand.begin() + (long)take);
+  std::sort(chosen.begin(), chosen.end());
+  uint64_t rec = 0;
+  int64_t seg = 0;
+  for (int64_t u : chosen) {
+    const int64_t S = state_off[u + 1] - state_off[u], A = arc_off[u + 1] - arc_off[u];
+    ChainLattice cl;
+    cl.lattice = (int32_t)u;
+    cl.num_states = (int32_t)S;
+    cl.seg_begin = (int32_t)seg;
+    cl.num_segs = (int32_t)(S / seg_len);
+    cl.span = std::max(1, lr[u].max_span);
+    cl.pad = 0;
+    cl.rec_f = (uint32_t)rec;
+    rec += (uint64_t)(A + 2 * S + 2);  // arcs, a constant term or a zero per state, final weights
+    cl.rec_b = (uint32_t)rec;
+    rec += (uint64_t)(A + S + 2);
+    seg += cl.num_segs;
+    if (rec >= ((uint64_t)1 << 31) || seg >= ((int64_t)1 << 24)) {  // 32-bit record numbers: the rest keeps its streams
+      break;
+    }
+    out->push_back(cl);
+    (*on_chain)[(size_t)u] = 1;
+    *num_records = (size_t)rec + 32;  // (the walks load a batch of records past a segment's last)
+  }
+  *seg_len_out = seg_len;
+  *c_out = cc;
 }
 
 // the lattices on the level-synchronous path (klat_level.hip), on the context's stream
@@ -507,13 +618,74 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         b->lv_records.take(records);
       }
     }
+    // Long lattices of a batch that waits for them are swept in segments (klat_chain.hip): the choice, their
+    // segments and their arc records.  Only with fused scales (the records hold exp(-cost)) and the automatic layout.
+    std::vector<uint8_t> on_chain((size_t)U, 0), skip(on_level);
+    {
+      double maxc = 0.0;
+      std::memcpy(&maxc, &h_maxcost, sizeof(maxc));
+      std::vector<ChainLattice> cl;
+      int seg_len = 0, cc = 0;
+      size_t nrec = 0;
+      // between two rescalings a lane's values may move by (6 + cost / ln 2) binary orders a record (klat_chain.hip)
+      const int rescale_records = (int)std::min(64.0, 600.0 / (6.0 + 1.4427 * maxc));
+      b->chain_rescale = std::max(1, rescale_records / 4);
+      if (b->fused && o.lanes_per_lattice == 0 && maxc <= kChainMaxCost && rescale_records >= 4)
+        choose_chain_lattices(U, d->state_off, d->arc_off, h_rounds.data(), o, on_level.data(), &on_chain, &cl, &seg_len, &cc, &nrec);
+      if (!cl.empty()) {
+        const size_t nseg = (size_t)cl.back().seg_begin + (size_t)cl.back().num_segs;
+        const int32_t zero[2] = {0, 0};
+        if ((rc = b->ch_lats.upload(cl.data(), cl.size(), c->stream)) || (rc = b->ch_segs.alloc(nseg)) || (rc = b->ch_recs.alloc(nrec)) ||
+            (rc = b->ch_qm.alloc(nseg * cc * cc)) || (rc = b->ch_qe.alloc(nseg * cc)) || (rc = b->ch_qfm.alloc(nseg * cc)) ||
+            (rc = b->ch_qfe.alloc(nseg * cc)) || (rc = b->ch_bfm.alloc(nseg * cc)) || (rc = b->ch_bfe.alloc(nseg)) ||
+            (rc = b->ch_bbm.alloc(nseg * cc)) || (rc = b->ch_bbe.alloc(nseg)) || (rc = b->ch_status.upload(zero, 2, c->stream))) {
+          klat_batch_destroy(b);
+          return rc;
+        }
+        ChainPrepArgs cp;
+        cp.lats = b->ch_lats.p;
+        cp.segs = b->ch_segs.p;
+        cp.recs = b->ch_recs.p;
+        cp.state_off = b->state_off.p;
+        cp.arc_off = b->arc_off.p;
+        cp.src = b->src.p;
+        cp.dst = b->dst.p;
+        cp.ilabel = b->ilabel.p;
+        cp.graph = b->graph.p;
+        cp.acoustic = b->acoustic.p;
+        cp.final_graph = b->final_graph.p;
+        cp.final_acoustic = b->final_acoustic.p;
+        cp.cnt = cnt.p;
+        cp.row = row.p;
+        cp.in_arc = in_arc.p;
+        cp.out_arc = out_arc.p;
+        cp.scratch_f = r0f.p;  // (the rounds pass fills them afterwards)
+        cp.scratch_b = r0b.p;
+        cp.sp = pa.fsp;
+        cp.seg_len = seg_len;
+        cp.status = b->ch_status.p;
+        KLAT_HIP_B(hipEventRecord(pev[9], c->stream));
+        KLAT_HIP_B(launch_chain_prep(cp, (int)cl.size(), c->stream));
+        KLAT_HIP_B(hipEventRecord(pev[10], c->stream));
+        b->pack_chain_timed = true;
+        b->num_chain = (int32_t)cl.size();
+        b->chain_segs = (int32_t)nseg;
+        b->chain_c = cc;
+        b->chain_seg_len = seg_len;
+        for (size_t u = 0; u < (size_t)U; ++u) skip[u] = on_level[u] | on_chain[u];
+        KLAT_HIP_B(hipStreamSynchronize(c->stream));  // (cl is read by the upload)
+      }
+    }
     // the plan: lanes per lattice, layout classes, jobs
     std::vector<int8_t> lat_g;
-    plan_layout(U, d->state_off, d->arc_off, h_rounds.data(), o, &lat_g, on_level.data());
+    plan_layout(U, d->state_off, d->arc_off, h_rounds.data(), o, &lat_g, skip.data());
+    // (the lattices swept in segments keep their streams, for klat_viterbi, with the lanes their fanout asks for)
+    for (int64_t u = 0; u < U; ++u)
+      if (on_chain[(size_t)u]) lat_g[(size_t)u] = (int8_t)base_lane_choice(d->state_off[u + 1] - d->state_off[u], d->arc_off[u + 1] - d->arc_off[u]);
     std::vector<std::vector<int64_t>> job_lats;
     int64_t chunk_total = 0;
     lap("level");
-    rc = build_jobs(U, d->state_off, h_rounds.data(), lat_g, o, &P, &job_lats, &chunk_total, &err);
+    rc = build_jobs(U, d->state_off, h_rounds.data(), lat_g, o, &P, &job_lats, &chunk_total, &err, b->num_chain > 0 ? on_chain.data() : nullptr);
     if (rc != KLAT_OK) FAIL(rc, err);
     lap("plan+jobs");
     // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, slot)
@@ -568,6 +740,11 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     }
     lap("entries+rounds+fill+wait");
     P.far_terms = h_status[3];
+    if (b->num_chain > 0) {  // (cannot happen: the batch's largest cost was checked; the streams of those lattices take over)
+      int32_t bad = 0;
+      KLAT_HIP_B(hipMemcpy(&bad, b->ch_status.p, sizeof(bad), hipMemcpyDeviceToHost));
+      if (bad) b->num_chain = 0;
+    }
     if (b->num_level > 0) {  // the level streams: the arcs as the level sweep consumes them
       if ((rc = b->lv_stream.alloc((size_t)lv_blocks * kLevelBlockDwords))) {
         klat_batch_destroy(b);
@@ -623,12 +800,21 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   b->info.max_rounds = P.max_rounds;
   b->info.num_layouts = (int32_t)P.classes.size();
   b->info.level_lattices = b->num_level;  // lattices on the level-synchronous path
+  b->info.chain_lattices = b->num_chain;
+  b->info.chain_segments = b->num_chain > 0 ? b->chain_segs : 0;
   if (host_pack) {
     UP(jobs, P.jobs.data(), P.jobs.size());
     UP(lanes, P.lanes.data(), P.lanes.size());
   }
   UP(items, P.items.data(), P.items.size());
   AL(job_flags, P.jobs.size());
+  if (!P.jobs.empty()) {  // (the jobs of a class the sweep leaves out never write theirs)
+    hipError_t me = hipMemsetAsync(b->job_flags.p, 0, P.jobs.size() * sizeof(int32_t), c->stream);
+    if (me != hipSuccess) {
+      klat_batch_destroy(b);
+      return hip_fail(me, "hipMemsetAsync");
+    }
+  }
   AL(sink, P.jobs.size() * 64);
   AL(total, b->U);
   AL(tot_fwd, b->U);
@@ -739,8 +925,19 @@ int klat_batch_get_pack_timings(klat_batch* b, klat_pack_timings* t) {
   KLAT_HIP(hipEventElapsedTime(&t->rounds_ms, b->pack_ev[4], b->pack_ev[5]));
   KLAT_HIP(hipEventElapsedTime(&t->fill_ms, b->pack_ev[5], b->pack_ev[6]));
   if (b->pack_prep_timed) KLAT_HIP(hipEventElapsedTime(&t->posterior_prep_ms, b->pack_ev[7], b->pack_ev[8]));
-  t->device_ms = t->count_ms + t->level_plan_ms + t->rounds_ms + t->fill_ms + t->posterior_prep_ms;
+  if (b->pack_chain_timed) KLAT_HIP(hipEventElapsedTime(&t->chain_prep_ms, b->pack_ev[9], b->pack_ev[10]));
+  t->device_ms = t->count_ms + t->level_plan_ms + t->rounds_ms + t->fill_ms + t->posterior_prep_ms + t->chain_prep_ms;
   t->host_ms = b->pack_host_ms;
+  return KLAT_OK;
+}
+
+int klat_batch_chain_fallback(klat_batch* b, int32_t* raised) {
+  if (!b || !raised) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  *raised = 0;
+  if (b->num_chain == 0 || !b->swept) return KLAT_OK;
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  KLAT_HIP(hipMemcpyAsync(raised, b->ch_status.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   return KLAT_OK;
 }
 
@@ -877,7 +1074,7 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
   // sweep_ms of a one-class batch is the fast sweep kernel alone (what rocprofv3 lists under its
   // name): the events sit right around its launch.  The exact sweep's launch after it (all of its
   // workgroups exit at once unless the fast sweep flagged a job) falls to totals_ms.
-  const bool one_class = b->classes.size() == 1 && b->num_level == 0;
+  const bool one_class = b->classes.size() == 1 && b->num_level == 0 && b->num_chain == 0;
   hipEvent_t* ev = c->evring[c->steps % klat_ctx::kTimingSlots];
   for (int i = 0; i < 4; ++i)
     if (!ev[i]) KLAT_HIP(hipEventCreate(&ev[i]));
@@ -887,17 +1084,68 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
   if (!one_class) KLAT_HIP(hipEventRecord(ev[0], c->stream));
   if (b->num_level > 0) KLAT_HIP(launch_level(b, b->alpha.p, b->beta.p, sp, false));
   {
-    const int rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
-      SweepArgs ca = sa;
-      ca.jobs = sa.jobs + lc.job_begin;
-      ca.job_flags = sa.job_flags + lc.job_begin;
-      ca.sink = sa.sink + (size_t)lc.job_begin * 64;
-      ca.ring_slots = lc.W;
-      ca.far_prefetch = lc.far;
-      ca.deep_prefetch = b->deep_prefetch;
-      return launch_sweep(ca, lc.job_end - lc.job_begin, lc.G, stream, one_class ? ev[0] : nullptr,
-                          one_class ? ev[1] : nullptr);
-    });
+    std::vector<SweepPiece> work;
+    ChainArgs ca;
+    if (b->num_chain > 0) {  // the long lattices, in segments: the piece with the longest chain of kernels goes first
+      ca.lats = b->ch_lats.p;
+      ca.segs = b->ch_segs.p;
+      ca.recs = b->ch_recs.p;
+      ca.num_lats = b->num_chain;
+      ca.num_segs = b->chain_segs;
+      ca.c = b->chain_c;
+      ca.lgc = 0;
+      while ((1 << ca.lgc) < ca.c) ++ca.lgc;
+      ca.W = 2 * ca.c;
+      ca.Qm = b->ch_qm.p;
+      ca.Qe = b->ch_qe.p;
+      ca.Qfm = b->ch_qfm.p;
+      ca.Qfe = b->ch_qfe.p;
+      ca.bnd_fm = b->ch_bfm.p;
+      ca.bnd_fe = b->ch_bfe.p;
+      ca.bnd_bm = b->ch_bbm.p;
+      ca.bnd_be = b->ch_bbe.p;
+      ca.rescale_iters = b->chain_rescale;
+      ca.flag = b->ch_status.p + 1;
+      ca.state_off = b->state_off.p;
+      ca.alpha = b->alpha.p;
+      ca.beta = b->beta.p;
+      ca.ln_table = c->ln_table.p;
+      // ... and behind them, on the same stream, the streams these lattices keep: their workgroups leave at once
+      // unless the segment path raised its flag (values that do not fit its arithmetic)
+      work.push_back([&](hipStream_t stream) {
+        hipError_t e = hipMemsetAsync(ca.flag, 0, sizeof(int32_t), stream);
+        if (e == hipSuccess) e = launch_chain_sweep(ca, stream);
+        for (const LayoutClass& lc : b->classes) {
+          if (!lc.chain || e != hipSuccess) continue;
+          SweepArgs fa = sa;
+          fa.jobs = sa.jobs + lc.job_begin;
+          fa.job_flags = sa.job_flags + lc.job_begin;
+          fa.sink = sa.sink + (size_t)lc.job_begin * 64;
+          fa.ring_slots = lc.W;
+          fa.far_prefetch = lc.far;
+          fa.deep_prefetch = 0;
+          fa.run_if = ca.flag;
+          e = launch_sweep(fa, lc.job_end - lc.job_begin, lc.G, stream);
+        }
+        return e;
+      });
+    }
+    for (const LayoutClass& lcr : b->classes) {
+      if (lcr.chain && b->num_chain > 0) continue;  // (their lattices are the chain piece's)
+      const LayoutClass* lcp = &lcr;
+      work.push_back([&, lcp](hipStream_t stream) {
+        const LayoutClass& lc = *lcp;
+        SweepArgs ca2 = sa;
+        ca2.jobs = sa.jobs + lc.job_begin;
+        ca2.job_flags = sa.job_flags + lc.job_begin;
+        ca2.sink = sa.sink + (size_t)lc.job_begin * 64;
+        ca2.ring_slots = lc.W;
+        ca2.far_prefetch = lc.far;
+        ca2.deep_prefetch = b->deep_prefetch;
+        return launch_sweep(ca2, lc.job_end - lc.job_begin, lc.G, stream, one_class ? ev[0] : nullptr, one_class ? ev[1] : nullptr);
+      });
+    }
+    const int rc = run_side_by_side(c, work);
     if (rc != KLAT_OK) return rc;
   }
   if (!one_class) KLAT_HIP(hipEventRecord(ev[1], c->stream));

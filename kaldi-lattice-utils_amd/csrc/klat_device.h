@@ -86,6 +86,7 @@ struct LatticeRounds {
   int32_t fwd[kNumLaneChoices], bwd[kNumLaneChoices];
   int32_t max_rel;
   int32_t max_terms;  // most terms of one position, forward stream in bits 0-15, backward in 16-31 (capped at 64)
+  int32_t max_span;   // longest arc, in states (max_rel without the final states' distance to the end)
 };
 
 // One lattice inside a job.

@@ -13,6 +13,7 @@
 #include "../../include/klat.h"
 #include "klat_device.h"
 #include "klat_accum.h"
+#include "klat_chain.h"
 #include "klat_kernels.h"
 #include "klat_level.h"
 #include "klat_pack.h"
@@ -267,9 +268,19 @@ struct klat_batch {
   int32_t num_level = 0, level_max_states = 0;
   klat::DevBuf<int32_t> lv_lattices, lv_records, lv_stream;
   // klat_batch_create's device passes: events around count | level plan | rounds | fill | posterior prep
-  static const int kPackEvents = 9;
+  static const int kPackEvents = 11;  // (9, 10: around the segment path's record pass)
   hipEvent_t pack_ev[kPackEvents] = {};
-  bool pack_level_timed = false, pack_prep_timed = false;
+  bool pack_level_timed = false, pack_prep_timed = false, pack_chain_timed = false;
+  // long lattices swept in segments (klat_chain.hip).  Their stream jobs stay, as layout classes of their own
+  // (LayoutClass::chain): klat_viterbi runs them, the log-semiring sweep leaves them out.
+  int32_t num_chain = 0, chain_segs = 0, chain_c = 0, chain_seg_len = 0;
+  klat::DevBuf<klat::ChainLattice> ch_lats;
+  klat::DevBuf<klat::ChainSegment> ch_segs;
+  klat::DevBuf<uint64_t> ch_recs;
+  klat::DevBuf<double> ch_qm, ch_qfm, ch_bfm, ch_bbm;
+  klat::DevBuf<int32_t> ch_qe, ch_qfe, ch_bfe, ch_bbe;
+  klat::DevBuf<int32_t> ch_status;  // [0] the record pass met a cost that fits no record, [1] the sweep's fall-back flag
+  int32_t chain_rescale = 1;        // ChainArgs::rescale_iters
   float pack_host_ms = 0.0f;  // wall time of klat_batch_create (uploads, host planning, waits included)
   klat::DevBuf<int64_t> lv_stream_off;
 };

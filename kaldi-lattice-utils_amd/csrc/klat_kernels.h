@@ -70,6 +70,9 @@ struct SweepArgs {
   const int16_t* sl = nullptr;
   double lo_unit = 0.0;
   int32_t fused = 0;
+  // null, or a device word: the launch does nothing while it is zero (the classes of the lattices swept in
+  // segments run only when klat_chain.hip raised its flag)
+  const int32_t* run_if = nullptr;
 };
 
 struct TotalsArgs {

@@ -127,6 +127,34 @@ __device__ __forceinline__ void arc_weight(double c, double& wm, int& k, bool& d
   wm = select64_or_zero(lane_mask(c < 1.0e30) & live, p);
 }
 
+// ln(m * 2^e) for a normalised mantissa m in [0.5,1) (or 0 = log-zero) with a 16-entry table in
+// LDS instead of the library log (~50 instructions): 2m = c_i * (1 + r), |r| <= 1/32, and
+// log1p(r) by its degree-10 series (next term < 3e-18).  The series runs as one block of
+// v_fma_f64 with its constants in scalar registers or inline (see arc_weight).
+// The table read is a separate step so that callers can overlap its LDS latency with other work.
+__device__ __forceinline__ int ln_table_index(double m) {
+  return (__double2hiint(m) >> 16) & (kLnTabSize - 1);  // top four mantissa bits
+}
+__device__ __forceinline__ double table_ln(double m, int e, const LnTabEntry& t) {
+  const double r = fma(m, t.inv2, -1.0);
+  const double c10 = -0.1;
+  double p, v;
+  asm("v_fma_f64 %0, %1, %2, %3\n\t"
+      "v_fma_f64 %0, %0, %2, %4\n\t"
+      "v_fma_f64 %0, %0, %2, %5\n\t"
+      "v_fma_f64 %0, %0, %2, %6\n\t"
+      "v_fma_f64 %0, %0, %2, %7\n\t"
+      "v_fma_f64 %0, %0, %2, %8\n\t"
+      "v_fma_f64 %0, %0, %2, %9\n\t"
+      "v_fma_f64 %0, %0, %2, -0.5\n\t"
+      "v_fma_f64 %0, %0, %2, 1.0"
+      : "=&v"(p)
+      : "v"(c10), "v"(r), "s"(1.0 / 9.0), "s"(-0.125), "s"(1.0 / 7.0), "s"(-1.0 / 6.0), "s"(0.2), "s"(-0.25), "s"(1.0 / 3.0));
+  const double lnm = fma(p, r, t.lnc);
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(v) : "v"((double)e), "s"(kLn2), "v"(lnm));
+  return select64(lane_mask(m == 0.0), -INFINITY, v);
+}
+
 // (M,E) += (tm,te) in the scaled-linear domain, safe for any exponent gap.
 __device__ __forceinline__ void me_accumulate(double& M, int& E, double tm, int te) {
   const int hi = max(E, te);

@@ -179,6 +179,20 @@ void plan_layout(int64_t U, const int64_t* state_off, const int64_t* arc_off, co
   if (best_cost.cycles < 0.95 * base_cycles) g = best;  // otherwise not worth the extra lanes
 }
 
+int base_lane_choice(int64_t S, int64_t A) {
+  const double fan = S > 0 ? (double)A / (double)S : 0.0;
+  int k = 0;
+  while ((1 << k) < fan && k < kNumLaneChoices - 1) ++k;
+  return k;
+}
+
+double plan_cycles(int64_t U, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* lr,
+                   const klat_pack_options& opt, const uint8_t* skip) {
+  std::vector<int8_t> g;
+  plan_layout(U, state_off, arc_off, lr, opt, &g, skip);
+  return plan_cost(U, lr, g).cycles;
+}
+
 int64_t slice_jobs(const int64_t* state_off, const LatticeRounds* lr, const std::vector<int64_t>& members,
                    const std::vector<int64_t>& rf, const std::vector<int64_t>& rb, int G, int W, int64_t chunk_base,
                    PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats) {
@@ -238,31 +252,32 @@ int64_t slice_jobs(const int64_t* state_off, const LatticeRounds* lr, const std:
     }
     (*job_lats)[j0 + j] = std::move(proto[j].lat);
   }
-  P.classes.push_back(LayoutClass{G, W, (int32_t)j0, (int32_t)(j0 + proto.size()), 0});
+  P.classes.push_back(LayoutClass{G, W, (int32_t)j0, (int32_t)(j0 + proto.size()), 0, 0});
   return chunk_total;
 }
 
 int build_jobs(int64_t U, const int64_t* state_off, const LatticeRounds* lr, const std::vector<int8_t>& lat_g,
                const klat_pack_options& opt, PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats,
-               int64_t* chunk_total, std::string* err) {
+               int64_t* chunk_total, std::string* err, const uint8_t* on_chain) {
   PackedBatch& P = *out;
   struct Proto {
-    int k;
+    int k, chain;
     int64_t longest, max_rel, slots;
     std::vector<int64_t> members;
   };
   std::vector<Proto> cls;
-  for (int k = 0; k < kNumLaneChoices; ++k) {
-    Proto c{k, 0, 1, 0, {}};
-    for (int64_t u = 0; u < U; ++u)
-      if (lat_g[(size_t)u] == k) {
-        c.members.push_back(u);
-        c.longest = std::max<int64_t>(c.longest, std::max(lr[u].fwd[k], lr[u].bwd[k]));
-        c.max_rel = std::max<int64_t>(c.max_rel, lr[u].max_rel);
-        c.slots += ((int64_t)lr[u].fwd[k] + lr[u].bwd[k]) << k;
-      }
-    if (!c.members.empty()) cls.push_back(std::move(c));
-  }
+  for (int chain = 0; chain < (on_chain ? 2 : 1); ++chain)
+    for (int k = 0; k < kNumLaneChoices; ++k) {
+      Proto c{k, chain, 0, 1, 0, {}};
+      for (int64_t u = 0; u < U; ++u)
+        if (lat_g[(size_t)u] == k && (on_chain ? on_chain[u] != 0 : false) == (chain != 0)) {
+          c.members.push_back(u);
+          c.longest = std::max<int64_t>(c.longest, std::max(lr[u].fwd[k], lr[u].bwd[k]));
+          c.max_rel = std::max<int64_t>(c.max_rel, lr[u].max_rel);
+          c.slots += ((int64_t)lr[u].fwd[k] + lr[u].bwd[k]) << k;
+        }
+      if (!c.members.empty()) cls.push_back(std::move(c));
+    }
   // launch order: the class with the longest chain first
   std::stable_sort(cls.begin(), cls.end(), [](const Proto& a, const Proto& b) { return a.longest > b.longest; });
   std::vector<int64_t> rf((size_t)U, 0), rb((size_t)U, 0);
@@ -279,6 +294,7 @@ int build_jobs(int64_t U, const int64_t* state_off, const LatticeRounds* lr, con
     for (int64_t u : c.members) rf[(size_t)u] = lr[u].fwd[c.k], rb[(size_t)u] = lr[u].bwd[c.k];
     chunks = slice_jobs(state_off, lr, c.members, rf, rb, G, W, chunks, &P, job_lats);
     P.classes.back().far = c.max_rel >= W ? 1 : 0;
+    P.classes.back().chain = c.chain;
     if (c.slots > most_slots) most_slots = c.slots, P.G = G, P.W = W;  // what klat_batch_info reports
   }
   if (cls.empty()) {
@@ -286,10 +302,17 @@ int build_jobs(int64_t U, const int64_t* state_off, const LatticeRounds* lr, con
     P.W = opt.ring_slots ? opt.ring_slots : choose_ring_slots(P.G, 1);
   }
   // wave priorities: in a skewed batch the long chains outrank the waves they share a SIMD with
-  int64_t sum_rounds = 0, longest = 0;
-  for (const SweepJob& j : P.jobs) sum_rounds += j.nchunks, longest = std::max<int64_t>(longest, j.nchunks);
-  if (!P.jobs.empty() && longest * (int64_t)P.jobs.size() > 2 * sum_rounds)
-    for (SweepJob& j : P.jobs) j.tag |= (int32_t)std::min<int64_t>(3, 4 * (int64_t)j.nchunks / (longest + 1));
+  // (the jobs the log-semiring sweep runs side by side: those outside the segment path's classes)
+  std::vector<uint8_t> in_chain(P.jobs.size(), 0);
+  for (const LayoutClass& lc : P.classes)
+    if (lc.chain)
+      for (int32_t j = lc.job_begin; j < lc.job_end; ++j) in_chain[(size_t)j] = 1;
+  int64_t sum_rounds = 0, longest = 0, count = 0;
+  for (size_t j = 0; j < P.jobs.size(); ++j)
+    if (!in_chain[j]) sum_rounds += P.jobs[j].nchunks, longest = std::max<int64_t>(longest, P.jobs[j].nchunks), ++count;
+  if (count > 0 && longest * count > 2 * sum_rounds)
+    for (size_t j = 0; j < P.jobs.size(); ++j)
+      if (!in_chain[j]) P.jobs[j].tag |= (int32_t)std::min<int64_t>(3, 4 * (int64_t)P.jobs[j].nchunks / (longest + 1));
   *chunk_total = chunks;
   return KLAT_OK;
 }
@@ -361,6 +384,7 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
       out_cnt[s]++;
       mr = std::max<int64_t>(mr, t - s);
     }
+    lr[(size_t)u].max_span = (int32_t)mr;
     int64_t nfinal = 0, f[kNumLaneChoices] = {0}, b[kNumLaneChoices] = {0};
     int64_t mtf = 1, mtb = 1;
     for (int64_t s = 0; s < S; ++s) {

@@ -44,6 +44,7 @@ class HostBuf {
 struct LayoutClass {
   int32_t G, W, job_begin, job_end;
   int32_t far;  // some lattice of the class has arcs (or final states) W or more positions long
+  int32_t chain;  // the class holds the lattices that klat_chain.hip sweeps in segments: the log-semiring sweep leaves it out
 };
 
 // The posterior kernel's work items of lattice u (arcs [a0, a1)): at least one, the first one marked.
@@ -76,7 +77,14 @@ void plan_layout(int64_t num_lattices, const int64_t* state_off, const int64_t* 
                  const uint8_t* skip = nullptr /* [num_lattices] lattices that take no stream (level path) */);
 int build_jobs(int64_t num_lattices, const int64_t* state_off, const LatticeRounds* rounds, const std::vector<int8_t>& lat_g,
                const klat_pack_options& opt, PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats,
-               int64_t* chunk_total, std::string* err);
+               int64_t* chunk_total, std::string* err,
+               const uint8_t* on_chain = nullptr /* [num_lattices] lattices of the segment path: layout classes of their own */);
+// The planner's model of a batch's sweep: cycles of the plan plan_layout would choose for the lattices not
+// in `skip` (what klat_batch_create weighs the segment path against).
+double plan_cycles(int64_t num_lattices, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* rounds,
+                   const klat_pack_options& opt, const uint8_t* skip);
+// log2(lanes) the planner starts from: the lattice's fanout rounded up to a power of two
+int base_lane_choice(int64_t states, int64_t arcs);
 
 // Ring slots when the options leave W at 0.
 int choose_ring_slots(int G, int64_t max_rel);

@@ -120,7 +120,7 @@ constexpr int kCountUnroll = KLAT_COUNT_UNROLL;
 __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_lo, int lds_hi) {
   extern __shared__ int32_t lds[];
   __shared__ int sh[3 * (kTC / 64)];
-  __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb, sh_linked;
+  __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb, sh_linked, sh_span;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
       pt = now;
     }
   };
-  if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0;
+  if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0, sh_span = 1;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
   for (int s = tid; s < 2 * (S + 2); s += kTC) lds[s] = 0;
   __syncthreads();
@@ -177,6 +177,11 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
         mr = max(mr, t - s);
       }
     }
+  }
+  {  // the longest arc alone (the final states join mr below)
+    int span = mr;
+    for (int d = 32; d > 0; d >>= 1) span = max(span, __shfl_xor(span, d, 64));
+    if ((tid & 63) == 0) atomicMax(&sh_span, span);
   }
   __syncthreads();
   stamp(1);
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
     atomicMax(&a.status[2], sh_mr);
     a.lat_rounds[u].max_rel = sh_mr;
     a.lat_rounds[u].max_terms = min(sh_mtf, 64) | (min(sh_mtb, 64) << 16);
+    a.lat_rounds[u].max_span = sh_span;
   }
 }
 
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
 // above `lds_hi` bytes of tables.
 __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, int lds_hi) {
   __shared__ int sh[kT / 64];
-  __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb, sh_linked;
+  __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb, sh_linked, sh_span;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
   int32_t* out_arc = a.out_arc + a0;
   const int32_t* src = a.src + a0;
   const int32_t* dst = a.dst + a0;
-  if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0;
+  if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0, sh_span = 1;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
   for (int s = tid; s < S + 2; s += kT) cnt[s] = 0;
   __syncthreads();
@@ -390,6 +396,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
       mr = max(mr, t - s);
     }
   }
+  atomicMax(&sh_span, mr);
   for (int s = tid; s < S; s += kT)
     if (dev_is_final(a, s0 + s)) mr = max(mr, S - s);
   atomicMax(&sh_mr, mr);
@@ -473,6 +480,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
     row[S + 1] = sh_linked;  // (the spare entry of the row table: the level planner's chain test)
     a.lat_rounds[u].max_rel = sh_mr;
     a.lat_rounds[u].max_terms = min(sh_mtf, 64) | (min(sh_mtb, 64) << 16);
+    a.lat_rounds[u].max_span = sh_span;
   }
 }
 

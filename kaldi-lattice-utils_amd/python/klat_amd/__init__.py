@@ -76,7 +76,7 @@ class BatchInfo(C.Structure):
                 ("bwd_slots", C.c_int64), ("far_terms", C.c_int64),
                 ("lanes_per_lattice", C.c_int32), ("ring_slots", C.c_int32),
                 ("num_jobs", C.c_int32), ("max_rounds", C.c_int32), ("num_layouts", C.c_int32),
-                ("level_lattices", C.c_int32)]
+                ("level_lattices", C.c_int32), ("chain_lattices", C.c_int32), ("chain_segments", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -93,7 +93,7 @@ class Timings(C.Structure):
 class PackTimings(C.Structure):
     _fields_ = [("count_ms", C.c_float), ("level_plan_ms", C.c_float), ("rounds_ms", C.c_float),
                 ("fill_ms", C.c_float), ("posterior_prep_ms", C.c_float), ("device_ms", C.c_float),
-                ("host_ms", C.c_float)]
+                ("host_ms", C.c_float), ("chain_prep_ms", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -311,6 +311,12 @@ class Batch:
         t = PackTimings()
         _check(lib().klat_batch_get_pack_timings(self.h, C.byref(t)))
         return t.as_dict()
+
+    def chain_fallback(self):
+        """True if the last forward_backward swept the segment path's lattices again through their streams"""
+        n = C.c_int32(0)
+        _check(lib().klat_batch_chain_fallback(self.h, C.byref(n)))
+        return bool(n.value)
 
     def topological_depth(self):
         d = np.zeros(max(self.U, 1), np.int32)

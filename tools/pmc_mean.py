@@ -5,8 +5,8 @@ import collections, csv, glob, os, sys
 acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[(r["Kernel_Name"][:48], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        acc[(r["Kernel_Name"][:int(os.environ.get("PMC_NAME_CHARS", "48"))], r["Counter_Name"])].append(float(r["Counter_Value"]))
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 for (k, c), v in sorted(acc.items()):
     if flt in k:
-        print("%-50s %-28s n=%-5d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
+        print("%-50s  %-28s n=%-5d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
