@@ -84,12 +84,23 @@ static int for_each_class(klat_batch* b, F launch) {
   return run_side_by_side(b->ctx, work);
 }
 
-// Which lattices are swept in segments (klat_chain.hip).  Candidates: at least two segments long, no arc longer
-// than kChainMaxSpan states, not on the level path.  A batch the chip is busy with anyway keeps its streams: the segment path walks every
-// arc (c + 2) / 2 times as often as a stream does.  Otherwise the planner's own model of the streams
-// (plan_cycles) is weighed against a model of the segment path for a few size thresholds -- everything at or
-// above the threshold goes -- and the cheapest choice is taken if it beats the streams by a quarter.
-// KLAT_CHAIN=0 / =1: never / every candidate; KLAT_CHAIN_SEG: states per segment (256).
+// Which lattices are swept in segments (klat_chain.hip), and into how many.  A lattice's segments are equally
+// long and hold about 4 x KLAT_CHAIN_SEG arc records each (default 128: the length, in states, of a segment of a
+// lattice of fanout 3), so that the walks' lanes finish together whatever the lattices' fanout.  Candidates: at
+// least two segments long, no arc longer than kChainMaxSpan states, not on the level path.  A batch the chip is
+// busy with anyway keeps its streams: the segment path walks every arc (c + 2) / 2 times as often as a stream
+// does.  Otherwise the planner's own model of the streams (plan_cycles) is weighed against a model of the
+// segment path for a few size thresholds -- everything at or above the threshold goes -- and the cheapest choice
+// is taken if it beats the streams by a quarter.  KLAT_CHAIN=0 / =1: never / every candidate.
+static int chain_segment_states(int64_t S, int64_t A, int seg) {
+  const double fan = S > 0 ? (double)A / (double)S : 1.0;
+  const int by_records = std::max(2 * kChainMaxSpan, (int)(4.0 * (double)seg / (fan + 1.0)));
+  // The combine step walks a lattice's segments one after the other (~1 us each) while the sweep walks a
+  // segment's records (~0.25 us each): a long lattice is cut into about sqrt(records / 4) segments, where the two
+  // chains are equally long, rather than into ever more segments of the batch's standard length.
+  const int64_t most = std::max<int64_t>(2, (int64_t)std::sqrt(0.25 * (double)(A + S)));
+  return (int)std::max<int64_t>(by_records, (S + most - 1) / most);
+}
 static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* lr,
                                   const klat_pack_options& o, const uint8_t* on_level, std::vector<uint8_t>* on_chain,
                                   std::vector<ChainLattice>* out, int* seg_len_out, int* c_out, size_t* num_records) {
@@ -98,8 +109,8 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
   out->clear();
   if (mode == 0 || U <= 0) return;
   const char* seg_env = std::getenv("KLAT_CHAIN_SEG");
-  int seg_len = seg_env ? std::atoi(seg_env) : 256;
-  seg_len = std::max(2 * kChainMaxSpan, std::min(seg_len, 1 << 20));
+  int seg = seg_env ? std::atoi(seg_env) : 128;
+  seg = std::max(kChainMaxSpan, std::min(seg, 1 << 20));
   std::vector<int64_t> cand;
   double sum_states = 0, longest = 0;
   for (int64_t u = 0; u < U; ++u) {
@@ -107,7 +118,7 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
     if (on_level[u] || S <= 0) continue;
     sum_states += (double)S;
     longest = std::max(longest, (double)S);
-    if (S >= 2 * (int64_t)seg_len && lr[u].max_span <= kChainMaxSpan) cand.push_back(u);
+    if (S >= 2 * (int64_t)chain_segment_states(S, arc_off[u + 1] - arc_off[u], seg) && lr[u].max_span <= kChainMaxSpan) cand.push_back(u);
   }
   if (cand.empty()) return;
   std::sort(cand.begin(), cand.end(), [&](int64_t x, int64_t y) {
@@ -122,31 +133,28 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
     std::vector<uint8_t> skip(on_level, on_level + U);
     double best = 0.75 * base;
     size_t best_take = 0, n = 0;
-    double arcs = 0, work_c = 2;
+    double arcs = 0, work_c = 2, segs_max = 1;
+    const int64_t floor_states = 8 * (int64_t)seg;  // (shorter lattices gain nothing: three kernels in a row are ~2 000 stream rounds)
     int64_t thr = state_off[cand[0] + 1] - state_off[cand[0]];
     for (int it = 0; it < 16 && n < cand.size(); ++it) {
-      thr = std::max<int64_t>(2 * (int64_t)seg_len, (int64_t)((double)thr * 0.7));
-      double fan_max = 1, segs_max = 1;
+      thr = std::max<int64_t>(floor_states, (int64_t)((double)thr * 0.7));
       while (n < cand.size() && state_off[cand[n] + 1] - state_off[cand[n]] >= thr) {
-        const int64_t u = cand[n++];
+        const int64_t u = cand[n++], S = state_off[u + 1] - state_off[u], A = arc_off[u + 1] - arc_off[u];
         skip[(size_t)u] = 1;
-        arcs += (double)(arc_off[u + 1] - arc_off[u]);
+        arcs += (double)(A + S);
         work_c = std::max(work_c, (double)lr[u].max_span);
-      }
-      for (size_t i = 0; i < n; ++i) {
-        const int64_t u = cand[i], S = state_off[u + 1] - state_off[u];
-        fan_max = std::max(fan_max, (double)(arc_off[u + 1] - arc_off[u]) / (double)S + 1.0);
-        segs_max = std::max(segs_max, (double)(S / seg_len));
+        segs_max = std::max(segs_max, (double)(S / chain_segment_states(S, A, seg)));
       }
       int cc = 2;
       while (cc < work_c) cc *= 2;
-      // two walks of a segment (transfer, sweep) at ~250 cycles a record, the serial combine at ~2500 a segment,
-      // four launches; the walks' work: 2.2 SIMD-cycles per record and lane, c lanes for the transfer, 2 for the sweep
-      const double latency = 2.0 * (double)seg_len * 1.5 * fan_max * 250.0 + segs_max * 2500.0 + 60000.0;
-      const double work = arcs * (cc + 2) * 2.2 / 1024.0;
+      // two walks of a segment (transfer, sweep: ~700 cycles a record for a wave on its own), the serial combine
+      // (~800 a segment), three launches; the walks' work: ~2 SIMD-cycles per record and lane, c lanes for the
+      // transfer, 2 for the sweep
+      const double latency = 2.0 * 4.0 * (double)seg * 700.0 + segs_max * 800.0 + 50000.0;
+      const double work = arcs * (cc + 2) * 2.0 / 1024.0;
       const double total = std::max(plan_cycles(U, state_off, arc_off, lr, o, skip.data()), latency) + work;
       if (total < best) best = total, best_take = n;
-      if (thr == 2 * (int64_t)seg_len) break;
+      if (thr == floor_states) break;
     }
     take = best_take;
   }
@@ -154,33 +162,33 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
   int cc = 2;
   for (size_t i = 0; i < take; ++i)
     while (cc < lr[cand[i]].max_span) cc *= 2;
-  seg_len = std::max(seg_len, 2 * cc);
   std::vector<int64_t> chosen(cand.begin(), cand.begin() + (long)take);
   std::sort(chosen.begin(), chosen.end());
   uint64_t rec = 0;
-  int64_t seg = 0;
+  int64_t nseg = 0;
   for (int64_t u : chosen) {
     const int64_t S = state_off[u + 1] - state_off[u], A = arc_off[u + 1] - arc_off[u];
     ChainLattice cl;
     cl.lattice = (int32_t)u;
     cl.num_states = (int32_t)S;
-    cl.seg_begin = (int32_t)seg;
-    cl.num_segs = (int32_t)(S / seg_len);
+    cl.seg_begin = (int32_t)nseg;
+    cl.num_segs = (int32_t)(S / std::max(chain_segment_states(S, A, seg), 2 * cc));
+    if (cl.num_segs < 2) continue;
     cl.span = std::max(1, lr[u].max_span);
     cl.pad = 0;
     cl.rec_f = (uint32_t)rec;
     rec += (uint64_t)(A + 2 * S + 2);  // arcs, a constant term or a zero per state, final weights
     cl.rec_b = (uint32_t)rec;
     rec += (uint64_t)(A + S + 2);
-    seg += cl.num_segs;
-    if (rec >= ((uint64_t)1 << 31) || seg >= ((int64_t)1 << 24)) {  // 32-bit record numbers: the rest keeps its streams
+    nseg += cl.num_segs;
+    if (rec >= ((uint64_t)1 << 31) || nseg >= ((int64_t)1 << 24)) {  // 32-bit record numbers: the rest keeps its streams
       break;
     }
     out->push_back(cl);
     (*on_chain)[(size_t)u] = 1;
     *num_records = (size_t)rec + 32;  // (the walks load a batch of records past a segment's last)
   }
-  *seg_len_out = seg_len;
+  *seg_len_out = seg;
   *c_out = cc;
 }
 
@@ -662,7 +670,6 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         cp.scratch_f = r0f.p;  // (the rounds pass fills them afterwards)
         cp.scratch_b = r0b.p;
         cp.sp = pa.fsp;
-        cp.seg_len = seg_len;
         cp.status = b->ch_status.p;
         KLAT_HIP_B(hipEventRecord(pev[9], c->stream));
         KLAT_HIP_B(launch_chain_prep(cp, (int)cl.size(), c->stream));
@@ -1145,8 +1152,32 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
         return launch_sweep(ca2, lc.job_end - lc.job_begin, lc.G, stream, one_class ? ev[0] : nullptr, one_class ? ev[1] : nullptr);
       });
     }
+    // KLAT_CHAIN_DEBUG=<file>: when and where (CU, SIMD) every wave of the segment path's walks ran, written after this sweep
+    DevBuf<unsigned long long> dbg;
+    const char* dbg_path = b->num_chain > 0 ? std::getenv("KLAT_CHAIN_DEBUG") : nullptr;
+    size_t dbg_words = 0;
+    if (dbg_path) {
+      const size_t waves_a = ((size_t)b->chain_segs * ca.c / 64 + 8) / 4 * 4 + 8, waves_c = 2 * (((size_t)b->chain_segs / 64 + 8) / 4 * 4 + 8);
+      dbg_words = 4 * waves_a + 8 * waves_c;
+      int drc = dbg.alloc(dbg_words);
+      if (drc != KLAT_OK) return drc;
+      KLAT_HIP(hipMemsetAsync(dbg.p, 0, dbg_words * sizeof(unsigned long long), c->stream));
+      ca.dbg = dbg.p;
+      ca.dbg_stride = 4 * waves_a;
+    }
     const int rc = run_side_by_side(c, work);
     if (rc != KLAT_OK) return rc;
+    if (dbg_path) {
+      std::vector<unsigned long long> h(dbg_words);
+      KLAT_HIP(hipStreamSynchronize(c->stream));
+      KLAT_HIP(hipMemcpy(h.data(), dbg.p, dbg_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      if (FILE* f = std::fopen(dbg_path, "wb")) {
+        const unsigned long long head[2] = {(unsigned long long)ca.dbg_stride, (unsigned long long)dbg_words};
+        std::fwrite(head, sizeof(head), 1, f);
+        std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+        std::fclose(f);
+      }
+    }
   }
   if (!one_class) KLAT_HIP(hipEventRecord(ev[1], c->stream));
   // (the totals are formed by the posterior kernel's first item of every lattice; totals_ms of the

@@ -69,7 +69,6 @@ struct ChainPrepArgs {
   const int32_t* cnt; const int32_t* row; const int32_t* in_arc; const int32_t* out_arc;
   int32_t* scratch_f; int32_t* scratch_b;  // same shape (the packer's r0f / r0b, not yet in use)
   ScaleParams sp;
-  int32_t seg_len;
   int32_t* status;  // [1] set when a cost does not fit a record
 };
 
@@ -85,7 +84,8 @@ struct ChainArgs {
   double* bnd_fm; int32_t* bnd_fe;  // [segments][c] alpha of the c states before the segment, to [segments] exponents
   double* bnd_bm; int32_t* bnd_be;  // [segments][c] what the arcs leaving the segment contribute to its last c states
   int32_t rescale_iters;  // a lane rescales every this many iterations of four records
-  int32_t exp = 0;        // (timing experiments: 1 one ring row, 2 no ring writes, 4 no ring reads)
+  unsigned long long* dbg = nullptr;  // (KLAT_CHAIN_DEBUG) four words per wave: begin, end (100 MHz), HW_ID, XCC_ID
+  size_t dbg_stride = 0;              //   the sweep's waves start here
   int32_t dir_first = 0;  // (the sweep's block row 0 walks this direction)
   int32_t* flag;          // [1] raised when a lattice's values do not fit this arithmetic: the streams sweep them again
   const int64_t* state_off;

@@ -18,10 +18,11 @@ namespace klat {
 namespace {
 
 constexpr int kTP = 256;  // chain_prep_kernel
-// Waves per workgroup of the walks.  The waves share nothing: four to a workgroup only because the dispatcher
-// spreads the waves of ONE workgroup over a CU's four SIMDs, while single-wave workgroups piled up on one
-// (measured: a CU finished a step every 104 cycles whether it held 4 or 16 such workgroups).
-constexpr int kWalkWaves = 4;
+// Waves per workgroup of the walks.  The waves share nothing, and single-wave workgroups pack a CU's LDS best
+// (the dispatcher spreads them evenly over the four SIMDs: KLAT_CHAIN_DEBUG shows where every wave ran).
+constexpr int kWalkWaves = 1;
+constexpr int kSweepWaves = 1;
+constexpr int kSweepBatch = 8;  // records per batch of the sweep (its output rows are LDS: 8 rows, 14.6 KB a wave, eleven waves a CU)
 
 __device__ __forceinline__ int wave_max_int(int v) {
   for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(kTP) void chain_prep_kernel(ChainPrepArgs a) {
   __threadfence_block();
   __syncthreads();
   const int Tb = carry_b;
-  for (int k = tid; k < cl.num_segs; k += kTP) {
-    const int b0 = k * a.seg_len, b1 = (k == cl.num_segs - 1) ? S : (k + 1) * a.seg_len;
+  for (int k = tid; k < cl.num_segs; k += kTP) {  // segments of equal length
+    const int b0 = (int)((int64_t)k * S / cl.num_segs), b1 = (int)((int64_t)(k + 1) * S / cl.num_segs);
     ChainSegment sg;
     sg.clat = blockIdx.x, sg.k = k, sg.first_state = b0, sg.num_states = b1 - b0;
     sg.rf_begin = cl.rec_f + (uint32_t)pf[b0], sg.rf_count = (uint32_t)(pf[b1] - pf[b0]);
@@ -189,7 +190,7 @@ __device__ __forceinline__ int wave_min_int(int v) {
 template <int MODE, int DIR>
 __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, double* outbuf, const LnTabEntry* lntab) {
   const int lane = threadIdx.x & 63;
-  const int job = blockIdx.x * kWalkWaves + (threadIdx.x >> 6);  // one wave = one job, the waves of a workgroup are on their own
+  const int job = blockIdx.x * (MODE == 0 ? kWalkWaves : kSweepWaves) + (threadIdx.x >> 6);  // one wave = one job, the waves of a workgroup are on their own
   const int W = a.W, Wm = a.W - 1, c = a.c;
   int seg, comp = 0;
   if (MODE == 0) {
@@ -200,6 +201,7 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
   }
   const bool have = seg < a.num_segs;
   int trouble = 0;  // why the lattice does not fit this arithmetic (bits: klat_chain.h)
+  unsigned long long dbg_flush = 0, dbg_wait = 0, dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
   int npend = 0;  // (a lane without a segment keeps 0: the wave-wide maximum below reads it)
   // the wave's shortest and longest record run, over the lanes that have a segment (the shuffles read all 64)
   const int n_all = have ? (int)(DIR ? a.segs[seg].rb_count : a.segs[seg].rf_count) : -1;
@@ -210,10 +212,9 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
     const int first = sg.first_state, end = sg.first_state + sg.num_states, span = cl.span;
     const bool last_seg = sg.k == cl.num_segs - 1;
     double* col = ring + lane;
-    int32_t* oute = reinterpret_cast<int32_t*>(outbuf + 16 * 64) + lane;  // exponents beside the output rows
+    int32_t* oute = reinterpret_cast<int32_t*>(outbuf + kSweepBatch * 64) + lane;  // exponents beside the output rows
     double* outx = outbuf + lane;
-    for (int r = 0; r < W + 2; ++r) col[r * 64] = 0.0;
-    col[W * 64] = 1.0;  // row W: the constant one; row W + 1: zero
+    for (int r = 0; r < W; ++r) col[r * 64] = 0.0;
     double acc = 0.0, lastX = 0.0, finA = 0.0;
     int E = 0, finR = 0;
     int pos = DIR ? end - 1 : first;
@@ -242,14 +243,15 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
       const double w = __hiloint2double((int)hi, (int)(lo & ~kChainCtlMask));
       const int rel = (int)(lo & kChainRelMask);
       const bool last = (lo & kChainLast) != 0;
-      int cell = (DIR ? pos + rel : pos - rel) & Wm;
-      if (a.exp & 1) cell = 0;
-      if (SPECIAL && (lo & kChainSpecial)) cell = W + (int)((lo >> 7) & 1u);  // constants
-      double x = (a.exp & 4) ? 1.0 : col[cell * 64];
+      const int cell = (DIR ? pos + rel : pos - rel) & Wm;
+      double x = col[cell * 64];
       if (MODE == 1) x = select64(lane_mask(rel == 1), lastX, x);  // the state finished by the previous step: from registers, not through LDS
-      if (SPECIAL && (lo & (kChainSpecial | kChainWhich)) == kChainSpecial) {  // the constant one, in the lane's scale
-        if (E > 900 || E < -900) trouble |= kChainTroubleOne;
-        x = ldexp(1.0, max(-2000, min(2000, -E)));
+      if (SPECIAL && (lo & kChainSpecial)) {  // a constant source: zero, or one in the lane's scale
+        x = 0.0;
+        if (!(lo & kChainWhich)) {
+          if (E > 900 || E < -900) trouble |= kChainTroubleOne;
+          x = ldexp(1.0, max(-2000, min(2000, -E)));
+        }
       }
       if (SPECIAL && (lo & kChainFinal)) {  // a final weight: into the lane's total (transfer), nothing (sweep)
         if (MODE == 0) chain_add_exact(finA, finR, x * w, E);
@@ -266,7 +268,7 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
         }
       }
       // every step leaves the open state's sum in the state's own ring cell (nobody reads it before its LAST)
-      if (!(a.exp & 2)) col[((a.exp & 1) ? 1 : (pos & Wm)) * 64] = acc;
+      col[(pos & Wm) * 64] = acc;
       const uint64_t L = lane_mask(last);
       if (MODE == 1) {
         lastX = select64(L, acc, lastX);
@@ -296,70 +298,132 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
     // the natural logs of the states finished since the last flush, into the batch's rows
     auto flush = [&]() {
       if (MODE == 1) {
-        const int mx = wave_max_int(npend);
-        for (int j = 0; j < mx; ++j) {
-          const double x = outx[j * 64];
-          const double m = __builtin_amdgcn_frexp_mant(x);
-          const int e = oute[j * 64] + __builtin_amdgcn_frexp_exp(x);
-          const double v = table_ln(m, e, lntab[ln_table_index(m)]);
-          if (j < npend) vals[DIR ? out_pos - j : out_pos + j] = v;
+        // two states per turn (their logarithms are two independent chains of fma), as long as some lane has one
+        for (int j = 0; __any(j < npend); j += 2) {
+          const double x0 = outx[j * 64], x1 = outx[(j + 1) * 64];
+          const int e0 = oute[j * 64], e1 = oute[(j + 1) * 64];
+          const double m0 = __builtin_amdgcn_frexp_mant(x0), m1 = __builtin_amdgcn_frexp_mant(x1);
+          const LnTabEntry t0 = lntab[ln_table_index(m0)], t1 = lntab[ln_table_index(m1)];
+          const double v0 = table_ln(m0, e0 + __builtin_amdgcn_frexp_exp(x0), t0);
+          const double v1 = table_ln(m1, e1 + __builtin_amdgcn_frexp_exp(x1), t1);
+          if (j < npend) vals[DIR ? out_pos - j : out_pos + j] = v0;
+          if (j + 1 < npend) vals[DIR ? out_pos - j - 1 : out_pos + j + 1] = v1;
         }
         out_pos = pos;
         npend = 0;
       }
     };
 
-    // The records come a BATCH of kB ahead: eight 16-byte loads per lane at the top of an iteration, used in the
-    // next one (a lane reads up to kB records past its segment: the array ends in slack).  Loads inside a branch,
-    // one load per step, or a batch of four made every step (or every fourth) wait a memory latency.  The outputs
-    // of a batch leave right before the next batch's loads are issued, so the one wait at the bottom (the
-    // compiler drains the queue there: loads and stores share its counter) covers both.
-    constexpr int kB = 16;
-    uint4 cur[kB / 2], nxt[kB / 2];
-    auto load_batch = [&](int t, uint4 (&q)[kB / 2]) {
-      const uint4* p = reinterpret_cast<const uint4*>(rp + min(t, n));
-#pragma unroll
-      for (int i = 0; i < kB / 2; ++i) q[i] = p[i];
-    };
+    // The records come a BATCH of kB ahead, loaded at the top of an iteration and used in the next one (a lane reads
+    // up to kB records past its segment: the array ends in slack).  Loads inside a branch, one load per step, or a
+    // batch of four made every step (or every fourth) wait a memory latency.
+    constexpr int kB = MODE == 0 ? 16 : kSweepBatch;
     int until = a.rescale_iters;
-    auto body = [&](auto special, auto guarded, int t0) {
-#pragma unroll
-      for (int i = 0; i < kB / 2; ++i) {
-        if (!decltype(guarded)::value || t0 + 2 * i < n) step(special, ((uint64_t)cur[i].y << 32) | cur[i].x);
-        if (!decltype(guarded)::value || t0 + 2 * i + 1 < n) step(special, ((uint64_t)cur[i].w << 32) | cur[i].z);
-        if ((i & 1) == 1 && --until == 0) {
-          until = a.rescale_iters;
-          rescale();
-        }
-      }
-    };
     const std::true_type yes;
     const std::false_type no;
-    load_batch(0, cur);
-    int t0 = 0;
-    for (; t0 + kB <= nmin; t0 += kB) {  // every lane has the whole batch
+    if constexpr (MODE == 0) {
+      // Transfer: the c lanes of a segment walk the SAME records.  Loaded by every lane, a batch was eight
+      // instructions of 64 separate requests each -- the texture path takes them lane by lane even when eight
+      // name the same address, and the kernel sat at ~500 of its cycles per wave and batch whatever the steps
+      // cost.  So the lanes of a segment share the work: each loads one 16-byte piece of the batch (two
+      // records), the pieces meet in the wave's LDS stage, and a step reads its record there (one broadcast read).
+      const int G = 64 >> a.lgc;
+      uint64_t* stg = reinterpret_cast<uint64_t*>(outbuf) + (size_t)(lane >> a.lgc) * kB;  // [2][G][kB], this segment's slice
+      uint4 pr[4];
+      auto issue = [&](int t) {
+        const uint4* p = reinterpret_cast<const uint4*>(rp + min(t, n));
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k * c < kB / 2) pr[k] = p[min(comp + k * c, kB / 2 - 1)];
+      };
+      auto land = [&](int buf) {
+        uint32_t ctl = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int q = comp + k * c;
+          if (k * c < kB / 2 && q < kB / 2) {
+            reinterpret_cast<uint4*>(stg + (size_t)buf * G * kB)[q] = pr[k];
+            ctl |= pr[k].x | pr[k].z;
+          }
+        }
+        return __any((ctl & (kChainSpecial | kChainFinal)) != 0);
+      };
+      auto body = [&](auto special, auto guarded, int t0, int buf) {
+        const uint64_t* r = stg + (size_t)buf * G * kB;
+#pragma unroll
+        for (int i = 0; i < kB; ++i) {
+          if (!decltype(guarded)::value || t0 + i < n) step(special, r[i]);
+          if ((i & 3) == 3 && --until == 0) {
+            until = a.rescale_iters;
+            rescale();
+          }
+        }
+      };
+      issue(0);
+      bool rare = land(0);
+      int buf = 0, t0 = 0;
+      for (; t0 < nmax; t0 += kB, buf ^= 1) {
+        issue(t0 + kB);
+        if (t0 + kB <= nmin) {  // every lane has the whole batch: no bounds tests; the rare terms only if some record asks
+          if (rare)
+            body(yes, no, t0, buf);
+          else
+            body(no, no, t0, buf);
+        } else {
+          body(yes, yes, t0, buf);
+        }
+        rare = land(buf ^ 1);
+      }
+    } else {
+      // Sweep: a lane walks its own records: eight 16-byte loads per lane.  The outputs of a batch leave right
+      // before the next batch's loads are issued, so the one wait at the bottom (the compiler drains the queue
+      // there: loads and stores share its counter) covers both.
+      uint4 cur[kB / 2], nxt[kB / 2];
+      auto load_batch = [&](int t, uint4 (&q)[kB / 2]) {
+        const uint4* p = reinterpret_cast<const uint4*>(rp + min(t, n));
+#pragma unroll
+        for (int i = 0; i < kB / 2; ++i) q[i] = p[i];
+      };
+      auto body = [&](auto special, auto guarded, int t0) {
+#pragma unroll
+        for (int i = 0; i < kB / 2; ++i) {
+          if (!decltype(guarded)::value || t0 + 2 * i < n) step(special, ((uint64_t)cur[i].y << 32) | cur[i].x);
+          if (!decltype(guarded)::value || t0 + 2 * i + 1 < n) step(special, ((uint64_t)cur[i].w << 32) | cur[i].z);
+          if ((i & 1) == 1 && --until == 0) {
+            until = a.rescale_iters;
+            rescale();
+          }
+        }
+      };
+      load_batch(0, cur);
+      for (int t0 = 0; t0 < nmax; t0 += kB) {
+        const unsigned long long tf0 = a.dbg ? __builtin_readcyclecounter() : 0;
+        flush();
+        if (a.dbg) dbg_flush += __builtin_readcyclecounter() - tf0;
+        load_batch(t0 + kB, nxt);
+        if (t0 + kB <= nmin) {
+          uint32_t any_ctl = 0;
+#pragma unroll
+          for (int i = 0; i < kB / 2; ++i) any_ctl |= cur[i].x | cur[i].z;
+          bool rare = (any_ctl & (kChainSpecial | kChainFinal)) != 0;
+          if (DIR == 1) rare |= !last_seg && pos >= end - c;
+          if (__any(rare))
+            body(yes, no, t0);
+          else
+            body(no, no, t0);
+        } else {
+          body(yes, yes, t0);
+        }
+        const unsigned long long tw0 = a.dbg ? __builtin_readcyclecounter() : 0;
+#pragma unroll
+        for (int i = 0; i < kB / 2; ++i) cur[i] = nxt[i];
+        if (a.dbg) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          dbg_wait += __builtin_readcyclecounter() - tw0;
+        }
+      }
       flush();
-      load_batch(t0 + kB, nxt);
-      uint32_t any_ctl = 0;
-#pragma unroll
-      for (int i = 0; i < kB / 2; ++i) any_ctl |= cur[i].x | cur[i].z;
-      bool rare = (any_ctl & (kChainSpecial | kChainFinal)) != 0;
-      if (MODE == 1 && DIR == 1) rare |= !last_seg && pos >= end - c;
-      if (__any(rare))
-        body(yes, no, t0);
-      else
-        body(no, no, t0);
-#pragma unroll
-      for (int i = 0; i < kB / 2; ++i) cur[i] = nxt[i];
     }
-    for (; t0 < nmax; t0 += kB) {  // the segments' ends
-      flush();
-      load_batch(t0 + kB, nxt);
-      body(yes, yes, t0);
-#pragma unroll
-      for (int i = 0; i < kB / 2; ++i) cur[i] = nxt[i];
-    }
-    flush();
 
     if (MODE == 0) {
       // the lane's row of Q: the segment's last c states, scaled once more -- those an arc of this lattice can
@@ -378,6 +442,10 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
     }
   }
   if (trouble) atomicOr(a.flag, trouble);
+  if (a.dbg && lane == 0 && MODE == 1) {  // (KLAT_CHAIN_DEBUG: cycles in the flushes, in the waits for the next batch, in all)
+    unsigned long long* d = a.dbg + a.dbg_stride + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    d[4] = dbg_flush, d[5] = dbg_wait, d[6] = __builtin_readcyclecounter() - dbg_t0;
+  }
 }
 
 template <int MODE>
@@ -385,11 +453,13 @@ __global__ __launch_bounds__(64 * kWalkWaves) void chain_walk_kernel(ChainArgs a
   extern __shared__ double smem[];
   LnTabEntry* lntab = reinterpret_cast<LnTabEntry*>(smem);
   const int wave = threadIdx.x >> 6;
-  const int per_wave = (a.W + 2) * 64 + (MODE == 1 ? 16 * 64 + 8 * 64 : 0);  // doubles: the ring; the sweep's output rows and their exponents
+  // doubles: the ring; then the sweep's output rows and their exponents, or the transfer's record stage [2][64 / c][16]
+  const int per_wave = a.W * 64 + (MODE == 1 ? kSweepBatch * 64 + kSweepBatch * 32 : 2 * (64 >> a.lgc) * 16);
   double* ring = smem + 2 * kLnTabSize + wave * per_wave;
-  double* outbuf = ring + (a.W + 2) * 64;
+  double* outbuf = ring + a.W * 64;
   if (threadIdx.x < kLnTabSize) lntab[threadIdx.x] = a.ln_table[threadIdx.x];
   __syncthreads();
+  const unsigned long long t_begin = a.dbg ? wall_clock64() : 0;
   if (MODE == 0) {
     chain_walk<0, 0>(a, ring, outbuf, lntab);
   } else if ((blockIdx.y ^ a.dir_first) == 0) {
@@ -397,15 +467,51 @@ __global__ __launch_bounds__(64 * kWalkWaves) void chain_walk_kernel(ChainArgs a
   } else {
     chain_walk<1, 1>(a, ring, outbuf, lntab);
   }
+  if (a.dbg && (threadIdx.x & 63) == 0) {  // (KLAT_CHAIN_DEBUG: where and when every wave ran)
+    const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (MODE == 0 ? kWalkWaves : kSweepWaves) + wave;
+    unsigned long long* d = a.dbg + (MODE == 0 ? 0 : a.dbg_stride) + w * (MODE == 0 ? 4 : 8);
+    d[0] = t_begin;
+    d[1] = wall_clock64();
+    d[2] = __builtin_amdgcn_s_getreg(63492);  // HW_ID
+    d[3] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
+  }
 }
 
-__device__ __forceinline__ int group_max_int(int v) {  // over the kChainMaxSpan lanes that hold a vector
-  for (int d = 1; d < kChainMaxSpan; d <<= 1) v = max(v, __shfl_xor(v, d, 64));
+// Over the 16 lanes that hold a vector (one DPP row): rotations within the row, no LDS traffic.
+template <int N>
+__device__ __forceinline__ int row_ror_int(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, true);
+}
+template <int N>
+__device__ __forceinline__ double row_ror_f64(double v) {
+  return __hiloint2double(row_ror_int<N>(__double2hiint(v)), row_ror_int<N>(__double2loint(v)));
+}
+__device__ __forceinline__ int group_max_int(int v) {
+  static_assert(kChainMaxSpan == 16, "one DPP row");
+  v = max(v, row_ror_int<8>(v));
+  v = max(v, row_ror_int<4>(v));
+  v = max(v, row_ror_int<2>(v));
+  v = max(v, row_ror_int<1>(v));
   return v;
 }
 __device__ __forceinline__ double group_sum_f64(double v) {
-  for (int d = 1; d < kChainMaxSpan; d <<= 1) v += __shfl_xor(v, d, 64);
+  v += row_ror_f64<8>(v);
+  v += row_ror_f64<4>(v);
+  v += row_ror_f64<2>(v);
+  v += row_ror_f64<1>(v);
   return v;
+}
+// lane j's value to every lane (j known at compile time: two v_readlane)
+template <int J>
+__device__ __forceinline__ double lane_value(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), J), __builtin_amdgcn_readlane(__double2loint(v), J));
+}
+template <int J, int N, class F>
+__device__ __forceinline__ void for_lanes(F f) {
+  if constexpr (J < N) {
+    f(std::integral_constant<int, J>());
+    for_lanes<J + 1, N>(f);
+  }
 }
 static constexpr int kNoExp = -(1 << 28);
 static constexpr int kCombineChunk = 8;  // segments whose matrices are in LDS together
@@ -414,10 +520,12 @@ static constexpr int kCombineChunk = 8;  // segments whose matrices are in LDS t
 // entry i of the running vector as a plain double, the vector shares one exponent.  The matrices come through
 // LDS a chunk of eight segments at a time, the next chunk's loads in flight while this one is used: a step
 // is a few hundred cycles, a trip to memory ten times that.
+template <int C>
 __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
   extern __shared__ double smem[];
   const ChainLattice cl = a.lats[blockIdx.x];
-  const int lane = threadIdx.x, c = a.c, K = cl.num_segs, cc = a.c * a.c;
+  constexpr int c = C, cc = C * C;
+  const int lane = threadIdx.x, K = cl.num_segs;
   const int pd = cc + c, pi = 2 * c;  // per segment: Qm and Qfm; Qe and Qfe
   double* sd = smem;                  // [2][kCombineChunk][pd]
   int32_t* si = reinterpret_cast<int32_t*>(smem + 2 * kCombineChunk * pd);  // [2][kCombineChunk][pi]
@@ -428,7 +536,7 @@ __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
   auto seg_of = [&](int s) { return (size_t)cl.seg_begin + (size_t)(bwd ? K - 1 - s : s); };
   int trouble = 0;
   // stage: registers <- memory (issue), later LDS <- registers
-  constexpr int kRD = (kChainMaxSpan * kChainMaxSpan + kChainMaxSpan + 63) / 64;  // doubles per lane and segment
+  constexpr int kRD = (C * C + C + 63) / 64;  // doubles per lane and segment
   double rd[kCombineChunk][kRD];
   int32_t ri[kCombineChunk];
   auto issue = [&](int chunk) {
@@ -499,11 +607,11 @@ __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
           r = ldexp(vec, re - Er);
         }
         double nw = 0.0;
-#pragma unroll
-        for (int j = 0; j < kChainMaxSpan; ++j) {
-          const double rj = __shfl(r, j, 64);
-          if (j < c && mine) nw = fma(rj, qd[j * c + lane], nw);
-        }
+        for_lanes<0, C>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const double rj = lane_value<j>(r);
+          if (mine) nw = fma(rj, qd[j * c + lane], nw);
+        });
         const int ne = (mine && nw != 0.0) ? __builtin_amdgcn_frexp_exp(nw) : kNoExp;
         const int ex = group_max_int(ne);
         if (ex == kNoExp) {  // nothing reaches the next cut
@@ -517,11 +625,11 @@ __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
         // backward: y_k[j] = what the paths that leave state (first state of segment k) - c + j through an arc
         // into segment k contribute to its beta: through Q_k to the y of the next cut, or into a final state
         double val = 0.0;
-#pragma unroll
-        for (int i = 0; i < kChainMaxSpan; ++i) {
-          const double yi = __shfl(vec, i, 64);
-          if (i < c && mine) val = fma(qd[lane * c + i], yi, val);
-        }
+        for_lanes<0, C>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          const double yi = lane_value<i>(vec);
+          if (mine) val = fma(qd[lane * c + i], yi, val);
+        });
         int ve = qe + Ev;
         if (mine) chain_add_exact(val, ve, qfm, qfe);
         const int ne = (mine && val != 0.0) ? ve + __builtin_amdgcn_frexp_exp(val) : kNoExp;
@@ -560,17 +668,20 @@ hipError_t launch_chain_prep(const ChainPrepArgs& a, int num_chain_lattices, hip
 
 hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream) {
   if (a.num_segs <= 0) return hipSuccess;
-  static const int exp_bits = std::getenv("KLAT_CHAIN_EXP") ? std::atoi(std::getenv("KLAT_CHAIN_EXP")) : 0;
-  const_cast<ChainArgs&>(a).exp = exp_bits;
   static const int pad = std::getenv("KLAT_CHAIN_LDS_PAD") ? std::atoi(std::getenv("KLAT_CHAIN_LDS_PAD")) : 0;  // (experiments)
-  const size_t ring_bytes = (size_t)(a.W + 2) * 64 * sizeof(double);
-  const size_t lds_a = kLnTabSize * sizeof(LnTabEntry) + kWalkWaves * ring_bytes + (size_t)pad;
-  const size_t lds_c = kLnTabSize * sizeof(LnTabEntry) + kWalkWaves * (ring_bytes + (16 + 8) * 64 * sizeof(double)) + (size_t)pad;
+  const size_t ring_bytes = (size_t)a.W * 64 * sizeof(double);
+  const size_t lds_a = kLnTabSize * sizeof(LnTabEntry) + kWalkWaves * (ring_bytes + (size_t)2 * (64 >> a.lgc) * 16 * sizeof(uint64_t)) + (size_t)pad;
+  const size_t lds_c = kLnTabSize * sizeof(LnTabEntry) + kSweepWaves * (ring_bytes + (size_t)kSweepBatch * 64 * (sizeof(double) + sizeof(int32_t))) + (size_t)pad;
   const size_t lds_b = (size_t)2 * kCombineChunk * ((size_t)(a.c * a.c + a.c) * sizeof(double) + (size_t)2 * a.c * sizeof(int32_t));
   const int jobs_a = (a.num_segs + (64 >> a.lgc) - 1) / (64 >> a.lgc), jobs_c = (a.num_segs + 63) / 64;
   hipLaunchKernelGGL(chain_walk_kernel<0>, dim3((jobs_a + kWalkWaves - 1) / kWalkWaves), dim3(64 * kWalkWaves), lds_a, stream, a);
-  hipLaunchKernelGGL(chain_combine_kernel, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a);
-  hipLaunchKernelGGL(chain_walk_kernel<1>, dim3((jobs_c + kWalkWaves - 1) / kWalkWaves, 2), dim3(64 * kWalkWaves), lds_c, stream, a);
+  switch (a.c) {
+    case 2: hipLaunchKernelGGL(chain_combine_kernel<2>, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a); break;
+    case 4: hipLaunchKernelGGL(chain_combine_kernel<4>, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a); break;
+    case 8: hipLaunchKernelGGL(chain_combine_kernel<8>, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a); break;
+    default: hipLaunchKernelGGL(chain_combine_kernel<16>, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a); break;
+  }
+  hipLaunchKernelGGL(chain_walk_kernel<1>, dim3((jobs_c + kSweepWaves - 1) / kSweepWaves, 2), dim3(64 * kSweepWaves), lds_c, stream, a);
   return hipGetLastError();
 }
 

@@ -80,14 +80,23 @@ def _run(ctx, arrays, scales, **env):
 @pytest.mark.parametrize("seg", [64, 256])
 @pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (0.7, 0.1, 0.5)])
 def test_segments_match_the_oracle_and_the_streams(ctx, seg, scales):
-    ns = [3000, 700, 5000, 40, 1300, 2 * seg, 2 * seg - 1, 4097, 1]
+    ns = [3000, 700, 5000, 40, 1300, 2 * seg + 2, 2 * seg - 2, 4097, 1]
     fo = [3, 2, 4, 3, 6, 3, 3, 1, 1]
     arrays = _lattices(20260005, ns, fo)
     b, got = _run(ctx, arrays, scales, KLAT_CHAIN=1, KLAT_CHAIN_SEG=seg)
     info = b.info()
-    want_chain = sum(1 for s in ns if s >= 2 * seg)
-    assert info["chain_lattices"] == want_chain and not b.chain_fallback(), info
-    assert info["chain_segments"] == sum(s // seg for s in ns if s >= 2 * seg), info
+    # a lattice's segments hold ~4 x seg records each (seg states at fanout 3, fewer at a larger fanout), and a
+    # lattice is never cut into more than sqrt(records / 4) of them
+    def seg_len(s, f):
+        if s < 2:
+            return 1 << 30
+        arcs = f * (s - 1)
+        most = max(2, int((0.25 * (arcs + s)) ** 0.5))
+        return max(max(32, int(4.0 * seg / (arcs / s + 1.0))), (s + most - 1) // most)
+    seg_states = [seg_len(s, f) for s, f in zip(ns, fo)]
+    want_chain = sum(1 for s, l in zip(ns, seg_states) if s >= 2 * l)
+    assert info["chain_lattices"] == want_chain and want_chain >= 4 and not b.chain_fallback(), info
+    assert info["chain_segments"] == sum(s // l for s, l in zip(ns, seg_states) if s >= 2 * l), info
     wa, wb, wt, wpost = _oracle_batch(arrays, *scales)
     alpha, beta, total, tf, tb, post = got
     _check(alpha, wa, 1e-8), _check(beta, wb, 1e-8), _check(total, wt, 1e-8), _check(post, wpost, 1e-8)
