@@ -157,10 +157,12 @@ def median(xs):
     return float(np.median(np.asarray(xs, dtype=np.float64))) if len(xs) else 0.0
 
 
-def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=10, wide=0, lanes=0):
+def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=30, warm=100, wide=0, lanes=0):
     """sweep / step time of one more batch shape on this GPU (medians over `steps` steps).  A batch
     of few lattices that are far wider than deep runs on the level path (klat_level.hip); for such
-    a batch the time through the streams (lanes fixed by the caller) is reported beside it."""
+    a batch the time through the streams (lanes fixed by the caller) is reported beside it.  (A hundred untimed
+    steps first: the seconds of host work that build a shape leave the GPU's clocks down, and ten steps of a
+    millisecond did not bring them back -- the same batch timed 1.39 ms cold and 1.10 ms warm.)"""
     arrays = klat_amd.synth(seed, ns, fo, host_threads=host_threads, wide=wide)
     b = klat_amd.Batch(ctx, arrays, host_threads=host_threads, lanes_per_lattice=lanes, fuse_scales=FUSE)
     info = b.info()
@@ -178,6 +180,7 @@ def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=20, warm=1
            "topological_depth": {"max": int(depth.max()), "mean": float(depth.mean()),
                                  "note": "states on a lattice's longest path; the sweep takes max_rounds rounds whatever the depth"},
            "lanes_per_lattice": info["lanes_per_lattice"], "layout_classes": info["num_layouts"],
+           "lattices_in_segments": info["chain_lattices"], "segments": info["chain_segments"],
            "sweep_waves": info["num_jobs"], "max_rounds": info["max_rounds"],
            "sweep_ms": sweep, "step_ms": step, "arcs_per_s": A / (step * 1e-3),
            "sweep_frac": (32.0 * A + 32.0 * S) / (sweep * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -64,9 +64,10 @@ static int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
     }
   }
   KLAT_HIP(hipEventRecord(c->fork_ev, c->stream));
-  const int used = (int)std::min<size_t>(n - 1, klat_ctx::kSideStreams);
+  static const int side_limit = std::getenv("KLAT_SIDE_STREAMS") ? std::max(1, std::min((int)klat_ctx::kSideStreams, std::atoi(std::getenv("KLAT_SIDE_STREAMS")))) : (int)klat_ctx::kSideStreams;
+  const int used = (int)std::min<size_t>(n - 1, (size_t)side_limit);
   for (int i = 0; i < used; ++i) KLAT_HIP(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
-  for (size_t k = 0; k < n; ++k) KLAT_HIP(work[k](k == 0 ? c->stream : c->side[(k - 1) % klat_ctx::kSideStreams]));
+  for (size_t k = 0; k < n; ++k) KLAT_HIP(work[k](k == 0 ? c->stream : c->side[(k - 1) % side_limit]));
   for (int i = 0; i < used; ++i) {
     KLAT_HIP(hipEventRecord(c->join_ev[i], c->side[i]));
     KLAT_HIP(hipStreamWaitEvent(c->stream, c->join_ev[i], 0));
@@ -251,11 +252,11 @@ void klat_host_free(void* ptr) {
 }
 
 int klat_ctx_create(int device, klat_ctx** out) {
-  // The layout classes of a skewed batch run on four streams at once (for_each_class).  The HIP
-  // runtime reads GPU_MAX_HW_QUEUES (default 4) when it starts: a host that has streams of its own
-  // leaves fewer than four queues and two classes would run one after the other.  No effect when
-  // the runtime is already up (such a host sets it itself).
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // The pieces of a skewed batch's sweep run on four streams at once (run_side_by_side).  The HIP runtime maps a
+  // process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) when it starts.  The default is the right
+  // number for a process whose only streams are this context's (measured on the C5/8 shard, segment path on: 1.04 ms
+  // with 4 queues, 1.24 - 1.39 ms with 8); a host with streams of its own (PyTorch holds one) exports
+  // GPU_MAX_HW_QUEUES=8 before the runtime starts, as bench.py does.
   if (!out) return set_error(KLAT_ERR_INVALID_ARG, "out is null");
   *out = nullptr;
   int n = 0;
