@@ -95,12 +95,7 @@ static int for_each_class(klat_batch* b, F launch) {
 // is taken if it beats the streams by a quarter.  KLAT_CHAIN=0 / =1: never / every candidate.
 static int chain_segment_states(int64_t S, int64_t A, int seg) {
   const double fan = S > 0 ? (double)A / (double)S : 1.0;
-  const int by_records = std::max(2 * kChainMaxSpan, (int)(4.0 * (double)seg / (fan + 1.0)));
-  // The combine step walks a lattice's segments one after the other (~1 us each) while the sweep walks a
-  // segment's records (~0.25 us each): a long lattice is cut into about sqrt(records / 4) segments, where the two
-  // chains are equally long, rather than into ever more segments of the batch's standard length.
-  const int64_t most = std::max<int64_t>(2, (int64_t)std::sqrt(0.25 * (double)(A + S)));
-  return (int)std::max<int64_t>(by_records, (S + most - 1) / most);
+  return std::max(2 * kChainMaxSpan, (int)(4.0 * (double)seg / (fan + 1.0)));
 }
 static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* lr,
                                   const klat_pack_options& o, const uint8_t* on_level, std::vector<uint8_t>* on_chain,
@@ -176,6 +171,8 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
     cl.num_segs = (int32_t)(S / std::max(chain_segment_states(S, A, seg), 2 * cc));
     if (cl.num_segs < 2) continue;
     cl.span = std::max(1, lr[u].max_span);
+    cl.grp_begin = out->empty() ? 0 : out->back().grp_begin + out->back().num_grps;
+    cl.num_grps = (cl.num_segs + kChainGroup - 1) / kChainGroup;
     cl.pad = 0;
     cl.rec_f = (uint32_t)rec;
     rec += (uint64_t)(A + 2 * S + 2);  // arcs, a constant term or a zero per state, final weights
@@ -643,11 +640,19 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         choose_chain_lattices(U, d->state_off, d->arc_off, h_rounds.data(), o, on_level.data(), &on_chain, &cl, &seg_len, &cc, &nrec);
       if (!cl.empty()) {
         const size_t nseg = (size_t)cl.back().seg_begin + (size_t)cl.back().num_segs;
+        const size_t ngrp = (size_t)cl.back().grp_begin + (size_t)cl.back().num_grps;
+        std::vector<ChainGroup> groups;
+        for (size_t i = 0; i < cl.size(); ++i)
+          for (int32_t g = 0; g < cl[i].num_grps; ++g)
+            groups.push_back(ChainGroup{(int32_t)i, cl[i].seg_begin + g * kChainGroup, std::min(kChainGroup, cl[i].num_segs - g * kChainGroup), 0});
         const int32_t zero[2] = {0, 0};
         if ((rc = b->ch_lats.upload(cl.data(), cl.size(), c->stream)) || (rc = b->ch_segs.alloc(nseg)) || (rc = b->ch_recs.alloc(nrec)) ||
             (rc = b->ch_qm.alloc(nseg * cc * cc)) || (rc = b->ch_qe.alloc(nseg * cc)) || (rc = b->ch_qfm.alloc(nseg * cc)) ||
             (rc = b->ch_qfe.alloc(nseg * cc)) || (rc = b->ch_bfm.alloc(nseg * cc)) || (rc = b->ch_bfe.alloc(nseg)) ||
-            (rc = b->ch_bbm.alloc(nseg * cc)) || (rc = b->ch_bbe.alloc(nseg)) || (rc = b->ch_status.upload(zero, 2, c->stream))) {
+            (rc = b->ch_bbm.alloc(nseg * cc)) || (rc = b->ch_bbe.alloc(nseg)) || (rc = b->ch_status.upload(zero, 2, c->stream)) ||
+            (rc = b->ch_grps.upload(groups.data(), groups.size(), c->stream)) || (rc = b->ch_gm.alloc(ngrp * cc * cc)) || (rc = b->ch_ge.alloc(ngrp * cc)) ||
+            (rc = b->ch_gfm.alloc(ngrp * cc)) || (rc = b->ch_gfe.alloc(ngrp * cc)) || (rc = b->ch_gbfm.alloc(ngrp * cc)) || (rc = b->ch_gbfe.alloc(ngrp)) ||
+            (rc = b->ch_gbbm.alloc(ngrp * cc)) || (rc = b->ch_gbbe.alloc(ngrp))) {
           klat_batch_destroy(b);
           return rc;
         }
@@ -678,6 +683,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         b->pack_chain_timed = true;
         b->num_chain = (int32_t)cl.size();
         b->chain_segs = (int32_t)nseg;
+        b->chain_grps = (int32_t)ngrp;
         b->chain_c = cc;
         b->chain_seg_len = seg_len;
         for (size_t u = 0; u < (size_t)U; ++u) skip[u] = on_level[u] | on_chain[u];
@@ -687,9 +693,11 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     // the plan: lanes per lattice, layout classes, jobs
     std::vector<int8_t> lat_g;
     plan_layout(U, d->state_off, d->arc_off, h_rounds.data(), o, &lat_g, skip.data());
-    // (the lattices swept in segments keep their streams, for klat_viterbi, with the lanes their fanout asks for)
+    // (the lattices swept in segments keep their streams -- for klat_viterbi, and for the sweeps that find a lattice's
+    // values outside the segment path's arithmetic -- all with four lanes, as ONE layout class: the launches that
+    // stand by behind every sweep cost ~20 us apiece, and three classes were six of them)
     for (int64_t u = 0; u < U; ++u)
-      if (on_chain[(size_t)u]) lat_g[(size_t)u] = (int8_t)base_lane_choice(d->state_off[u + 1] - d->state_off[u], d->arc_off[u + 1] - d->arc_off[u]);
+      if (on_chain[(size_t)u]) lat_g[(size_t)u] = 2;
     std::vector<std::vector<int64_t>> job_lats;
     int64_t chunk_total = 0;
     lap("level");
@@ -1112,6 +1120,10 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
       ca.bnd_fe = b->ch_bfe.p;
       ca.bnd_bm = b->ch_bbm.p;
       ca.bnd_be = b->ch_bbe.p;
+      ca.grps = b->ch_grps.p;
+      ca.num_grps = b->chain_grps;
+      ca.Gm = b->ch_gm.p, ca.Ge = b->ch_ge.p, ca.Gfm = b->ch_gfm.p, ca.Gfe = b->ch_gfe.p;
+      ca.gb_fm = b->ch_gbfm.p, ca.gb_fe = b->ch_gbfe.p, ca.gb_bm = b->ch_gbbm.p, ca.gb_be = b->ch_gbbe.p;
       ca.rescale_iters = b->chain_rescale;
       ca.flag = b->ch_status.p + 1;
       ca.state_off = b->state_off.p;

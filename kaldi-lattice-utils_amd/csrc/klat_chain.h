@@ -51,7 +51,12 @@ static const int kChainTroubleVector = 32;  // combine: the entries of a boundar
 struct ChainLattice {
   int32_t lattice, num_states, seg_begin, num_segs;
   uint32_t rec_f, rec_b;  // first forward / backward record
-  int32_t span, pad;      // the lattice's longest arc, in states
+  int32_t span;           // the lattice's longest arc, in states
+  int32_t grp_begin, num_grps, pad;  // its groups of kChainGroup segments (the two-level combine)
+};
+static const int kChainGroup = 16;
+struct ChainGroup {
+  int32_t clat, seg_first, nseg, pad;
 };
 struct ChainSegment {  // (filled by chain_prep_kernel)
   int32_t clat, k, first_state, num_states;
@@ -83,6 +88,9 @@ struct ChainArgs {
   double* Qfm; int32_t* Qfe;      // [segments][c] Qf, mantissa and exponent
   double* bnd_fm; int32_t* bnd_fe;  // [segments][c] alpha of the c states before the segment, to [segments] exponents
   double* bnd_bm; int32_t* bnd_be;  // [segments][c] what the arcs leaving the segment contribute to its last c states
+  const ChainGroup* grps; int32_t num_grps;
+  double* Gm; int32_t* Ge; double* Gfm; int32_t* Gfe;  // [groups]...: the product of a group's matrices, its final-state vector
+  double* gb_fm; int32_t* gb_fe; double* gb_bm; int32_t* gb_be;  // [groups][c]: the running vector before / behind every group
   int32_t rescale_iters;  // a lane rescales every this many iterations of four records
   unsigned long long* dbg = nullptr;  // (KLAT_CHAIN_DEBUG) four words per wave: begin, end (100 MHz), HW_ID, XCC_ID
   size_t dbg_stride = 0;              //   the sweep's waves start here

@@ -516,39 +516,60 @@ __device__ __forceinline__ void for_lanes(F f) {
 static constexpr int kNoExp = -(1 << 28);
 static constexpr int kCombineChunk = 8;  // segments whose matrices are in LDS together
 
-// One wave per (lattice, direction): the serial part, in the same scaled arithmetic -- lane i < c holds
-// entry i of the running vector as a plain double, the vector shares one exponent.  The matrices come through
-// LDS a chunk of eight segments at a time, the next chunk's loads in flight while this one is used: a step
-// is a few hundred cycles, a trip to memory ten times that.
-template <int C>
+// The serial part, in the same scaled arithmetic, on TWO levels: a lattice's segments form groups of
+// kChainGroup; chain_group_kernel multiplies every group's matrices (all groups at once: M = Q Q' Q'' ..., and
+// Mf, the paths into the group's final states); LEVEL 0 of this kernel walks a lattice's GROUPS with those
+// products -- the running vector before every group, forward (alpha of the c states before it) and backward (the
+// y of the cut behind it), and tot_forward; LEVEL 1 walks the segments of ONE group from the vector LEVEL 0 left
+// for it.  A lattice of K segments is K / 16 + 2 x 16 serial steps instead of K (the single-level kernel was the
+// longest of the path: 0.2 ms for the 187 segments of a 20 000-state lattice).
+// One wave per (lattice | group, direction); lane i < c holds entry i of the running vector as a plain double, the
+// vector shares one exponent.  The matrices come through LDS a chunk of eight at a time, the next chunk's loads
+// in flight while this one is used: a step is a few hundred cycles, a trip to memory ten times that.
+template <int C, int LEVEL>
 __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
   extern __shared__ double smem[];
-  const ChainLattice cl = a.lats[blockIdx.x];
   constexpr int c = C, cc = C * C;
-  const int lane = threadIdx.x, K = cl.num_segs;
-  const int pd = cc + c, pi = 2 * c;  // per segment: Qm and Qfm; Qe and Qfe
+  const int lane = threadIdx.x;
+  const bool bwd = blockIdx.y != 0;
+  // the items this wave walks: LEVEL 0 the groups of lattice blockIdx.x, LEVEL 1 the segments of group blockIdx.x
+  int first, count, lat_first_seg = -1;
+  ChainLattice cl;
+  if (LEVEL == 0) {
+    cl = a.lats[blockIdx.x];
+    first = cl.grp_begin, count = cl.num_grps;
+  } else {
+    const ChainGroup g = a.grps[blockIdx.x];
+    cl = a.lats[g.clat];
+    first = g.seg_first, count = g.nseg, lat_first_seg = cl.seg_begin;
+  }
+  const double* Mm = LEVEL == 0 ? a.Gm : a.Qm;
+  const int32_t* Me = LEVEL == 0 ? a.Ge : a.Qe;
+  const double* Mfm = LEVEL == 0 ? a.Gfm : a.Qfm;
+  const int32_t* Mfe = LEVEL == 0 ? a.Gfe : a.Qfe;
+  double* out_m = LEVEL == 0 ? (bwd ? a.gb_bm : a.gb_fm) : (bwd ? a.bnd_bm : a.bnd_fm);
+  int32_t* out_e = LEVEL == 0 ? (bwd ? a.gb_be : a.gb_fe) : (bwd ? a.bnd_be : a.bnd_fe);
+  const int pd = cc + c, pi = 2 * c;  // per item: the matrix and its final-state vector; their exponents
   double* sd = smem;                  // [2][kCombineChunk][pd]
   int32_t* si = reinterpret_cast<int32_t*>(smem + 2 * kCombineChunk * pd);  // [2][kCombineChunk][pi]
-  const bool bwd = blockIdx.y != 0;
   const bool mine = lane < c;
   const int me = mine ? lane : 0;
-  const int nsteps = bwd ? K - 1 : K;  // forward: k = 0 .. K-1; backward: k = K-1 .. 1
-  auto seg_of = [&](int s) { return (size_t)cl.seg_begin + (size_t)(bwd ? K - 1 - s : s); };
+  auto item_of = [&](int s) { return (size_t)first + (size_t)(bwd ? count - 1 - s : s); };
   int trouble = 0;
   // stage: registers <- memory (issue), later LDS <- registers
-  constexpr int kRD = (C * C + C + 63) / 64;  // doubles per lane and segment
+  constexpr int kRD = (C * C + C + 63) / 64;  // doubles per lane and item
   double rd[kCombineChunk][kRD];
   int32_t ri[kCombineChunk];
   auto issue = [&](int chunk) {
 #pragma unroll
     for (int s = 0; s < kCombineChunk; ++s) {
-      const size_t seg = seg_of(min(chunk * kCombineChunk + s, nsteps - 1));
+      const size_t it = item_of(min(chunk * kCombineChunk + s, count - 1));
 #pragma unroll
       for (int r = 0; r < kRD; ++r) {
         const int idx = lane + 64 * r;
-        rd[s][r] = idx < cc ? a.Qm[seg * cc + idx] : (idx < pd ? a.Qfm[seg * c + idx - cc] : 0.0);
+        rd[s][r] = idx < cc ? Mm[it * cc + idx] : (idx < pd ? Mfm[it * c + idx - cc] : 0.0);
       }
-      ri[s] = lane < c ? a.Qe[seg * c + lane] : (lane < pi ? a.Qfe[seg * c + lane - c] : 0);
+      ri[s] = lane < c ? Me[it * c + lane] : (lane < pi ? Mfe[it * c + lane - c] : 0);
     }
   };
   auto land = [&](int buf) {
@@ -562,43 +583,49 @@ __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
       if (lane < pi) si[(buf * kCombineChunk + s) * pi + lane] = ri[s];
     }
   };
-  if (nsteps <= 0) return;
+  if (count <= 0) return;
   issue(0);
+  // forward: alpha of the c states before the item (the lattice's start: entry 0 alone carries weight -- every row
+  // of its first matrix is the row of the start state, the constant-one term feeds all lanes alike); backward: the y
+  // of the cut behind the item (the lattice's end: nothing)
+  double vec = (!bwd && lane == 0) ? 1.0 : 0.0;
+  int Ev = 0;
+  if (LEVEL == 1) {
+    const double* gm = bwd ? a.gb_bm : a.gb_fm;
+    const int32_t* ge = bwd ? a.gb_be : a.gb_fe;
+    vec = mine ? gm[(size_t)blockIdx.x * c + lane] : 0.0;
+    Ev = ge[blockIdx.x];
+  }
   land(0);
   __syncthreads();
-  double vec = (!bwd && lane == 0) ? 1.0 : 0.0;  // forward: alpha before the segment; backward: y of the next cut
-  int Ev = 0;
   double tot = 0.0;
   int totE = 0;
-  const int nchunks = (nsteps + kCombineChunk - 1) / kCombineChunk;
+  const int nchunks = (count + kCombineChunk - 1) / kCombineChunk;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunks) issue(ch + 1);
-    for (int s = 0; s < kCombineChunk && ch * kCombineChunk + s < nsteps; ++s) {
+    for (int s = 0; s < kCombineChunk && ch * kCombineChunk + s < count; ++s) {
       const int step = ch * kCombineChunk + s;
-      const size_t seg = seg_of(step);
+      const size_t it = item_of(step);
       const double* qd = sd + (buf * kCombineChunk + s) * pd;
       const int32_t* qi = si + (buf * kCombineChunk + s) * pi;
       const double qfm = qd[cc + me];
       const int qe = qi[me], qfe = qi[c + me];
+      // the vector at this item's cut
+      if (LEVEL == 0 || bwd || (int)it != lat_first_seg) {
+        if (mine) out_m[it * c + lane] = vec;
+        if (lane == 0) out_e[it] = Ev;
+      }
       if (!bwd) {
-        // forward: alpha of the c states before segment k+1 = alpha before segment k, through Q_k; the total
-        // collects every segment's paths into its final states.  (Segment 0: every row of Q_0 is the row of
-        // the start state -- the constant-one term feeds all lanes alike -- so entry 0 alone carries weight.)
-        const int k = step;
-        if (k > 0) {
-          if (mine) a.bnd_fm[seg * c + lane] = vec;
-          if (lane == 0) a.bnd_fe[seg] = Ev;
-        }
-        {  // tot += sum_j a[j] Qf[j]
+        if (LEVEL == 0) {  // tot += sum_j a[j] Mf[j]: every group's paths into its final states
           const double t = mine ? vec * qfm : 0.0;
           const int te = t != 0.0 ? Ev + qfe : kNoExp;
           const int hi = group_max_int(te);
           const double sum = group_sum_f64(t != 0.0 ? ldexp(t, te - hi) : 0.0);
           if (hi != kNoExp) chain_add_exact(tot, totE, sum, hi);
         }
-        if (k == K - 1) break;
-        // r[j] = a[j] 2^(Qe[j]) to one exponent Er; new[i] = sum_j r[j] Qm[j][i]
+        if (step == count - 1) break;
+        // r[j] = a[j] 2^(Me[j]) to one exponent Er; new[i] = sum_j r[j] M[j][i]
         const int re = (mine && vec != 0.0 && qe != kZeroRowExp) ? qe : kNoExp;
         const int Er = group_max_int(re);
         double r = 0.0;
@@ -622,15 +649,15 @@ __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
           Ev += Er + ex;
         }
       } else {
-        // backward: y_k[j] = what the paths that leave state (first state of segment k) - c + j through an arc
-        // into segment k contribute to its beta: through Q_k to the y of the next cut, or into a final state
+        if (step == count - 1) break;
+        // y[j] <- sum_i M[j][i] y[i] + Mf[j]: through the item to the y of the cut behind it, or into a final state
         double val = 0.0;
         for_lanes<0, C>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
           const double yi = lane_value<i>(vec);
           if (mine) val = fma(qd[lane * c + i], yi, val);
         });
-        int ve = qe + Ev;
+        int ve = (qe == kZeroRowExp ? 0 : qe) + Ev;
         if (mine) chain_add_exact(val, ve, qfm, qfe);
         const int ne = (mine && val != 0.0) ? ve + __builtin_amdgcn_frexp_exp(val) : kNoExp;
         const int ex = group_max_int(ne);
@@ -641,8 +668,6 @@ __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
           if (ne != kNoExp && ne - ex < -400) trouble |= kChainTroubleVector;
           Ev = ex;
         }
-        if (mine) a.bnd_bm[(seg - 1) * c + lane] = vec;
-        if (lane == 0) a.bnd_be[seg - 1] = Ev;
       }
     }
     if (ch + 1 < nchunks) {
@@ -650,10 +675,146 @@ __global__ __launch_bounds__(64) void chain_combine_kernel(ChainArgs a) {
       __syncthreads();
     }
   }
-  if (!bwd && lane == 0) {  // tot_forward, natural log, into the row's extra slot
+  if (LEVEL == 0 && !bwd && lane == 0) {  // tot_forward, natural log, into the row's extra slot
     const double m = __builtin_amdgcn_frexp_mant(tot);
     const double e = (double)(totE + __builtin_amdgcn_frexp_exp(tot));
     a.alpha[padded_state_base(a.state_off[cl.lattice], cl.lattice) + cl.num_states] = tot == 0.0 ? -INFINITY : log(m) + e * kLn2;
+  }
+  if (trouble) atomicOr(a.flag, trouble);
+}
+
+// The product of a group's transfer matrices and its final-state vector (one wave per group; all in LDS):
+//   P = Q_1;  Pf = Qf_1;  for t = 2 .. n:  Pf += P Qf_t;  P = P Q_t
+// Rows are plain doubles to one exponent each, as the walks leave them; a row of zeros has the exponent kZeroRowExp.
+template <int C>
+__global__ __launch_bounds__(64) void chain_group_kernel(ChainArgs a) {
+  constexpr int c = C, cc = C * C;
+  constexpr int kRE = (cc + 63) / 64;  // matrix entries per lane
+  __shared__ double P[cc], Q[cc], Qf[c];
+  __shared__ int32_t Pe[c], Qe[c], Qfe[c], rowx[c];
+  const ChainGroup g = a.grps[blockIdx.x];
+  const int lane = threadIdx.x;
+  const bool mine = lane < c;
+  int trouble = 0;
+  double pf = 0.0;  // lane j < c: Pf[j] aligned to 2^pfe
+  int pfe = 0;
+  for (int t = 0; t < g.nseg; ++t) {
+    const size_t seg = (size_t)g.seg_first + t;
+    __syncthreads();  // (the previous turn's reads of Q)
+    // Q_t into LDS, its rows brought to one exponent (that of its largest nonzero row)
+    const int qe_own = mine ? a.Qe[seg * c + lane] : kZeroRowExp;
+    const int re = qe_own != kZeroRowExp ? qe_own : kNoExp;
+    const int Er = group_max_int(re);  // (lanes 0 .. 15 hold it; the others get it below)
+    if (mine) {
+      Qe[lane] = qe_own;
+      Qf[lane] = a.Qfm[seg * c + lane];
+      Qfe[lane] = a.Qfe[seg * c + lane];
+    }
+    if (lane == 0) rowx[0] = Er;
+    __syncthreads();
+    const int Eall = rowx[0];
+#pragma unroll
+    for (int r = 0; r < kRE; ++r) {
+      const int e = lane + 64 * r;
+      if (e < cc) {
+        const int m = e / c;
+        const int qe = Qe[m];
+        double v = a.Qm[seg * cc + e];
+        if (t > 0) {
+          if (qe == kZeroRowExp) {
+            v = 0.0;
+          } else {
+            if (v != 0.0 && qe - Eall < -900) trouble |= kChainTroubleRows;
+            v = ldexp(v, max(-2000, qe - Eall));
+          }
+        }
+        Q[e] = v;
+      }
+    }
+    __syncthreads();
+    if (t == 0) {  // P = Q_1, Pf = Qf_1
+#pragma unroll
+      for (int r = 0; r < kRE; ++r) {
+        const int e = lane + 64 * r;
+        if (e < cc) P[e] = Q[e];
+      }
+      if (mine) {
+        Pe[lane] = Qe[lane] == kZeroRowExp ? 0 : Qe[lane];
+        pf = Qf[lane];
+        pfe = Qfe[lane];
+      }
+      continue;
+    }
+    // Pf[j] += sum_m P[j][m] Qf_t[m], the Qf to one exponent (their largest)
+    {
+      const int fe = (mine && Qf[lane] != 0.0) ? Qfe[lane] : kNoExp;
+      const int Fm = group_max_int(fe);
+      if (lane == 0) rowx[1 % c] = Fm;  // (c >= 2)
+      __syncthreads();
+      const int Fall = rowx[1 % c];
+      if (mine && Fall != kNoExp) {
+        double sum = 0.0;
+        for (int m = 0; m < c; ++m) {
+          const double f = Qf[m];
+          if (f == 0.0) continue;
+          if (Qfe[m] - Fall < -900) trouble |= kChainTroubleRows;
+          sum = fma(P[lane * c + m], ldexp(f, max(-2000, Qfe[m] - Fall)), sum);
+        }
+        chain_add_exact(pf, pfe, sum, Pe[lane] + Fall);
+      }
+      __syncthreads();
+    }
+    // P <- P Q_t (entry by entry), then every row back to [0.5, 1)
+    double nw[kRE];
+#pragma unroll
+    for (int r = 0; r < kRE; ++r) {
+      const int e = lane + 64 * r;
+      nw[r] = 0.0;
+      if (e < cc) {
+        const int j = e / c, i = e % c;
+        for (int m = 0; m < c; ++m) nw[r] = fma(P[j * c + m], Q[m * c + i], nw[r]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRE; ++r) {
+      const int e = lane + 64 * r;
+      if (e < cc) P[e] = nw[r];
+    }
+    __syncthreads();
+    if (mine) {
+      double mx = 0.0;
+      for (int i = 0; i < c; ++i) mx = fmax(mx, P[lane * c + i]);
+      rowx[lane] = mx != 0.0 ? __builtin_amdgcn_frexp_exp(mx) : kNoExp;
+      if (!(mx < 1.0e300)) trouble |= kChainTroubleRange;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRE; ++r) {
+      const int e = lane + 64 * r;
+      if (e < cc) {
+        const int ex = rowx[e / c];
+        if (ex != kNoExp) {
+          const double v = ldexp(P[e], -ex);
+          if (v != 0.0 && v < kChainTiny) trouble |= kChainTroubleSpread;
+          P[e] = v;
+        }
+      }
+    }
+    if (mine && rowx[lane] != kNoExp && Eall != kNoExp) Pe[lane] += Eall + rowx[lane];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRE; ++r) {
+    const int e = lane + 64 * r;
+    if (e < cc) a.Gm[(size_t)blockIdx.x * cc + e] = P[e];
+  }
+  if (mine) {
+    double mx = 0.0;
+    for (int i = 0; i < c; ++i) mx = fmax(mx, P[lane * c + i]);
+    a.Ge[(size_t)blockIdx.x * c + lane] = mx != 0.0 ? Pe[lane] : kZeroRowExp;
+    a.Gfm[(size_t)blockIdx.x * c + lane] = __builtin_amdgcn_frexp_mant(pf);
+    a.Gfe[(size_t)blockIdx.x * c + lane] = pfe + __builtin_amdgcn_frexp_exp(pf);
   }
   if (trouble) atomicOr(a.flag, trouble);
 }
@@ -675,11 +836,17 @@ hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream) {
   const size_t lds_b = (size_t)2 * kCombineChunk * ((size_t)(a.c * a.c + a.c) * sizeof(double) + (size_t)2 * a.c * sizeof(int32_t));
   const int jobs_a = (a.num_segs + (64 >> a.lgc) - 1) / (64 >> a.lgc), jobs_c = (a.num_segs + 63) / 64;
   hipLaunchKernelGGL(chain_walk_kernel<0>, dim3((jobs_a + kWalkWaves - 1) / kWalkWaves), dim3(64 * kWalkWaves), lds_a, stream, a);
+  auto combine = [&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    hipLaunchKernelGGL(chain_group_kernel<C>, dim3(a.num_grps), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((chain_combine_kernel<C, 0>), dim3(a.num_lats, 2), dim3(64), lds_b, stream, a);
+    hipLaunchKernelGGL((chain_combine_kernel<C, 1>), dim3(a.num_grps, 2), dim3(64), lds_b, stream, a);
+  };
   switch (a.c) {
-    case 2: hipLaunchKernelGGL(chain_combine_kernel<2>, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a); break;
-    case 4: hipLaunchKernelGGL(chain_combine_kernel<4>, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a); break;
-    case 8: hipLaunchKernelGGL(chain_combine_kernel<8>, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a); break;
-    default: hipLaunchKernelGGL(chain_combine_kernel<16>, dim3(a.num_lats, 2), dim3(64), lds_b, stream, a); break;
+    case 2: combine(std::integral_constant<int, 2>()); break;
+    case 4: combine(std::integral_constant<int, 4>()); break;
+    case 8: combine(std::integral_constant<int, 8>()); break;
+    default: combine(std::integral_constant<int, 16>()); break;
   }
   hipLaunchKernelGGL(chain_walk_kernel<1>, dim3((jobs_c + kSweepWaves - 1) / kSweepWaves, 2), dim3(64 * kSweepWaves), lds_c, stream, a);
   return hipGetLastError();

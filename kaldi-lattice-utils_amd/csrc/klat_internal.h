@@ -279,6 +279,10 @@ struct klat_batch {
   klat::DevBuf<uint64_t> ch_recs;
   klat::DevBuf<double> ch_qm, ch_qfm, ch_bfm, ch_bbm;
   klat::DevBuf<int32_t> ch_qe, ch_qfe, ch_bfe, ch_bbe;
+  int32_t chain_grps = 0;  // groups of kChainGroup segments (the two-level combine)
+  klat::DevBuf<klat::ChainGroup> ch_grps;
+  klat::DevBuf<double> ch_gm, ch_gfm, ch_gbfm, ch_gbbm;
+  klat::DevBuf<int32_t> ch_ge, ch_gfe, ch_gbfe, ch_gbbe;
   klat::DevBuf<int32_t> ch_status;  // [0] the record pass met a cost that fits no record, [1] the sweep's fall-back flag
   int32_t chain_rescale = 1;        // ChainArgs::rescale_iters
   float pack_host_ms = 0.0f;  // wall time of klat_batch_create (uploads, host planning, waits included)

@@ -85,14 +85,11 @@ def test_segments_match_the_oracle_and_the_streams(ctx, seg, scales):
     arrays = _lattices(20260005, ns, fo)
     b, got = _run(ctx, arrays, scales, KLAT_CHAIN=1, KLAT_CHAIN_SEG=seg)
     info = b.info()
-    # a lattice's segments hold ~4 x seg records each (seg states at fanout 3, fewer at a larger fanout), and a
-    # lattice is never cut into more than sqrt(records / 4) of them
+    # a lattice's segments hold ~4 x seg records each: seg states at fanout 3, fewer at a larger fanout
     def seg_len(s, f):
         if s < 2:
             return 1 << 30
-        arcs = f * (s - 1)
-        most = max(2, int((0.25 * (arcs + s)) ** 0.5))
-        return max(max(32, int(4.0 * seg / (arcs / s + 1.0))), (s + most - 1) // most)
+        return max(32, int(4.0 * seg / (f * (s - 1) / s + 1.0)))
     seg_states = [seg_len(s, f) for s, f in zip(ns, fo)]
     want_chain = sum(1 for s, l in zip(ns, seg_states) if s >= 2 * l)
     assert info["chain_lattices"] == want_chain and want_chain >= 4 and not b.chain_fallback(), info
