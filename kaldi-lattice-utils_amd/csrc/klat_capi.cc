@@ -49,11 +49,19 @@ using namespace klat;
 // streams that fork from it and join it again, so that the few long workgroups of a skewed batch run
 // beside the many short ones.  The pieces are the layout classes (the class with the longest chain
 // first) and, before them, the lattices swept in segments (klat_chain.hip).
-typedef std::function<hipError_t(hipStream_t)> SweepPiece;
+// A piece names its stream (0: the context's; 1 ..: a side stream) and is launched in list order, so one stream
+// may take several pieces: a class's fast sweep goes out FIRST, before the eight launches of the segment path
+// (a launch is ~10 us of host time, and a class that started 200 us late finished 200 us late), its exact
+// sweep after them.
+struct SweepPiece {
+  int slot;
+  std::function<hipError_t(hipStream_t)> launch;
+};
 static int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
-  const size_t n = work.size();
-  if (n <= 1) {
-    if (n == 1) KLAT_HIP(work[0](c->stream));
+  int most = 0;
+  for (const SweepPiece& w : work) most = std::max(most, w.slot);
+  if (most == 0) {
+    for (const SweepPiece& w : work) KLAT_HIP(w.launch(c->stream));
     return KLAT_OK;
   }
   if (!c->fork_ev) {
@@ -63,11 +71,11 @@ static int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
       KLAT_HIP(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
     }
   }
-  KLAT_HIP(hipEventRecord(c->fork_ev, c->stream));
   static const int side_limit = std::getenv("KLAT_SIDE_STREAMS") ? std::max(1, std::min((int)klat_ctx::kSideStreams, std::atoi(std::getenv("KLAT_SIDE_STREAMS")))) : (int)klat_ctx::kSideStreams;
-  const int used = (int)std::min<size_t>(n - 1, (size_t)side_limit);
+  KLAT_HIP(hipEventRecord(c->fork_ev, c->stream));
+  const int used = std::min(most, side_limit);
   for (int i = 0; i < used; ++i) KLAT_HIP(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
-  for (size_t k = 0; k < n; ++k) KLAT_HIP(work[k](k == 0 ? c->stream : c->side[(k - 1) % side_limit]));
+  for (const SweepPiece& w : work) KLAT_HIP(w.launch(w.slot == 0 ? c->stream : c->side[(w.slot - 1) % side_limit]));
   for (int i = 0; i < used; ++i) {
     KLAT_HIP(hipEventRecord(c->join_ev[i], c->side[i]));
     KLAT_HIP(hipStreamWaitEvent(c->stream, c->join_ev[i], 0));
@@ -78,9 +86,10 @@ static int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
 template <class F>
 static int for_each_class(klat_batch* b, F launch) {
   std::vector<SweepPiece> work;
+  int slot = 0;
   for (const LayoutClass& lc : b->classes) {
     const LayoutClass* lcp = &lc;
-    work.push_back([&launch, lcp](hipStream_t s) { return launch(*lcp, s); });
+    work.push_back(SweepPiece{slot++, [&launch, lcp](hipStream_t s) { return launch(*lcp, s); }});
   }
   return run_side_by_side(b->ctx, work);
 }
@@ -1130,40 +1139,49 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
       ca.alpha = b->alpha.p;
       ca.beta = b->beta.p;
       ca.ln_table = c->ln_table.p;
-      // ... and behind them, on the same stream, the streams these lattices keep: their workgroups leave at once
-      // unless the segment path raised its flag (values that do not fit its arithmetic)
-      work.push_back([&](hipStream_t stream) {
-        hipError_t e = hipMemsetAsync(ca.flag, 0, sizeof(int32_t), stream);
-        if (e == hipSuccess) e = launch_chain_sweep(ca, stream);
-        for (const LayoutClass& lc : b->classes) {
-          if (!lc.chain || e != hipSuccess) continue;
-          SweepArgs fa = sa;
-          fa.jobs = sa.jobs + lc.job_begin;
-          fa.job_flags = sa.job_flags + lc.job_begin;
-          fa.sink = sa.sink + (size_t)lc.job_begin * 64;
-          fa.ring_slots = lc.W;
-          fa.far_prefetch = lc.far;
-          fa.deep_prefetch = 0;
-          fa.run_if = ca.flag;
-          e = launch_sweep(fa, lc.job_end - lc.job_begin, lc.G, stream);
-        }
-        return e;
-      });
     }
-    for (const LayoutClass& lcr : b->classes) {
-      if (lcr.chain && b->num_chain > 0) continue;  // (their lattices are the chain piece's)
-      const LayoutClass* lcp = &lcr;
-      work.push_back([&, lcp](hipStream_t stream) {
-        const LayoutClass& lc = *lcp;
-        SweepArgs ca2 = sa;
-        ca2.jobs = sa.jobs + lc.job_begin;
-        ca2.job_flags = sa.job_flags + lc.job_begin;
-        ca2.sink = sa.sink + (size_t)lc.job_begin * 64;
-        ca2.ring_slots = lc.W;
-        ca2.far_prefetch = lc.far;
-        ca2.deep_prefetch = b->deep_prefetch;
-        return launch_sweep(ca2, lc.job_end - lc.job_begin, lc.G, stream, one_class ? ev[0] : nullptr, one_class ? ev[1] : nullptr);
-      });
+    // the launches, in this order: the classes' fast sweeps (a few long workgroups each: they take their CUs before
+    // the segment path's thousands of waves fill the chip), the segment path on the context's stream, the classes'
+    // exact sweeps (all of their workgroups leave at once unless the fast sweep flagged a job)
+    auto class_args = [&](const LayoutClass& lc) {
+      SweepArgs ca2 = sa;
+      ca2.jobs = sa.jobs + lc.job_begin;
+      ca2.job_flags = sa.job_flags + lc.job_begin;
+      ca2.sink = sa.sink + (size_t)lc.job_begin * 64;
+      ca2.ring_slots = lc.W;
+      ca2.far_prefetch = lc.far;
+      ca2.deep_prefetch = b->deep_prefetch;
+      return ca2;
+    };
+    const bool with_chain = b->num_chain > 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      int slot = with_chain ? 1 : 0;
+      for (const LayoutClass& lcr : b->classes) {
+        if (lcr.chain && with_chain) continue;  // (their lattices are the chain piece's)
+        const LayoutClass* lcp = &lcr;
+        const int which = with_chain ? (pass == 0 ? kSweepFast : kSweepExact) : (pass == 0 ? kSweepFast | kSweepExact : 0);
+        if (which)
+          work.push_back(SweepPiece{slot, [&, lcp, which](hipStream_t stream) {
+            return launch_sweep(class_args(*lcp), lcp->job_end - lcp->job_begin, lcp->G, stream, one_class ? ev[0] : nullptr, one_class ? ev[1] : nullptr, which);
+          }});
+        ++slot;
+      }
+      if (pass == 0 && with_chain) {
+        // ... and behind the segment path's kernels, on the same stream, the streams its lattices keep: their
+        // workgroups leave at once unless it raised its flag (values that do not fit its arithmetic)
+        work.push_back(SweepPiece{0, [&](hipStream_t stream) {
+          hipError_t e = hipMemsetAsync(ca.flag, 0, sizeof(int32_t), stream);
+          if (e == hipSuccess) e = launch_chain_sweep(ca, stream);
+          for (const LayoutClass& lc : b->classes) {
+            if (!lc.chain || e != hipSuccess) continue;
+            SweepArgs fa = class_args(lc);
+            fa.deep_prefetch = 0;
+            fa.run_if = ca.flag;
+            e = launch_sweep(fa, lc.job_end - lc.job_begin, lc.G, stream);
+          }
+          return e;
+        }});
+      }
     }
     // KLAT_CHAIN_DEBUG=<file>: when and where (CU, SIMD) every wave of the segment path's walks ran, written after this sweep
     DevBuf<unsigned long long> dbg;

@@ -146,8 +146,10 @@ hipError_t launch_sweep_tropical(const SweepArgs& args, int num_jobs, int G, hip
 hipError_t launch_prune(const PruneArgs& a, int num_lattices, hipStream_t stream);
 
 // fast_begin / fast_end (may be null): events recorded right before and after the fast kernel
+// which: the fast sweep, the exact one (for the jobs the fast one flagged), or both one after the other
+static const int kSweepFast = 1, kSweepExact = 2;
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream, hipEvent_t fast_begin = nullptr,
-                        hipEvent_t fast_end = nullptr);
+                        hipEvent_t fast_end = nullptr, int which = kSweepFast | kSweepExact);
 hipError_t launch_totals(const TotalsArgs& a, hipStream_t stream);
 hipError_t launch_unpad(const UnpadArgs& a, hipStream_t stream);
 void fill_ln_table(LnTabEntry* host_table);  // kLnTabSize entries

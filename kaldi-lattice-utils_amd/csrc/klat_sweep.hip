@@ -620,20 +620,24 @@ static size_t sweep_lds_bytes(int ring_slots, int LPW, int cpb) {
 }
 
 template <int G>
-static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream, hipEvent_t fast_begin, hipEvent_t fast_end) {
+static void launch_pair(const SweepArgs& args, int num_jobs, hipStream_t stream, hipEvent_t fast_begin, hipEvent_t fast_end, int which) {
   const int LPW = 64 / G;
   // the producer copies a period's states out one period later: the ring must hold two periods
   const int cpb = args.ring_slots >= 32 ? 2 : 1;
   const size_t lds = sweep_lds_bytes(args.ring_slots, LPW, cpb);
-  auto launch = [&](auto kernel) {
+  auto launch_one = [&](auto kernel) {
     // the largest rings (4032 cells) take the workgroup past the default 64 KiB of dynamic LDS
     if (lds > 60 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, dim3(num_jobs), dim3(128), lds, stream, args);
   };
+  auto launch = [&](auto kernel) {  // the exact sweep
+    if (which & kSweepExact) launch_one(kernel);
+  };
   auto launch_fast = [&](auto kernel) {
+    if (!(which & kSweepFast)) return;
     if (fast_begin) (void)hipEventRecord(fast_begin, stream);
-    launch(kernel);
+    launch_one(kernel);
     if (fast_end) (void)hipEventRecord(fast_end, stream);
   };
   if (cpb == 2 && args.far_prefetch) {
@@ -691,7 +695,7 @@ hipError_t launch_sweep_tropical(const SweepArgs& args, int num_jobs, int G, hip
 // Runs the fast sweep over every job (it writes every job's flag) and the exact sweep over the jobs the
 // fast one flagged (normally none: those workgroups exit at once).
 hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t stream, hipEvent_t fast_begin,
-                        hipEvent_t fast_end) {
+                        hipEvent_t fast_end, int which) {
   if (num_jobs <= 0) {  // nothing to sweep: the timing events must still be recorded
     hipError_t e = fast_begin ? hipEventRecord(fast_begin, stream) : hipSuccess;
     if (e == hipSuccess && fast_end) e = hipEventRecord(fast_end, stream);
@@ -700,13 +704,13 @@ hipError_t launch_sweep(const SweepArgs& args, int num_jobs, int G, hipStream_t 
   const int LPW = 64 / G;
   if ((size_t)args.ring_slots * LPW + 64 > kCellMask + 1) return hipErrorInvalidValue;
   switch (G) {
-    case 1: launch_pair<1>(args, num_jobs, stream, fast_begin, fast_end); break;
-    case 2: launch_pair<2>(args, num_jobs, stream, fast_begin, fast_end); break;
-    case 4: launch_pair<4>(args, num_jobs, stream, fast_begin, fast_end); break;
-    case 8: launch_pair<8>(args, num_jobs, stream, fast_begin, fast_end); break;
-    case 16: launch_pair<16>(args, num_jobs, stream, fast_begin, fast_end); break;
-    case 32: launch_pair<32>(args, num_jobs, stream, fast_begin, fast_end); break;
-    case 64: launch_pair<64>(args, num_jobs, stream, fast_begin, fast_end); break;
+    case 1: launch_pair<1>(args, num_jobs, stream, fast_begin, fast_end, which); break;
+    case 2: launch_pair<2>(args, num_jobs, stream, fast_begin, fast_end, which); break;
+    case 4: launch_pair<4>(args, num_jobs, stream, fast_begin, fast_end, which); break;
+    case 8: launch_pair<8>(args, num_jobs, stream, fast_begin, fast_end, which); break;
+    case 16: launch_pair<16>(args, num_jobs, stream, fast_begin, fast_end, which); break;
+    case 32: launch_pair<32>(args, num_jobs, stream, fast_begin, fast_end, which); break;
+    case 64: launch_pair<64>(args, num_jobs, stream, fast_begin, fast_end, which); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

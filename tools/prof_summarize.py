@@ -4,7 +4,7 @@ profiles/: the --kernel-trace --stats table, and per-kernel HBM traffic from the
 (FETCH_SIZE and WRITE_SIZE collected in separate runs; both in KiB; FETCH_SIZE doubled as
 /opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes for 16 B/lane streaming reads on gfx950).
 
-usage: tools/prof_summarize.py <round-tag>   e.g. r01
+usage: tools/prof_summarize.py <round-tag> [dir-prefix]   e.g. r01, or r03_chain chainprof (gpurun_out/chainprof_{stats,fetch,write})
 """
 import collections
 import csv
@@ -15,19 +15,20 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "prof"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]
-stats = newest(glob.glob(os.path.join(src, "prof_stats", "**", "*_kernel_stats.csv"), recursive=True))
+stats = newest(glob.glob(os.path.join(src, prefix + "_stats", "**", "*_kernel_stats.csv"), recursive=True))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
 
 traffic = collections.defaultdict(dict)
 for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    files = newest(glob.glob(os.path.join(src, "prof_%s" % name, "**", "*_counter_collection.csv"), recursive=True))
+    files = newest(glob.glob(os.path.join(src, "%s_%s" % (prefix, name), "**", "*_counter_collection.csv"), recursive=True))
     if not files:
         continue
     acc = collections.defaultdict(list)
