@@ -100,8 +100,8 @@ static int for_each_class(klat_batch* b, F launch) {
 // least two segments long, no arc longer than kChainMaxSpan states, not on the level path.  A batch the chip is
 // busy with anyway keeps its streams: the segment path walks every arc (c + 2) / 2 times as often as a stream
 // does.  Otherwise the planner's own model of the streams (plan_cycles) is weighed against a model of the
-// segment path for a few size thresholds -- everything at or above the threshold goes -- and the cheapest choice
-// is taken if it beats the streams by a quarter.  KLAT_CHAIN=0 / =1: never / every candidate.
+// segment path with every candidate in it, and they all go if that beats the streams by a quarter.
+// KLAT_CHAIN=0 / =1: never / every candidate whatever the models say.
 static int chain_segment_states(int64_t S, int64_t A, int seg) {
   const double fan = S > 0 ? (double)A / (double)S : 1.0;
   return std::max(2 * kChainMaxSpan, (int)(4.0 * (double)seg / (fan + 1.0)));
@@ -134,34 +134,30 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
   if (mode < 0) {
     // cycles: a stream round of a lone workgroup ~320, a state of a full chip ~60 SIMD-cycles over 1024 SIMDs
     if (longest * 320.0 < 1.3 * sum_states * 60.0 / 1024.0) return;
+    // All the candidates or none.  (Round 3 first took the lattices above the cheapest size threshold and left the
+    // others to three classes of streams beside the segment path: 0.90 ms on the C5/8 shard when the four HIP
+    // streams got a hardware queue each, 1.05 - 1.4 ms when the runtime's queue lottery made one of the classes
+    // start 200 us late or starved it.  With every candidate in segments the streams that are left are a few
+    // hundred states long and it does not matter when they run: 0.94 ms, every time.)
     const double base = plan_cycles(U, state_off, arc_off, lr, o, on_level);
     std::vector<uint8_t> skip(on_level, on_level + U);
-    double best = 0.75 * base;
-    size_t best_take = 0, n = 0;
-    double arcs = 0, work_c = 2, segs_max = 1;
-    const int64_t floor_states = 8 * (int64_t)seg;  // (shorter lattices gain nothing: three kernels in a row are ~2 000 stream rounds)
-    int64_t thr = state_off[cand[0] + 1] - state_off[cand[0]];
-    for (int it = 0; it < 16 && n < cand.size(); ++it) {
-      thr = std::max<int64_t>(floor_states, (int64_t)((double)thr * 0.7));
-      while (n < cand.size() && state_off[cand[n] + 1] - state_off[cand[n]] >= thr) {
-        const int64_t u = cand[n++], S = state_off[u + 1] - state_off[u], A = arc_off[u + 1] - arc_off[u];
-        skip[(size_t)u] = 1;
-        arcs += (double)(A + S);
-        work_c = std::max(work_c, (double)lr[u].max_span);
-        segs_max = std::max(segs_max, (double)(S / chain_segment_states(S, A, seg)));
-      }
-      int cc = 2;
-      while (cc < work_c) cc *= 2;
-      // two walks of a segment (transfer, sweep: ~700 cycles a record for a wave on its own), the serial combine
-      // (~800 a segment), three launches; the walks' work: ~2 SIMD-cycles per record and lane, c lanes for the
-      // transfer, 2 for the sweep
-      const double latency = 2.0 * 4.0 * (double)seg * 700.0 + segs_max * 800.0 + 50000.0;
-      const double work = arcs * (cc + 2) * 2.0 / 1024.0;
-      const double total = std::max(plan_cycles(U, state_off, arc_off, lr, o, skip.data()), latency) + work;
-      if (total < best) best = total, best_take = n;
-      if (thr == floor_states) break;
+    double records = 0, span = 2, segs_max = 1;
+    for (int64_t u : cand) {
+      const int64_t S = state_off[u + 1] - state_off[u], A = arc_off[u + 1] - arc_off[u];
+      skip[(size_t)u] = 1;
+      records += (double)(A + S);
+      span = std::max(span, (double)lr[u].max_span);
+      segs_max = std::max(segs_max, (double)(S / chain_segment_states(S, A, seg)));
     }
-    take = best_take;
+    int cc = 2;
+    while (cc < span) cc *= 2;
+    // two walks of a segment (transfer, sweep: ~700 cycles a record for a wave on its own), the two-level combine
+    // (~2 500 a step: a lattice's groups of 16 segments, then 2 x 16 steps), six launches; the walks' work: ~2
+    // SIMD-cycles per record and lane, c lanes for the transfer, 2 for the sweep
+    const double latency = 2.0 * 4.0 * (double)seg * 700.0 + (segs_max / kChainGroup + 2.0 * kChainGroup) * 2500.0 + 100000.0;
+    const double work = records * (cc + 2) * 2.0 / 1024.0;
+    const double total = std::max(plan_cycles(U, state_off, arc_off, lr, o, skip.data()), latency) + work;
+    if (total >= 0.75 * base) return;
   }
   if (take == 0) return;
   int cc = 2;
