@@ -632,6 +632,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     // Long lattices of a batch that waits for them are swept in segments (klat_chain.hip): the choice, their
     // segments and their arc records.  Only with fused scales (the records hold exp(-cost)) and the automatic layout.
     std::vector<uint8_t> on_chain((size_t)U, 0), skip(on_level);
+    size_t nrec_chain = 0;
     {
       double maxc = 0.0;
       std::memcpy(&maxc, &h_maxcost, sizeof(maxc));
@@ -681,12 +682,14 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         cp.scratch_f = r0f.p;  // (the rounds pass fills them afterwards)
         cp.scratch_b = r0b.p;
         cp.sp = pa.fsp;
+        cp.tropical = 0;
         cp.status = b->ch_status.p;
         KLAT_HIP_B(hipEventRecord(pev[9], c->stream));
         KLAT_HIP_B(launch_chain_prep(cp, (int)cl.size(), c->stream));
         KLAT_HIP_B(hipEventRecord(pev[10], c->stream));
         b->pack_chain_timed = true;
         b->num_chain = (int32_t)cl.size();
+        nrec_chain = nrec;
         b->chain_segs = (int32_t)nseg;
         b->chain_grps = (int32_t)ngrp;
         b->chain_c = cc;
@@ -799,6 +802,13 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     }
     for (int64_t u = 0; u < U; ++u)
       append_post_items(&P.items, d->arc_off[u], d->arc_off[u + 1], u);
+    if (b->num_chain > 0) {  // the count pass's tables stay: klat_viterbi builds the segment path's COST records from them, when it first runs
+      b->ch_cnt.take(cnt);
+      b->ch_row.take(row);
+      b->ch_in_arc.take(in_arc);
+      b->ch_out_arc.take(out_arc);
+      b->chain_records = nrec_chain;
+    }
   }
   b->G = P.G;
   b->W = P.W;
@@ -1042,6 +1052,38 @@ static void fill_posterior_args(klat_batch* b, const ScaleParams& sp, PosteriorA
   pa->span = b->arc_span.p;
 }
 
+// the segment path's argument block for the log-semiring sweep of batch b (klat_viterbi swaps records and rows)
+static void fill_chain_args(klat_batch* b, ChainArgs* out) {
+  ChainArgs& ca = *out;
+  ca.lats = b->ch_lats.p;
+  ca.segs = b->ch_segs.p;
+  ca.recs = b->ch_recs.p;
+  ca.num_lats = b->num_chain;
+  ca.num_segs = b->chain_segs;
+  ca.c = b->chain_c;
+  ca.lgc = 0;
+  while ((1 << ca.lgc) < ca.c) ++ca.lgc;
+  ca.W = 2 * ca.c;
+  ca.Qm = b->ch_qm.p;
+  ca.Qe = b->ch_qe.p;
+  ca.Qfm = b->ch_qfm.p;
+  ca.Qfe = b->ch_qfe.p;
+  ca.bnd_fm = b->ch_bfm.p;
+  ca.bnd_fe = b->ch_bfe.p;
+  ca.bnd_bm = b->ch_bbm.p;
+  ca.bnd_be = b->ch_bbe.p;
+  ca.grps = b->ch_grps.p;
+  ca.num_grps = b->chain_grps;
+  ca.Gm = b->ch_gm.p, ca.Ge = b->ch_ge.p, ca.Gfm = b->ch_gfm.p, ca.Gfe = b->ch_gfe.p;
+  ca.gb_fm = b->ch_gbfm.p, ca.gb_fe = b->ch_gbfe.p, ca.gb_bm = b->ch_gbbm.p, ca.gb_be = b->ch_gbbe.p;
+  ca.rescale_iters = b->chain_rescale;
+  ca.flag = b->ch_status.p + 1;
+  ca.state_off = b->state_off.p;
+  ca.alpha = b->alpha.p;
+  ca.beta = b->beta.p;
+  ca.ln_table = b->ctx->ln_table.p;
+}
+
 int klat_forward_backward(klat_batch* b, const klat_scales* sc) { return klat_forward_backward_ex(b, sc, 0); }
 
 int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flags) {
@@ -1108,33 +1150,7 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
     std::vector<SweepPiece> work;
     ChainArgs ca;
     if (b->num_chain > 0) {  // the long lattices, in segments: the piece with the longest chain of kernels goes first
-      ca.lats = b->ch_lats.p;
-      ca.segs = b->ch_segs.p;
-      ca.recs = b->ch_recs.p;
-      ca.num_lats = b->num_chain;
-      ca.num_segs = b->chain_segs;
-      ca.c = b->chain_c;
-      ca.lgc = 0;
-      while ((1 << ca.lgc) < ca.c) ++ca.lgc;
-      ca.W = 2 * ca.c;
-      ca.Qm = b->ch_qm.p;
-      ca.Qe = b->ch_qe.p;
-      ca.Qfm = b->ch_qfm.p;
-      ca.Qfe = b->ch_qfe.p;
-      ca.bnd_fm = b->ch_bfm.p;
-      ca.bnd_fe = b->ch_bfe.p;
-      ca.bnd_bm = b->ch_bbm.p;
-      ca.bnd_be = b->ch_bbe.p;
-      ca.grps = b->ch_grps.p;
-      ca.num_grps = b->chain_grps;
-      ca.Gm = b->ch_gm.p, ca.Ge = b->ch_ge.p, ca.Gfm = b->ch_gfm.p, ca.Gfe = b->ch_gfe.p;
-      ca.gb_fm = b->ch_gbfm.p, ca.gb_fe = b->ch_gbfe.p, ca.gb_bm = b->ch_gbbm.p, ca.gb_be = b->ch_gbbe.p;
-      ca.rescale_iters = b->chain_rescale;
-      ca.flag = b->ch_status.p + 1;
-      ca.state_off = b->state_off.p;
-      ca.alpha = b->alpha.p;
-      ca.beta = b->beta.p;
-      ca.ln_table = c->ln_table.p;
+      fill_chain_args(b, &ca);
     }
     // the launches, in this order: the classes' fast sweeps (a few long workgroups each: they take their CUs before
     // the segment path's thousands of waves fill the chip), the segment path on the context's stream, the classes'
@@ -1277,7 +1293,7 @@ int klat_viterbi(klat_batch* b, const klat_scales* sc) {
     va.fused = 1;
   }
   if (b->num_level > 0) KLAT_HIP(launch_level(b, b->fwd_cost.p, b->bwd_cost.p, va.sp, true));
-  rc = for_each_class(b, [&](const LayoutClass& lc, hipStream_t stream) {
+  auto class_launch = [&](const LayoutClass& lc, hipStream_t stream) {
     SweepArgs ca = va;
     ca.jobs = va.jobs + lc.job_begin;
     ca.job_flags = va.job_flags + lc.job_begin;
@@ -1285,7 +1301,56 @@ int klat_viterbi(klat_batch* b, const klat_scales* sc) {
     ca.ring_slots = lc.W;
     ca.far_prefetch = lc.far;
     return launch_sweep_tropical(ca, lc.job_end - lc.job_begin, lc.G, stream);
-  });
+  };
+  if (b->num_chain > 0 && std::getenv("KLAT_CHAIN_VITERBI_STREAMS") == nullptr) {
+    // The lattices swept in segments take the (min,+) twin of that path (klat_chain.hip) over COST records, built
+    // from the count pass's tables when this first runs on the batch; the others their streams, beside it.
+    if (!b->chain_trop_ready) {
+      DevBuf<int32_t> sf, sb2;
+      if ((rc = b->ch_recs_t.alloc(b->chain_records)) || (rc = sf.alloc((size_t)(b->S + 2 * b->U))) || (rc = sb2.alloc((size_t)(b->S + 2 * b->U)))) return rc;
+      ChainPrepArgs cp;
+      cp.lats = b->ch_lats.p;
+      cp.segs = b->ch_segs.p;
+      cp.recs = b->ch_recs_t.p;
+      cp.state_off = b->state_off.p;
+      cp.arc_off = b->arc_off.p;
+      cp.src = b->src.p;
+      cp.dst = b->dst.p;
+      cp.ilabel = b->ilabel.p;
+      cp.graph = b->graph.p;
+      cp.acoustic = b->acoustic.p;
+      cp.final_graph = b->final_graph.p;
+      cp.final_acoustic = b->final_acoustic.p;
+      cp.cnt = b->ch_cnt.p;
+      cp.row = b->ch_row.p;
+      cp.in_arc = b->ch_in_arc.p;
+      cp.out_arc = b->ch_out_arc.p;
+      cp.scratch_f = sf.p;
+      cp.scratch_b = sb2.p;
+      cp.sp = va.sp;
+      cp.tropical = 1;
+      cp.status = b->ch_status.p;
+      KLAT_HIP(launch_chain_prep(cp, b->num_chain, c->stream));
+      KLAT_HIP(hipStreamSynchronize(c->stream));  // (the scratch rows go out of scope)
+      b->chain_trop_ready = true;
+    }
+    ChainArgs ca;
+    fill_chain_args(b, &ca);
+    ca.recs = b->ch_recs_t.p;
+    ca.alpha = b->fwd_cost.p;
+    ca.beta = b->bwd_cost.p;
+    std::vector<SweepPiece> work;
+    int slot = 1;
+    for (const LayoutClass& lcr : b->classes) {
+      if (lcr.chain) continue;
+      const LayoutClass* lcp = &lcr;
+      work.push_back(SweepPiece{slot++, [&, lcp](hipStream_t stream) { return class_launch(*lcp, stream); }});
+    }
+    work.push_back(SweepPiece{0, [&](hipStream_t stream) { return launch_chain_sweep(ca, stream, true); }});
+    rc = run_side_by_side(c, work);
+  } else {
+    rc = for_each_class(b, class_launch);
+  }
   if (rc != KLAT_OK) return rc;
   b->viterbi_done = true;
   return KLAT_OK;

@@ -74,6 +74,7 @@ struct ChainPrepArgs {
   const int32_t* cnt; const int32_t* row; const int32_t* in_arc; const int32_t* out_arc;
   int32_t* scratch_f; int32_t* scratch_b;  // same shape (the packer's r0f / r0b, not yet in use)
   ScaleParams sp;
+  int32_t tropical;  // the records hold the costs themselves (klat_viterbi), not exp(-cost)
   int32_t* status;  // [1] set when a cost does not fit a record
 };
 
@@ -102,8 +103,9 @@ struct ChainArgs {
 };
 
 hipError_t launch_chain_prep(const ChainPrepArgs& a, int num_chain_lattices, hipStream_t stream);
-// transfer, combine and sweep, one after the other on `stream`
-hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream);
+// transfer, combine and sweep, one after the other on `stream`; tropical: the (min,+) twin over cost records -- alpha /
+// beta are then the padded rows of the Viterbi forward / backward costs
+hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream, bool tropical = false);
 
 }  // namespace klat
 #endif

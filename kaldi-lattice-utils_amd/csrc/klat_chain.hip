@@ -50,8 +50,12 @@ __device__ void block_scan2(int v0, int v1, int* ex0, int* ex1, int* tot0, int* 
 
 // exp(-cost) as a record: the double with its low nine fraction bits replaced by `ctl`.  A dead term
 // (infinite cost, NaN) reads the constant zero.  A cost the double cannot hold sets *status.
-__device__ __forceinline__ uint64_t chain_record(double cost, uint32_t ctl, double c9v, int32_t* status) {
+__device__ __forceinline__ uint64_t chain_record(double cost, uint32_t ctl, double c9v, int32_t* status, bool tropical) {
   if (!(cost < 1.0e30)) return (uint64_t)__double_as_longlong(1.0) | (ctl & (kChainLast | kChainFinal)) | kChainSpecial | kChainWhich;
+  if (tropical) {  // the (min,+) twin walks the costs themselves
+    const uint64_t cb = (uint64_t)__double_as_longlong(cost);
+    return ((cb + 0x100ull) & ~(uint64_t)kChainCtlMask) | ctl;
+  }
   if (fabs(cost) > kChainMaxCost) {
     atomicOr(status, 1);
     cost = cost > 0 ? kChainMaxCost : -kChainMaxCost;
@@ -117,30 +121,30 @@ __global__ __launch_bounds__(kTP) void chain_prep_kernel(ChainPrepArgs a) {
       uint64_t* r = a.recs + cl.rec_f + pf[s];
       const int i0 = cnt[s], i1 = cnt[s + 1];
       const int nterm = i1 - i0 + (s == 0 ? 1 : 0);
-      if (s == 0) *r++ = chain_record(0.0, kChainSpecial | (nterm == 1 ? kChainLast : 0), c9v, a.status);
+      if (s == 0) *r++ = chain_record(0.0, kChainSpecial | (nterm == 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
       for (int i = i0; i < i1; ++i) {
         const int64_t x = a0 + in_arc[i];
         const double cost = arc_cost(a.graph[x], a.acoustic[x], a.ilabel[x] != 0, a.sp);
-        *r++ = chain_record(cost, (uint32_t)(s - a.src[x]) | (i == i1 - 1 ? kChainLast : 0), c9v, a.status);
+        *r++ = chain_record(cost, (uint32_t)(s - a.src[x]) | (i == i1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
       }
-      if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status);
-      if (fin) *r++ = chain_record(fcost, 1u | kChainFinal, c9v, a.status);
+      if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, a.tropical != 0);
+      if (fin) *r++ = chain_record(fcost, 1u | kChainFinal, c9v, a.status, a.tropical != 0);
     }
     {
       uint64_t* r = a.recs + cl.rec_b + (Tb - pb[s + 1]);
       const int o0 = row[s], o1 = row[s + 1];
       const int nterm = o1 - o0 + (fin ? 1 : 0);
       if (fin) {
-        uint64_t rec = chain_record(fcost, nterm == 1 ? kChainLast : 0, c9v, a.status);
+        uint64_t rec = chain_record(fcost, nterm == 1 ? kChainLast : 0, c9v, a.status, a.tropical != 0);
         if (!(rec & kChainSpecial)) rec |= kChainSpecial;  // (a dead final weight already reads the constant zero)
         *r++ = rec;
       }
       for (int i = o0; i < o1; ++i) {
         const int64_t x = a0 + out_arc[i];
         const double cost = arc_cost(a.graph[x], a.acoustic[x], a.ilabel[x] != 0, a.sp);
-        *r++ = chain_record(cost, (uint32_t)(a.dst[x] - s) | (i == o1 - 1 ? kChainLast : 0), c9v, a.status);
+        *r++ = chain_record(cost, (uint32_t)(a.dst[x] - s) | (i == o1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
       }
-      if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status);
+      if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, a.tropical != 0);
     }
   }
 }
@@ -187,7 +191,10 @@ __device__ __forceinline__ int wave_min_int(int v) {
 // lane of the wave still has a whole batch the steps carry no bounds test; the rare terms (constants, final
 // weights, the values injected at a cut) live in a second copy of the batch's body that a batch takes only
 // when one of its 16 x 64 records asks for it.
-template <int MODE, int DIR>
+// TROP: the (min,+) twin over cost records -- a value is the cheapest cost, a term source + cost, a state the minimum of
+// its terms; no scale, nothing to rescale, nothing that does not fit (klat_viterbi: ComputeLatticeBeam / PruneLattice,
+// latbin/lattice-prune-dyn-beam.cc:27-90).
+template <int MODE, int DIR, bool TROP>
 __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, double* outbuf, const LnTabEntry* lntab) {
   const int lane = threadIdx.x & 63;
   const int job = blockIdx.x * (MODE == 0 ? kWalkWaves : kSweepWaves) + (threadIdx.x >> 6);  // one wave = one job, the waves of a workgroup are on their own
@@ -214,22 +221,24 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
     double* col = ring + lane;
     int32_t* oute = reinterpret_cast<int32_t*>(outbuf + kSweepBatch * 64) + lane;  // exponents beside the output rows
     double* outx = outbuf + lane;
-    for (int r = 0; r < W; ++r) col[r * 64] = 0.0;
-    double acc = 0.0, lastX = 0.0, finA = 0.0;
+    constexpr double kZero = TROP ? (double)INFINITY : 0.0;  // the semiring's zero and one
+    constexpr double kOne = TROP ? 0.0 : 1.0;
+    for (int r = 0; r < W; ++r) col[r * 64] = kZero;
+    double acc = kZero, lastX = kZero, finA = kZero;
     int E = 0, finR = 0;
     int pos = DIR ? end - 1 : first;
     if (MODE == 0) {
-      if (sg.k > 0) col[((first - c + comp) & Wm) * 64] = 1.0;  // the lane's own state is one, the others zero
+      if (sg.k > 0) col[((first - c + comp) & Wm) * 64] = kOne;  // the lane's own state is one, the others zero
     } else if (DIR == 0) {
       if (sg.k > 0) {  // alpha of the c states before the segment (chain_combine_kernel), already to one exponent
-        E = a.bnd_fe[seg];
+        if (!TROP) E = a.bnd_fe[seg];
         for (int i = 0; i < c; ++i) {
           lastX = a.bnd_fm[(size_t)seg * c + i];
           col[((first - c + i) & Wm) * 64] = lastX;
         }
       }
     } else {
-      if (!last_seg) E = a.bnd_be[seg];  // (the first values to arrive are the ones injected below)
+      if (!TROP && !last_seg) E = a.bnd_be[seg];  // (the first values to arrive are the ones injected below)
     }
     double* vals = nullptr;
     if (MODE == 1) vals = (DIR ? a.beta : a.alpha) + padded_state_base(a.state_off[cl.lattice], cl.lattice);
@@ -247,24 +256,37 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
       double x = col[cell * 64];
       if (MODE == 1) x = select64(lane_mask(rel == 1), lastX, x);  // the state finished by the previous step: from registers, not through LDS
       if (SPECIAL && (lo & kChainSpecial)) {  // a constant source: zero, or one in the lane's scale
-        x = 0.0;
+        x = kZero;
         if (!(lo & kChainWhich)) {
-          if (E > 900 || E < -900) trouble |= kChainTroubleOne;
-          x = ldexp(1.0, max(-2000, min(2000, -E)));
+          if (TROP) {
+            x = kOne;
+          } else {
+            if (E > 900 || E < -900) trouble |= kChainTroubleOne;
+            x = ldexp(1.0, max(-2000, min(2000, -E)));
+          }
         }
       }
       if (SPECIAL && (lo & kChainFinal)) {  // a final weight: into the lane's total (transfer), nothing (sweep)
-        if (MODE == 0) chain_add_exact(finA, finR, x * w, E);
-        x = 0.0;
+        if (MODE == 0) {
+          if (TROP)
+            finA = fmin(finA, x + w);
+          else
+            chain_add_exact(finA, finR, x * w, E);
+        }
+        x = kZero;
       }
-      acc = fma(x, w, acc);
+      acc = TROP ? fmin(acc, x + w) : fma(x, w, acc);
       if (SPECIAL && MODE == 1 && DIR == 1) {  // what the arcs that leave the segment contribute to its last c states
         const int i = pos - (end - c);
         if (last && !last_seg && i >= 0) {
           const double y = a.bnd_bm[(size_t)seg * c + i];
-          const int sh = a.bnd_be[seg] - E;
-          if (y != 0.0 && (sh > 900 || sh < -900)) trouble |= kChainTroubleInject;
-          acc += ldexp(y, max(-2000, min(2000, sh)));
+          if (TROP) {
+            acc = fmin(acc, y);
+          } else {
+            const int sh = a.bnd_be[seg] - E;
+            if (y != 0.0 && (sh > 900 || sh < -900)) trouble |= kChainTroubleInject;
+            acc += ldexp(y, max(-2000, min(2000, sh)));
+          }
         }
       }
       // every step leaves the open state's sum in the state's own ring cell (nobody reads it before its LAST)
@@ -276,11 +298,12 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
         oute[npend * 64] = E;
         npend += last ? 1 : 0;
       }
-      acc = select64(L, 0.0, acc);
+      acc = select64(L, kZero, acc);
       pos += last ? (DIR ? -1 : 1) : 0;
     };
     // the largest of the live values (the open state's sum, the states behind it that an arc can reach) back to [0.5, 1)
     auto rescale = [&]() {
+      if (TROP) return;
       double mx = acc;
       for (int i = 1; i <= span; ++i) mx = fmax(mx, col[((DIR ? pos + i : pos - i) & Wm) * 64]);
       const int ex = __builtin_amdgcn_frexp_exp(mx);
@@ -304,8 +327,8 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
           const int e0 = oute[j * 64], e1 = oute[(j + 1) * 64];
           const double m0 = __builtin_amdgcn_frexp_mant(x0), m1 = __builtin_amdgcn_frexp_mant(x1);
           const LnTabEntry t0 = lntab[ln_table_index(m0)], t1 = lntab[ln_table_index(m1)];
-          const double v0 = table_ln(m0, e0 + __builtin_amdgcn_frexp_exp(x0), t0);
-          const double v1 = table_ln(m1, e1 + __builtin_amdgcn_frexp_exp(x1), t1);
+          const double v0 = TROP ? x0 : table_ln(m0, e0 + __builtin_amdgcn_frexp_exp(x0), t0);
+          const double v1 = TROP ? x1 : table_ln(m1, e1 + __builtin_amdgcn_frexp_exp(x1), t1);
           if (j < npend) vals[DIR ? out_pos - j : out_pos + j] = v0;
           if (j + 1 < npend) vals[DIR ? out_pos - j - 1 : out_pos + j + 1] = v1;
         }
@@ -432,13 +455,17 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
       rescale();
       double row_max = 0.0;
       for (int i = 0; i < c; ++i) {
-        const double v = i >= c - span ? col[((end - c + i) & Wm) * 64] : 0.0;
+        const double v = i >= c - span ? col[((end - c + i) & Wm) * 64] : kZero;
         row_max = fmax(row_max, v);
         a.Qm[((size_t)seg * c + comp) * c + i] = v;
       }
-      a.Qe[(size_t)seg * c + comp] = row_max != 0.0 ? E : kZeroRowExp;  // (a row of zeros has no scale: it must not set the others')
-      a.Qfm[(size_t)seg * c + comp] = __builtin_amdgcn_frexp_mant(finA);
-      a.Qfe[(size_t)seg * c + comp] = finR + __builtin_amdgcn_frexp_exp(finA);
+      if (TROP) {
+        a.Qfm[(size_t)seg * c + comp] = finA;
+      } else {
+        a.Qe[(size_t)seg * c + comp] = row_max != 0.0 ? E : kZeroRowExp;  // (a row of zeros has no scale: it must not set the others')
+        a.Qfm[(size_t)seg * c + comp] = __builtin_amdgcn_frexp_mant(finA);
+        a.Qfe[(size_t)seg * c + comp] = finR + __builtin_amdgcn_frexp_exp(finA);
+      }
     }
   }
   if (trouble) atomicOr(a.flag, trouble);
@@ -448,7 +475,7 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, double* ring, dou
   }
 }
 
-template <int MODE>
+template <int MODE, bool TROP>
 __global__ __launch_bounds__(64 * kWalkWaves) void chain_walk_kernel(ChainArgs a) {
   extern __shared__ double smem[];
   LnTabEntry* lntab = reinterpret_cast<LnTabEntry*>(smem);
@@ -461,11 +488,11 @@ __global__ __launch_bounds__(64 * kWalkWaves) void chain_walk_kernel(ChainArgs a
   __syncthreads();
   const unsigned long long t_begin = a.dbg ? wall_clock64() : 0;
   if (MODE == 0) {
-    chain_walk<0, 0>(a, ring, outbuf, lntab);
+    chain_walk<0, 0, TROP>(a, ring, outbuf, lntab);
   } else if ((blockIdx.y ^ a.dir_first) == 0) {
-    chain_walk<1, 0>(a, ring, outbuf, lntab);
+    chain_walk<1, 0, TROP>(a, ring, outbuf, lntab);
   } else {
-    chain_walk<1, 1>(a, ring, outbuf, lntab);
+    chain_walk<1, 1, TROP>(a, ring, outbuf, lntab);
   }
   if (a.dbg && (threadIdx.x & 63) == 0) {  // (KLAT_CHAIN_DEBUG: where and when every wave ran)
     const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (MODE == 0 ? kWalkWaves : kSweepWaves) + wave;
@@ -819,6 +846,117 @@ __global__ __launch_bounds__(64) void chain_group_kernel(ChainArgs a) {
   if (trouble) atomicOr(a.flag, trouble);
 }
 
+// ---- the (min,+) twin of the combine: the same two levels, no scales ----
+// P = Q_1;  Pf = Qf_1;  for t = 2 .. n:  Pf = min(Pf, P (x) Qf_t);  P = P (x) Q_t    ((x): min over the inner index of the sums)
+template <int C>
+__global__ __launch_bounds__(64) void chain_group_trop_kernel(ChainArgs a) {
+  constexpr int c = C, cc = C * C;
+  constexpr int kRE = (cc + 63) / 64;
+  __shared__ double P[cc], Q[cc], Qf[c];
+  const ChainGroup g = a.grps[blockIdx.x];
+  const int lane = threadIdx.x;
+  const bool mine = lane < c;
+  double pf = INFINITY;
+  for (int t = 0; t < g.nseg; ++t) {
+    const size_t seg = (size_t)g.seg_first + t;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRE; ++r) {
+      const int e = lane + 64 * r;
+      if (e < cc) Q[e] = a.Qm[seg * cc + e];
+    }
+    if (mine) Qf[lane] = a.Qfm[seg * c + lane];
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+      for (int r = 0; r < kRE; ++r) {
+        const int e = lane + 64 * r;
+        if (e < cc) P[e] = Q[e];
+      }
+      if (mine) pf = Qf[lane];
+      continue;
+    }
+    if (mine)
+      for (int m = 0; m < c; ++m) pf = fmin(pf, P[lane * c + m] + Qf[m]);
+    double nw[kRE];
+#pragma unroll
+    for (int r = 0; r < kRE; ++r) {
+      const int e = lane + 64 * r;
+      nw[r] = INFINITY;
+      if (e < cc) {
+        const int j = e / c, i = e % c;
+        for (int m = 0; m < c; ++m) nw[r] = fmin(nw[r], P[j * c + m] + Q[m * c + i]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRE; ++r) {
+      const int e = lane + 64 * r;
+      if (e < cc) P[e] = nw[r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRE; ++r) {
+    const int e = lane + 64 * r;
+    if (e < cc) a.Gm[(size_t)blockIdx.x * cc + e] = P[e];
+  }
+  if (mine) a.Gfm[(size_t)blockIdx.x * c + lane] = pf;
+}
+
+// LEVEL 0: the groups of lattice blockIdx.x; LEVEL 1: the segments of group blockIdx.x (see chain_combine_kernel).
+// Lane i < c holds entry i of the running vector; the best complete path goes into the forward row's extra slot.
+template <int C, int LEVEL>
+__global__ __launch_bounds__(64) void chain_combine_trop_kernel(ChainArgs a) {
+  constexpr int c = C;
+  const int lane = threadIdx.x;
+  const bool bwd = blockIdx.y != 0;
+  int first, count, lat_first_seg = -1;
+  ChainLattice cl;
+  if (LEVEL == 0) {
+    cl = a.lats[blockIdx.x];
+    first = cl.grp_begin, count = cl.num_grps;
+  } else {
+    const ChainGroup g = a.grps[blockIdx.x];
+    cl = a.lats[g.clat];
+    first = g.seg_first, count = g.nseg, lat_first_seg = cl.seg_begin;
+  }
+  const double* Mm = LEVEL == 0 ? a.Gm : a.Qm;
+  const double* Mfm = LEVEL == 0 ? a.Gfm : a.Qfm;
+  double* out_m = LEVEL == 0 ? (bwd ? a.gb_bm : a.gb_fm) : (bwd ? a.bnd_bm : a.bnd_fm);
+  const bool mine = lane < c;
+  double vec = (!bwd && lane == 0) ? 0.0 : INFINITY;
+  if (LEVEL == 1) vec = mine ? (bwd ? a.gb_bm : a.gb_fm)[(size_t)blockIdx.x * c + lane] : INFINITY;
+  double tot = INFINITY;
+  for (int step = 0; step < count; ++step) {
+    const size_t it = (size_t)first + (size_t)(bwd ? count - 1 - step : step);
+    if ((LEVEL == 0 || bwd || (int)it != lat_first_seg) && mine) out_m[it * c + lane] = vec;
+    if (!bwd && LEVEL == 0) {
+      double t = mine ? vec + Mfm[it * c + lane] : INFINITY;
+      t = fmin(t, row_ror_f64<8>(t)), t = fmin(t, row_ror_f64<4>(t)), t = fmin(t, row_ror_f64<2>(t)), t = fmin(t, row_ror_f64<1>(t));
+      tot = fmin(tot, t);
+    }
+    if (step == count - 1) break;
+    double nw = INFINITY;
+    if (!bwd) {
+      for_lanes<0, C>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const double vj = lane_value<j>(vec);
+        if (mine) nw = fmin(nw, vj + Mm[(it * c + j) * c + lane]);
+      });
+    } else {
+      for_lanes<0, C>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const double yi = lane_value<i>(vec);
+        if (mine) nw = fmin(nw, Mm[(it * c + lane) * c + i] + yi);
+      });
+      if (mine) nw = fmin(nw, Mfm[it * c + lane]);
+    }
+    vec = mine ? nw : INFINITY;
+  }
+  if (LEVEL == 0 && !bwd && lane == 0) a.alpha[padded_state_base(a.state_off[cl.lattice], cl.lattice) + cl.num_states] = tot;
+}
+
 }  // namespace
 
 hipError_t launch_chain_prep(const ChainPrepArgs& a, int num_chain_lattices, hipStream_t stream) {
@@ -827,7 +965,7 @@ hipError_t launch_chain_prep(const ChainPrepArgs& a, int num_chain_lattices, hip
   return hipGetLastError();
 }
 
-hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream) {
+hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream, bool tropical) {
   if (a.num_segs <= 0) return hipSuccess;
   static const int pad = std::getenv("KLAT_CHAIN_LDS_PAD") ? std::atoi(std::getenv("KLAT_CHAIN_LDS_PAD")) : 0;  // (experiments)
   const size_t ring_bytes = (size_t)a.W * 64 * sizeof(double);
@@ -835,12 +973,22 @@ hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream) {
   const size_t lds_c = kLnTabSize * sizeof(LnTabEntry) + kSweepWaves * (ring_bytes + (size_t)kSweepBatch * 64 * (sizeof(double) + sizeof(int32_t))) + (size_t)pad;
   const size_t lds_b = (size_t)2 * kCombineChunk * ((size_t)(a.c * a.c + a.c) * sizeof(double) + (size_t)2 * a.c * sizeof(int32_t));
   const int jobs_a = (a.num_segs + (64 >> a.lgc) - 1) / (64 >> a.lgc), jobs_c = (a.num_segs + 63) / 64;
-  hipLaunchKernelGGL(chain_walk_kernel<0>, dim3((jobs_a + kWalkWaves - 1) / kWalkWaves), dim3(64 * kWalkWaves), lds_a, stream, a);
+  const dim3 grid_a((jobs_a + kWalkWaves - 1) / kWalkWaves), grid_c((jobs_c + kSweepWaves - 1) / kSweepWaves, 2);
+  if (tropical)
+    hipLaunchKernelGGL((chain_walk_kernel<0, true>), grid_a, dim3(64 * kWalkWaves), lds_a, stream, a);
+  else
+    hipLaunchKernelGGL((chain_walk_kernel<0, false>), grid_a, dim3(64 * kWalkWaves), lds_a, stream, a);
   auto combine = [&](auto cc) {
     constexpr int C = decltype(cc)::value;
-    hipLaunchKernelGGL(chain_group_kernel<C>, dim3(a.num_grps), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL((chain_combine_kernel<C, 0>), dim3(a.num_lats, 2), dim3(64), lds_b, stream, a);
-    hipLaunchKernelGGL((chain_combine_kernel<C, 1>), dim3(a.num_grps, 2), dim3(64), lds_b, stream, a);
+    if (tropical) {
+      hipLaunchKernelGGL(chain_group_trop_kernel<C>, dim3(a.num_grps), dim3(64), 0, stream, a);
+      hipLaunchKernelGGL((chain_combine_trop_kernel<C, 0>), dim3(a.num_lats, 2), dim3(64), 0, stream, a);
+      hipLaunchKernelGGL((chain_combine_trop_kernel<C, 1>), dim3(a.num_grps, 2), dim3(64), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL(chain_group_kernel<C>, dim3(a.num_grps), dim3(64), 0, stream, a);
+      hipLaunchKernelGGL((chain_combine_kernel<C, 0>), dim3(a.num_lats, 2), dim3(64), lds_b, stream, a);
+      hipLaunchKernelGGL((chain_combine_kernel<C, 1>), dim3(a.num_grps, 2), dim3(64), lds_b, stream, a);
+    }
   };
   switch (a.c) {
     case 2: combine(std::integral_constant<int, 2>()); break;
@@ -848,7 +996,10 @@ hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream) {
     case 8: combine(std::integral_constant<int, 8>()); break;
     default: combine(std::integral_constant<int, 16>()); break;
   }
-  hipLaunchKernelGGL(chain_walk_kernel<1>, dim3((jobs_c + kSweepWaves - 1) / kSweepWaves, 2), dim3(64 * kSweepWaves), lds_c, stream, a);
+  if (tropical)
+    hipLaunchKernelGGL((chain_walk_kernel<1, true>), grid_c, dim3(64 * kSweepWaves), lds_c, stream, a);
+  else
+    hipLaunchKernelGGL((chain_walk_kernel<1, false>), grid_c, dim3(64 * kSweepWaves), lds_c, stream, a);
   return hipGetLastError();
 }
 

@@ -283,6 +283,11 @@ struct klat_batch {
   klat::DevBuf<klat::ChainGroup> ch_grps;
   klat::DevBuf<double> ch_gm, ch_gfm, ch_gbfm, ch_gbbm;
   klat::DevBuf<int32_t> ch_ge, ch_gfe, ch_gbfe, ch_gbbe;
+  // for klat_viterbi on those lattices: the count pass's tables and, once it has run, the COST records of the (min,+) twin
+  klat::DevBuf<int32_t> ch_cnt, ch_row, ch_in_arc, ch_out_arc;
+  klat::DevBuf<uint64_t> ch_recs_t;
+  size_t chain_records = 0;
+  bool chain_trop_ready = false;
   klat::DevBuf<int32_t> ch_status;  // [0] the record pass met a cost that fits no record, [1] the sweep's fall-back flag
   int32_t chain_rescale = 1;        // ChainArgs::rescale_iters
   float pack_host_ms = 0.0f;  // wall time of klat_batch_create (uploads, host planning, waits included)

@@ -173,7 +173,9 @@ def test_the_path_is_taken_when_the_batch_waits_for_its_longest_lattices(ctx):
         for f in ("label", "t0", "t1"):
             assert np.array_equal(r[f], r0[f])
         assert np.max(np.abs(r["logp"] - r0["logp"]), initial=0.0) < 1e-9
-    assert np.array_equal(fw, fw0) and np.array_equal(bw, bw0) and np.array_equal(best, best0)
+    # (the Viterbi twin of the segment path adds a path's costs in another order, from costs kept to 43 fraction bits)
+    for g, w in ((fw, fw0), (bw, bw0), (best, best0)):
+        assert np.array_equal(np.isinf(g), np.isinf(w)) and np.allclose(g, w, rtol=1e-12, atol=1e-9)
     b0.close()
     uniform = klat_amd.synth(12, np.full(3000, 2000, np.int32), np.full(3000, 3, np.int32))
     with _env(KLAT_CHAIN=None):
@@ -236,3 +238,39 @@ def test_final_states_in_the_middle_of_a_long_lattice(ctx):
     alpha, beta, total, tf, tb, post = got
     _check(alpha, wa, 1e-8), _check(beta, wb, 1e-8), _check(total, wt, 1e-8), _check(post, wpost, 1e-8)
     b.close()
+
+
+@pytest.mark.parametrize("seg", [64, 256])
+def test_viterbi_twin_in_segments(ctx, seg):
+    """klat_viterbi on lattices cut into segments: the (min,+) twin of the three kernels over cost records, against the
+    streams on the same lattices (themselves checked against the oracle in test_gpu_viterbi.py), costs and keep masks;
+    final states anywhere are no trouble here (no scale to leave)."""
+    ns = [3000, 700, 5000, 40, 1300, 2 * seg + 2, 4097, 1]
+    fo = [3, 2, 4, 3, 6, 3, 1, 1]
+    arrays = _lattices(20260007, ns, fo, finals_anywhere=True)
+    scales = (0.7, 0.1, 0.5)
+    res = []
+    for chain in (1, 0):
+        with _env(KLAT_CHAIN=chain, KLAT_CHAIN_SEG=seg):
+            b = klat_amd.Batch(ctx, arrays, fuse_scales=scales)
+        assert (b.info()["chain_lattices"] >= 5) == (chain == 1)
+        b.viterbi(*scales)
+        fw, bw, best = b.viterbi_costs()
+        ka, kf, lb = b.prune_mask(8.0)
+        res.append((fw, bw, best, ka, kf, lb))
+        b.close()
+    (fw, bw, best, ka, kf, lb), (fw0, bw0, best0, ka0, kf0, lb0) = res
+    for g, w in ((fw, fw0), (bw, bw0), (best, best0), (lb, lb0)):
+        assert np.array_equal(np.isinf(g), np.isinf(w)) and np.allclose(g, w, rtol=1e-12, atol=1e-9)
+    # decisions within 1e-7 of the cutoff may differ (sums in another order); the others may not
+    so, ao = arrays["state_off"], arrays["arc_off"]
+    lat_of_arc = np.repeat(np.arange(len(ns)), np.diff(ao))
+    gsrc = arrays["src"] + so[lat_of_arc]
+    gdst = arrays["dst"] + so[lat_of_arc]
+    g = np.where(np.isinf(arrays["graph"]), np.inf, np.float32(scales[0]) * arrays["graph"]).astype(np.float32)
+    g = np.where(arrays["ilabel"] != 0, g + np.float32(scales[2]), g).astype(np.float32)
+    ac = (np.float32(scales[1]) * arrays["acoustic"]).astype(np.float32)
+    through = fw0[gsrc] + (g.astype(np.float64) + ac.astype(np.float64)) + bw0[gdst]
+    sure = ~(np.abs(through - (best0[lat_of_arc] + 8.0)) <= 1e-7)
+    assert np.array_equal(ka[sure], ka0[sure]) and np.mean(ka != ka0) < 1e-4
+    assert np.mean(kf != kf0) < 1e-3
