@@ -630,19 +630,15 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       }
     }
     // Long lattices of a batch that waits for them are swept in segments (klat_chain.hip): the choice, their
-    // segments and their arc records.  Only with fused scales (the records hold exp(-cost)) and the automatic layout.
+    // segments.  (Their arc records are built when a sweep first needs them, for the scales it is called with:
+    // ensure_chain_records.)  Only with the automatic layout.
     std::vector<uint8_t> on_chain((size_t)U, 0), skip(on_level);
     size_t nrec_chain = 0;
     {
-      double maxc = 0.0;
-      std::memcpy(&maxc, &h_maxcost, sizeof(maxc));
       std::vector<ChainLattice> cl;
       int seg_len = 0, cc = 0;
       size_t nrec = 0;
-      // between two rescalings a lane's values may move by (6 + cost / ln 2) binary orders a record (klat_chain.hip)
-      const int rescale_records = (int)std::min(64.0, 600.0 / (6.0 + 1.4427 * maxc));
-      b->chain_rescale = std::max(1, rescale_records / 4);
-      if (b->fused && o.lanes_per_lattice == 0 && maxc <= kChainMaxCost && rescale_records >= 4)
+      if (o.lanes_per_lattice == 0)
         choose_chain_lattices(U, d->state_off, d->arc_off, h_rounds.data(), o, on_level.data(), &on_chain, &cl, &seg_len, &cc, &nrec);
       if (!cl.empty()) {
         const size_t nseg = (size_t)cl.back().seg_begin + (size_t)cl.back().num_segs;
@@ -651,43 +647,17 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         for (size_t i = 0; i < cl.size(); ++i)
           for (int32_t g = 0; g < cl[i].num_grps; ++g)
             groups.push_back(ChainGroup{(int32_t)i, cl[i].seg_begin + g * kChainGroup, std::min(kChainGroup, cl[i].num_segs - g * kChainGroup), 0});
-        const int32_t zero[2] = {0, 0};
-        if ((rc = b->ch_lats.upload(cl.data(), cl.size(), c->stream)) || (rc = b->ch_segs.alloc(nseg)) || (rc = b->ch_recs.alloc(nrec)) ||
+        const int32_t zero[4] = {0, 0, 0, 0};
+        if ((rc = b->ch_lats.upload(cl.data(), cl.size(), c->stream)) || (rc = b->ch_segs.alloc(nseg)) ||
             (rc = b->ch_qm.alloc(nseg * cc * cc)) || (rc = b->ch_qe.alloc(nseg * cc)) || (rc = b->ch_qfm.alloc(nseg * cc)) ||
             (rc = b->ch_qfe.alloc(nseg * cc)) || (rc = b->ch_bfm.alloc(nseg * cc)) || (rc = b->ch_bfe.alloc(nseg)) ||
-            (rc = b->ch_bbm.alloc(nseg * cc)) || (rc = b->ch_bbe.alloc(nseg)) || (rc = b->ch_status.upload(zero, 2, c->stream)) ||
+            (rc = b->ch_bbm.alloc(nseg * cc)) || (rc = b->ch_bbe.alloc(nseg)) || (rc = b->ch_status.upload(zero, 4, c->stream)) ||
             (rc = b->ch_grps.upload(groups.data(), groups.size(), c->stream)) || (rc = b->ch_gm.alloc(ngrp * cc * cc)) || (rc = b->ch_ge.alloc(ngrp * cc)) ||
             (rc = b->ch_gfm.alloc(ngrp * cc)) || (rc = b->ch_gfe.alloc(ngrp * cc)) || (rc = b->ch_gbfm.alloc(ngrp * cc)) || (rc = b->ch_gbfe.alloc(ngrp)) ||
             (rc = b->ch_gbbm.alloc(ngrp * cc)) || (rc = b->ch_gbbe.alloc(ngrp))) {
           klat_batch_destroy(b);
           return rc;
         }
-        ChainPrepArgs cp;
-        cp.lats = b->ch_lats.p;
-        cp.segs = b->ch_segs.p;
-        cp.recs = b->ch_recs.p;
-        cp.state_off = b->state_off.p;
-        cp.arc_off = b->arc_off.p;
-        cp.src = b->src.p;
-        cp.dst = b->dst.p;
-        cp.ilabel = b->ilabel.p;
-        cp.graph = b->graph.p;
-        cp.acoustic = b->acoustic.p;
-        cp.final_graph = b->final_graph.p;
-        cp.final_acoustic = b->final_acoustic.p;
-        cp.cnt = cnt.p;
-        cp.row = row.p;
-        cp.in_arc = in_arc.p;
-        cp.out_arc = out_arc.p;
-        cp.scratch_f = r0f.p;  // (the rounds pass fills them afterwards)
-        cp.scratch_b = r0b.p;
-        cp.sp = pa.fsp;
-        cp.tropical = 0;
-        cp.status = b->ch_status.p;
-        KLAT_HIP_B(hipEventRecord(pev[9], c->stream));
-        KLAT_HIP_B(launch_chain_prep(cp, (int)cl.size(), c->stream));
-        KLAT_HIP_B(hipEventRecord(pev[10], c->stream));
-        b->pack_chain_timed = true;
         b->num_chain = (int32_t)cl.size();
         nrec_chain = nrec;
         b->chain_segs = (int32_t)nseg;
@@ -764,11 +734,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     }
     lap("entries+rounds+fill+wait");
     P.far_terms = h_status[3];
-    if (b->num_chain > 0) {  // (cannot happen: the batch's largest cost was checked; the streams of those lattices take over)
-      int32_t bad = 0;
-      KLAT_HIP_B(hipMemcpy(&bad, b->ch_status.p, sizeof(bad), hipMemcpyDeviceToHost));
-      if (bad) b->num_chain = 0;
-    }
+
     if (b->num_level > 0) {  // the level streams: the arcs as the level sweep consumes them
       if ((rc = b->lv_stream.alloc((size_t)lv_blocks * kLevelBlockDwords))) {
         klat_batch_destroy(b);
@@ -1052,6 +1018,70 @@ static void fill_posterior_args(klat_batch* b, const ScaleParams& sp, PosteriorA
   pa->span = b->arc_span.p;
 }
 
+// The segment path's arc records for the scales of this call: exp(-cost) for the log-semiring sweep, the cost itself
+// for klat_viterbi.  Built from the count pass's tables (which the batch keeps) when a sweep first asks, again when the
+// scales change.  *usable = false when the log-semiring records cannot hold these costs (|cost| above 690, or costs so
+// large that a lane would have to rescale more often than every four records): the lattices' streams sweep them then.
+static int ensure_chain_records(klat_batch* b, const klat_scales& s, const ScaleParams& sp, bool tropical, bool* usable) {
+  klat_ctx* c = b->ctx;
+  bool& ready = tropical ? b->chain_trop_ready : b->chain_log_ready;
+  klat_scales& have = tropical ? b->chain_trop_scales : b->chain_log_scales;
+  const bool same = ready && have.graph_scale == s.graph_scale && have.acoustic_scale == s.acoustic_scale && have.insertion_penalty == s.insertion_penalty;
+  if (!same) {
+    int rc;
+    DevBuf<int32_t> sf, sb2;
+    DevBuf<uint64_t>& recs = tropical ? b->ch_recs_t : b->ch_recs;
+    if ((rc = recs.alloc(b->chain_records)) || (rc = sf.alloc((size_t)(b->S + 2 * b->U))) || (rc = sb2.alloc((size_t)(b->S + 2 * b->U)))) return rc;
+    KLAT_HIP(hipMemsetAsync(b->ch_status.p, 0, sizeof(int32_t), c->stream));       // [0]: a cost that fits no record
+    KLAT_HIP(hipMemsetAsync(b->ch_status.p + 2, 0, 2 * sizeof(int32_t), c->stream));  // [2..3]: the largest |cost| (a double's bits)
+    ChainPrepArgs cp;
+    cp.lats = b->ch_lats.p;
+    cp.segs = b->ch_segs.p;
+    cp.recs = recs.p;
+    cp.state_off = b->state_off.p;
+    cp.arc_off = b->arc_off.p;
+    cp.src = b->src.p;
+    cp.dst = b->dst.p;
+    cp.ilabel = b->ilabel.p;
+    cp.graph = b->graph.p;
+    cp.acoustic = b->acoustic.p;
+    cp.final_graph = b->final_graph.p;
+    cp.final_acoustic = b->final_acoustic.p;
+    cp.cnt = b->ch_cnt.p;
+    cp.row = b->ch_row.p;
+    cp.in_arc = b->ch_in_arc.p;
+    cp.out_arc = b->ch_out_arc.p;
+    cp.scratch_f = sf.p;
+    cp.scratch_b = sb2.p;
+    cp.sp = sp;
+    cp.tropical = tropical ? 1 : 0;
+    cp.status = b->ch_status.p;
+    cp.maxcost = reinterpret_cast<unsigned long long*>(b->ch_status.p + 2);
+    const bool timed = !b->pack_chain_timed && b->pack_ev[9] && b->pack_ev[10];
+    if (timed) KLAT_HIP(hipEventRecord(b->pack_ev[9], c->stream));
+    KLAT_HIP(launch_chain_prep(cp, b->num_chain, c->stream));
+    if (timed) {
+      KLAT_HIP(hipEventRecord(b->pack_ev[10], c->stream));
+      b->pack_chain_timed = true;
+    }
+    int32_t h[4] = {0, 0, 0, 0};
+    KLAT_HIP(hipMemcpyAsync(h, b->ch_status.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    KLAT_HIP(hipStreamSynchronize(c->stream));  // (the scratch rows go out of scope)
+    have = s;
+    ready = true;
+    if (!tropical) {
+      double maxc = 0.0;
+      std::memcpy(&maxc, &h[2], sizeof(maxc));
+      // between two rescalings a lane's values may move by (6 + cost / ln 2) binary orders a record (klat_chain.hip)
+      const int rescale_records = (int)std::min(64.0, 600.0 / (6.0 + 1.4427 * maxc));
+      b->chain_rescale = std::max(1, rescale_records / 4);
+      b->chain_log_ok = h[0] == 0 && rescale_records >= 4;
+    }
+  }
+  *usable = tropical ? true : b->chain_log_ok;
+  return KLAT_OK;
+}
+
 // the segment path's argument block for the log-semiring sweep of batch b (klat_viterbi swaps records and rows)
 static void fill_chain_args(klat_batch* b, ChainArgs* out) {
   ChainArgs& ca = *out;
@@ -1149,8 +1179,11 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
   {
     std::vector<SweepPiece> work;
     ChainArgs ca;
-    if (b->num_chain > 0) {  // the long lattices, in segments: the piece with the longest chain of kernels goes first
-      fill_chain_args(b, &ca);
+    bool chain_ok = false;
+    if (b->num_chain > 0) {  // the long lattices, in segments
+      const int erc = ensure_chain_records(b, s, sp, false, &chain_ok);
+      if (erc != KLAT_OK) return erc;
+      if (chain_ok) fill_chain_args(b, &ca);
     }
     // the launches, in this order: the classes' fast sweeps (a few long workgroups each: they take their CUs before
     // the segment path's thousands of waves fill the chip), the segment path on the context's stream, the classes'
@@ -1165,7 +1198,7 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
       ca2.deep_prefetch = b->deep_prefetch;
       return ca2;
     };
-    const bool with_chain = b->num_chain > 0;
+    const bool with_chain = chain_ok;
     for (int pass = 0; pass < 2; ++pass) {
       int slot = with_chain ? 1 : 0;
       for (const LayoutClass& lcr : b->classes) {
@@ -1197,7 +1230,7 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
     }
     // KLAT_CHAIN_DEBUG=<file>: when and where (CU, SIMD) every wave of the segment path's walks ran, written after this sweep
     DevBuf<unsigned long long> dbg;
-    const char* dbg_path = b->num_chain > 0 ? std::getenv("KLAT_CHAIN_DEBUG") : nullptr;
+    const char* dbg_path = chain_ok ? std::getenv("KLAT_CHAIN_DEBUG") : nullptr;
     size_t dbg_words = 0;
     if (dbg_path) {
       const size_t waves_a = ((size_t)b->chain_segs * ca.c / 64 + 8) / 4 * 4 + 8, waves_c = 2 * (((size_t)b->chain_segs / 64 + 8) / 4 * 4 + 8);
@@ -1305,35 +1338,8 @@ int klat_viterbi(klat_batch* b, const klat_scales* sc) {
   if (b->num_chain > 0 && std::getenv("KLAT_CHAIN_VITERBI_STREAMS") == nullptr) {
     // The lattices swept in segments take the (min,+) twin of that path (klat_chain.hip) over COST records, built
     // from the count pass's tables when this first runs on the batch; the others their streams, beside it.
-    if (!b->chain_trop_ready) {
-      DevBuf<int32_t> sf, sb2;
-      if ((rc = b->ch_recs_t.alloc(b->chain_records)) || (rc = sf.alloc((size_t)(b->S + 2 * b->U))) || (rc = sb2.alloc((size_t)(b->S + 2 * b->U)))) return rc;
-      ChainPrepArgs cp;
-      cp.lats = b->ch_lats.p;
-      cp.segs = b->ch_segs.p;
-      cp.recs = b->ch_recs_t.p;
-      cp.state_off = b->state_off.p;
-      cp.arc_off = b->arc_off.p;
-      cp.src = b->src.p;
-      cp.dst = b->dst.p;
-      cp.ilabel = b->ilabel.p;
-      cp.graph = b->graph.p;
-      cp.acoustic = b->acoustic.p;
-      cp.final_graph = b->final_graph.p;
-      cp.final_acoustic = b->final_acoustic.p;
-      cp.cnt = b->ch_cnt.p;
-      cp.row = b->ch_row.p;
-      cp.in_arc = b->ch_in_arc.p;
-      cp.out_arc = b->ch_out_arc.p;
-      cp.scratch_f = sf.p;
-      cp.scratch_b = sb2.p;
-      cp.sp = va.sp;
-      cp.tropical = 1;
-      cp.status = b->ch_status.p;
-      KLAT_HIP(launch_chain_prep(cp, b->num_chain, c->stream));
-      KLAT_HIP(hipStreamSynchronize(c->stream));  // (the scratch rows go out of scope)
-      b->chain_trop_ready = true;
-    }
+    bool usable = true;
+    if ((rc = ensure_chain_records(b, s, va.sp, true, &usable))) return rc;
     ChainArgs ca;
     fill_chain_args(b, &ca);
     ca.recs = b->ch_recs_t.p;

@@ -76,6 +76,7 @@ struct ChainPrepArgs {
   ScaleParams sp;
   int32_t tropical;  // the records hold the costs themselves (klat_viterbi), not exp(-cost)
   int32_t* status;  // [1] set when a cost does not fit a record
+  unsigned long long* maxcost;  // [1] the largest finite |cost| among the records, as the bits of a double (atomicMax)
 };
 
 struct ChainArgs {

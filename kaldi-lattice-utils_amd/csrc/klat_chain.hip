@@ -114,9 +114,15 @@ __global__ __launch_bounds__(kTP) void chain_prep_kernel(ChainPrepArgs a) {
   const double c9v = arc_weight_c9();
   const int32_t* in_arc = a.in_arc + a0;
   const int32_t* out_arc = a.out_arc + a0;
+  double mxc = 0.0;  // the largest finite |cost| this thread meets
+  auto note = [&](double cost) {
+    const double ac = fabs(cost);
+    if (ac < 1.0e30) mxc = fmax(mxc, ac);
+  };
   for (int s = tid; s < S; s += kTP) {
     const bool fin = is_final(s);
     const double fcost = fin ? arc_cost(a.final_graph[s0 + s], a.final_acoustic[s0 + s], false, a.sp) : 0.0;
+    note(fcost);
     {
       uint64_t* r = a.recs + cl.rec_f + pf[s];
       const int i0 = cnt[s], i1 = cnt[s + 1];
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(kTP) void chain_prep_kernel(ChainPrepArgs a) {
       for (int i = i0; i < i1; ++i) {
         const int64_t x = a0 + in_arc[i];
         const double cost = arc_cost(a.graph[x], a.acoustic[x], a.ilabel[x] != 0, a.sp);
+        note(cost);
         *r++ = chain_record(cost, (uint32_t)(s - a.src[x]) | (i == i1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
       }
       if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, a.tropical != 0);
@@ -147,6 +154,8 @@ __global__ __launch_bounds__(kTP) void chain_prep_kernel(ChainPrepArgs a) {
       if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, a.tropical != 0);
     }
   }
+  for (int d = 32; d > 0; d >>= 1) mxc = fmax(mxc, __shfl_xor(mxc, d, 64));
+  if ((tid & 63) == 0 && a.maxcost) atomicMax(a.maxcost, (unsigned long long)__double_as_longlong(mxc));  // (positive doubles order like their bits)
 }
 
 // (acc * 2^ref) += x * 2^xe for any exponents; acc keeps its alignment to 2^ref

@@ -287,8 +287,9 @@ struct klat_batch {
   klat::DevBuf<int32_t> ch_cnt, ch_row, ch_in_arc, ch_out_arc;
   klat::DevBuf<uint64_t> ch_recs_t;
   size_t chain_records = 0;
-  bool chain_trop_ready = false;
-  klat::DevBuf<int32_t> ch_status;  // [0] the record pass met a cost that fits no record, [1] the sweep's fall-back flag
+  bool chain_trop_ready = false, chain_log_ready = false, chain_log_ok = false;
+  klat_scales chain_trop_scales = {1.f, 1.f, 0.f}, chain_log_scales = {1.f, 1.f, 0.f};  // what the records were built for
+  klat::DevBuf<int32_t> ch_status;  // [0] the record pass met a cost that fits no record, [1] the sweep's fall-back flag, [2..3] the largest |cost|
   int32_t chain_rescale = 1;        // ChainArgs::rescale_iters
   float pack_host_ms = 0.0f;  // wall time of klat_batch_create (uploads, host planning, waits included)
   klat::DevBuf<int64_t> lv_stream_off;

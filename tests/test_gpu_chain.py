@@ -145,7 +145,7 @@ def test_arcs_of_every_length_a_cut_allows(ctx):
 
 def test_the_path_is_taken_when_the_batch_waits_for_its_longest_lattices(ctx):
     """A scaled-down BASELINE configs[4] mix (sizes log-uniform over two decades): the long lattices go; a
-    uniform batch that fills the chip keeps its streams; without fused scales nothing goes."""
+    uniform batch that fills the chip keeps its streams; fused scales or not."""
     rng = np.random.RandomState(3)
     ns = np.exp(rng.uniform(np.log(200), np.log(20000), 300)).astype(np.int32)
     fo = rng.choice([2, 3, 4, 6], 300).astype(np.int32)
@@ -182,8 +182,15 @@ def test_the_path_is_taken_when_the_batch_waits_for_its_longest_lattices(ctx):
         bu = klat_amd.Batch(ctx, uniform, fuse_scales=scales)
         assert bu.info()["chain_lattices"] == 0
         bu.close()
+        # without fused scales the segment path's records are built for the scales of the call, again when they change
         bn = klat_amd.Batch(ctx, arrays)
-        assert bn.info()["chain_lattices"] == 0
+        assert bn.info()["chain_lattices"] == info["chain_lattices"]
+        for sc in ((1.0, 0.1, 0.0), (0.7, 0.3, 0.5), (1.0, 0.1, 0.0)):
+            bn.forward_backward(*sc)
+            assert not bn.chain_fallback()
+            wa2, wb2, wt2, _ = _oracle_batch(arrays, *sc)
+            a2, b2 = bn.alpha_beta()
+            _check(a2, wa2, 1e-8), _check(b2, wb2, 1e-8), _check(bn.totals()[0], wt2, 1e-8)
         bn.close()
 
 
@@ -274,3 +281,20 @@ def test_viterbi_twin_in_segments(ctx, seg):
     sure = ~(np.abs(through - (best0[lat_of_arc] + 8.0)) <= 1e-7)
     assert np.array_equal(ka[sure], ka0[sure]) and np.mean(ka != ka0) < 1e-4
     assert np.mean(kf != kf0) < 1e-3
+
+
+def test_costs_the_records_cannot_hold_leave_the_lattices_to_their_streams(ctx):
+    """exp(-cost) as a double holds |cost| up to ~700: with larger costs among a cut lattice's arcs (acoustic scale 1 on
+    costs of hundreds) the records are not used and the streams sweep, silently and correctly."""
+    ns, fo = [2000, 900], [3, 2]
+    arrays = klat_amd.synth(9, np.asarray(ns, np.int32), np.asarray(fo, np.int32))
+    arrays["acoustic"] *= 25.0  # up to 1000
+    with _env(KLAT_CHAIN=1, KLAT_CHAIN_SEG=128):
+        b = klat_amd.Batch(ctx, arrays)
+    assert b.info()["chain_lattices"] == 2
+    for scales in ((1.0, 1.0, 0.0), (1.0, 0.1, 0.0)):  # the first cannot use the records, the second can
+        b.forward_backward(*scales)
+        wa, wb, wt, wpost = _oracle_batch(arrays, *scales)
+        alpha, beta = b.alpha_beta()
+        _check(alpha, wa, 1e-8), _check(beta, wb, 1e-8), _check(b.totals()[0], wt, 1e-8), _check(b.arc_logpost(), wpost, 1e-8)
+    b.close()
