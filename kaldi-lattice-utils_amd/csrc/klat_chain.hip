@@ -17,7 +17,7 @@ namespace klat {
 
 namespace {
 
-constexpr int kTP = 256;  // chain_prep_kernel
+constexpr int kTP = 1024;  // chain_prep_kernel: a lattice of 20 000 states is 20 turns of its workgroup (256 threads: 80, and the batch waited for them)
 // Waves per workgroup of the walks.  The waves share nothing, and single-wave workgroups pack a CU's LDS best
 // (the dispatcher spreads them evenly over the four SIMDs: KLAT_CHAIN_DEBUG shows where every wave ran).
 constexpr int kWalkWaves = 1;

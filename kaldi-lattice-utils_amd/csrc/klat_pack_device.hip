@@ -32,7 +32,9 @@ namespace klat {
 
 namespace {
 
-constexpr int kT = 256;       // pack_rounds_kernel, pack_fill_kernel, pack_count_global_kernel
+constexpr int kT = 256;       // pack_rounds_kernel, pack_fill_kernel
+constexpr int kTG = 1024;     // pack_count_global_kernel: its passes are chains of L2 atomics and gathers, one per thread and turn;
+                              // with 256 threads the few lattices above the LDS classes took 4.4 ms of the C5/8 shard's count pass
 constexpr int kTC = 512;      // pack_count_kernel
 
 
@@ -361,8 +363,8 @@ __global__ __launch_bounds__(kTC) void pack_count_kernel(PackDevArgs a, int lds_
 
 // The same pass with the lattice's tables in its scratch rows in HBM (L2 atomics): for the lattices
 // above `lds_hi` bytes of tables.
-__global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, int lds_hi) {
-  __shared__ int sh[kT / 64];
+__global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, int lds_hi) {
+  __shared__ int sh[kTG / 64];
   __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb, sh_linked, sh_span;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
   const int u = blockIdx.x, tid = threadIdx.x;
@@ -381,10 +383,10 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
   const int32_t* dst = a.dst + a0;
   if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0, sh_span = 1;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
-  for (int s = tid; s < S + 2; s += kT) cnt[s] = 0;
+  for (int s = tid; s < S + 2; s += kTG) cnt[s] = 0;
   __syncthreads();
   int mr = 1;
-  for (int i = tid; i < A; i += kT) {
+  for (int i = tid; i < A; i += kTG) {
     const int s = src[i], t = dst[i];
     const int prev = i > 0 ? src[i - 1] : 0;
     if (s < 0 || s >= S || s < prev) {
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
     }
   }
   atomicMax(&sh_span, mr);
-  for (int s = tid; s < S; s += kT)
+  for (int s = tid; s < S; s += kTG)
     if (dev_is_final(a, s0 + s)) mr = max(mr, S - s);
   atomicMax(&sh_mr, mr);
   __syncthreads();
@@ -407,18 +409,18 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
   }
   if (tid == 0) atomicMax(&a.status[2], sh_mr);
   int carry = 0;
-  for (int base = 0; base < S; base += kT) {
+  for (int base = 0; base < S; base += kTG) {
     const int s = base + tid;
     const int f = (s < S && dev_is_final(a, s0 + s)) ? 1 : 0;
     int tot;
-    const int ex = block_scan<kT>(f, &tot, sh);
+    const int ex = block_scan<kTG>(f, &tot, sh);
     if (f) flist[carry + ex] = s;
     carry += tot;
   }
   const int nfinal = carry;
   int fsum[kNumLaneChoices] = {0}, bsum[kNumLaneChoices] = {0};
   int carry_c = 0, mtf = 1, mtb = 1;
-  for (int base = 0; base <= S; base += kT) {
+  for (int base = 0; base <= S; base += kTG) {
     const int p = base + tid;
     const int c = (p < S) ? cnt[p] : 0;
     const int nterm = (p < S) ? c + (p == 0 ? 1 : 0) : nfinal;
@@ -427,18 +429,18 @@ __global__ __launch_bounds__(kT) void pack_count_global_kernel(PackDevArgs a, in
       for (int k = 0; k < kNumLaneChoices; ++k) fsum[k] += (max(nterm, 1) + (1 << k) - 1) >> k;
     }
     int tot_c;
-    const int ex_c = block_scan<kT>(c, &tot_c, sh);
+    const int ex_c = block_scan<kTG>(c, &tot_c, sh);
     if (p <= S) cnt[p] = carry_c + ex_c;
     carry_c += tot_c;
   }
   if (tid == 0) cnt[S + 1] = A + nfinal;
   __syncthreads();
-  for (int s = tid; s < S; s += kT) cur[s] = cnt[s];
-  for (int s = tid; s <= S; s += kT) row[s] = lower_bound_src(src, A, s);
+  for (int s = tid; s < S; s += kTG) cur[s] = cnt[s];
+  for (int s = tid; s <= S; s += kTG) row[s] = lower_bound_src(src, A, s);
   __syncthreads();
-  for (int i = tid; i < A; i += kT) in_arc[atomicAdd(&cur[dst[i]], 1)] = i;
+  for (int i = tid; i < A; i += kTG) in_arc[atomicAdd(&cur[dst[i]], 1)] = i;
   __syncthreads();
-  for (int s = tid; s < S; s += kT) {
+  for (int s = tid; s < S; s += kTG) {
     const int b = cnt[s], e = cnt[s + 1];
     for (int i = b + 1; i < e; ++i) {
       const int v = in_arc[i];
@@ -828,7 +830,7 @@ hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, const int c
     if (class_need[c] > 0)
       hipLaunchKernelGGL(pack_count_kernel, dim3(num_lattices), dim3(kTC), (size_t)class_need[c], stream, a,
                          c == 0 ? -1 : kPackCountClassLds[c - 1], kPackCountClassLds[c]);
-  if (any_global) hipLaunchKernelGGL(pack_count_global_kernel, dim3(num_lattices), dim3(kT), 0, stream, a, kPackCountMaxLds);
+  if (any_global) hipLaunchKernelGGL(pack_count_global_kernel, dim3(num_lattices), dim3(kTG), 0, stream, a, kPackCountMaxLds);
   return hipGetLastError();
 }
 
