@@ -756,7 +756,13 @@ def main():
                 ("wide: 10000 lattices x 2000 states x fanout 3 in levels of 32 states (depth ~63)", 20260005,
                  np.full(10000, 2000, np.int32), np.full(10000, 3, np.int32), 32),
                 ("few and wide: 64 lattices x 2000 states x fanout 3 in levels of 64 states (depth ~32), the level path", 20260006,
-                 np.full(64, 2000, np.int32), np.full(64, 3, np.int32), 64)):
+                 np.full(64, 2000, np.int32), np.full(64, 3, np.int32), 64),
+                # what ONE call of the reference's interface holds (B2: one lattice per TaskSequencer worker,
+                # kwsbin2/lattice-word-index-segment.cc:264-272): a lone lattice is all chain -- swept in segments
+                ("one lattice of 5000 states x fanout 3 (a configs[3] lattice on its own)", 20260007,
+                 np.full(1, 5000, np.int32), np.full(1, 3, np.int32), 0),
+                ("one lattice of 20000 states x fanout 3 (the longest of the configs[4] mix on its own)", 20260008,
+                 np.full(1, 20000, np.int32), np.full(1, 3, np.int32), 0)):
             try:
                 shapes.append(time_shape(ctx, klat_amd, name, seed, sn, sf, host_threads, wide=wide))
             except Exception as e:  # a shape that fails must not take the headline with it

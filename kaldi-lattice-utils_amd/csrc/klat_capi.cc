@@ -151,10 +151,11 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
     }
     int cc = 2;
     while (cc < span) cc *= 2;
-    // two walks of a segment (transfer, sweep: ~700 cycles a record for a wave on its own), the two-level combine
-    // (~2 500 a step: a lattice's groups of 16 segments, then 2 x 16 steps), six launches; the walks' work: ~2
-    // SIMD-cycles per record and lane, c lanes for the transfer, 2 for the sweep
-    const double latency = 2.0 * 4.0 * (double)seg * 700.0 + (segs_max / kChainGroup + 2.0 * kChainGroup) * 2500.0 + 100000.0;
+    // two walks of a segment (transfer, sweep: ~350 cycles a record for a wave on its own), the two-level combine
+    // (~1 200 a step: a lattice's groups of 16 segments, then 2 x 16 steps), six launches (measured: one lattice of
+    // 5 000 or of 20 000 states 0.18 / 0.20 ms = 440 000 / 480 000 cycles); the walks' work: ~2 SIMD-cycles per record
+    // and lane, c lanes for the transfer, 2 for the sweep
+    const double latency = 2.0 * 4.0 * (double)seg * 350.0 + (segs_max / kChainGroup + 2.0 * kChainGroup) * 1200.0 + 60000.0;
     const double work = records * (cc + 2) * 2.0 / 1024.0;
     const double total = std::max(plan_cycles(U, state_off, arc_off, lr, o, skip.data()), latency) + work;
     if (total >= 0.75 * base) return;
