@@ -71,7 +71,7 @@ static int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
       KLAT_HIP(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
     }
   }
-  static const int side_limit = std::getenv("KLAT_SIDE_STREAMS") ? std::max(1, std::min((int)klat_ctx::kSideStreams, std::atoi(std::getenv("KLAT_SIDE_STREAMS")))) : (int)klat_ctx::kSideStreams;
+  const int side_limit = klat_ctx::kSideStreams;
   KLAT_HIP(hipEventRecord(c->fork_ev, c->stream));
   const int used = std::min(most, side_limit);
   for (int i = 0; i < used; ++i) KLAT_HIP(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));

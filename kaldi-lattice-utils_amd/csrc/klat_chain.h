@@ -96,7 +96,6 @@ struct ChainArgs {
   int32_t rescale_iters;  // a lane rescales every this many iterations of four records
   unsigned long long* dbg = nullptr;  // (KLAT_CHAIN_DEBUG) four words per wave: begin, end (100 MHz), HW_ID, XCC_ID
   size_t dbg_stride = 0;              //   the sweep's waves start here
-  int32_t dir_first = 0;  // (the sweep's block row 0 walks this direction)
   int32_t* flag;          // [1] raised when a lattice's values do not fit this arithmetic: the streams sweep them again
   const int64_t* state_off;
   double* alpha; double* beta;  // padded rows (klat_kernels.h)

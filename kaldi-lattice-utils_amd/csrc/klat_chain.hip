@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void chain_walk_kernel(ChainArgs a
   const unsigned long long t_begin = a.dbg ? wall_clock64() : 0;
   if (MODE == 0) {
     chain_walk<0, 0, TROP>(a, ring, outbuf, lntab);
-  } else if ((blockIdx.y ^ a.dir_first) == 0) {
+  } else if (blockIdx.y == 0) {
     chain_walk<1, 0, TROP>(a, ring, outbuf, lntab);
   } else {
     chain_walk<1, 1, TROP>(a, ring, outbuf, lntab);
@@ -976,10 +976,9 @@ hipError_t launch_chain_prep(const ChainPrepArgs& a, int num_chain_lattices, hip
 
 hipError_t launch_chain_sweep(const ChainArgs& a, hipStream_t stream, bool tropical) {
   if (a.num_segs <= 0) return hipSuccess;
-  static const int pad = std::getenv("KLAT_CHAIN_LDS_PAD") ? std::atoi(std::getenv("KLAT_CHAIN_LDS_PAD")) : 0;  // (experiments)
   const size_t ring_bytes = (size_t)a.W * 64 * sizeof(double);
-  const size_t lds_a = kLnTabSize * sizeof(LnTabEntry) + kWalkWaves * (ring_bytes + (size_t)2 * (64 >> a.lgc) * 16 * sizeof(uint64_t)) + (size_t)pad;
-  const size_t lds_c = kLnTabSize * sizeof(LnTabEntry) + kSweepWaves * (ring_bytes + (size_t)kSweepBatch * 64 * (sizeof(double) + sizeof(int32_t))) + (size_t)pad;
+  const size_t lds_a = kLnTabSize * sizeof(LnTabEntry) + kWalkWaves * (ring_bytes + (size_t)2 * (64 >> a.lgc) * 16 * sizeof(uint64_t));
+  const size_t lds_c = kLnTabSize * sizeof(LnTabEntry) + kSweepWaves * (ring_bytes + (size_t)kSweepBatch * 64 * (sizeof(double) + sizeof(int32_t)));
   const size_t lds_b = (size_t)2 * kCombineChunk * ((size_t)(a.c * a.c + a.c) * sizeof(double) + (size_t)2 * a.c * sizeof(int32_t));
   const int jobs_a = (a.num_segs + (64 >> a.lgc) - 1) / (64 >> a.lgc), jobs_c = (a.num_segs + 63) / 64;
   const dim3 grid_a((jobs_a + kWalkWaves - 1) / kWalkWaves), grid_c((jobs_c + kSweepWaves - 1) / kSweepWaves, 2);
