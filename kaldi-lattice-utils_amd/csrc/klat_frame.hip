@@ -33,6 +33,7 @@
 namespace klat {
 
 static constexpr int kFrThreads = 256;
+static constexpr int kFrLeanThreads = 512;  // the lean kernel's workgroup (frame_kernel<true>)
 static constexpr int kFrTile = 2048;    // 16-byte keys per LDS tile of the cooperative sort (32 KiB)
 static constexpr int kFrRegs = 16;      // bucket entries a frame's thread sorts in registers
 static constexpr int kFrBigList = 64;
@@ -51,6 +52,46 @@ __device__ __forceinline__ double fr_log_add(double x, double y) {
   }
   if (diff >= -36.04365338911715) return x + log1p(exp(diff));  // log(DBL_EPSILON)
   return x;
+}
+
+// The same LogAdd for the lean kernel, ~45 instructions instead of the library's ~200 and no constants held
+// in vector registers: exp(d) = 2^k 2^f with 2^f by the degree-11 polynomial of tools/exp2_poly.py (relative
+// error 2e-17 before rounding), ln(1 + exp(d)) by the sweep's table ln (klat_math.h); the result is within
+// ~3e-16 of the library's before the final sum rounds it (the reference narrows it to float, :126).
+__device__ __forceinline__ double fr_log_add_fast(double x, double y, const LnTabEntry* lntab /* LDS */) {
+  double hi, lo;
+  asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+  asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+  const double d = lo - hi;  // <= 0; -inf or NaN (both log-zero) fail the test below
+  const double kf = rint(d * kLog2e);
+  const double f = fma(d, kLog2e, -kf);
+  int k;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(k) : "v"(kf));  // (saturates)
+  double p, c11;
+  asm("v_mov_b64 %0, %1" : "=v"(c11) : "s"(4.45581790833606449045e-10));
+  asm("v_fma_f64 %0, %1, %2, %3\n\t"
+      "v_fma_f64 %0, %0, %2, %4\n\t"
+      "v_fma_f64 %0, %0, %2, %5\n\t"
+      "v_fma_f64 %0, %0, %2, %6\n\t"
+      "v_fma_f64 %0, %0, %2, %7\n\t"
+      "v_fma_f64 %0, %0, %2, %8\n\t"
+      "v_fma_f64 %0, %0, %2, %9\n\t"
+      "v_fma_f64 %0, %0, %2, %10\n\t"
+      "v_fma_f64 %0, %0, %2, %11\n\t"
+      "v_fma_f64 %0, %0, %2, %12\n\t"
+      "v_fma_f64 %0, %0, %2, 1.0"
+      : "=&v"(p)
+      : "v"(c11), "v"(f), "s"(7.07419429728852105635e-09), "s"(1.01780570877339407473e-07),
+        "s"(1.32154325359123752878e-06), "s"(1.52527338415567733184e-05), "s"(1.54035304637243529923e-04),
+        "s"(1.33335581464064708429e-03), "s"(9.61812910758725637950e-03), "s"(5.55041086648216247523e-02),
+        "s"(2.40226506959101582250e-01), "s"(6.93147180559945286227e-01));
+  const double s1 = 1.0 + ldexp(p, k);  // in (1, 2]
+  double m;
+  int e;
+  asm("v_frexp_mant_f64 %0, %1" : "=v"(m) : "v"(s1));
+  asm("v_frexp_exp_i32_f64 %0, %1" : "=v"(e) : "v"(s1));
+  const double r = hi + table_ln(m, e, lntab[ln_table_index(m)]);
+  return select64(lane_mask(d >= -36.04365338911715), r, hi);  // log(DBL_EPSILON)
 }
 
 __device__ __forceinline__ uint32_t fr_bias(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
@@ -139,8 +180,9 @@ __device__ void fr_bitonic_sort(FKey* data, int n, FKey* tile, Less less) {
   }
 }
 
-// block-wide exclusive scan of one int per thread
-__device__ int fr_block_scan(int v, int* total, int* sh /* [kFrThreads/64] */) {
+// block-wide exclusive scan of one int per thread (NT threads)
+template <int NT = kFrThreads>
+__device__ int fr_block_scan(int v, int* total, int* sh /* [NT/64] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
   for (int off = 1; off < 64; off <<= 1) {
@@ -150,7 +192,7 @@ __device__ int fr_block_scan(int v, int* total, int* sh /* [kFrThreads/64] */) {
   if (lane == 63) sh[wave] = inc;
   __syncthreads();
   int pre = 0, tot = 0;
-  for (int w = 0; w < kFrThreads / 64; ++w) {
+  for (int w = 0; w < NT / 64; ++w) {
     if (w < wave) pre += sh[w];
     tot += sh[w];
   }
@@ -160,19 +202,20 @@ __device__ int fr_block_scan(int v, int* total, int* sh /* [kFrThreads/64] */) {
 }
 
 // the same for two ints per thread at once (one pair of barriers)
-__device__ int2 fr_block_scan2(int v, int w, int* total_v, int* total_w, int* sh /* [2 * kFrThreads/64] */) {
+template <int NT = kFrThreads>
+__device__ int2 fr_block_scan2(int v, int w, int* total_v, int* total_w, int* sh /* [2 * NT/64] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int iv = v, iw = w;
   for (int off = 1; off < 64; off <<= 1) {
     const int t = __shfl_up(iv, off, 64), x = __shfl_up(iw, off, 64);
     if (lane >= off) iv += t, iw += x;
   }
-  if (lane == 63) sh[wave] = iv, sh[kFrThreads / 64 + wave] = iw;
+  if (lane == 63) sh[wave] = iv, sh[NT / 64 + wave] = iw;
   __syncthreads();
   int pv = 0, tv = 0, pw = 0, tw = 0;
-  for (int k = 0; k < kFrThreads / 64; ++k) {
-    if (k < wave) pv += sh[k], pw += sh[kFrThreads / 64 + k];
-    tv += sh[k], tw += sh[kFrThreads / 64 + k];
+  for (int k = 0; k < NT / 64; ++k) {
+    if (k < wave) pv += sh[k], pw += sh[NT / 64 + k];
+    tv += sh[k], tw += sh[NT / 64 + k];
   }
   __syncthreads();
   *total_v = tv, *total_w = tw;
@@ -334,7 +377,13 @@ __device__ __forceinline__ int fr_fold_bucket(int w, Entry E) {
   return m;
 }
 
-__global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span_cap) {
+// LEAN: the kernel of lattices whose every tile keeps its buckets in LDS, whose keys fit 32 bits and whose
+// frames hold at most kFrRegs arcs -- twice the threads, half the registers (four waves per SIMD), nothing
+// but the register path in its frames phase.  A lattice that does not fit raises redo[u] and is left to the
+// general kernel, launched behind this one over the raised lattices alone.
+template <bool LEAN>
+__global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kernel(FrameArgs a, int span_cap) {
+  constexpr int NT = LEAN ? kFrLeanThreads : kFrThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
   FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrTile]: the cooperative sort's tile
   uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kFrLdsEntries]: a tile's buckets as arc numbers (same memory)
@@ -348,11 +397,14 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   __shared__ uint16_t cframe[kFrTileFrames + 2];  // the c-th changed frame (cframe[nc] = tf)
   __shared__ int lboff[kFrTileFrames + 1];  // first expansion of every changed frame of the tile (tile-local)
   __shared__ int lcur[kFrTileFrames];       // scatter cursors; then -(folded entries) - 1 for a bucket the workgroup folded
-  __shared__ int sh[2 * kFrThreads / 64];
+  __shared__ int sh[2 * NT / 64];
   __shared__ int big_list[kFrBigList];
   __shared__ int big_n;
+  __shared__ LnTabEntry lntab[LEAN ? kLnTabSize : 1];
   const int u = blockIdx.x;
   const int tid = threadIdx.x;
+  if (!LEAN && a.redo && !a.redo[u]) return;  // (done by the lean kernel)
+  if (LEAN && tid < kLnTabSize) lntab[tid] = a.ln_table[tid];  // (barriers follow before its first use)
   const int64_t a0 = a.arc_off[u];
   const int nA = (int)(a.arc_off[u + 1] - a0);
   const int64_t s0 = a.state_off[u];
@@ -383,13 +435,13 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unsorted = 0;
   __syncthreads();
   int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0;
-  for (int base = 0; base < nA; base += kFrSpanBatch * kFrThreads) {  // eight arcs per thread at a time: loads batched, no branch around them
+  for (int base = 0; base < nA; base += kFrSpanBatch * NT) {  // eight arcs per thread at a time: loads batched, no branch around them
     int il[kFrSpanBatch], t0[kFrSpanBatch], t1[kFrSpanBatch];
     float gr[kFrSpanBatch], ac4[kFrSpanBatch];
     double lp[kFrSpanBatch];
 #pragma unroll
     for (int q = 0; q < kFrSpanBatch; ++q) {
-      const int i = min(base + q * kFrThreads + tid, nA - 1);
+      const int i = min(base + q * NT + tid, nA - 1);
       il[q] = a.ilabel[a0 + i];
       t0[q] = a.src[a0 + i];
       t1[q] = a.dst[a0 + i];
@@ -407,7 +459,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     }
 #pragma unroll
     for (int q = 0; q < kFrSpanBatch; ++q) {
-      const int i = base + q * kFrThreads + tid;
+      const int i = base + q * NT + tid;
       if (i >= nA) continue;
       FrameArc r;
       r.k0 = r.k1 = 0;
@@ -442,7 +494,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   // (two binary searches over the spans in LDS) and its passes need not visit the others.
   if (spans_lds) {
     bool desc = false;
-    for (int i = tid + 1; i < nA; i += kFrThreads) desc |= (lspan[i] & 0xFFFFu) < (lspan[i - 1] & 0xFFFFu);
+    for (int i = tid + 1; i < nA; i += NT) desc |= (lspan[i] & 0xFFFFu) < (lspan[i - 1] & 0xFFFFu);
     if (__any(desc) && (tid & 63) == 0) atomicOr(&unsorted, 1);
   }
   __syncthreads();
@@ -456,6 +508,12 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   const int lab_base = lab_min;
   const bool dsort = key32 && (int64_t)lab_max - (int64_t)lab_min < ((int64_t)1 << 30);  // folded keys sortable as doubles
 
+  if constexpr (LEAN) {
+    if (!(ranged && key32 && dsort)) {  // workgroup-uniform
+      if (tid == 0) a.redo[u] = 1;
+      return;
+    }
+  }
   FR_LAP(0);
   int nbase = 0;  // expansions of the tiles before this one
   int mbase = 0;  // records written so far
@@ -464,8 +522,8 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     const int tf = min(kFrTileFrames, T - f0);
     // ---- 1. entries per frame from a difference array over the spans, the changed frames of the
     // tile, and the bucket offsets of the changed frames: one pass over the arcs, three scans ----
-    constexpr int kCh = (kFrTileFrames + 1 + kFrThreads - 1) / kFrThreads;
-    for (int k = tid; k <= tf; k += kFrThreads) lboff[k] = 0, cidx[k] = (k == 0) ? 1 : 0;
+    constexpr int kCh = (kFrTileFrames + 1 + NT - 1) / NT;
+    for (int k = tid; k <= tf; k += NT) lboff[k] = 0, cidx[k] = (k == 0) ? 1 : 0;
     if (tid == 0) big_n = 0;
     __syncthreads();
     // arcs that can cover a frame of the tile: first frame below the tile's end, and (no arc is
@@ -489,7 +547,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
       const int k0 = spans_lds ? (int)(sp32 & 0xFFFFu) : ai[i].k0, k1 = spans_lds ? (int)(sp32 >> 16) : ai[i].k1;
       lo = max(k0, f0) - f0, hi = min(k1, f0 + tf) - f0;
     };
-    for (int i = arc_lo + tid; i < arc_hi; i += kFrThreads) {
+    for (int i = arc_lo + tid; i < arc_hi; i += NT) {
       int lo, hi;
       span_of(i, lo, hi);
       if (hi > lo) {
@@ -513,7 +571,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         sum_f += fl[q];
       }
       int tot_d;
-      const int2 pre = fr_block_scan2(sum_d, sum_f, &tot_d, &nc, sh);  // (all reads of the two arrays are done)
+      const int2 pre = fr_block_scan2<NT>(sum_d, sum_f, &tot_d, &nc, sh);  // (all reads of the two arrays are done)
       int run = pre.x, sum_c = 0;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
@@ -522,7 +580,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         cmax = max(cmax, dl[q]);
         sum_c += dl[q];
       }
-      int off = fr_block_scan(sum_c, &n, sh);
+      int off = fr_block_scan<NT>(sum_c, &n, sh);
       int c = pre.y;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
@@ -544,11 +602,17 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     if ((tid & 63) == 0) atomicMax(&tile_max, cmax);
     __syncthreads();
     const bool in_lds = nA <= 65535 && n <= kFrLdsEntries && tile_max <= kFrSerialMax;  // workgroup-uniform
+    if constexpr (LEAN) {
+      if (!in_lds || tile_max > kFrRegs) {
+        if (tid == 0) a.redo[u] = 1;
+        return;
+      }
+    }
 
     FR_LAP(1);
     // ---- 2. every arc drops itself into the buckets of its frames ----
-    if (in_lds) {
-      for (int i = arc_lo + tid; i < arc_hi; i += kFrThreads) {
+    if (LEAN || in_lds) {
+      for (int i = arc_lo + tid; i < arc_hi; i += NT) {
         int lo, hi;
         span_of(i, lo, hi);
         if (hi <= lo) continue;
@@ -563,7 +627,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         }
       }
     } else {
-      for (int i = tid; i < nA; i += kFrThreads) {
+      for (int i = tid; i < nA; i += NT) {
         int lo, hi;
         span_of(i, lo, hi);
         if (hi <= lo) continue;
@@ -580,8 +644,8 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     // ---- 3a. buckets above kFrSerialMax entries, kFrBigList at a time: sorted through the LDS
     // tile (which overlays the slabs), folded by the heads of the runs, sorted again; the folded
     // keys stay at the bucket's start ----
-    for (; !in_lds;) {  // (a tile whose buckets sit in LDS has no such frame)
-      for (int k = tid; k < nc; k += kFrThreads)
+    for (; !LEAN && !in_lds;) {  // (a tile whose buckets sit in LDS has no such frame)
+      for (int k = tid; k < nc; k += NT)
         if (lboff[k + 1] - lboff[k] > kFrSerialMax && lcur[k] >= 0) {
           const int slot = atomicAdd(&big_n, 1);
           if (slot < kFrBigList) big_list[slot] = k;
@@ -594,7 +658,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         const int o = nbase + lboff[k], w = lboff[k + 1] - lboff[k];
         int np = 1;
         while (np < w) np <<= 1;
-        for (int i = tid; i < np; i += kFrThreads) {
+        for (int i = tid; i < np; i += NT) {
           FKey e;
           e.a = e.b = ~0ull;
           if (i < w) e = keys[o + i];
@@ -603,7 +667,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         __syncthreads();
         fr_bitonic_sort(tmp, np, slab, FKeyLess());
         int m = 0;
-        for (int base = 0; base < w; base += kFrThreads) {
+        for (int base = 0; base < w; base += NT) {
           const int i = base + tid;
           bool head = false;
           FKey out;
@@ -619,14 +683,14 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
             }
           }
           int tot;
-          const int off = fr_block_scan(head ? 1 : 0, &tot, sh);
+          const int off = fr_block_scan<NT>(head ? 1 : 0, &tot, sh);
           if (head) keys[o + m + off] = out;
           m += tot;
         }
         __syncthreads();
         int mp = 1;
         while (mp < m) mp <<= 1;
-        for (int i = tid; i < mp; i += kFrThreads) {
+        for (int i = tid; i < mp; i += NT) {
           FKey e;
           e.a = e.b = ~0ull;
           if (i < m) e = keys[o + i];
@@ -634,7 +698,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         }
         __syncthreads();
         fr_bitonic_sort(tmp, mp, slab, FKeyLess());
-        for (int i = tid; i < m; i += kFrThreads) keys[o + i] = tmp[i];
+        for (int i = tid; i < m; i += NT) keys[o + i] = tmp[i];
         if (tid == 0) lcur[k] = -m - 1;
         __syncthreads();
       }
@@ -643,12 +707,64 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     }
 
     FR_LAP(3);
-    // ---- 3b. one thread per changed frame, kFrThreads at a time: sort, fold, sort, place (once
+    // ---- 3b. one thread per changed frame, NT at a time: sort, fold, sort, place (once
     // for the frame and once more for every unchanged frame that follows it) ----
-    for (int r0 = 0; r0 < nc; r0 += kFrThreads) {
+    for (int r0 = 0; r0 < nc; r0 += NT) {
       const int k = r0 + tid;
       int o = 0, w = 0, mk = 0;
       bool in_regs = false;
+      uint64_t ek[kFrRegs];
+      if constexpr (LEAN) {
+        // every bucket of the tile has at most kFrRegs entries, in LDS, and 32-bit keys
+        const int lo = (k < nc) ? lboff[k] : 0;
+        w = (k < nc) ? lboff[k + 1] - lo : 0;
+        in_regs = true;
+        uint32_t k32[kFrRegs];
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? (uint32_t)lbucket[lo + j] : 0xFFFFFFFFu;
+        // (gathers served by L2; 32-bit byte offsets from the lattice's first arc: one address register each)
+        const char* lab_row = reinterpret_cast<const char*>(a.ilabel + a0);
+        const char* x_row = reinterpret_cast<const char*>(&ai[0].x);
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j)
+          if (j < w) k32[j] |= (uint32_t)(*reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2)) - lab_base) << abits;
+        const bool narrow = __all(w <= 8);  // wave-uniform: the 8-wide network is enough
+        if (narrow)
+          fr_sort32_sizes<8, 2>(k32);
+        else
+          fr_sort32_sizes<kFrRegs, 2>(k32);
+        const uint32_t amask = (1u << abits) - 1u;
+        double ex[kFrRegs];
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) ex[j] = (j < w) ? *reinterpret_cast<const double*>(x_row + ((k32[j] & amask) << 4)) : 0.0;
+        // fold on the sort keys themselves: the key of a run is emitted at its last entry as the positive
+        // finite double desc(float logp) << 30 | label - lab_base, the other entries turn into padding
+        double dk[kFrRegs];
+        double acc = ex[0];
+#pragma unroll
+        for (int j = 1; j <= kFrRegs; ++j) {
+          const uint32_t lab = k32[j - 1] >> abits;
+          const bool cont = j < kFrRegs && j < w && (k32[j < kFrRegs ? j : 0] >> abits) == lab;
+          const bool emit = !cont && j - 1 < w;
+          const uint64_t key = ((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab;  // BaseFloat narrowing of :126
+          dk[j - 1] = __longlong_as_double((long long)(emit ? key : 0x7FEFFFFFFFFFFFFFull));
+          mk += emit ? 1 : 0;
+          if (j < kFrRegs) {
+            double folded = ex[j];
+            if (__any(cont)) folded = fr_log_add_fast(acc, ex[j], lntab);  // (skipped unless some frame of the wave has two arcs of one word here)
+            acc = cont ? folded : ex[j];
+          }
+        }
+        if (narrow)
+          fr_sortd_sizes<8, 2>(dk);
+        else
+          fr_sortd_sizes<kFrRegs, 2>(dk);
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) {
+          const uint64_t key = (uint64_t)__double_as_longlong(dk[j]);
+          ek[j] = ((key >> 30) << 32) | fr_bias((int32_t)(uint32_t)(key & 0x3FFFFFFFull) + lab_base);
+        }
+      } else {
       if (k < nc) {
         o = nbase + lboff[k];
         w = lboff[k + 1] - lboff[k];
@@ -668,7 +784,6 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
           in_regs = w > 0;
         }
       }
-      uint64_t ek[kFrRegs];
       double ex[kFrRegs];
       bool narrow;
       if (in_lds && key32) {
@@ -770,9 +885,10 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
       } else {
         fr_sort_regs<kFrRegs, false>(ek, ex);
       }
+      }  // (!LEAN)
       const int frame = (k < nc) ? (int)cframe[k] : 0, run = (k < nc) ? (int)cframe[k + 1] - frame : 0;
       int tot, tot_dense;
-      const int dst = mbase + fr_block_scan2(mk, mk * run, &tot, &tot_dense, sh).x;
+      const int dst = mbase + fr_block_scan2<NT>(mk, mk * run, &tot, &tot_dense, sh).x;
       // 8 bytes per record -- desc(float logp) | biased label, the sort key itself -- written ONCE per
       // changed frame; every frame names its records by (first record, count), so the unchanged frames
       // that follow share them, and the gather kernel expands the runs into the dense output
@@ -780,7 +896,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
         a.frame_count[fbase + f0 + frame + r] = mk;
         a.frame_src[fbase + f0 + frame + r] = dst;
       }
-      if (in_regs) {
+      if (LEAN || in_regs) {
 #pragma unroll
         for (int j = 0; j < kFrRegs; ++j)
           if (j < mk) rec8[dst + j] = ek[j];
@@ -795,6 +911,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     FR_LAP(4);
   }
   if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase;
+  if (LEAN && tid == 0) a.redo[u] = 0;
   if (a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
@@ -854,9 +971,15 @@ hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipS
   static_assert(sizeof(FKey) * kFrTile <= sizeof(uint16_t) * kFrLdsEntries, "the sort tile lies under the buckets");
   const int span_cap = max_arcs < kFrLdsSpans ? (max_arcs > 0 ? max_arcs : 0) : kFrLdsSpans;
   const size_t lds = sizeof(uint16_t) * kFrLdsEntries + sizeof(uint32_t) * (size_t)span_cap;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
+  if (a.redo) {  // the lean kernel first; the general one over the lattices it left
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(frame_kernel<true>, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(frame_kernel<false>, dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
   return hipGetLastError();
 }
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
