@@ -152,7 +152,8 @@ struct FrameArgs {
   const int64_t* frame_base;  // [U+1] first frame of every lattice in the batch-wide frame numbering
   int32_t* frame_count;       // [sum of num_frames] records per frame
   int32_t* frame_src;         // [sum of num_frames] first record of the frame in the lattice's record rows
-  int32_t* redo;              // [U] or null: written by the lean kernel, 1 where a lattice is left to the general one
+  int32_t* redo_list;         // [U] or null: the lattices the lean kernel leaves to the general one, ...
+  int32_t* redo_n;            // [1] ... and their number
   const LnTabEntry* ln_table;  // [kLnTabSize] (klat_kernels.h), the lean kernel's LogAdd
 };
 

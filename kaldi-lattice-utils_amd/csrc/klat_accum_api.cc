@@ -369,8 +369,9 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     if ((rc = st.num_stored.alloc((size_t)b->U))) return rc;
     a.num_stored = st.num_stored.p;
     if (!std::getenv("KLAT_FRAME_GENERAL")) {  // (the general kernel alone: tests, comparisons)
-      if ((rc = st.redo.alloc((size_t)b->U))) return rc;
-      a.redo = st.redo.p;
+      if ((rc = st.redo.alloc((size_t)b->U + 1))) return rc;
+      a.redo_list = st.redo.p;
+      a.redo_n = st.redo.p + b->U;
       a.ln_table = c->ln_table.p;
     }
     a.num_frames = st.num_frames.p;

@@ -246,10 +246,25 @@ __global__ __launch_bounds__(256) void frame_count_kernel(FrameArgs a) {
   if (threadIdx.x == 0) s_sum = 0;
   __syncthreads();
   unsigned long long mine = 0;
-  for (int i = threadIdx.x; i < nA; i += 256) {
-    int k0, k1;
-    fr_span(a, a0, s0, T, i, k0, k1);
-    mine += (unsigned long long)(k1 - k0);
+  for (int base = 0; base < nA; base += 8 * 256) {  // eight arcs per thread at a time: their loads in flight together
+    int il[8], t0[8], t1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = min(base + q * 256 + (int)threadIdx.x, nA - 1);
+      il[q] = a.ilabel[a0 + i];
+      t0[q] = a.src[a0 + i];
+      t1[q] = a.dst[a0 + i];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      t0[q] = a.state_time[s0 + t0[q]];
+      t1[q] = a.state_time[s0 + t1[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int lo = max(t0[q], 0), hi = min(t1[q], T);
+      if (base + q * 256 + (int)threadIdx.x < nA && il[q] != 0 && hi > lo) mine += (unsigned long long)(hi - lo);
+    }
   }
   atomicAdd(&s_sum, mine);
   __syncthreads();
@@ -381,8 +396,8 @@ __device__ __forceinline__ int fr_fold_bucket(int w, Entry E) {
 // frames hold at most kFrRegs arcs -- twice the threads, half the registers (four waves per SIMD), nothing
 // but the register path in its frames phase.  A lattice that does not fit raises redo[u] and is left to the
 // general kernel, launched behind this one over the raised lattices alone.
-template <bool LEAN>
-__global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kernel(FrameArgs a, int span_cap) {
+template <bool LEAN, bool CLOCK>
+__device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span_cap, const int u) {
   constexpr int NT = LEAN ? kFrLeanThreads : kFrThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
   FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrTile]: the cooperative sort's tile
@@ -401,9 +416,7 @@ __global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kern
   __shared__ int big_list[kFrBigList];
   __shared__ int big_n;
   __shared__ LnTabEntry lntab[LEAN ? kLnTabSize : 1];
-  const int u = blockIdx.x;
   const int tid = threadIdx.x;
-  if (!LEAN && a.redo && !a.redo[u]) return;  // (done by the lean kernel)
   if (LEAN && tid < kLnTabSize) lntab[tid] = a.ln_table[tid];  // (barriers follow before its first use)
   const int64_t a0 = a.arc_off[u];
   const int nA = (int)(a.arc_off[u + 1] - a0);
@@ -422,10 +435,10 @@ __global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kern
 
   const bool spans_lds = nA <= span_cap && T <= 65535;  // workgroup-uniform
   long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, crowded, frames, (unused)
-  long long t_prev = (long long)__builtin_amdgcn_s_memtime();
+  long long t_prev = CLOCK ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define FR_LAP(k)                                                      \
   do {                                                                 \
-    if (a.phase_clock) {                                               \
+    if (CLOCK && a.phase_clock) {                                      \
       const long long t_now = (long long)__builtin_amdgcn_s_memtime(); \
       clk[k] += t_now - t_prev;                                        \
       t_prev = t_now;                                                  \
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kern
 
   if constexpr (LEAN) {
     if (!(ranged && key32 && dsort)) {  // workgroup-uniform
-      if (tid == 0) a.redo[u] = 1;
+      if (tid == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = u;
       return;
     }
   }
@@ -604,7 +617,7 @@ __global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kern
     const bool in_lds = nA <= 65535 && n <= kFrLdsEntries && tile_max <= kFrSerialMax;  // workgroup-uniform
     if constexpr (LEAN) {
       if (!in_lds || tile_max > kFrRegs) {
-        if (tid == 0) a.redo[u] = 1;
+        if (tid == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = u;
         return;
       }
     }
@@ -719,15 +732,26 @@ __global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kern
         const int lo = (k < nc) ? lboff[k] : 0;
         w = (k < nc) ? lboff[k + 1] - lo : 0;
         in_regs = true;
+        // (every load below is unconditional: a load inside a branch waits for its data before the branch
+        // closes, and sixteen gathers would take sixteen trips to L2 one after the other.  The slots beyond
+        // the bucket all read the lattice's first arc: one more request per instruction, not one per lane)
         uint32_t k32[kFrRegs];
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? (uint32_t)lbucket[lo + j] : 0xFFFFFFFFu;
+        for (int j = 0; j < kFrRegs; ++j) k32[j] = (uint32_t)lbucket[min(lo + j, kFrLdsEntries - 1)];
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? k32[j] : 0u;
         // (gathers served by L2; 32-bit byte offsets from the lattice's first arc: one address register each)
         const char* lab_row = reinterpret_cast<const char*>(a.ilabel + a0);
         const char* x_row = reinterpret_cast<const char*>(&ai[0].x);
+        {
+          int32_t lab[kFrRegs];
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j)
-          if (j < w) k32[j] |= (uint32_t)(*reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2)) - lab_base) << abits;
+          for (int j = 0; j < kFrRegs; ++j) lab[j] = *reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2));
+#pragma unroll
+          for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? (k32[j] | ((uint32_t)(lab[j] - lab_base) << abits)) : 0xFFFFFFFFu;
+        }
         const bool narrow = __all(w <= 8);  // wave-uniform: the 8-wide network is enough
         if (narrow)
           fr_sort32_sizes<8, 2>(k32);
@@ -736,7 +760,7 @@ __global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kern
         const uint32_t amask = (1u << abits) - 1u;
         double ex[kFrRegs];
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) ex[j] = (j < w) ? *reinterpret_cast<const double*>(x_row + ((k32[j] & amask) << 4)) : 0.0;
+        for (int j = 0; j < kFrRegs; ++j) ex[j] = *reinterpret_cast<const double*>(x_row + ((j < w ? k32[j] & amask : 0u) << 4));
         // fold on the sort keys themselves: the key of a run is emitted at its last entry as the positive
         // finite double desc(float logp) << 30 | label - lab_base, the other entries turn into padding
         double dk[kFrRegs];
@@ -911,10 +935,23 @@ __global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kern
     FR_LAP(4);
   }
   if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase;
-  if (LEAN && tid == 0) a.redo[u] = 0;
-  if (a.phase_clock && tid == 0)
+  if (CLOCK && a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
+}
+
+// CLOCK: with the phases' shader clocks (KLAT_ACCUM_PROFILE); its own instantiation of the lean kernel, whose
+// scalar registers are short as it is
+template <bool LEAN, bool CLOCK>
+__global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kernel(FrameArgs a, int span_cap) {
+  if constexpr (LEAN) {
+    frame_lattice<true, CLOCK>(a, span_cap, (int)blockIdx.x);
+  } else {
+    // alone: every lattice.  Behind the lean kernel: the lattices it listed (the other workgroups leave at once)
+    const int i = (int)blockIdx.x;
+    if (a.redo_list && i >= *a.redo_n) return;
+    frame_lattice<false, CLOCK>(a, span_cap, a.redo_list ? a.redo_list[i] : i);
+  }
 }
 
 // Dense output: entries of lattice u at entry_off[u].., frame offsets at frame_base[u]...  A wave
@@ -971,15 +1008,17 @@ hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipS
   static_assert(sizeof(FKey) * kFrTile <= sizeof(uint16_t) * kFrLdsEntries, "the sort tile lies under the buckets");
   const int span_cap = max_arcs < kFrLdsSpans ? (max_arcs > 0 ? max_arcs : 0) : kFrLdsSpans;
   const size_t lds = sizeof(uint16_t) * kFrLdsEntries + sizeof(uint32_t) * (size_t)span_cap;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  if (a.redo) {  // the lean kernel first; the general one over the lattices it left
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (a.redo_list) {  // the lean kernel first; the general one over the lattices it lists
+    auto lean = a.phase_clock ? &frame_kernel<true, true> : &frame_kernel<true, false>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(frame_kernel<true>, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);
+    if ((e = hipMemsetAsync(a.redo_n, 0, sizeof(int32_t), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(frame_kernel<false>, dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
+  hipLaunchKernelGGL((frame_kernel<false, true>), dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
   return hipGetLastError();
 }
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
