@@ -33,7 +33,7 @@
 namespace klat {
 
 static constexpr int kFrThreads = 256;
-static constexpr int kFrLeanThreads = 512;  // the lean kernel's workgroup (frame_kernel<true>)
+static constexpr int kFrLeanThreads = 512;  // the lean kernel's workgroup (frame_lean_kernel)
 static constexpr int kFrTile = 2048;    // 16-byte keys per LDS tile of the cooperative sort (32 KiB)
 static constexpr int kFrRegs = 16;      // bucket entries a frame's thread sorts in registers
 static constexpr int kFrBigList = 64;
@@ -392,13 +392,7 @@ __device__ __forceinline__ int fr_fold_bucket(int w, Entry E) {
   return m;
 }
 
-// LEAN: the kernel of lattices whose every tile keeps its buckets in LDS, whose keys fit 32 bits and whose
-// frames hold at most kFrRegs arcs -- twice the threads, half the registers (four waves per SIMD), nothing
-// but the register path in its frames phase.  A lattice that does not fit raises redo[u] and is left to the
-// general kernel, launched behind this one over the raised lattices alone.
-template <bool LEAN, bool CLOCK>
-__device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span_cap, const int u) {
-  constexpr int NT = LEAN ? kFrLeanThreads : kFrThreads;
+__global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
   FKey* slab = reinterpret_cast<FKey*>(fr_smem);  // [kFrTile]: the cooperative sort's tile
   uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kFrLdsEntries]: a tile's buckets as arc numbers (same memory)
@@ -412,12 +406,13 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
   __shared__ uint16_t cframe[kFrTileFrames + 2];  // the c-th changed frame (cframe[nc] = tf)
   __shared__ int lboff[kFrTileFrames + 1];  // first expansion of every changed frame of the tile (tile-local)
   __shared__ int lcur[kFrTileFrames];       // scatter cursors; then -(folded entries) - 1 for a bucket the workgroup folded
-  __shared__ int sh[2 * NT / 64];
+  __shared__ int sh[2 * kFrThreads / 64];
   __shared__ int big_list[kFrBigList];
   __shared__ int big_n;
-  __shared__ LnTabEntry lntab[LEAN ? kLnTabSize : 1];
+  // alone: every lattice.  Behind the lean kernel: the lattices it listed (the other workgroups leave at once)
+  if (a.redo_list && (int)blockIdx.x >= *a.redo_n) return;
+  const int u = a.redo_list ? a.redo_list[blockIdx.x] : (int)blockIdx.x;
   const int tid = threadIdx.x;
-  if (LEAN && tid < kLnTabSize) lntab[tid] = a.ln_table[tid];  // (barriers follow before its first use)
   const int64_t a0 = a.arc_off[u];
   const int nA = (int)(a.arc_off[u + 1] - a0);
   const int64_t s0 = a.state_off[u];
@@ -435,10 +430,10 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
 
   const bool spans_lds = nA <= span_cap && T <= 65535;  // workgroup-uniform
   long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, crowded, frames, (unused)
-  long long t_prev = CLOCK ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  long long t_prev = (long long)__builtin_amdgcn_s_memtime();
 #define FR_LAP(k)                                                      \
   do {                                                                 \
-    if (CLOCK && a.phase_clock) {                                      \
+    if (a.phase_clock) {                                               \
       const long long t_now = (long long)__builtin_amdgcn_s_memtime(); \
       clk[k] += t_now - t_prev;                                        \
       t_prev = t_now;                                                  \
@@ -448,13 +443,13 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
   if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unsorted = 0;
   __syncthreads();
   int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0;
-  for (int base = 0; base < nA; base += kFrSpanBatch * NT) {  // eight arcs per thread at a time: loads batched, no branch around them
+  for (int base = 0; base < nA; base += kFrSpanBatch * kFrThreads) {  // eight arcs per thread at a time: loads batched, no branch around them
     int il[kFrSpanBatch], t0[kFrSpanBatch], t1[kFrSpanBatch];
     float gr[kFrSpanBatch], ac4[kFrSpanBatch];
     double lp[kFrSpanBatch];
 #pragma unroll
     for (int q = 0; q < kFrSpanBatch; ++q) {
-      const int i = min(base + q * NT + tid, nA - 1);
+      const int i = min(base + q * kFrThreads + tid, nA - 1);
       il[q] = a.ilabel[a0 + i];
       t0[q] = a.src[a0 + i];
       t1[q] = a.dst[a0 + i];
@@ -472,7 +467,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
     }
 #pragma unroll
     for (int q = 0; q < kFrSpanBatch; ++q) {
-      const int i = base + q * NT + tid;
+      const int i = base + q * kFrThreads + tid;
       if (i >= nA) continue;
       FrameArc r;
       r.k0 = r.k1 = 0;
@@ -507,7 +502,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
   // (two binary searches over the spans in LDS) and its passes need not visit the others.
   if (spans_lds) {
     bool desc = false;
-    for (int i = tid + 1; i < nA; i += NT) desc |= (lspan[i] & 0xFFFFu) < (lspan[i - 1] & 0xFFFFu);
+    for (int i = tid + 1; i < nA; i += kFrThreads) desc |= (lspan[i] & 0xFFFFu) < (lspan[i - 1] & 0xFFFFu);
     if (__any(desc) && (tid & 63) == 0) atomicOr(&unsorted, 1);
   }
   __syncthreads();
@@ -521,12 +516,6 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
   const int lab_base = lab_min;
   const bool dsort = key32 && (int64_t)lab_max - (int64_t)lab_min < ((int64_t)1 << 30);  // folded keys sortable as doubles
 
-  if constexpr (LEAN) {
-    if (!(ranged && key32 && dsort)) {  // workgroup-uniform
-      if (tid == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = u;
-      return;
-    }
-  }
   FR_LAP(0);
   int nbase = 0;  // expansions of the tiles before this one
   int mbase = 0;  // records written so far
@@ -535,8 +524,8 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
     const int tf = min(kFrTileFrames, T - f0);
     // ---- 1. entries per frame from a difference array over the spans, the changed frames of the
     // tile, and the bucket offsets of the changed frames: one pass over the arcs, three scans ----
-    constexpr int kCh = (kFrTileFrames + 1 + NT - 1) / NT;
-    for (int k = tid; k <= tf; k += NT) lboff[k] = 0, cidx[k] = (k == 0) ? 1 : 0;
+    constexpr int kCh = (kFrTileFrames + 1 + kFrThreads - 1) / kFrThreads;
+    for (int k = tid; k <= tf; k += kFrThreads) lboff[k] = 0, cidx[k] = (k == 0) ? 1 : 0;
     if (tid == 0) big_n = 0;
     __syncthreads();
     // arcs that can cover a frame of the tile: first frame below the tile's end, and (no arc is
@@ -560,7 +549,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
       const int k0 = spans_lds ? (int)(sp32 & 0xFFFFu) : ai[i].k0, k1 = spans_lds ? (int)(sp32 >> 16) : ai[i].k1;
       lo = max(k0, f0) - f0, hi = min(k1, f0 + tf) - f0;
     };
-    for (int i = arc_lo + tid; i < arc_hi; i += NT) {
+    for (int i = arc_lo + tid; i < arc_hi; i += kFrThreads) {
       int lo, hi;
       span_of(i, lo, hi);
       if (hi > lo) {
@@ -584,7 +573,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
         sum_f += fl[q];
       }
       int tot_d;
-      const int2 pre = fr_block_scan2<NT>(sum_d, sum_f, &tot_d, &nc, sh);  // (all reads of the two arrays are done)
+      const int2 pre = fr_block_scan2(sum_d, sum_f, &tot_d, &nc, sh);  // (all reads of the two arrays are done)
       int run = pre.x, sum_c = 0;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
@@ -593,7 +582,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
         cmax = max(cmax, dl[q]);
         sum_c += dl[q];
       }
-      int off = fr_block_scan<NT>(sum_c, &n, sh);
+      int off = fr_block_scan(sum_c, &n, sh);
       int c = pre.y;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
@@ -615,17 +604,11 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
     if ((tid & 63) == 0) atomicMax(&tile_max, cmax);
     __syncthreads();
     const bool in_lds = nA <= 65535 && n <= kFrLdsEntries && tile_max <= kFrSerialMax;  // workgroup-uniform
-    if constexpr (LEAN) {
-      if (!in_lds || tile_max > kFrRegs) {
-        if (tid == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = u;
-        return;
-      }
-    }
 
     FR_LAP(1);
     // ---- 2. every arc drops itself into the buckets of its frames ----
-    if (LEAN || in_lds) {
-      for (int i = arc_lo + tid; i < arc_hi; i += NT) {
+    if (in_lds) {
+      for (int i = arc_lo + tid; i < arc_hi; i += kFrThreads) {
         int lo, hi;
         span_of(i, lo, hi);
         if (hi <= lo) continue;
@@ -640,7 +623,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
         }
       }
     } else {
-      for (int i = tid; i < nA; i += NT) {
+      for (int i = tid; i < nA; i += kFrThreads) {
         int lo, hi;
         span_of(i, lo, hi);
         if (hi <= lo) continue;
@@ -657,8 +640,8 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
     // ---- 3a. buckets above kFrSerialMax entries, kFrBigList at a time: sorted through the LDS
     // tile (which overlays the slabs), folded by the heads of the runs, sorted again; the folded
     // keys stay at the bucket's start ----
-    for (; !LEAN && !in_lds;) {  // (a tile whose buckets sit in LDS has no such frame)
-      for (int k = tid; k < nc; k += NT)
+    for (; !in_lds;) {  // (a tile whose buckets sit in LDS has no such frame)
+      for (int k = tid; k < nc; k += kFrThreads)
         if (lboff[k + 1] - lboff[k] > kFrSerialMax && lcur[k] >= 0) {
           const int slot = atomicAdd(&big_n, 1);
           if (slot < kFrBigList) big_list[slot] = k;
@@ -671,7 +654,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
         const int o = nbase + lboff[k], w = lboff[k + 1] - lboff[k];
         int np = 1;
         while (np < w) np <<= 1;
-        for (int i = tid; i < np; i += NT) {
+        for (int i = tid; i < np; i += kFrThreads) {
           FKey e;
           e.a = e.b = ~0ull;
           if (i < w) e = keys[o + i];
@@ -680,7 +663,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
         __syncthreads();
         fr_bitonic_sort(tmp, np, slab, FKeyLess());
         int m = 0;
-        for (int base = 0; base < w; base += NT) {
+        for (int base = 0; base < w; base += kFrThreads) {
           const int i = base + tid;
           bool head = false;
           FKey out;
@@ -696,14 +679,14 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
             }
           }
           int tot;
-          const int off = fr_block_scan<NT>(head ? 1 : 0, &tot, sh);
+          const int off = fr_block_scan(head ? 1 : 0, &tot, sh);
           if (head) keys[o + m + off] = out;
           m += tot;
         }
         __syncthreads();
         int mp = 1;
         while (mp < m) mp <<= 1;
-        for (int i = tid; i < mp; i += NT) {
+        for (int i = tid; i < mp; i += kFrThreads) {
           FKey e;
           e.a = e.b = ~0ull;
           if (i < m) e = keys[o + i];
@@ -711,7 +694,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
         }
         __syncthreads();
         fr_bitonic_sort(tmp, mp, slab, FKeyLess());
-        for (int i = tid; i < m; i += NT) keys[o + i] = tmp[i];
+        for (int i = tid; i < m; i += kFrThreads) keys[o + i] = tmp[i];
         if (tid == 0) lcur[k] = -m - 1;
         __syncthreads();
       }
@@ -720,75 +703,12 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
     }
 
     FR_LAP(3);
-    // ---- 3b. one thread per changed frame, NT at a time: sort, fold, sort, place (once
+    // ---- 3b. one thread per changed frame, kFrThreads at a time: sort, fold, sort, place (once
     // for the frame and once more for every unchanged frame that follows it) ----
-    for (int r0 = 0; r0 < nc; r0 += NT) {
+    for (int r0 = 0; r0 < nc; r0 += kFrThreads) {
       const int k = r0 + tid;
       int o = 0, w = 0, mk = 0;
       bool in_regs = false;
-      uint64_t ek[kFrRegs];
-      if constexpr (LEAN) {
-        // every bucket of the tile has at most kFrRegs entries, in LDS, and 32-bit keys
-        const int lo = (k < nc) ? lboff[k] : 0;
-        w = (k < nc) ? lboff[k + 1] - lo : 0;
-        in_regs = true;
-        // (every load below is unconditional: a load inside a branch waits for its data before the branch
-        // closes, and sixteen gathers would take sixteen trips to L2 one after the other.  The slots beyond
-        // the bucket all read the lattice's first arc: one more request per instruction, not one per lane)
-        uint32_t k32[kFrRegs];
-#pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) k32[j] = (uint32_t)lbucket[min(lo + j, kFrLdsEntries - 1)];
-#pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
-#pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? k32[j] : 0u;
-        // (gathers served by L2; 32-bit byte offsets from the lattice's first arc: one address register each)
-        const char* lab_row = reinterpret_cast<const char*>(a.ilabel + a0);
-        const char* x_row = reinterpret_cast<const char*>(&ai[0].x);
-        {
-          int32_t lab[kFrRegs];
-#pragma unroll
-          for (int j = 0; j < kFrRegs; ++j) lab[j] = *reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2));
-#pragma unroll
-          for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? (k32[j] | ((uint32_t)(lab[j] - lab_base) << abits)) : 0xFFFFFFFFu;
-        }
-        const bool narrow = __all(w <= 8);  // wave-uniform: the 8-wide network is enough
-        if (narrow)
-          fr_sort32_sizes<8, 2>(k32);
-        else
-          fr_sort32_sizes<kFrRegs, 2>(k32);
-        const uint32_t amask = (1u << abits) - 1u;
-        double ex[kFrRegs];
-#pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) ex[j] = *reinterpret_cast<const double*>(x_row + ((j < w ? k32[j] & amask : 0u) << 4));
-        // fold on the sort keys themselves: the key of a run is emitted at its last entry as the positive
-        // finite double desc(float logp) << 30 | label - lab_base, the other entries turn into padding
-        double dk[kFrRegs];
-        double acc = ex[0];
-#pragma unroll
-        for (int j = 1; j <= kFrRegs; ++j) {
-          const uint32_t lab = k32[j - 1] >> abits;
-          const bool cont = j < kFrRegs && j < w && (k32[j < kFrRegs ? j : 0] >> abits) == lab;
-          const bool emit = !cont && j - 1 < w;
-          const uint64_t key = ((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab;  // BaseFloat narrowing of :126
-          dk[j - 1] = __longlong_as_double((long long)(emit ? key : 0x7FEFFFFFFFFFFFFFull));
-          mk += emit ? 1 : 0;
-          if (j < kFrRegs) {
-            double folded = ex[j];
-            if (__any(cont)) folded = fr_log_add_fast(acc, ex[j], lntab);  // (skipped unless some frame of the wave has two arcs of one word here)
-            acc = cont ? folded : ex[j];
-          }
-        }
-        if (narrow)
-          fr_sortd_sizes<8, 2>(dk);
-        else
-          fr_sortd_sizes<kFrRegs, 2>(dk);
-#pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) {
-          const uint64_t key = (uint64_t)__double_as_longlong(dk[j]);
-          ek[j] = ((key >> 30) << 32) | fr_bias((int32_t)(uint32_t)(key & 0x3FFFFFFFull) + lab_base);
-        }
-      } else {
       if (k < nc) {
         o = nbase + lboff[k];
         w = lboff[k + 1] - lboff[k];
@@ -808,6 +728,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
           in_regs = w > 0;
         }
       }
+      uint64_t ek[kFrRegs];
       double ex[kFrRegs];
       bool narrow;
       if (in_lds && key32) {
@@ -909,10 +830,9 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
       } else {
         fr_sort_regs<kFrRegs, false>(ek, ex);
       }
-      }  // (!LEAN)
       const int frame = (k < nc) ? (int)cframe[k] : 0, run = (k < nc) ? (int)cframe[k + 1] - frame : 0;
       int tot, tot_dense;
-      const int dst = mbase + fr_block_scan2<NT>(mk, mk * run, &tot, &tot_dense, sh).x;
+      const int dst = mbase + fr_block_scan2(mk, mk * run, &tot, &tot_dense, sh).x;
       // 8 bytes per record -- desc(float logp) | biased label, the sort key itself -- written ONCE per
       // changed frame; every frame names its records by (first record, count), so the unchanged frames
       // that follow share them, and the gather kernel expands the runs into the dense output
@@ -920,7 +840,7 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
         a.frame_count[fbase + f0 + frame + r] = mk;
         a.frame_src[fbase + f0 + frame + r] = dst;
       }
-      if (LEAN || in_regs) {
+      if (in_regs) {
 #pragma unroll
         for (int j = 0; j < kFrRegs; ++j)
           if (j < mk) rec8[dst + j] = ek[j];
@@ -935,23 +855,341 @@ __device__ __forceinline__ void frame_lattice(const FrameArgs& a, const int span
     FR_LAP(4);
   }
   if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase;
-  if (CLOCK && a.phase_clock && tid == 0)
+  if (a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
 }
 
-// CLOCK: with the phases' shader clocks (KLAT_ACCUM_PROFILE); its own instantiation of the lean kernel, whose
-// scalar registers are short as it is
-template <bool LEAN, bool CLOCK>
-__global__ __launch_bounds__(LEAN ? kFrLeanThreads : kFrThreads) void frame_kernel(FrameArgs a, int span_cap) {
-  if constexpr (LEAN) {
-    frame_lattice<true, CLOCK>(a, span_cap, (int)blockIdx.x);
-  } else {
-    // alone: every lattice.  Behind the lean kernel: the lattices it listed (the other workgroups leave at once)
-    const int i = (int)blockIdx.x;
-    if (a.redo_list && i >= *a.redo_n) return;
-    frame_lattice<false, CLOCK>(a, span_cap, a.redo_list ? a.redo_list[i] : i);
+// ---- the lean kernel ----
+// Lattices whose state times do not descend with the state number, with at most kLnStates states, kFrLdsSpans
+// arcs and 65 535 frames, sort keys of 32 bits, and at most kFrRegs word arcs across any frame: on the
+// synthetic and the shipped lattices, all of them.  Twice the threads and half the registers of the general
+// kernel (four waves per SIMD), and the work laid out over the lattice's distinct state times instead of its
+// frames: a frame's posteriors differ from its predecessor's only where some arc starts or ends, i.e. at a state's
+// time, so the r-th distinct time below T (its RANK r) stands for the frames from there to the next one.  An arc
+// covers the ranks [rank(src), rank(dst)); a tile is kLnTile ranks -- two full rounds of one thread per rank --
+// whatever the frames between them.  A lattice that does not fit is listed for the general kernel, which is
+// launched behind this one over the list.
+static constexpr int kLnStates = 4096;  // states whose ranks (during the arc pass) and rank times stay in LDS
+static constexpr int kLnTile = 1024;    // ranks per tile
+
+template <bool CLOCK>
+__global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a, int span_cap) {
+  constexpr int NT = kFrLeanThreads;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
+  uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kFrLdsEntries]: a tile's buckets as arc numbers
+  uint16_t* lrank = lbucket;                                 // [S]: rank of every state, during the arc pass only
+  uint16_t* rtime = reinterpret_cast<uint16_t*>(fr_smem + sizeof(uint16_t) * kFrLdsEntries);  // [kLnStates + 2]: the time of rank r; rtime[nr] = T
+  uint32_t* lspan = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2));  // [span_cap]: rank(src) | rank(dst) << 16
+  __shared__ int lboff[kLnTile + 1];  // first bucket entry of every rank of the tile
+  __shared__ int lcur[kLnTile];       // scatter cursors
+  __shared__ int sh[2 * NT / 64];
+  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks;
+  __shared__ LnTabEntry lntab[kLnTabSize];
+  const int u = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid < kLnTabSize) lntab[tid] = a.ln_table[tid];  // (barriers follow before its first use)
+  const int64_t a0 = a.arc_off[u];
+  const int nA = (int)(a.arc_off[u + 1] - a0);
+  const int64_t s0 = a.state_off[u];
+  const int S = (int)(a.state_off[u + 1] - s0);
+  const int64_t pb = padded_state_base(s0, u);
+  const double tot = a.total[u];
+  const int T = a.num_frames[u];
+  uint64_t* rec8 = reinterpret_cast<uint64_t*>(reinterpret_cast<FKey*>(a.rec_scratch) + a.scratch_off[u]);
+  double* xs = reinterpret_cast<double*>(a.arc_info + a0);  // x of every arc (the front half of the lattice's rows)
+  const int64_t fbase = a.frame_base[u];
+  const ScaleParams sp = a.sp;
+  auto leave = [&]() {  // (workgroup-uniform)
+    if (tid == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = u;
+  };
+  if (nA > span_cap || nA > 65535 || S > kLnStates || T > 65535) {
+    leave();
+    return;
   }
+  long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, (unused), frames, (unused)
+  long long t_prev = CLOCK ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define FR_LAP(k)                                                      \
+  do {                                                                 \
+    if (CLOCK && a.phase_clock) {                                      \
+      const long long t_now = (long long)__builtin_amdgcn_s_memtime(); \
+      clk[k] += t_now - t_prev;                                        \
+      t_prev = t_now;                                                  \
+    }                                                                  \
+  } while (0)
+  // ---- 0a. ranks: every thread owns kSt consecutive states ----
+  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unfit = 0;
+  {
+    constexpr int kSt = kLnStates / NT;
+    int tm[kSt], fl[kSt], mine = 0;
+    const int sfirst = tid * kSt;
+    int prev = (sfirst > 0 && sfirst <= S) ? min(max(a.state_time[s0 + sfirst - 1], 0), T) : -1;
+    bool descends = false;
+#pragma unroll
+    for (int q = 0; q < kSt; ++q) {
+      const int s = sfirst + q;
+      tm[q] = (s < S) ? min(max(a.state_time[s0 + s], 0), T) : T;
+      descends |= s < S && tm[q] < prev;
+      fl[q] = (s < S && tm[q] > prev && tm[q] < T) ? 1 : 0;  // the first state of a time below T: a rank
+      prev = (s < S) ? tm[q] : prev;
+      mine += fl[q];
+    }
+    int nr;
+    int r = fr_block_scan<NT>(mine, &nr, sh);
+    __syncthreads();  // (lab_min ... are set)
+    if (__any(descends) && (tid & 63) == 0) atomicOr(&unfit, 1);
+#pragma unroll
+    for (int q = 0; q < kSt; ++q) {
+      const int s = sfirst + q;
+      if (fl[q]) rtime[r] = (uint16_t)tm[q];
+      r += fl[q];
+      if (s < S) lrank[s] = (uint16_t)(r - (tm[q] < T ? 1 : 0));  // ranks whose time is below this state's
+    }
+    if (tid == 0) rtime[nr] = (uint16_t)T, num_ranks = nr;
+  }
+  __syncthreads();
+  if (unfit) {
+    leave();
+    return;
+  }
+  const int nr = num_ranks;
+  // ---- 0b. rank span and x of every arc; the label range of the lattice ----
+  int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0;
+  for (int base = 0; base < nA; base += kFrSpanBatch * NT) {  // eight arcs per thread at a time: loads batched, no branch around them
+    int il[kFrSpanBatch], t0[kFrSpanBatch], t1[kFrSpanBatch];
+    float gr[kFrSpanBatch], ac4[kFrSpanBatch];
+    double lp[kFrSpanBatch];
+#pragma unroll
+    for (int q = 0; q < kFrSpanBatch; ++q) {
+      const int i = min(base + q * NT + tid, nA - 1);
+      il[q] = a.ilabel[a0 + i];
+      t0[q] = a.src[a0 + i];
+      t1[q] = a.dst[a0 + i];
+      gr[q] = a.graph[a0 + i];
+      ac4[q] = a.acoustic[a0 + i];
+    }
+#pragma unroll
+    for (int q = 0; q < kFrSpanBatch; ++q) {
+      // fw[u] + bw[nextstate] - cost - total (latbin/lattice-to-word-frame-post.cc:102-104,122), formed
+      // here from alpha / beta: no posterior pass has to run before this kernel
+      const double through = a.alpha[pb + t0[q]] + a.beta[pb + t1[q]] - arc_cost(gr[q], ac4[q], il[q] != 0, sp);
+      lp[q] = (through > -INFINITY) ? through - tot : -INFINITY;
+      t0[q] = (int)lrank[t0[q]];
+      t1[q] = (int)lrank[t1[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < kFrSpanBatch; ++q) {
+      const int i = base + q * NT + tid;
+      if (i >= nA) continue;
+      double x = 0.0;
+      int r1 = t0[q];  // (an empty span is kept as [r, r) at its source's rank: the first ranks of the arcs then ascend with the arc number)
+      if (il[q] != 0 && t1[q] > t0[q]) {
+        r1 = t1[q];
+        lmin_t = min(lmin_t, il[q]), lmax_t = max(lmax_t, il[q]);
+        // lp holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
+        // cost here as a float sum, so swap the double sum for the float one
+        float g, ac;
+        arc_cost_parts(gr[q], ac4[q], true, sp, g, ac);
+        // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
+        x = (lp[q] > -INFINITY) ? lp[q] + ((double)g + (double)ac) - (double)(g + ac) : lp[q];
+        span_max_t = max(span_max_t, r1 - t0[q]);
+      }
+      xs[i] = x;
+      lspan[i] = (uint32_t)t0[q] | ((uint32_t)r1 << 16);
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) lmin_t = min(lmin_t, __shfl_xor(lmin_t, d, 64)), lmax_t = max(lmax_t, __shfl_xor(lmax_t, d, 64));
+  for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64));
+  if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t), atomicMax(&span_max, span_max_t);
+  __syncthreads();
+  {  // the arcs' first ranks ascend with the arc number: a tile's arcs are one range of arcs
+    bool desc = false;
+    for (int i = tid + 1; i < nA; i += NT) desc |= (lspan[i] & 0xFFFFu) < (lspan[i - 1] & 0xFFFFu);
+    if (__any(desc) && (tid & 63) == 0) atomicOr(&unfit, 1);
+  }
+  __syncthreads();  // (the ranks of the states are not read beyond this point: the buckets take their place)
+  const int longest = span_max;
+  // (label - lab_min) and the arc number fit one 32-bit sort key (0xFFFFFFFF stays free for padding), and the
+  // label range 30 bits (the folded keys sort as doubles)
+  int abits = 1;
+  while ((1 << abits) < nA) ++abits;
+  const int lab_base = lab_min;
+  const bool keys_fit = lab_max < lab_min ||
+                        ((uint64_t)((int64_t)lab_max - (int64_t)lab_min) < ((1ull << (32 - abits)) - 1ull) &&
+                         (int64_t)lab_max - (int64_t)lab_min < ((int64_t)1 << 30));
+  if (unfit || !keys_fit) {
+    leave();
+    return;
+  }
+  const uint32_t amask = (1u << abits) - 1u;
+  // the frames before the first rank hold nothing
+  for (int f = tid, first = (nr > 0) ? (int)rtime[0] : T; f < first; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
+  FR_LAP(0);
+  int mbase = 0;  // records written so far
+  int dense = 0;  // (frame, word) entries so far: every frame counts its records, shared or not
+  for (int c0 = 0; c0 < nr; c0 += kLnTile) {
+    const int tc = min(kLnTile, nr - c0);
+    // ---- 1. entries per rank from a difference array over the spans, and the buckets' offsets ----
+    for (int k = tid; k <= tc; k += NT) lboff[k] = 0;
+    if (tid == 0) tile_max = 0;
+    auto first_at_least = [&](int rank) {  // first arc whose first rank is >= rank
+      int l = 0, h = nA;
+      while (l < h) {
+        const int mid = (l + h) >> 1;
+        if ((int)(lspan[mid] & 0xFFFFu) < rank) l = mid + 1;
+        else h = mid;
+      }
+      return l;
+    };
+    // arcs that can cover a rank of the tile: first rank below the tile's end, and (no arc is longer than
+    // `longest`) above its start less that
+    const int arc_lo = first_at_least(c0 - longest + 1), arc_hi = first_at_least(c0 + tc);
+    __syncthreads();
+    for (int i = arc_lo + tid; i < arc_hi; i += NT) {
+      const uint32_t sp32 = lspan[i];
+      const int lo = max((int)(sp32 & 0xFFFFu), c0) - c0, hi = min((int)(sp32 >> 16), c0 + tc) - c0;
+      if (hi > lo) {
+        atomicAdd(&lboff[lo], 1);
+        atomicAdd(&lboff[hi], -1);
+      }
+    }
+    __syncthreads();
+    int n = 0;
+    {
+      constexpr int kCh = kLnTile / NT;  // every thread owns kCh consecutive ranks
+      int dl[kCh], sum_d = 0;
+#pragma unroll
+      for (int q = 0; q < kCh; ++q) {
+        const int k = tid * kCh + q;
+        dl[q] = (k < tc) ? lboff[k] : 0;
+        sum_d += dl[q];
+      }
+      int tot_d;
+      int run = fr_block_scan<NT>(sum_d, &tot_d, sh);  // (all reads of the array are done)
+      int sum_c = 0, cmax = 0;
+#pragma unroll
+      for (int q = 0; q < kCh; ++q) {
+        run += dl[q];
+        dl[q] = (tid * kCh + q < tc) ? run : 0;  // entries of the rank
+        cmax = max(cmax, dl[q]);
+        sum_c += dl[q];
+      }
+      int off = fr_block_scan<NT>(sum_c, &n, sh);
+#pragma unroll
+      for (int q = 0; q < kCh; ++q) {
+        const int k = tid * kCh + q;
+        if (k < tc) lboff[k] = off, lcur[k] = off;
+        off += dl[q];
+      }
+      if (tid == 0) lboff[tc] = n;
+      for (int d = 32; d > 0; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d, 64));
+      if ((tid & 63) == 0) atomicMax(&tile_max, cmax);
+    }
+    __syncthreads();
+    if (tile_max > kFrRegs || n > kFrLdsEntries) {  // workgroup-uniform
+      leave();
+      return;
+    }
+    FR_LAP(1);
+    // ---- 2. every arc drops its number into the buckets of its ranks ----
+    for (int i = arc_lo + tid; i < arc_hi; i += NT) {
+      const uint32_t sp32 = lspan[i];
+      const int lo = max((int)(sp32 & 0xFFFFu), c0) - c0, hi = min((int)(sp32 >> 16), c0 + tc) - c0;
+      for (int c = lo; c < hi; c += 4) {  // four cursors at a time: the atomics' round trips overlap
+        int at[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) at[q] = (c + q < hi) ? atomicAdd(&lcur[c + q], 1) : -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (at[q] >= 0) lbucket[at[q]] = (uint16_t)i;
+      }
+    }
+    __syncthreads();
+    FR_LAP(2);
+    // ---- 3. one thread per rank, NT at a time: sort by (word, arc), fold, sort by (logp desc, word), place ----
+    for (int r0 = 0; r0 < tc; r0 += NT) {
+      const int k = r0 + tid;
+      const int lo = (k < tc) ? lboff[k] : 0;
+      const int w = (k < tc) ? lboff[k + 1] - lo : 0;
+      int mk = 0;
+      // (every load below is unconditional: a load inside a branch waits for its data before the branch
+      // closes, and sixteen gathers would take sixteen trips to L2 one after the other.  The slots beyond
+      // the bucket all read the lattice's first arc: one more request per instruction, not one per lane)
+      uint32_t k32[kFrRegs];
+#pragma unroll
+      for (int j = 0; j < kFrRegs; ++j) k32[j] = (uint32_t)lbucket[min(lo + j, kFrLdsEntries - 1)];
+#pragma unroll
+      for (int j = 0; j < kFrRegs; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
+#pragma unroll
+      for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? k32[j] : 0u;
+      // (gathers served by L2; 32-bit byte offsets from the lattice's first arc: one address register each)
+      const char* lab_row = reinterpret_cast<const char*>(a.ilabel + a0);
+      const char* x_row = reinterpret_cast<const char*>(xs);
+      {
+        int32_t lab[kFrRegs];
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) lab[j] = *reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2));
+        // sort keys (label - lab_base | arc number) in 32 bits: a compare-exchange is two instructions and no
+        // payload moves; x is fetched by arc number after the sort
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? (k32[j] | ((uint32_t)(lab[j] - lab_base) << abits)) : 0xFFFFFFFFu;
+      }
+      const bool narrow = __all(w <= 8);  // wave-uniform: the 8-wide network is enough
+      if (narrow)
+        fr_sort32_sizes<8, 2>(k32);
+      else
+        fr_sort32_sizes<kFrRegs, 2>(k32);
+      double ex[kFrRegs];
+#pragma unroll
+      for (int j = 0; j < kFrRegs; ++j) ex[j] = *reinterpret_cast<const double*>(x_row + ((j < w ? k32[j] & amask : 0u) << 3));
+      // fold on the sort keys themselves, the runs of one word in arc order: the key of a run is emitted at its
+      // last entry as the positive finite double desc(float logp) << 30 | label - lab_base (sorted by v_min_f64 /
+      // v_max_f64), the other entries turn into padding
+      double dk[kFrRegs];
+      double acc = ex[0];
+#pragma unroll
+      for (int j = 1; j <= kFrRegs; ++j) {
+        const uint32_t lab = k32[j - 1] >> abits;
+        const bool cont = j < kFrRegs && j < w && (k32[j < kFrRegs ? j : 0] >> abits) == lab;
+        const bool emit = !cont && j - 1 < w;
+        const uint64_t key = ((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab;  // BaseFloat narrowing of :126
+        dk[j - 1] = __longlong_as_double((long long)(emit ? key : 0x7FEFFFFFFFFFFFFFull));
+        mk += emit ? 1 : 0;
+        if (j < kFrRegs) {
+          double folded = ex[j];
+          if (__any(cont)) folded = fr_log_add_fast(acc, ex[j], lntab);  // (skipped unless some frame of the wave has two arcs of one word here)
+          acc = cont ? folded : ex[j];
+        }
+      }
+      if (narrow)
+        fr_sortd_sizes<8, 2>(dk);
+      else
+        fr_sortd_sizes<kFrRegs, 2>(dk);
+      const int frame = (k < tc) ? (int)rtime[c0 + k] : 0, run = (k < tc) ? (int)rtime[c0 + k + 1] - frame : 0;
+      int tot_st, tot_dense;
+      const int dst = mbase + fr_block_scan2<NT>(mk, mk * run, &tot_st, &tot_dense, sh).x;
+      // 8 bytes per record -- desc(float logp) | biased label -- written ONCE per rank; every frame names its
+      // records by (first record, count), so the frames up to the next rank share them, and the gather kernel
+      // expands the runs into the dense output
+      for (int r = 0; r < run; ++r) {
+        a.frame_count[fbase + frame + r] = mk;
+        a.frame_src[fbase + frame + r] = dst;
+      }
+#pragma unroll
+      for (int j = 0; j < kFrRegs; ++j) {
+        const uint64_t key = (uint64_t)__double_as_longlong(dk[j]);
+        if (j < mk) rec8[dst + j] = ((key >> 30) << 32) | fr_bias((int32_t)(uint32_t)(key & 0x3FFFFFFFull) + lab_base);
+      }
+      dense += tot_dense;
+      mbase += tot_st;
+    }
+    __syncthreads();
+    FR_LAP(4);
+  }
+  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase;
+  if (CLOCK && a.phase_clock && tid == 0)
+    for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
+#undef FR_LAP
 }
 
 // Dense output: entries of lattice u at entry_off[u].., frame offsets at frame_base[u]...  A wave
@@ -1006,19 +1244,21 @@ hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t 
 hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
   static_assert(sizeof(FKey) * kFrTile <= sizeof(uint16_t) * kFrLdsEntries, "the sort tile lies under the buckets");
+  static_assert(sizeof(uint16_t) * kLnStates <= sizeof(uint16_t) * kFrLdsEntries, "the states' ranks lie under the buckets");
   const int span_cap = max_arcs < kFrLdsSpans ? (max_arcs > 0 ? max_arcs : 0) : kFrLdsSpans;
   const size_t lds = sizeof(uint16_t) * kFrLdsEntries + sizeof(uint32_t) * (size_t)span_cap;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   if (a.redo_list) {  // the lean kernel first; the general one over the lattices it lists
-    auto lean = a.phase_clock ? &frame_kernel<true, true> : &frame_kernel<true, false>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lean_lds = sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2) + sizeof(uint32_t) * (size_t)span_cap;
+    auto lean = a.phase_clock ? &frame_lean_kernel<true> : &frame_lean_kernel<false>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lean_lds);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(a.redo_n, 0, sizeof(int32_t), stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);
+    hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lean_lds, stream, a, span_cap);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((frame_kernel<false, true>), dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
+  hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
   return hipGetLastError();
 }
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
