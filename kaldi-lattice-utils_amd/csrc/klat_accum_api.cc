@@ -367,59 +367,93 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     if ((rc = st.num_expansions.alloc((size_t)b->U))) return rc;
     if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
     if ((rc = st.num_stored.alloc((size_t)b->U))) return rc;
+    if ((rc = st.rec_ptr.alloc((size_t)b->U))) return rc;
     a.num_stored = st.num_stored.p;
-    if (!std::getenv("KLAT_FRAME_GENERAL")) {  // (the general kernel alone: tests, comparisons)
-      if ((rc = st.redo.alloc((size_t)b->U + 1))) return rc;
-      a.redo_list = st.redo.p;
-      a.redo_n = st.redo.p + b->U;
-      a.ln_table = c->ln_table.p;
-    }
     a.num_frames = st.num_frames.p;
     a.num_expansions = st.num_expansions.p;
     a.num_records = st.num_records.p;
+    a.rec_ptr = st.rec_ptr.p;
+    a.arc_info = reinterpret_cast<FrameArc*>(st.arc_scratch.p);
     if (!st.ev[0]) {
       KLAT_HIP(hipEventCreate(&st.ev[0]));
       KLAT_HIP(hipEventCreate(&st.ev[1]));
     }
-    KLAT_HIP(hipEventRecord(st.ev[0], c->stream));
-    KLAT_HIP(launch_frame_count(a, (int)b->U, c->stream));
-    std::vector<int64_t> nexp((size_t)b->U);
-    if (b->U > 0)
-      KLAT_HIP(hipMemcpyAsync(nexp.data(), st.num_expansions.p, sizeof(int64_t) * (size_t)b->U,
-                              hipMemcpyDeviceToHost, c->stream));
-    KLAT_HIP(hipStreamSynchronize(c->stream));
-    std::vector<int64_t> off((size_t)b->U + 1, 0);
-    for (int64_t u = 0; u < b->U; ++u) {
-      if (nexp[u] > (int64_t)1 << 30) return set_error(KLAT_ERR_OOM, "lattice has more than 2^30 (frame,word) expansions");
-      off[u + 1] = off[u] + next_pow2(nexp[u]) + frame_sort_slots(b->h_arc_off[(size_t)u + 1] - b->h_arc_off[(size_t)u]);
-    }
-    if ((rc = st.scratch_off.upload(off.data(), off.size(), c->stream))) return rc;
-    if ((rc = st.key_scratch.alloc((size_t)off[b->U] * 16))) return rc;
-    if ((rc = st.rec_scratch.alloc((size_t)off[b->U] * 16))) return rc;
-    a.scratch_off = st.scratch_off.p;
-    a.key_scratch = st.key_scratch.p;
-    a.rec_scratch = st.rec_scratch.p;
-    a.arc_info = reinterpret_cast<FrameArc*>(st.arc_scratch.p);
     DevBuf<long long> d_clock;
     if (std::getenv("KLAT_ACCUM_PROFILE")) {
       if ((rc = d_clock.alloc((size_t)b->U * 8))) return rc;
       KLAT_HIP(hipMemsetAsync(d_clock.p, 0, sizeof(long long) * (size_t)b->U * 8, c->stream));
       a.phase_clock = d_clock.p;
     }
-    int64_t fr_max_arcs = 0;
-    for (int64_t u = 0; u < b->U; ++u) fr_max_arcs = std::max(fr_max_arcs, b->h_arc_off[u + 1] - b->h_arc_off[u]);
-    KLAT_HIP(launch_frame(a, (int)b->U, (int)std::min<int64_t>(fr_max_arcs, 1 << 30), c->stream));
-    if (a.phase_clock) {
+    auto print_clock = [&](const char* which) -> int {
+      if (!a.phase_clock) return KLAT_OK;
       std::vector<long long> clk((size_t)b->U * 8);
       KLAT_HIP(hipMemcpyAsync(clk.data(), d_clock.p, sizeof(long long) * clk.size(), hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipStreamSynchronize(c->stream));
       double sum[5] = {0};
       for (int64_t u = 0; u < b->U; ++u)
         for (int k = 0; k < 5; ++k) sum[k] += (double)clk[(size_t)u * 8 + k];
-      std::fprintf(stderr, "frame_kernel: mean shader cycles per workgroup over %lld lattices: spans %.0f  counts+scan %.0f  scatter %.0f  crowded %.0f  frames %.0f\n",
-                   (long long)b->U, sum[0] / b->U, sum[1] / b->U, sum[2] / b->U, sum[3] / b->U, sum[4] / b->U);
-      a.phase_clock = nullptr;
+      std::fprintf(stderr, "%s: mean shader cycles per workgroup over %lld lattices: spans %.0f  counts+scan %.0f  scatter %.0f  crowded %.0f  frames %.0f\n",
+                   which, (long long)b->U, sum[0] / b->U, sum[1] / b->U, sum[2] / b->U, sum[3] / b->U, sum[4] / b->U);
+      return KLAT_OK;
+    };
+    int64_t fr_max_arcs = 0;
+    for (int64_t u = 0; u < b->U; ++u) fr_max_arcs = std::max(fr_max_arcs, b->h_arc_off[u + 1] - b->h_arc_off[u]);
+    const int max_arcs = (int)std::min<int64_t>(fr_max_arcs, 1 << 30);
+    KLAT_HIP(hipEventRecord(st.ev[0], c->stream));
+    // The lean kernel first (csrc/klat_frame.hip): it takes its records from a pool sized by what the context's
+    // batches needed so far, so nothing counts the (frame, word) entries beforehand.  The lattices it lists --
+    // they do not fit it, or the pool was short -- go through the count pass and the general kernel.
+    const bool general_only = std::getenv("KLAT_FRAME_GENERAL") != nullptr;  // (tests, comparisons)
+    int32_t redo_n = (int32_t)b->U;
+    std::vector<int32_t> redo_list;
+    if (!general_only && b->U > 0) {
+      const double ratio = std::getenv("KLAT_FRAME_POOL_RATIO") ? std::atof(std::getenv("KLAT_FRAME_POOL_RATIO")) : c->frame_pool_ratio;  // (the variable: tests)
+      const int64_t cap = std::min<int64_t>(((int64_t)1 << 31) - 1, (int64_t)(ratio * (double)b->A) + 4096);
+      if ((rc = st.pool.alloc((size_t)cap))) return rc;
+      if ((rc = st.redo.alloc((size_t)b->U + 1))) return rc;
+      if ((rc = st.pool_used.alloc(1))) return rc;
+      a.pool = st.pool.p;
+      a.pool_cap = cap;
+      a.pool_used = st.pool_used.p;
+      a.redo_list = st.redo.p;
+      a.redo_n = st.redo.p + b->U;
+      a.ln_table = c->ln_table.p;
+      KLAT_HIP(hipMemsetAsync(a.redo_n, 0, sizeof(int32_t), c->stream));
+      KLAT_HIP(hipMemsetAsync(a.pool_used, 0, sizeof(unsigned long long), c->stream));
+      KLAT_HIP(launch_frame_lean(a, (int)b->U, max_arcs, c->stream));
+      if ((rc = print_clock("frame_lean_kernel"))) return rc;
+      unsigned long long used = 0;
+      KLAT_HIP(hipMemcpyAsync(&redo_n, a.redo_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipMemcpyAsync(&used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipStreamSynchronize(c->stream));
+      if ((int64_t)used > cap && b->A > 0) c->frame_pool_ratio = 1.1 * (double)used / (double)b->A;  // the next call's pool holds this batch
+      if (redo_n > 0) {
+        redo_list.resize((size_t)redo_n);
+        KLAT_HIP(hipMemcpyAsync(redo_list.data(), a.redo_list, sizeof(int32_t) * (size_t)redo_n, hipMemcpyDeviceToHost, c->stream));
+      }
     }
+    if (redo_n > 0) {
+      KLAT_HIP(launch_frame_count(a, (int)b->U, c->stream));
+      std::vector<int64_t> nexp((size_t)b->U);
+      KLAT_HIP(hipMemcpyAsync(nexp.data(), st.num_expansions.p, sizeof(int64_t) * (size_t)b->U, hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipStreamSynchronize(c->stream));
+      std::vector<uint8_t> listed((size_t)b->U, general_only ? 1 : 0);
+      for (int32_t u : redo_list) listed[(size_t)u] = 1;
+      std::vector<int64_t> off((size_t)b->U + 1, 0);
+      for (int64_t u = 0; u < b->U; ++u) {
+        if (nexp[u] > (int64_t)1 << 30) return set_error(KLAT_ERR_OOM, "lattice has more than 2^30 (frame,word) expansions");
+        off[u + 1] = off[u] + (listed[(size_t)u] ? next_pow2(nexp[u]) + frame_sort_slots(b->h_arc_off[(size_t)u + 1] - b->h_arc_off[(size_t)u]) : 0);
+      }
+      if ((rc = st.scratch_off.upload(off.data(), off.size(), c->stream))) return rc;
+      if ((rc = st.key_scratch.alloc((size_t)off[b->U] * 16))) return rc;
+      if ((rc = st.rec_scratch.alloc((size_t)off[b->U] * 16))) return rc;
+      a.scratch_off = st.scratch_off.p;
+      a.key_scratch = st.key_scratch.p;
+      a.rec_scratch = st.rec_scratch.p;
+      KLAT_HIP(launch_frame(a, (int)redo_n, max_arcs, c->stream));
+      if ((rc = print_clock("frame_kernel"))) return rc;
+    }
+    a.phase_clock = nullptr;
     KLAT_HIP(hipEventRecord(st.ev[1], c->stream));
     std::vector<int32_t> counts((size_t)b->U), stored((size_t)b->U);
     if (b->U > 0) {
@@ -444,8 +478,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
   const int64_t total = st.entry_off[b->U], T = st.frame_base[b->U];
   if (capacity < total) return set_error(KLAT_ERR_INVALID_ARG, "capacity too small");
   a.num_frames = st.num_frames.p;
-  a.scratch_off = st.scratch_off.p;
-  a.rec_scratch = st.rec_scratch.p;
+  a.rec_ptr = st.rec_ptr.p;
   a.frame_base = st.d_frame_base.p;
   a.frame_count = st.frame_count.p;
   a.frame_src = st.frame_src.p;

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     __syncthreads();
     FR_LAP(4);
   }
-  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase;
+  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = rec8;
   if (a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
@@ -884,7 +884,8 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   __shared__ int lboff[kLnTile + 1];  // first bucket entry of every rank of the tile
   __shared__ int lcur[kLnTile];       // scatter cursors
   __shared__ int sh[2 * NT / 64];
-  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks;
+  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries;
+  __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
   const int u = blockIdx.x;
   const int tid = threadIdx.x;
@@ -896,7 +897,6 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   const int64_t pb = padded_state_base(s0, u);
   const double tot = a.total[u];
   const int T = a.num_frames[u];
-  uint64_t* rec8 = reinterpret_cast<uint64_t*>(reinterpret_cast<FKey*>(a.rec_scratch) + a.scratch_off[u]);
   double* xs = reinterpret_cast<double*>(a.arc_info + a0);  // x of every arc (the front half of the lattice's rows)
   const int64_t fbase = a.frame_base[u];
   const ScaleParams sp = a.sp;
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     }                                                                  \
   } while (0)
   // ---- 0a. ranks: every thread owns kSt consecutive states ----
-  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unfit = 0;
+  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unfit = 0, entries = 0;
   {
     constexpr int kSt = kLnStates / NT;
     int tm[kSt], fl[kSt], mine = 0;
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   }
   const int nr = num_ranks;
   // ---- 0b. rank span and x of every arc; the label range of the lattice ----
-  int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0;
+  int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0, entries_t = 0;
   for (int base = 0; base < nA; base += kFrSpanBatch * NT) {  // eight arcs per thread at a time: loads batched, no branch around them
     int il[kFrSpanBatch], t0[kFrSpanBatch], t1[kFrSpanBatch];
     float gr[kFrSpanBatch], ac4[kFrSpanBatch];
@@ -993,21 +993,31 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
         // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
         x = (lp[q] > -INFINITY) ? lp[q] + ((double)g + (double)ac) - (double)(g + ac) : lp[q];
         span_max_t = max(span_max_t, r1 - t0[q]);
+        entries_t += r1 - t0[q];
       }
       xs[i] = x;
       lspan[i] = (uint32_t)t0[q] | ((uint32_t)r1 << 16);
     }
   }
   for (int d = 32; d > 0; d >>= 1) lmin_t = min(lmin_t, __shfl_xor(lmin_t, d, 64)), lmax_t = max(lmax_t, __shfl_xor(lmax_t, d, 64));
-  for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64));
-  if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t), atomicMax(&span_max, span_max_t);
+  for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64)), entries_t += __shfl_xor(entries_t, d, 64);
+  if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t), atomicMax(&span_max, span_max_t), atomicAdd(&entries, entries_t);
   __syncthreads();
   {  // the arcs' first ranks ascend with the arc number: a tile's arcs are one range of arcs
     bool desc = false;
     for (int i = tid + 1; i < nA; i += NT) desc |= (lspan[i] & 0xFFFFu) < (lspan[i - 1] & 0xFFFFu);
     if (__any(desc) && (tid & 63) == 0) atomicOr(&unfit, 1);
   }
+  // the lattice's records: at most one per (arc, rank) entry, taken from the batch's pool in one piece (so that
+  // nothing has to count the entries before this kernel); a pool that is short leaves the lattice to the general
+  // kernel, and the caller learns from pool_used what the next call needs
+  if (tid == 0) {
+    const unsigned long long at = atomicAdd(a.pool_used, (unsigned long long)entries);
+    if (at + (unsigned long long)entries > (unsigned long long)a.pool_cap) atomicOr(&unfit, 1);
+    rec_at = at;
+  }
   __syncthreads();  // (the ranks of the states are not read beyond this point: the buckets take their place)
+  uint64_t* rec8 = a.pool + rec_at;
   const int longest = span_max;
   // (label - lab_min) and the arc number fit one 32-bit sort key (0xFFFFFFFF stays free for padding), and the
   // label range 30 bits (the folded keys sort as doubles)
@@ -1186,7 +1196,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     __syncthreads();
     FR_LAP(4);
   }
-  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase;
+  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = rec8;
   if (CLOCK && a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
@@ -1202,7 +1212,7 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(FrameArgs a, const in
   __shared__ int sh[2 * kFrThreads / 64];
   const int u = blockIdx.x;
   const int lane = threadIdx.x & 63;
-  const uint64_t* rec8 = reinterpret_cast<const uint64_t*>(reinterpret_cast<const FKey*>(a.rec_scratch) + a.scratch_off[u]);
+  const uint64_t* rec8 = a.rec_ptr[u];
   const int64_t o = entry_off[u];
   const int64_t fb = frame_base[u];
   const int T = a.num_frames[u];
@@ -1241,24 +1251,28 @@ hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t 
   hipLaunchKernelGGL(frame_count_kernel, dim3(num_lattices), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
+static int frame_span_cap(int max_arcs) { return max_arcs < kFrLdsSpans ? (max_arcs > 0 ? max_arcs : 0) : kFrLdsSpans; }
+// the general kernel: every lattice, or (a.redo_list set) the lattices the lean kernel listed
 hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
   static_assert(sizeof(FKey) * kFrTile <= sizeof(uint16_t) * kFrLdsEntries, "the sort tile lies under the buckets");
-  static_assert(sizeof(uint16_t) * kLnStates <= sizeof(uint16_t) * kFrLdsEntries, "the states' ranks lie under the buckets");
-  const int span_cap = max_arcs < kFrLdsSpans ? (max_arcs > 0 ? max_arcs : 0) : kFrLdsSpans;
+  const int span_cap = frame_span_cap(max_arcs);
   const size_t lds = sizeof(uint16_t) * kFrLdsEntries + sizeof(uint32_t) * (size_t)span_cap;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  if (a.redo_list) {  // the lean kernel first; the general one over the lattices it lists
-    const size_t lean_lds = sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2) + sizeof(uint32_t) * (size_t)span_cap;
-    auto lean = a.phase_clock ? &frame_lean_kernel<true> : &frame_lean_kernel<false>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lean_lds);
-    if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(a.redo_n, 0, sizeof(int32_t), stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lean_lds, stream, a, span_cap);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-  }
   hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
+  return hipGetLastError();
+}
+// the lean kernel: needs neither scratch_off nor the scratch rows, takes its records from a.pool
+hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream) {
+  if (num_lattices <= 0) return hipSuccess;
+  static_assert(sizeof(uint16_t) * kLnStates <= sizeof(uint16_t) * kFrLdsEntries, "the states' ranks lie under the buckets");
+  const int span_cap = frame_span_cap(max_arcs);
+  const size_t lds = sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2) + sizeof(uint32_t) * (size_t)span_cap;
+  auto lean = a.phase_clock ? &frame_lean_kernel<true> : &frame_lean_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);
   return hipGetLastError();
 }
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,

@@ -171,6 +171,7 @@ struct DevBuf {
 }  // namespace klat
 
 struct klat_ctx {
+  double frame_pool_ratio = 4.0;  // records per arc the frame posteriors' pool is sized for: raised to what a batch asked for
   // A context lives until its handle AND every batch created on it are gone: a caller that destroys
   // the context first (a test fixture torn down while a failed test still holds its batch, an exit
   // handler closing things in the wrong order) must not leave the batches with a dangling stream --
@@ -219,6 +220,9 @@ struct klat_frame_state {
   int64_t stored_records = 0;  // records the last run stored (the (frame, word) entries share them)
   klat::DevBuf<int64_t> d_frame_base;
   klat::DevBuf<unsigned char> key_scratch, rec_scratch, arc_scratch;
+  klat::DevBuf<uint64_t> pool;             // the lean kernel's records (csrc/klat_frame.hip)
+  klat::DevBuf<unsigned long long> pool_used;
+  klat::DevBuf<const uint64_t*> rec_ptr;   // [U] where every lattice's records begin
 };
 
 struct klat_batch {

@@ -294,8 +294,20 @@ def test_frame_post_word_lattice(ctx, golden_dir):
     assert [int(x) for x in labels[off[9]:off[10]]] == [5]
 
 
+# the frame kernels: the lean one with the general one behind it (default), the general one alone, and a record
+# pool that holds the first few lattices only (the others go through the count pass and the general kernel)
+FRAME_MODES = {"lean": {}, "general": {"KLAT_FRAME_GENERAL": "1"}, "short_pool": {"KLAT_FRAME_POOL_RATIO": "0.2"}}
+
+
+@pytest.fixture(params=sorted(FRAME_MODES))
+def frame_mode(request, monkeypatch):
+    for k, v in FRAME_MODES[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
+
 @pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (1.0, 0.1, 0.5)])
-def test_frame_post_synthetic(ctx, scales):
+def test_frame_post_synthetic(ctx, scales, frame_mode):
     rng = np.random.RandomState(3)
     ns = np.concatenate([[1, 2], rng.randint(3, 300, size=30), [1500]]).astype(np.int32)
     fo = rng.choice([1, 2, 3, 4], size=len(ns)).astype(np.int32)
@@ -318,6 +330,46 @@ def test_frame_post_synthetic(ctx, scales):
         alpha, beta, total, _, _ = orc.alphas_betas(sl)
         t = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
         want, mis = orc.frame_post(sl, t, nframes[u], alpha, beta, total)
+        _check_frames(off, labels, logps, fb, want)
+        fb += nframes[u]
+    assert off[-1] == len(labels)
+
+
+@pytest.mark.parametrize("times", ["ties", "clipped", "descending"])
+def test_frame_post_state_times(ctx, times, frame_mode):
+    """The lean kernel works over the distinct state times: states that share a time share a rank, times beyond
+    num_frames (and below 0) are clipped as latbin/lattice-to-word-frame-post.cc:96-99 clips an arc's frames, and
+    a lattice whose times descend somewhere is left to the general kernel."""
+    rng = np.random.RandomState(11)
+    ns = np.concatenate([[1, 2, 3], rng.randint(4, 400, size=20)]).astype(np.int32)
+    fo = rng.choice([1, 2, 3], size=len(ns)).astype(np.int32)
+    arrays = klat_amd.synth(77, ns, fo)
+    arrays["ilabel"] = (arrays["ilabel"] % 40).astype(np.int32)
+    arrays["olabel"] = arrays["ilabel"].copy()
+    t = arrays["state_time"].copy()
+    nframes = []
+    for u in range(len(ns)):
+        lo, hi = arrays["state_off"][u], arrays["state_off"][u + 1]
+        if times == "ties":  # runs of states at one time, the first states among them
+            t[lo:hi] = (t[lo:hi] // 5) * 5
+            t[lo:hi] -= t[lo]
+        elif times == "clipped":  # some times below 0, the last states beyond num_frames
+            t[lo:hi] -= 3
+        elif times == "descending" and hi - lo > 3:
+            t[lo + 2] = t[lo + 1] - 1 if u % 2 else t[lo + 2]
+        last = int(t[hi - 1])
+        nframes.append(max(0, last - (4 if times == "clipped" else 0)))
+    arrays["state_time"] = t.astype(np.int32)
+    lats = _split(arrays)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward()
+    off, labels, logps = b.frame_post(nframes)
+    b.close()
+    fb = 0
+    for u, lat in enumerate(lats):
+        alpha, beta, total, _, _ = orc.alphas_betas(lat)
+        tt = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
+        want, _ = orc.frame_post(lat, tt, nframes[u], alpha, beta, total)
         _check_frames(off, labels, logps, fb, want)
         fb += nframes[u]
     assert off[-1] == len(labels)
