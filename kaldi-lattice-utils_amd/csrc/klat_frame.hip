@@ -860,6 +860,57 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
 #undef FR_LAP
 }
 
+// A rank of the lean kernel with more than kFrRegs (and at most 64) entries, by one wave: one lane per entry, both
+// sorts as bitonic networks across the lanes, the fold entry by entry in arc order; returns the records written.
+// (Rare, and kept out of line: inlined, its registers would be the lean kernel's.)
+__device__ __noinline__ int fr_lean_wide_rank(const uint16_t* bucket /* LDS */, int w, const int32_t* labels, const double* xs,
+                                          int lab_base, int abits, const LnTabEntry* lntab /* LDS */, uint64_t* out) {
+  const int lane = threadIdx.x & 63;
+  uint32_t key = 0xFFFFFFFFu;
+  double x = 0.0;
+  if (lane < w) {
+    const int arc = (int)bucket[lane];
+    key = (uint32_t)arc | ((uint32_t)(labels[arc] - lab_base) << abits);
+    x = xs[arc];
+  }
+  for (int size = 2; size <= 64; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const uint32_t okey = (uint32_t)__shfl_xor((int)key, stride, 64);
+      const double ox = __shfl_xor(x, stride, 64);
+      const bool up = (lane & size) == 0, lower = (lane & stride) == 0;
+      const bool take = (okey < key) == (up == lower);  // the lower lane of an ascending pair keeps the smaller key (keys are distinct; padding sorts last)
+      if (okey != key && take) key = okey, x = ox;
+    }
+  // entry by entry (wave-uniform trips): a run of one word is folded in arc order, its key emitted into lane m
+  double outk = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
+  int m = 0;
+  double acc = __shfl(x, 0, 64);
+  uint32_t lab = (uint32_t)__shfl((int)key, 0, 64) >> abits;
+  for (int j = 1; j <= w; ++j) {
+    const uint32_t lj = j < w ? (uint32_t)__shfl((int)key, j, 64) >> abits : 0xFFFFFFFFu;
+    const double xj = __shfl(x, j < w ? j : 0, 64);
+    if (lj == lab) {
+      acc = fr_log_add_fast(acc, xj, lntab);
+    } else {
+      if (lane == m) outk = __longlong_as_double((long long)(((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab));  // BaseFloat narrowing of :126
+      ++m;
+      acc = xj, lab = lj;
+    }
+  }
+  for (int size = 2; size <= 64; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const double o = __shfl_xor(outk, stride, 64);
+      const bool up = (lane & size) == 0, lower = (lane & stride) == 0;
+      const bool take_min = up == lower;
+      outk = take_min ? fmin(outk, o) : fmax(outk, o);
+    }
+  if (lane < m) {
+    const uint64_t kk = (uint64_t)__double_as_longlong(outk);
+    out[lane] = ((kk >> 30) << 32) | fr_bias((int32_t)(uint32_t)(kk & 0x3FFFFFFFull) + lab_base);
+  }
+  return m;
+}
+
 // ---- the lean kernel ----
 // Lattices whose state times do not descend with the state number, with at most kLnStates states, kFrLdsSpans
 // arcs and 65 535 frames, sort keys of 32 bits, and at most kFrRegs word arcs across any frame: on the
@@ -872,6 +923,8 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
 // launched behind this one over the list.
 static constexpr int kLnStates = 4096;  // states whose ranks (during the arc pass) and rank times stay in LDS
 static constexpr int kLnTile = 1024;    // ranks per tile
+static constexpr int kLnWideMax = 64;   // a rank with more than kFrRegs entries and at most this many is folded by a whole wave
+static constexpr int kLnWideList = 32;  // such ranks per tile
 
 template <bool CLOCK>
 __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a, int span_cap) {
@@ -884,7 +937,8 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   __shared__ int lboff[kLnTile + 1];  // first bucket entry of every rank of the tile
   __shared__ int lcur[kLnTile];       // scatter cursors
   __shared__ int sh[2 * NT / 64];
-  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries;
+  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, wide_dense;
+  __shared__ int wide_rank[kLnWideList], wide_dst[kLnWideList];
   __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
   const int u = blockIdx.x;
@@ -1041,7 +1095,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     const int tc = min(kLnTile, nr - c0);
     // ---- 1. entries per rank from a difference array over the spans, and the buckets' offsets ----
     for (int k = tid; k <= tc; k += NT) lboff[k] = 0;
-    if (tid == 0) tile_max = 0;
+    if (tid == 0) tile_max = 0, wide_n = 0, wide_dense = 0;
     auto first_at_least = [&](int rank) {  // first arc whose first rank is >= rank
       int l = 0, h = nA;
       while (l < h) {
@@ -1096,7 +1150,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       if ((tid & 63) == 0) atomicMax(&tile_max, cmax);
     }
     __syncthreads();
-    if (tile_max > kFrRegs || n > kFrLdsEntries) {  // workgroup-uniform
+    if (tile_max > kLnWideMax || n > kFrLdsEntries) {  // workgroup-uniform
       leave();
       return;
     }
@@ -1120,7 +1174,9 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     for (int r0 = 0; r0 < tc; r0 += NT) {
       const int k = r0 + tid;
       const int lo = (k < tc) ? lboff[k] : 0;
-      const int w = (k < tc) ? lboff[k + 1] - lo : 0;
+      const int w_all = (k < tc) ? lboff[k + 1] - lo : 0;
+      const bool wide = w_all > kFrRegs;  // (rare: left to a whole wave below; its slots are reserved here)
+      const int w = wide ? 0 : w_all;
       int mk = 0;
       // (every load below is unconditional: a load inside a branch waits for its data before the branch
       // closes, and sixteen gathers would take sixteen trips to L2 one after the other.  The slots beyond
@@ -1177,11 +1233,15 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
         fr_sortd_sizes<kFrRegs, 2>(dk);
       const int frame = (k < tc) ? (int)rtime[c0 + k] : 0, run = (k < tc) ? (int)rtime[c0 + k + 1] - frame : 0;
       int tot_st, tot_dense;
-      const int dst = mbase + fr_block_scan2<NT>(mk, mk * run, &tot_st, &tot_dense, sh).x;
+      const int dst = mbase + fr_block_scan2<NT>(wide ? w_all : mk, mk * run, &tot_st, &tot_dense, sh).x;
+      if (wide) {
+        const int slot = atomicAdd(&wide_n, 1);
+        if (slot < kLnWideList) wide_rank[slot] = k, wide_dst[slot] = dst;
+      }
       // 8 bytes per record -- desc(float logp) | biased label -- written ONCE per rank; every frame names its
       // records by (first record, count), so the frames up to the next rank share them, and the gather kernel
       // expands the runs into the dense output
-      for (int r = 0; r < run; ++r) {
+      for (int r = 0; r < (wide ? 0 : run); ++r) {
         a.frame_count[fbase + frame + r] = mk;
         a.frame_src[fbase + frame + r] = dst;
       }
@@ -1194,6 +1254,27 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       mbase += tot_st;
     }
     __syncthreads();
+    // ---- 3w. the ranks with more than kFrRegs entries, a wave each: one lane per entry, both sorts as bitonic
+    // networks across the lanes, the fold entry by entry in arc order ----
+    if (wide_n > kLnWideList) {  // workgroup-uniform
+      leave();
+      return;
+    }
+    for (int wi = tid >> 6; wi < wide_n; wi += NT / 64) {  // (wave-uniform)
+      const int lane = tid & 63;
+      const int k = wide_rank[wi], dst = wide_dst[wi];
+      const int lo = lboff[k], w = lboff[k + 1] - lo;  // kFrRegs < w <= kLnWideMax
+      const int m = fr_lean_wide_rank(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, rec8 + dst);
+      const int frame = (int)rtime[c0 + k], run = (int)rtime[c0 + k + 1] - frame;
+      for (int r = lane; r < run; r += 64) {
+        a.frame_count[fbase + frame + r] = m;
+        a.frame_src[fbase + frame + r] = dst;
+      }
+      if (lane == 0) atomicAdd(&wide_dense, m * run);
+    }
+    __syncthreads();
+    dense += wide_dense;
+    __syncthreads();  // (wide_dense is reset at the next tile's start)
     FR_LAP(4);
   }
   if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = rec8;
