@@ -923,6 +923,7 @@ __device__ __noinline__ int fr_lean_wide_rank(const uint16_t* bucket /* LDS */, 
 // launched behind this one over the list.
 static constexpr int kLnStates = 4096;  // states whose ranks (during the arc pass) and rank times stay in LDS
 static constexpr int kLnTile = 1024;    // ranks per tile
+static constexpr int kLnBatch = 6;      // arcs per thread and round of the arc pass
 static constexpr int kLnWideMax = 64;   // a rank with more than kFrRegs entries and at most this many is folded by a whole wave
 static constexpr int kLnWideList = 32;  // such ranks per tile
 
@@ -959,6 +960,11 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   };
   if (nA > span_cap || nA > 65535 || S > kLnStates || T > 65535) {
     leave();
+    return;
+  }
+  if (nA == 0) {  // nothing crosses any frame (and the unconditional loads below read the lattice's first arc)
+    for (int f = tid; f < T; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
+    if (tid == 0) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = a.pool;
     return;
   }
   long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, (unused), frames, (unused)
@@ -1007,51 +1013,73 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     return;
   }
   const int nr = num_ranks;
+  FR_LAP(3);
   // ---- 0b. rank span and x of every arc; the label range of the lattice ----
+  // At most two rounds of kLnBatch arcs per thread (nA <= span_cap <= 2 * kLnBatch * NT): the arrays of both rounds
+  // are asked for before anything waits, the gathers of alpha / beta follow round by round, and nothing is stored
+  // before the last load has landed (a store among pending loads makes every later wait a wait for all of them).
   int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0, entries_t = 0;
-  for (int base = 0; base < nA; base += kFrSpanBatch * NT) {  // eight arcs per thread at a time: loads batched, no branch around them
-    int il[kFrSpanBatch], t0[kFrSpanBatch], t1[kFrSpanBatch];
-    float gr[kFrSpanBatch], ac4[kFrSpanBatch];
-    double lp[kFrSpanBatch];
+  {
+    static_assert(2 * kLnBatch * NT >= kFrLdsSpans, "two rounds cover the arcs of a lean lattice");
+    int il[2][kLnBatch], t0[2][kLnBatch], t1[2][kLnBatch];
+    float gr[2][kLnBatch], ac4[2][kLnBatch];
+    double xq[2][kLnBatch];
+    const int last = nA - 1;
 #pragma unroll
-    for (int q = 0; q < kFrSpanBatch; ++q) {
-      const int i = min(base + q * NT + tid, nA - 1);
-      il[q] = a.ilabel[a0 + i];
-      t0[q] = a.src[a0 + i];
-      t1[q] = a.dst[a0 + i];
-      gr[q] = a.graph[a0 + i];
-      ac4[q] = a.acoustic[a0 + i];
-    }
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int q = 0; q < kFrSpanBatch; ++q) {
-      // fw[u] + bw[nextstate] - cost - total (latbin/lattice-to-word-frame-post.cc:102-104,122), formed
-      // here from alpha / beta: no posterior pass has to run before this kernel
-      const double through = a.alpha[pb + t0[q]] + a.beta[pb + t1[q]] - arc_cost(gr[q], ac4[q], il[q] != 0, sp);
-      lp[q] = (through > -INFINITY) ? through - tot : -INFINITY;
-      t0[q] = (int)lrank[t0[q]];
-      t1[q] = (int)lrank[t1[q]];
-    }
-#pragma unroll
-    for (int q = 0; q < kFrSpanBatch; ++q) {
-      const int i = base + q * NT + tid;
-      if (i >= nA) continue;
-      double x = 0.0;
-      int r1 = t0[q];  // (an empty span is kept as [r, r) at its source's rank: the first ranks of the arcs then ascend with the arc number)
-      if (il[q] != 0 && t1[q] > t0[q]) {
-        r1 = t1[q];
-        lmin_t = min(lmin_t, il[q]), lmax_t = max(lmax_t, il[q]);
-        // lp holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
-        // cost here as a float sum, so swap the double sum for the float one
-        float g, ac;
-        arc_cost_parts(gr[q], ac4[q], true, sp, g, ac);
-        // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
-        x = (lp[q] > -INFINITY) ? lp[q] + ((double)g + (double)ac) - (double)(g + ac) : lp[q];
-        span_max_t = max(span_max_t, r1 - t0[q]);
-        entries_t += r1 - t0[q];
+      for (int q = 0; q < kLnBatch; ++q) {
+        const int i = min((h * kLnBatch + q) * NT + tid, last);
+        il[h][q] = a.ilabel[a0 + i];
+        t0[h][q] = a.src[a0 + i];
+        t1[h][q] = a.dst[a0 + i];
+        gr[h][q] = a.graph[a0 + i];
+        ac4[h][q] = a.acoustic[a0 + i];
       }
-      xs[i] = x;
-      lspan[i] = (uint32_t)t0[q] | ((uint32_t)r1 << 16);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double al[kLnBatch], be[kLnBatch];
+#pragma unroll
+      for (int q = 0; q < kLnBatch; ++q) {
+        al[q] = a.alpha[pb + t0[h][q]];
+        be[q] = a.beta[pb + t1[h][q]];
+        t0[h][q] = (int)lrank[t0[h][q]];
+        t1[h][q] = (int)lrank[t1[h][q]];
+      }
+#pragma unroll
+      for (int q = 0; q < kLnBatch; ++q) {
+        // fw[u] + bw[nextstate] - cost - total (latbin/lattice-to-word-frame-post.cc:102-104,122), formed
+        // here from alpha / beta: no posterior pass has to run before this kernel
+        const double through = al[q] + be[q] - arc_cost(gr[h][q], ac4[h][q], il[h][q] != 0, sp);
+        const double lp = (through > -INFINITY) ? through - tot : -INFINITY;
+        double x = 0.0;
+        int r1 = t0[h][q];  // (an empty span is kept as [r, r) at its source's rank: the first ranks of the arcs then ascend with the arc number)
+        if ((h * kLnBatch + q) * NT + tid < nA && il[h][q] != 0 && t1[h][q] > t0[h][q]) {
+          r1 = t1[h][q];
+          lmin_t = min(lmin_t, il[h][q]), lmax_t = max(lmax_t, il[h][q]);
+          // lp holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
+          // cost here as a float sum, so swap the double sum for the float one
+          float g, ac;
+          arc_cost_parts(gr[h][q], ac4[h][q], true, sp, g, ac);
+          // (an arc of infinite cost is log-zero either way; the correction would be inf - inf)
+          x = (lp > -INFINITY) ? lp + ((double)g + (double)ac) - (double)(g + ac) : lp;
+          span_max_t = max(span_max_t, r1 - t0[h][q]);
+          entries_t += r1 - t0[h][q];
+        }
+        xq[h][q] = x;
+        t1[h][q] = r1;
+      }
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < kLnBatch; ++q) {
+        const int i = (h * kLnBatch + q) * NT + tid;
+        if (i < nA) {
+          xs[i] = xq[h][q];
+          lspan[i] = (uint32_t)t0[h][q] | ((uint32_t)t1[h][q] << 16);
+        }
+      }
   }
   for (int d = 32; d > 0; d >>= 1) lmin_t = min(lmin_t, __shfl_xor(lmin_t, d, 64)), lmax_t = max(lmax_t, __shfl_xor(lmax_t, d, 64));
   for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64)), entries_t += __shfl_xor(entries_t, d, 64);
@@ -1065,13 +1093,10 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   // the lattice's records: at most one per (arc, rank) entry, taken from the batch's pool in one piece (so that
   // nothing has to count the entries before this kernel); a pool that is short leaves the lattice to the general
   // kernel, and the caller learns from pool_used what the next call needs
-  if (tid == 0) {
-    const unsigned long long at = atomicAdd(a.pool_used, (unsigned long long)entries);
-    if (at + (unsigned long long)entries > (unsigned long long)a.pool_cap) atomicOr(&unfit, 1);
-    rec_at = at;
-  }
+  // (asked for here, looked at behind the first tile's counts: the atomic's trip to memory is not waited for)
+  unsigned long long my_at = 0;
+  if (tid == 0) my_at = atomicAdd(a.pool_used, (unsigned long long)entries);
   __syncthreads();  // (the ranks of the states are not read beyond this point: the buckets take their place)
-  uint64_t* rec8 = a.pool + rec_at;
   const int longest = span_max;
   // (label - lab_min) and the arc number fit one 32-bit sort key (0xFFFFFFFF stays free for padding), and the
   // label range 30 bits (the folded keys sort as doubles)
@@ -1108,6 +1133,10 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     // arcs that can cover a rank of the tile: first rank below the tile's end, and (no arc is longer than
     // `longest`) above its start less that
     const int arc_lo = first_at_least(c0 - longest + 1), arc_hi = first_at_least(c0 + tc);
+    if (c0 == 0 && tid == 0) {
+      rec_at = my_at;
+      if (my_at + (unsigned long long)entries > (unsigned long long)a.pool_cap) atomicOr(&unfit, 1);
+    }
     __syncthreads();
     for (int i = arc_lo + tid; i < arc_hi; i += NT) {
       const uint32_t sp32 = lspan[i];
@@ -1150,10 +1179,11 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       if ((tid & 63) == 0) atomicMax(&tile_max, cmax);
     }
     __syncthreads();
-    if (tile_max > kLnWideMax || n > kFrLdsEntries) {  // workgroup-uniform
+    if (tile_max > kLnWideMax || n > kFrLdsEntries || unfit) {  // workgroup-uniform
       leave();
       return;
     }
+    uint64_t* rec8 = a.pool + rec_at;
     FR_LAP(1);
     // ---- 2. every arc drops its number into the buckets of its ranks ----
     for (int i = arc_lo + tid; i < arc_hi; i += NT) {
@@ -1277,7 +1307,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     __syncthreads();  // (wide_dense is reset at the next tile's start)
     FR_LAP(4);
   }
-  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = rec8;
+  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = a.pool + (nr > 0 ? rec_at : 0ull);
   if (CLOCK && a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
