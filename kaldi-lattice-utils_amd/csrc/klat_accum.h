@@ -159,6 +159,7 @@ struct FrameArgs {
   unsigned long long* pool_used;  // [1] records asked for so far (also by the lattices the pool had no room for)
   int64_t pool_cap;
   const uint64_t** rec_ptr;   // [U] where a lattice's records begin (the pool, or its rows of rec_scratch)
+  int64_t* rec_fmt;           // [U] 0: desc(float logp) << 32 | biased label; 1 << 32 | lab_base: the lean kernel's keys
 };
 
 hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t stream);

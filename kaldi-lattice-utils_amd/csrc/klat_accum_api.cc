@@ -368,11 +368,13 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
     if ((rc = st.num_stored.alloc((size_t)b->U))) return rc;
     if ((rc = st.rec_ptr.alloc((size_t)b->U))) return rc;
+    if ((rc = st.rec_fmt.alloc((size_t)b->U))) return rc;
     a.num_stored = st.num_stored.p;
     a.num_frames = st.num_frames.p;
     a.num_expansions = st.num_expansions.p;
     a.num_records = st.num_records.p;
     a.rec_ptr = st.rec_ptr.p;
+    a.rec_fmt = st.rec_fmt.p;
     a.arc_info = reinterpret_cast<FrameArc*>(st.arc_scratch.p);
     if (!st.ev[0]) {
       KLAT_HIP(hipEventCreate(&st.ev[0]));
@@ -479,6 +481,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
   if (capacity < total) return set_error(KLAT_ERR_INVALID_ARG, "capacity too small");
   a.num_frames = st.num_frames.p;
   a.rec_ptr = st.rec_ptr.p;
+  a.rec_fmt = st.rec_fmt.p;
   a.frame_base = st.d_frame_base.p;
   a.frame_count = st.frame_count.p;
   a.frame_src = st.frame_src.p;

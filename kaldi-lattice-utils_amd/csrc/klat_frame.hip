@@ -854,7 +854,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
     __syncthreads();
     FR_LAP(4);
   }
-  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = rec8;
+  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = rec8, a.rec_fmt[u] = 0;
   if (a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
@@ -905,8 +905,7 @@ __device__ __noinline__ int fr_lean_wide_rank(const uint16_t* bucket /* LDS */, 
       outk = take_min ? fmin(outk, o) : fmax(outk, o);
     }
   if (lane < m) {
-    const uint64_t kk = (uint64_t)__double_as_longlong(outk);
-    out[lane] = ((kk >> 30) << 32) | fr_bias((int32_t)(uint32_t)(kk & 0x3FFFFFFFull) + lab_base);
+    out[lane] = (uint64_t)__double_as_longlong(outk);
   }
   return m;
 }
@@ -964,7 +963,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   }
   if (nA == 0) {  // nothing crosses any frame (and the unconditional loads below read the lattice's first arc)
     for (int f = tid; f < T; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
-    if (tid == 0) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = a.pool;
+    if (tid == 0) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = a.pool, a.rec_fmt[u] = 0;
     return;
   }
   long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, (unused), frames, (unused)
@@ -1252,9 +1251,12 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
         dk[j - 1] = __longlong_as_double((long long)(emit ? key : 0x7FEFFFFFFFFFFFFFull));
         mk += emit ? 1 : 0;
         if (j < kFrRegs) {
-          double folded = ex[j];
-          if (__any(cont)) folded = fr_log_add_fast(acc, ex[j], lntab);  // (skipped unless some frame of the wave has two arcs of one word here)
-          acc = cont ? folded : ex[j];
+          double next = ex[j];
+          if (__any(cont)) {  // (skipped unless some frame of the wave has two arcs of one word here)
+            const double folded = fr_log_add_fast(acc, ex[j], lntab);
+            next = cont ? folded : next;
+          }
+          acc = next;
         }
       }
       if (narrow)
@@ -1268,18 +1270,16 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
         const int slot = atomicAdd(&wide_n, 1);
         if (slot < kLnWideList) wide_rank[slot] = k, wide_dst[slot] = dst;
       }
-      // 8 bytes per record -- desc(float logp) | biased label -- written ONCE per rank; every frame names its
-      // records by (first record, count), so the frames up to the next rank share them, and the gather kernel
-      // expands the runs into the dense output
+      // 8 bytes per record -- the sort key itself, desc(float logp) << 30 | label - lab_base (rec_fmt tells the gather
+      // kernel) -- written ONCE per rank; every frame names its records by (first record, count), so the frames up
+      // to the next rank share them, and the gather kernel expands the runs into the dense output
       for (int r = 0; r < (wide ? 0 : run); ++r) {
         a.frame_count[fbase + frame + r] = mk;
         a.frame_src[fbase + frame + r] = dst;
       }
 #pragma unroll
-      for (int j = 0; j < kFrRegs; ++j) {
-        const uint64_t key = (uint64_t)__double_as_longlong(dk[j]);
-        if (j < mk) rec8[dst + j] = ((key >> 30) << 32) | fr_bias((int32_t)(uint32_t)(key & 0x3FFFFFFFull) + lab_base);
-      }
+      for (int j = 0; j < kFrRegs; ++j)
+        if (j < mk) rec8[dst + j] = (uint64_t)__double_as_longlong(dk[j]);
       dense += tot_dense;
       mbase += tot_st;
     }
@@ -1307,7 +1307,10 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     __syncthreads();  // (wide_dense is reset at the next tile's start)
     FR_LAP(4);
   }
-  if (tid == 0) a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = a.pool + (nr > 0 ? rec_at : 0ull);
+  if (tid == 0) {
+    a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = a.pool + (nr > 0 ? rec_at : 0ull);
+    a.rec_fmt[u] = ((int64_t)1 << 32) | (int64_t)(uint32_t)lab_base;  // the records are the sort keys themselves
+  }
   if (CLOCK && a.phase_clock && tid == 0)
     for (int k = 0; k < 5; ++k) a.phase_clock[(size_t)u * 8 + k] = clk[k];
 #undef FR_LAP
@@ -1324,6 +1327,7 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(FrameArgs a, const in
   const int u = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const uint64_t* rec8 = a.rec_ptr[u];
+  const int64_t fmt = a.rec_fmt[u];
   const int64_t o = entry_off[u];
   const int64_t fb = frame_base[u];
   const int T = a.num_frames[u];
@@ -1349,8 +1353,13 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(FrameArgs a, const in
       const int at = __shfl(src, g, 64) + (e - (__shfl(ex, g, 64) - first));
       if (e < count) {
         const uint64_t r = rec8[at];
-        labels[out + e] = fr_unbias((uint32_t)r);
-        logps[out + e] = fr_desc_unkey((uint32_t)(r >> 32));
+        if (fmt >> 32) {  // the lean kernel's records: desc(float logp) << 30 | label - lab_base
+          labels[out + e] = (int32_t)(uint32_t)(r & 0x3FFFFFFFull) + (int32_t)(uint32_t)fmt;
+          logps[out + e] = fr_desc_unkey((uint32_t)(r >> 30));
+        } else {
+          labels[out + e] = fr_unbias((uint32_t)r);
+          logps[out + e] = fr_desc_unkey((uint32_t)(r >> 32));
+        }
       }
     }
     carry += tot;

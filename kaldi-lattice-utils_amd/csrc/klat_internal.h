@@ -223,6 +223,7 @@ struct klat_frame_state {
   klat::DevBuf<uint64_t> pool;             // the lean kernel's records (csrc/klat_frame.hip)
   klat::DevBuf<unsigned long long> pool_used;
   klat::DevBuf<const uint64_t*> rec_ptr;   // [U] where every lattice's records begin
+  klat::DevBuf<int64_t> rec_fmt;           // [U] their format (klat_accum.h)
 };
 
 struct klat_batch {
