@@ -355,6 +355,37 @@ __device__ __forceinline__ void fr_sortd_sizes(double (&k)[kFrRegs]) {
   if constexpr (SIZE < N) fr_sortd_sizes<N, SIZE * 2>(k);
 }
 
+// Sixteen keys by the 60-comparator network of ten layers (the bitonic network above takes 80; checked over all
+// 2^16 zero-one inputs by tools/sort_net_check.py).  ce(lo, hi) leaves the smaller key in lo.
+template <class T, class CE>
+__device__ __forceinline__ void fr_sort16_net(T (&k)[kFrRegs], CE ce) {
+  static_assert(kFrRegs == 16, "the network is for sixteen keys");
+  ce(k[0], k[13]); ce(k[1], k[12]); ce(k[2], k[15]); ce(k[3], k[14]); ce(k[4], k[8]); ce(k[5], k[6]); ce(k[7], k[11]); ce(k[9], k[10]);
+  ce(k[0], k[5]); ce(k[1], k[7]); ce(k[2], k[9]); ce(k[3], k[4]); ce(k[6], k[13]); ce(k[8], k[14]); ce(k[10], k[15]); ce(k[11], k[12]);
+  ce(k[0], k[1]); ce(k[2], k[3]); ce(k[4], k[5]); ce(k[6], k[8]); ce(k[7], k[9]); ce(k[10], k[11]); ce(k[12], k[13]); ce(k[14], k[15]);
+  ce(k[0], k[2]); ce(k[1], k[3]); ce(k[4], k[10]); ce(k[5], k[11]); ce(k[6], k[7]); ce(k[8], k[9]); ce(k[12], k[14]); ce(k[13], k[15]);
+  ce(k[1], k[2]); ce(k[3], k[12]); ce(k[4], k[6]); ce(k[5], k[7]); ce(k[8], k[10]); ce(k[9], k[11]); ce(k[13], k[14]);
+  ce(k[1], k[4]); ce(k[2], k[6]); ce(k[5], k[8]); ce(k[7], k[10]); ce(k[9], k[13]); ce(k[11], k[14]);
+  ce(k[2], k[4]); ce(k[3], k[6]); ce(k[9], k[12]); ce(k[11], k[13]);
+  ce(k[3], k[5]); ce(k[6], k[8]); ce(k[7], k[9]); ce(k[10], k[12]);
+  ce(k[3], k[4]); ce(k[5], k[6]); ce(k[7], k[8]); ce(k[9], k[10]); ce(k[11], k[12]);
+  ce(k[6], k[7]); ce(k[8], k[9]);
+}
+struct FrCeU32 {
+  __device__ __forceinline__ void operator()(uint32_t& lo, uint32_t& hi) const {
+    const uint32_t a = min(lo, hi), b = max(lo, hi);
+    lo = a, hi = b;
+  }
+};
+struct FrCeF64 {  // (positive finite doubles as bit patterns: see fr_sortd_stage)
+  __device__ __forceinline__ void operator()(double& lo, double& hi) const {
+    double a, b;
+    asm("v_min_f64 %0, %1, %2" : "=v"(a) : "v"(lo), "v"(hi));
+    asm("v_max_f64 %0, %1, %2" : "=v"(b) : "v"(lo), "v"(hi));
+    lo = a, hi = b;
+  }
+};
+
 // Sorts a bucket of w entries by (label, arc), folds the runs of one label in arc order, sorts the
 // folded keys (desc(float logp) | label); returns their number.  E(j) is the j-th entry.
 template <class Entry>
@@ -937,8 +968,8 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   __shared__ int lboff[kLnTile + 1];  // first bucket entry of every rank of the tile
   __shared__ int lcur[kLnTile];       // scatter cursors
   __shared__ int sh[2 * NT / 64];
-  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, wide_dense;
-  __shared__ int wide_rank[kLnWideList], wide_dst[kLnWideList];
+  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, sum_stored, sum_dense;
+  __shared__ int wide_rank[kLnWideList];
   __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
   const int u = blockIdx.x;
@@ -977,7 +1008,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     }                                                                  \
   } while (0)
   // ---- 0a. ranks: every thread owns kSt consecutive states ----
-  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unfit = 0, entries = 0;
+  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unfit = 0, entries = 0, sum_stored = 0, sum_dense = 0;
   {
     constexpr int kSt = kLnStates / NT;
     int tm[kSt], fl[kSt], mine = 0;
@@ -1113,13 +1144,14 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   // the frames before the first rank hold nothing
   for (int f = tid, first = (nr > 0) ? (int)rtime[0] : T; f < first; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
   FR_LAP(0);
-  int mbase = 0;  // records written so far
-  int dense = 0;  // (frame, word) entries so far: every frame counts its records, shared or not
+  int nbase = 0;   // bucket entries of the tiles before this one
+  int stored = 0;  // records this thread wrote
+  int dense = 0;   // (frame, word) entries of its ranks: every frame counts its records, shared or not
   for (int c0 = 0; c0 < nr; c0 += kLnTile) {
     const int tc = min(kLnTile, nr - c0);
     // ---- 1. entries per rank from a difference array over the spans, and the buckets' offsets ----
     for (int k = tid; k <= tc; k += NT) lboff[k] = 0;
-    if (tid == 0) tile_max = 0, wide_n = 0, wide_dense = 0;
+    if (tid == 0) tile_max = 0, wide_n = 0;
     auto first_at_least = [&](int rank) {  // first arc whose first rank is >= rank
       int l = 0, h = nA;
       while (l < h) {
@@ -1212,7 +1244,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       // the bucket all read the lattice's first arc: one more request per instruction, not one per lane)
       uint32_t k32[kFrRegs];
 #pragma unroll
-      for (int j = 0; j < kFrRegs; ++j) k32[j] = (uint32_t)lbucket[min(lo + j, kFrLdsEntries - 1)];
+      for (int j = 0; j < kFrRegs; ++j) k32[j] = (uint32_t)lbucket[lo + j];  // (beyond the buckets lies rtime: read, not used)
 #pragma unroll
       for (int j = 0; j < kFrRegs; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
 #pragma unroll
@@ -1233,7 +1265,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       if (narrow)
         fr_sort32_sizes<8, 2>(k32);
       else
-        fr_sort32_sizes<kFrRegs, 2>(k32);
+        fr_sort16_net(k32, FrCeU32());
       double ex[kFrRegs];
 #pragma unroll
       for (int j = 0; j < kFrRegs; ++j) ex[j] = *reinterpret_cast<const double*>(x_row + ((j < w ? k32[j] & amask : 0u) << 3));
@@ -1262,13 +1294,14 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       if (narrow)
         fr_sortd_sizes<8, 2>(dk);
       else
-        fr_sortd_sizes<kFrRegs, 2>(dk);
+        fr_sort16_net(dk, FrCeF64());
       const int frame = (k < tc) ? (int)rtime[c0 + k] : 0, run = (k < tc) ? (int)rtime[c0 + k + 1] - frame : 0;
-      int tot_st, tot_dense;
-      const int dst = mbase + fr_block_scan2<NT>(wide ? w_all : mk, mk * run, &tot_st, &tot_dense, sh).x;
+      // the records of a rank go where its bucket's entries would (the lattice's piece of the pool has a slot per
+      // entry, and a rank has at most as many records as entries): no scan places them, the waves do not meet here
+      const int dst = nbase + lo;
       if (wide) {
         const int slot = atomicAdd(&wide_n, 1);
-        if (slot < kLnWideList) wide_rank[slot] = k, wide_dst[slot] = dst;
+        if (slot < kLnWideList) wide_rank[slot] = k;
       }
       // 8 bytes per record -- the sort key itself, desc(float logp) << 30 | label - lab_base (rec_fmt tells the gather
       // kernel) -- written ONCE per rank; every frame names its records by (first record, count), so the frames up
@@ -1280,8 +1313,8 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
 #pragma unroll
       for (int j = 0; j < kFrRegs; ++j)
         if (j < mk) rec8[dst + j] = (uint64_t)__double_as_longlong(dk[j]);
-      dense += tot_dense;
-      mbase += tot_st;
+      dense += mk * run;
+      stored += mk;
     }
     __syncthreads();
     // ---- 3w. the ranks with more than kFrRegs entries, a wave each: one lane per entry, both sorts as bitonic
@@ -1292,23 +1325,26 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     }
     for (int wi = tid >> 6; wi < wide_n; wi += NT / 64) {  // (wave-uniform)
       const int lane = tid & 63;
-      const int k = wide_rank[wi], dst = wide_dst[wi];
+      const int k = wide_rank[wi];
       const int lo = lboff[k], w = lboff[k + 1] - lo;  // kFrRegs < w <= kLnWideMax
+      const int dst = nbase + lo;
       const int m = fr_lean_wide_rank(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, rec8 + dst);
       const int frame = (int)rtime[c0 + k], run = (int)rtime[c0 + k + 1] - frame;
       for (int r = lane; r < run; r += 64) {
         a.frame_count[fbase + frame + r] = m;
         a.frame_src[fbase + frame + r] = dst;
       }
-      if (lane == 0) atomicAdd(&wide_dense, m * run);
+      if (lane == 0) dense += m * run, stored += m;
     }
+    nbase += n;
     __syncthreads();
-    dense += wide_dense;
-    __syncthreads();  // (wide_dense is reset at the next tile's start)
     FR_LAP(4);
   }
+  for (int d = 32; d > 0; d >>= 1) stored += __shfl_xor(stored, d, 64), dense += __shfl_xor(dense, d, 64);
+  if ((tid & 63) == 0) atomicAdd(&sum_stored, stored), atomicAdd(&sum_dense, dense);
+  __syncthreads();
   if (tid == 0) {
-    a.num_records[u] = dense, a.num_stored[u] = mbase, a.rec_ptr[u] = a.pool + (nr > 0 ? rec_at : 0ull);
+    a.num_records[u] = sum_dense, a.num_stored[u] = sum_stored, a.rec_ptr[u] = a.pool + (nr > 0 ? rec_at : 0ull);
     a.rec_fmt[u] = ((int64_t)1 << 32) | (int64_t)(uint32_t)lab_base;  // the records are the sort keys themselves
   }
   if (CLOCK && a.phase_clock && tid == 0)
