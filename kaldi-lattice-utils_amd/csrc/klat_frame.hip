@@ -181,7 +181,8 @@ __device__ void fr_bitonic_sort(FKey* data, int n, FKey* tile, Less less) {
 }
 
 // block-wide exclusive scan of one int per thread (NT threads)
-template <int NT = kFrThreads>
+// (TAIL = false: no barrier behind the last read of sh -- the caller does not write sh again before its next barrier)
+template <int NT = kFrThreads, bool TAIL = true>
 __device__ int fr_block_scan(int v, int* total, int* sh /* [NT/64] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
@@ -196,7 +197,7 @@ __device__ int fr_block_scan(int v, int* total, int* sh /* [NT/64] */) {
     if (w < wave) pre += sh[w];
     tot += sh[w];
   }
-  __syncthreads();
+  if (TAIL) __syncthreads();
   *total = tot;
   return pre + inc - v;
 }
@@ -1025,8 +1026,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       mine += fl[q];
     }
     int nr;
-    int r = fr_block_scan<NT>(mine, &nr, sh);
-    __syncthreads();  // (lab_min ... are set)
+    int r = fr_block_scan<NT, false>(mine, &nr, sh);  // (behind its barrier lab_min ... are set)
     if (__any(descends) && (tid & 63) == 0) atomicOr(&unfit, 1);
 #pragma unroll
     for (int q = 0; q < kSt; ++q) {
@@ -1115,18 +1115,16 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64)), entries_t += __shfl_xor(entries_t, d, 64);
   if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t), atomicMax(&span_max, span_max_t), atomicAdd(&entries, entries_t);
   __syncthreads();
-  {  // the arcs' first ranks ascend with the arc number: a tile's arcs are one range of arcs
-    bool desc = false;
-    for (int i = tid + 1; i < nA; i += NT) desc |= (lspan[i] & 0xFFFFu) < (lspan[i - 1] & 0xFFFFu);
-    if (__any(desc) && (tid & 63) == 0) atomicOr(&unfit, 1);
-  }
-  // the lattice's records: at most one per (arc, rank) entry, taken from the batch's pool in one piece (so that
+  // The arcs' first ranks ascend with the arc number -- a tile's arcs are one range of arcs -- because klat_batch_create
+  // takes only arcs grouped by ascending source (csrc/klat_pack.cc:378, csrc/klat_pack_device.hip:158) and the ranks
+  // do not descend with the state number.  (The ranks of the states are not read beyond this barrier: the buckets
+  // take their place.)
+  // The lattice's records: at most one per (arc, rank) entry, taken from the batch's pool in one piece (so that
   // nothing has to count the entries before this kernel); a pool that is short leaves the lattice to the general
-  // kernel, and the caller learns from pool_used what the next call needs
-  // (asked for here, looked at behind the first tile's counts: the atomic's trip to memory is not waited for)
+  // kernel, and the caller learns from pool_used what the next call needs.  Asked for here, looked at behind the
+  // first tile's counts: the atomic's trip to memory is not waited for.
   unsigned long long my_at = 0;
   if (tid == 0) my_at = atomicAdd(a.pool_used, (unsigned long long)entries);
-  __syncthreads();  // (the ranks of the states are not read beyond this point: the buckets take their place)
   const int longest = span_max;
   // (label - lab_min) and the arc number fit one 32-bit sort key (0xFFFFFFFF stays free for padding), and the
   // label range 30 bits (the folded keys sort as doubles)
@@ -1189,7 +1187,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
         sum_d += dl[q];
       }
       int tot_d;
-      int run = fr_block_scan<NT>(sum_d, &tot_d, sh);  // (all reads of the array are done)
+      int run = fr_block_scan<NT, false>(sum_d, &tot_d, sh);  // (all reads of the array are done)
       int sum_c = 0, cmax = 0;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
@@ -1198,7 +1196,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
         cmax = max(cmax, dl[q]);
         sum_c += dl[q];
       }
-      int off = fr_block_scan<NT>(sum_c, &n, sh);
+      int off = fr_block_scan<NT, false>(sum_c, &n, sh + NT / 64);
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
         const int k = tid * kCh + q;
