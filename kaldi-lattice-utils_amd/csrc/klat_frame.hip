@@ -5,6 +5,11 @@
 //   x = fw[src] + bw[dst] - (float)(Value1 + Value2)          (a FLOAT sum, :102-104)
 // then :121-135: logp = acc - total narrowed to float, per-frame sort by (logp desc, label asc).
 //
+// Two kernels.  frame_lean_kernel (below, "the lean kernel") takes the lattices that fit it -- on the synthetic
+// and the shipped lattices all of them -- and lists the others for frame_kernel, the general one, described
+// first: the lean kernel is the same plan over the lattice's distinct state times instead of its frames, with
+// its records out of a pool.
+//
 // One workgroup owns one lattice.  A frame holds only the few words whose arcs cross it, so the
 // (frame, word) expansions are bucketed by frame instead of sorted as a whole:
 //   0. every arc forms its clipped span and its x once (16 B per arc in scratch);
