@@ -465,6 +465,11 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   // the last frame_sort_slots(nA) record rows of the lattice are the cooperative sort's scratch
   FKey* tmp = recs + ((a.scratch_off[u + 1] - a.scratch_off[u]) - frame_sort_slots(nA));
 
+  if (nA == 0) {  // nothing crosses any frame (and the unconditional gathers of the frames phase read the lattice's first arc)
+    for (int f = tid; f < T; f += kFrThreads) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
+    if (tid == 0) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = rec8, a.rec_fmt[u] = 0;
+    return;
+  }
   const bool spans_lds = nA <= span_cap && T <= 65535;  // workgroup-uniform
   long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, crowded, frames, (unused)
   long long t_prev = (long long)__builtin_amdgcn_s_memtime();
@@ -771,13 +776,25 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
       if (in_lds && key32) {
         // sort keys (label - lab_base | arc number) in 32 bits: a compare-exchange is two instructions
         // and no payload moves; x is fetched by arc number after the sort
+        // (every load here is unconditional -- a load inside a branch waits for its data before the branch closes, and
+        // sixteen gathers would take sixteen trips to L2 one after the other; the slots beyond the bucket read the
+        // lattice's first arc.  nA > 0: the tile has a bucket entry)
         uint32_t k32[kFrRegs];
         const int lo = (k < nc) ? lboff[k] : 0;
+        const int wr = in_regs ? w : 0;
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) k32[j] = (in_regs && j < w) ? (uint32_t)lbucket[lo + j] : 0xFFFFFFFFu;
+        for (int j = 0; j < kFrRegs; ++j) k32[j] = (uint32_t)lbucket[min(lo + j, kFrLdsEntries - 1)];
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j)
-          if (k32[j] != 0xFFFFFFFFu) k32[j] |= (uint32_t)(a.ilabel[a0 + (int)k32[j]] - lab_base) << abits;  // gathers served by L2
+        for (int j = 0; j < kFrRegs; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
+#pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < wr) ? k32[j] : 0u;
+        {
+          int32_t lab[kFrRegs];
+#pragma unroll
+          for (int j = 0; j < kFrRegs; ++j) lab[j] = a.ilabel[a0 + (int)k32[j]];  // gathers served by L2
+#pragma unroll
+          for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < wr) ? (k32[j] | ((uint32_t)(lab[j] - lab_base) << abits)) : 0xFFFFFFFFu;
+        }
         narrow = __all(!in_regs || w <= 8);  // wave-uniform: the 8-wide network is enough
         if (narrow)
           fr_sort32_sizes<8, 2>(k32);
@@ -785,14 +802,13 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
           fr_sort32_sizes<kFrRegs, 2>(k32);
         const uint32_t amask = (1u << abits) - 1u;
 #pragma unroll
+        for (int j = 0; j < kFrRegs; ++j) ex[j] = ai[(k32[j] != 0xFFFFFFFFu) ? (int)(k32[j] & amask) : 0].x;
+#pragma unroll
         for (int j = 0; j < kFrRegs; ++j) {
-          ek[j] = ~0ull;
-          ex[j] = 0.0;
-          if (k32[j] != 0xFFFFFFFFu) {
-            const int arc = (int)(k32[j] & amask);
-            ek[j] = ((uint64_t)fr_bias((int32_t)(k32[j] >> abits) + lab_base) << 32) | (uint32_t)arc;
-            ex[j] = ai[arc].x;
-          }
+          const int arc = (int)(k32[j] & amask);
+          const bool real = k32[j] != 0xFFFFFFFFu;
+          ek[j] = real ? (((uint64_t)fr_bias((int32_t)(k32[j] >> abits) + lab_base) << 32) | (uint32_t)arc) : ~0ull;
+          ex[j] = real ? ex[j] : 0.0;
         }
       } else {
         if (in_lds) {
