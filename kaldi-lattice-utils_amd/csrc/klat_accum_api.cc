@@ -429,6 +429,9 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       KLAT_HIP(hipMemcpyAsync(&used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipStreamSynchronize(c->stream));
       if ((int64_t)used > cap && b->A > 0) c->frame_pool_ratio = 1.1 * (double)used / (double)b->A;  // the next call's pool holds this batch
+      if (a.phase_clock)
+        std::fprintf(stderr, "frame_lean_kernel: %d of %lld lattices left to the general kernel; %llu records asked of a pool of %lld\n",
+                     (int)redo_n, (long long)b->U, used, (long long)cap);
       if (redo_n > 0) {
         redo_list.resize((size_t)redo_n);
         KLAT_HIP(hipMemcpyAsync(redo_list.data(), a.redo_list, sizeof(int32_t) * (size_t)redo_n, hipMemcpyDeviceToHost, c->stream));

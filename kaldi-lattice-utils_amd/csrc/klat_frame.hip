@@ -964,9 +964,8 @@ __device__ __noinline__ int fr_lean_wide_rank(const uint16_t* bucket /* LDS */, 
 }
 
 // ---- the lean kernel ----
-// Lattices whose state times do not descend with the state number, with at most kLnStates states, kFrLdsSpans
-// arcs and 65 535 frames, sort keys of 32 bits, and at most kFrRegs word arcs across any frame: on the
-// synthetic and the shipped lattices, all of them.  Twice the threads and half the registers of the general
+// Lattices with at most kLnStates states, kFrLdsSpans arcs and 65 535 frames, sort keys of 32 bits, and at most
+// kLnWideMax word arcs across any frame: on the synthetic and the shipped lattices, all of them.  Twice the threads and half the registers of the general
 // kernel (four waves per SIMD), and the work laid out over the lattice's distinct state times instead of its
 // frames: a frame's posteriors differ from its predecessor's only where some arc starts or ends, i.e. at a state's
 // time, so the r-th distinct time below T (its RANK r) stands for the frames from there to the next one.  An arc
@@ -990,7 +989,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   __shared__ int lboff[kLnTile + 1];  // first bucket entry of every rank of the tile
   __shared__ int lcur[kLnTile];       // scatter cursors
   __shared__ int sh[2 * NT / 64];
-  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, sum_stored, sum_dense;
+  __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, sum_stored, sum_dense, descending;
   __shared__ int wide_rank[kLnWideList];
   __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
@@ -1030,7 +1029,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     }                                                                  \
   } while (0)
   // ---- 0a. ranks: every thread owns kSt consecutive states ----
-  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unfit = 0, entries = 0, sum_stored = 0, sum_dense = 0;
+  if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unfit = 0, entries = 0, sum_stored = 0, sum_dense = 0, descending = 0;
   {
     constexpr int kSt = kLnStates / NT;
     int tm[kSt], fl[kSt], mine = 0;
@@ -1048,7 +1047,9 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     }
     int nr;
     int r = fr_block_scan<NT, false>(mine, &nr, sh);  // (behind its barrier lab_min ... are set)
-    if (__any(descends) && (tid & 63) == 0) atomicOr(&unfit, 1);
+    if (__any(descends) && (tid & 63) == 0) atomicOr(&descending, 1);
+    // times that do not descend with the state number (the synthetic lattices; a top-sorted lattice need not be
+    // like that): a state opens a rank where its time exceeds its predecessor's
 #pragma unroll
     for (int q = 0; q < kSt; ++q) {
       const int s = sfirst + q;
@@ -1057,12 +1058,40 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       if (s < S) lrank[s] = (uint16_t)(r - (tm[q] < T ? 1 : 0));  // ranks whose time is below this state's
     }
     if (tid == 0) rtime[nr] = (uint16_t)T, num_ranks = nr;
+    __syncthreads();
+    if (descending) {  // (workgroup-uniform)
+      // any order of the times: a bit per frame that some state sits at, ranks by counting the bits below
+      uint32_t* bits = reinterpret_cast<uint32_t*>(lrank + kLnStates);   // [2048]: frames 0 .. 65535 (behind the ranks, under the buckets)
+      uint16_t* wpre = reinterpret_cast<uint16_t*>(bits + 2048);         // [2048]: bits set in the words before this one
+      constexpr int kW = 2048 / NT;
+      for (int w = tid; w < 2048; w += NT) bits[w] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kSt; ++q)
+        if (sfirst + q < S && tm[q] < T) atomicOr(&bits[tm[q] >> 5], 1u << (tm[q] & 31));
+      __syncthreads();
+      uint32_t wd[kW];
+      int cnt = 0;
+#pragma unroll
+      for (int q = 0; q < kW; ++q) wd[q] = bits[tid * kW + q], cnt += __popc(wd[q]);
+      int r2 = fr_block_scan<NT, false>(cnt, &nr, sh + NT / 64);
+#pragma unroll
+      for (int q = 0; q < kW; ++q) {
+        wpre[tid * kW + q] = (uint16_t)r2;
+        for (uint32_t m = wd[q]; m; m &= m - 1) rtime[r2++] = (uint16_t)((tid * kW + q) * 32 + __ffs((int)m) - 1);
+      }
+      if (tid == 0) rtime[nr] = (uint16_t)T, num_ranks = nr;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kSt; ++q) {
+        const int s = sfirst + q, t = tm[q];
+        if (s < S) lrank[s] = (uint16_t)(t < T ? (int)wpre[t >> 5] + __popc(bits[t >> 5] & ((1u << (t & 31)) - 1u)) : nr);
+      }
+      __syncthreads();
+    }
   }
-  __syncthreads();
-  if (unfit) {
-    leave();
-    return;
-  }
+  // descending times: the arcs' first ranks need not ascend with the arc number, every tile looks at all arcs
+  const bool ranged = descending == 0;
   const int nr = num_ranks;
   FR_LAP(3);
   // ---- 0b. rank span and x of every arc; the label range of the lattice ----
@@ -1136,9 +1165,9 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64)), entries_t += __shfl_xor(entries_t, d, 64);
   if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t), atomicMax(&span_max, span_max_t), atomicAdd(&entries, entries_t);
   __syncthreads();
-  // The arcs' first ranks ascend with the arc number -- a tile's arcs are one range of arcs -- because klat_batch_create
-  // takes only arcs grouped by ascending source (csrc/klat_pack.cc:378, csrc/klat_pack_device.hip:158) and the ranks
-  // do not descend with the state number.  (The ranks of the states are not read beyond this barrier: the buckets
+  // Where the times do not descend with the state number, the arcs' first ranks ascend with the arc number -- a tile's
+  // arcs are one range of arcs -- because klat_batch_create takes only arcs grouped by ascending source
+  // (csrc/klat_pack.cc:378, csrc/klat_pack_device.hip:158).  (The ranks of the states are not read beyond this barrier: the buckets
   // take their place.)
   // The lattice's records: at most one per (arc, rank) entry, taken from the batch's pool in one piece (so that
   // nothing has to count the entries before this kernel); a pool that is short leaves the lattice to the general
@@ -1182,7 +1211,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     };
     // arcs that can cover a rank of the tile: first rank below the tile's end, and (no arc is longer than
     // `longest`) above its start less that
-    const int arc_lo = first_at_least(c0 - longest + 1), arc_hi = first_at_least(c0 + tc);
+    const int arc_lo = ranged ? first_at_least(c0 - longest + 1) : 0, arc_hi = ranged ? first_at_least(c0 + tc) : nA;
     if (c0 == 0 && tid == 0) {
       rec_at = my_at;
       if (my_at + (unsigned long long)entries > (unsigned long long)a.pool_cap) atomicOr(&unfit, 1);
@@ -1441,7 +1470,7 @@ hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipS
 // the lean kernel: needs neither scratch_off nor the scratch rows, takes its records from a.pool
 hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
-  static_assert(sizeof(uint16_t) * kLnStates <= sizeof(uint16_t) * kFrLdsEntries, "the states' ranks lie under the buckets");
+  static_assert(sizeof(uint16_t) * kLnStates + 2048 * 6 <= sizeof(uint16_t) * kFrLdsEntries, "the states' ranks and the frame bits lie under the buckets");
   const int span_cap = frame_span_cap(max_arcs);
   const size_t lds = sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2) + sizeof(uint32_t) * (size_t)span_cap;
   auto lean = a.phase_clock ? &frame_lean_kernel<true> : &frame_lean_kernel<false>;

@@ -335,11 +335,11 @@ def test_frame_post_synthetic(ctx, scales, frame_mode):
     assert off[-1] == len(labels)
 
 
-@pytest.mark.parametrize("times", ["ties", "clipped", "descending"])
+@pytest.mark.parametrize("times", ["ties", "clipped", "descending", "jitter"])
 def test_frame_post_state_times(ctx, times, frame_mode):
     """The lean kernel works over the distinct state times: states that share a time share a rank, times beyond
     num_frames (and below 0) are clipped as latbin/lattice-to-word-frame-post.cc:96-99 clips an arc's frames, and
-    a lattice whose times descend somewhere is left to the general kernel."""
+    a lattice whose times descend somewhere gets its ranks from a bit per frame (and looks at all arcs per tile)."""
     rng = np.random.RandomState(11)
     ns = np.concatenate([[1, 2, 3], rng.randint(4, 400, size=20)]).astype(np.int32)
     fo = rng.choice([1, 2, 3], size=len(ns)).astype(np.int32)
@@ -357,6 +357,8 @@ def test_frame_post_state_times(ctx, times, frame_mode):
             t[lo:hi] -= 3
         elif times == "descending" and hi - lo > 3:
             t[lo + 2] = t[lo + 1] - 1 if u % 2 else t[lo + 2]
+        elif times == "jitter":  # any order: a top-sorted lattice's times need not ascend with the state number
+            t[lo:hi] = np.maximum(t[lo:hi] + rng.randint(-6, 7, size=hi - lo), 0)
         last = int(t[hi - 1])
         nframes.append(max(0, last - (4 if times == "clipped" else 0)))
     arrays["state_time"] = t.astype(np.int32)
