@@ -154,6 +154,8 @@ struct FrameArgs {
   int32_t* frame_src;         // [sum of num_frames] first record of the frame in the lattice's record rows
   int32_t* redo_list;         // [U] or null: the lattices the lean kernel leaves to the general one, ...
   int32_t* redo_n;            // [1] ... and their number
+  int32_t* redo2_list;        // [U], [1]: what the lean kernel's second instantiation (over redo_list) leaves in its turn
+  int32_t* redo2_n;
   const LnTabEntry* ln_table;  // [kLnTabSize] (klat_kernels.h), the lean kernel's LogAdd
   uint64_t* pool;             // the lean kernel's records, a lattice's in one piece
   unsigned long long* pool_used;  // [1] records asked for so far (also by the lattices the pool had no room for)
@@ -164,7 +166,7 @@ struct FrameArgs {
 
 hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t stream);
 hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream);
-hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream);
+hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, bool big, hipStream_t stream);
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
                                const int64_t* frame_base, int64_t* frame_off, int32_t* labels, float* logps,
                                hipStream_t stream);

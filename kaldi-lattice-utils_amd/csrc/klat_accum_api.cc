@@ -412,29 +412,43 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       const double ratio = std::getenv("KLAT_FRAME_POOL_RATIO") ? std::atof(std::getenv("KLAT_FRAME_POOL_RATIO")) : c->frame_pool_ratio;  // (the variable: tests)
       const int64_t cap = std::min<int64_t>(((int64_t)1 << 31) - 1, (int64_t)(ratio * (double)b->A) + 4096);
       if ((rc = st.pool.alloc((size_t)cap))) return rc;
-      if ((rc = st.redo.alloc((size_t)b->U + 1))) return rc;
+      if ((rc = st.redo.alloc(2 * (size_t)b->U + 2))) return rc;
       if ((rc = st.pool_used.alloc(1))) return rc;
       a.pool = st.pool.p;
       a.pool_cap = cap;
       a.pool_used = st.pool_used.p;
       a.redo_list = st.redo.p;
-      a.redo_n = st.redo.p + b->U;
+      a.redo_n = st.redo.p + 2 * b->U;
+      a.redo2_list = st.redo.p + b->U;
+      a.redo2_n = st.redo.p + 2 * b->U + 1;
       a.ln_table = c->ln_table.p;
-      KLAT_HIP(hipMemsetAsync(a.redo_n, 0, sizeof(int32_t), c->stream));
+      KLAT_HIP(hipMemsetAsync(a.redo_n, 0, 2 * sizeof(int32_t), c->stream));
       KLAT_HIP(hipMemsetAsync(a.pool_used, 0, sizeof(unsigned long long), c->stream));
-      KLAT_HIP(launch_frame_lean(a, (int)b->U, max_arcs, c->stream));
+      KLAT_HIP(launch_frame_lean(a, (int)b->U, max_arcs, false, c->stream));
       if ((rc = print_clock("frame_lean_kernel"))) return rc;
+      int32_t first_n = 0;
       unsigned long long used = 0;
-      KLAT_HIP(hipMemcpyAsync(&redo_n, a.redo_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipMemcpyAsync(&first_n, a.redo_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipMemcpyAsync(&used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipStreamSynchronize(c->stream));
+      redo_n = first_n;
+      if (first_n > 0) {  // larger lattices (spans in L2), and one more try for what else did not fit
+        KLAT_HIP(launch_frame_lean(a, (int)first_n, max_arcs, true, c->stream));
+        if ((rc = print_clock("frame_lean_kernel (second instantiation)"))) return rc;
+        KLAT_HIP(hipMemcpyAsync(&redo_n, a.redo2_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        KLAT_HIP(hipMemcpyAsync(&used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+        KLAT_HIP(hipStreamSynchronize(c->stream));
+      }
       if ((int64_t)used > cap && b->A > 0) c->frame_pool_ratio = 1.1 * (double)used / (double)b->A;  // the next call's pool holds this batch
       if (a.phase_clock)
-        std::fprintf(stderr, "frame_lean_kernel: %d of %lld lattices left to the general kernel; %llu records asked of a pool of %lld\n",
-                     (int)redo_n, (long long)b->U, used, (long long)cap);
+        std::fprintf(stderr, "frame_lean_kernel: %d of %lld lattices left by the first instantiation, %d to the general kernel; %llu records asked of a pool of %lld\n",
+                     (int)first_n, (long long)b->U, (int)redo_n, used, (long long)cap);
       if (redo_n > 0) {
         redo_list.resize((size_t)redo_n);
-        KLAT_HIP(hipMemcpyAsync(redo_list.data(), a.redo_list, sizeof(int32_t) * (size_t)redo_n, hipMemcpyDeviceToHost, c->stream));
+        KLAT_HIP(hipMemcpyAsync(redo_list.data(), a.redo2_list, sizeof(int32_t) * (size_t)redo_n, hipMemcpyDeviceToHost, c->stream));
+        // the general kernel reads its lattices from redo_list / redo_n
+        a.redo_list = a.redo2_list;
+        a.redo_n = a.redo2_n;
       }
     }
     if (redo_n > 0) {

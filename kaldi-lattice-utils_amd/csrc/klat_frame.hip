@@ -29,6 +29,8 @@
 //      are sorted by the whole workgroup first (bitonic network through an LDS tile).
 // The gather kernel lays the records out densely with per-frame offsets.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 
@@ -964,36 +966,45 @@ __device__ __noinline__ int fr_lean_wide_rank(const uint16_t* bucket /* LDS */, 
 }
 
 // ---- the lean kernel ----
-// Lattices with at most kLnStates states, kFrLdsSpans arcs and 65 535 frames, sort keys of 32 bits, and at most
-// kLnWideMax word arcs across any frame: on the synthetic and the shipped lattices, all of them.  Twice the threads and half the registers of the general
+// Lattices with at most kLnStates states, 65 535 arcs and 65 535 frames, sort keys of 32 bits, and at most
+// kLnWideMax word arcs across any frame: on the synthetic and the shipped lattices, all of them.  (Up to kFrLdsSpans
+// arcs and kLnStatesLds states the arcs' rank spans stay in LDS, beyond that in the lattice's scratch rows.)  Twice the threads and half the registers of the general
 // kernel (four waves per SIMD), and the work laid out over the lattice's distinct state times instead of its
 // frames: a frame's posteriors differ from its predecessor's only where some arc starts or ends, i.e. at a state's
 // time, so the r-th distinct time below T (its RANK r) stands for the frames from there to the next one.  An arc
 // covers the ranks [rank(src), rank(dst)); a tile is kLnTile ranks -- two full rounds of one thread per rank --
 // whatever the frames between them.  A lattice that does not fit is listed for the general kernel, which is
 // launched behind this one over the list.
-static constexpr int kLnStates = 4096;  // states whose ranks (during the arc pass) and rank times stay in LDS
+static constexpr int kLnStates = 8192;     // states of a lattice at most: their ranks lie under the buckets during the arc pass
+static constexpr int kLnStatesLds = 4096;  // ... and of a lattice whose spans stay in LDS: the rank times end where the spans begin
+static constexpr int kLnBlock = 128;       // ranks per entry of the table of first arcs (lattices whose spans lie in L2)
 static constexpr int kLnTile = 1024;    // ranks per tile
 static constexpr int kLnBatch = 6;      // arcs per thread and round of the arc pass
 static constexpr int kLnWideMax = 64;   // a rank with more than kFrRegs entries and at most this many is folded by a whole wave
 static constexpr int kLnWideList = 32;  // such ranks per tile
 
-template <bool CLOCK>
-__global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a, int span_cap) {
+// BIG: the instantiation for the lattices the first one lists (spans in L2, up to kLnStates states; whatever else did
+// not fit is tried once more and listed for the general kernel); the first one keeps the shorter code of a lattice
+// whose spans stay in LDS.
+template <bool BIG, bool CLOCK>
+__global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
   constexpr int NT = kFrLeanThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
   uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kFrLdsEntries]: a tile's buckets as arc numbers
   uint16_t* lrank = lbucket;                                 // [S]: rank of every state, during the arc pass only
-  uint16_t* rtime = reinterpret_cast<uint16_t*>(fr_smem + sizeof(uint16_t) * kFrLdsEntries);  // [kLnStates + 2]: the time of rank r; rtime[nr] = T
-  uint32_t* lspan = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2));  // [span_cap]: rank(src) | rank(dst) << 16
+  // [kLnStatesLds + 2], or into the spans' place for a lattice whose spans lie in L2: the time of rank r; rtime[nr] = T
+  uint16_t* rtime = reinterpret_cast<uint16_t*>(fr_smem + sizeof(uint16_t) * kFrLdsEntries);
+  uint32_t* lspan = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kFrLdsEntries + kLnStatesLds + 2));  // [span_cap]: rank(src) | rank(dst) << 16
   __shared__ int lboff[kLnTile + 1];  // first bucket entry of every rank of the tile
   __shared__ int lcur[kLnTile];       // scatter cursors
   __shared__ int sh[2 * NT / 64];
   __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, sum_stored, sum_dense, descending;
   __shared__ int wide_rank[kLnWideList];
+  __shared__ int blk_first[kLnStates / kLnBlock + 2];  // first arc whose first rank lies in or behind block b of kLnBlock ranks
   __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
-  const int u = blockIdx.x;
+  if (BIG && (int)blockIdx.x >= *a.redo_n) return;
+  const int u = BIG ? a.redo_list[blockIdx.x] : (int)blockIdx.x;
   const int tid = threadIdx.x;
   if (tid < kLnTabSize) lntab[tid] = a.ln_table[tid];  // (barriers follow before its first use)
   const int64_t a0 = a.arc_off[u];
@@ -1007,12 +1018,19 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   const int64_t fbase = a.frame_base[u];
   const ScaleParams sp = a.sp;
   auto leave = [&]() {  // (workgroup-uniform)
-    if (tid == 0) a.redo_list[atomicAdd(a.redo_n, 1)] = u;
+    if (tid == 0) {
+      if (BIG) a.redo2_list[atomicAdd(a.redo2_n, 1)] = u;
+      else a.redo_list[atomicAdd(a.redo_n, 1)] = u;
+    }
   };
-  if (nA > span_cap || nA > 65535 || S > kLnStates || T > 65535) {
+  if (nA > 65535 || S > kLnStates || T > 65535 || (!BIG && (nA > span_cap || S > kLnStatesLds))) {
     leave();
     return;
   }
+  // the spans of the arcs in LDS (two 16-bit ranks each), or -- more arcs or states than fit -- in the back half of
+  // the lattice's scratch rows (L2): the tiles then read them a batch per thread, and the rank times take their place
+  const bool spans_lds = BIG ? (nA <= span_cap && S <= kLnStatesLds) : true;  // workgroup-uniform
+  uint32_t* gspan = reinterpret_cast<uint32_t*>(xs + nA);
   if (nA == 0) {  // nothing crosses any frame (and the unconditional loads below read the lattice's first arc)
     for (int f = tid; f < T; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
     if (tid == 0) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = a.pool, a.rec_fmt[u] = 0;
@@ -1030,8 +1048,9 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   } while (0)
   // ---- 0a. ranks: every thread owns kSt consecutive states ----
   if (tid == 0) lab_min = 0x7FFFFFFF, lab_max = (int)0x80000000, span_max = 0, unfit = 0, entries = 0, sum_stored = 0, sum_dense = 0, descending = 0;
-  {
-    constexpr int kSt = kLnStates / NT;
+  if (tid < kLnStates / kLnBlock + 2) blk_first[tid] = nA;
+  auto rank_pass = [&](auto per_thread) {  // (two sizes: a thread of a small lattice should not walk sixteen states while three in four idle)
+    constexpr int kSt = decltype(per_thread)::value;
     int tm[kSt], fl[kSt], mine = 0;
     const int sfirst = tid * kSt;
     int prev = (sfirst > 0 && sfirst <= S) ? min(max(a.state_time[s0 + sfirst - 1], 0), T) : -1;
@@ -1089,18 +1108,23 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       }
       __syncthreads();
     }
-  }
+  };
+  if (!BIG || S <= kLnStatesLds)  // (workgroup-uniform)
+    rank_pass(std::integral_constant<int, kLnStatesLds / NT>());
+  else
+    rank_pass(std::integral_constant<int, kLnStates / NT>());
   // descending times: the arcs' first ranks need not ascend with the arc number, every tile looks at all arcs
   const bool ranged = descending == 0;
   const int nr = num_ranks;
   FR_LAP(3);
   // ---- 0b. rank span and x of every arc; the label range of the lattice ----
-  // At most two rounds of kLnBatch arcs per thread (nA <= span_cap <= 2 * kLnBatch * NT): the arrays of both rounds
-  // are asked for before anything waits, the gathers of alpha / beta follow round by round, and nothing is stored
-  // before the last load has landed (a store among pending loads makes every later wait a wait for all of them).
-  int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0, entries_t = 0;
-  {
-    static_assert(2 * kLnBatch * NT >= kFrLdsSpans, "two rounds cover the arcs of a lean lattice");
+  // Two rounds of kLnBatch arcs per thread at a time (one trip of the loop for a lattice whose spans stay in LDS): the
+  // arrays of both rounds are asked for before anything waits, the gathers of alpha / beta follow round by round, and
+  // nothing is stored before the last load has landed (a store among pending loads makes every later wait a wait
+  // for all of them).
+  for (int base = 0; base < (BIG ? nA : 1); base += 2 * kLnBatch * NT) {
+    int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0, entries_t = 0;  // (reduced at the end of the trip: nothing of a thread's lives across trips)
+    static_assert(2 * kLnBatch * NT >= kFrLdsSpans, "one trip covers the arcs of a lattice whose spans stay in LDS");
     int il[2][kLnBatch], t0[2][kLnBatch], t1[2][kLnBatch];
     float gr[2][kLnBatch], ac4[2][kLnBatch];
     double xq[2][kLnBatch];
@@ -1109,7 +1133,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int q = 0; q < kLnBatch; ++q) {
-        const int i = min((h * kLnBatch + q) * NT + tid, last);
+        const int i = min(base + (h * kLnBatch + q) * NT + tid, last);
         il[h][q] = a.ilabel[a0 + i];
         t0[h][q] = a.src[a0 + i];
         t1[h][q] = a.dst[a0 + i];
@@ -1134,7 +1158,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
         const double lp = (through > -INFINITY) ? through - tot : -INFINITY;
         double x = 0.0;
         int r1 = t0[h][q];  // (an empty span is kept as [r, r) at its source's rank: the first ranks of the arcs then ascend with the arc number)
-        if ((h * kLnBatch + q) * NT + tid < nA && il[h][q] != 0 && t1[h][q] > t0[h][q]) {
+        if (base + (h * kLnBatch + q) * NT + tid < nA && il[h][q] != 0 && t1[h][q] > t0[h][q]) {
           r1 = t1[h][q];
           lmin_t = min(lmin_t, il[h][q]), lmax_t = max(lmax_t, il[h][q]);
           // lp holds alpha - (double)g - (double)a + beta - total; the reference forms the arc
@@ -1150,20 +1174,38 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
         t1[h][q] = r1;
       }
     }
+    if (spans_lds) {  // (workgroup-uniform)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int q = 0; q < kLnBatch; ++q) {
-        const int i = (h * kLnBatch + q) * NT + tid;
-        if (i < nA) {
-          xs[i] = xq[h][q];
-          lspan[i] = (uint32_t)t0[h][q] | ((uint32_t)t1[h][q] << 16);
+        for (int q = 0; q < kLnBatch; ++q) {
+          const int i = base + (h * kLnBatch + q) * NT + tid;
+          if (i < nA) {
+            xs[i] = xq[h][q];
+            lspan[i] = (uint32_t)t0[h][q] | ((uint32_t)t1[h][q] << 16);
+          }
         }
-      }
+    } else {
+      // spans to L2, and the table of first arcs per block of ranks: the lanes of a wave hold consecutive arcs, the
+      // first lane of every run of one block speaks for it (where the first ranks ascend with the arc number)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < kLnBatch; ++q) {
+          const int i = base + (h * kLnBatch + q) * NT + tid;
+          const int blk = t0[h][q] / kLnBlock;
+          const int before = __shfl_up(blk, 1, 64);
+          if (i < nA) {
+            xs[i] = xq[h][q];
+            gspan[i] = (uint32_t)t0[h][q] | ((uint32_t)t1[h][q] << 16);
+            if ((tid & 63) == 0 || before != blk) atomicMin(&blk_first[blk], i);
+          }
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) lmin_t = min(lmin_t, __shfl_xor(lmin_t, d, 64)), lmax_t = max(lmax_t, __shfl_xor(lmax_t, d, 64));
+    for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64)), entries_t += __shfl_xor(entries_t, d, 64);
+    if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t), atomicMax(&span_max, span_max_t), atomicAdd(&entries, entries_t);
   }
-  for (int d = 32; d > 0; d >>= 1) lmin_t = min(lmin_t, __shfl_xor(lmin_t, d, 64)), lmax_t = max(lmax_t, __shfl_xor(lmax_t, d, 64));
-  for (int d = 32; d > 0; d >>= 1) span_max_t = max(span_max_t, __shfl_xor(span_max_t, d, 64)), entries_t += __shfl_xor(entries_t, d, 64);
-  if ((tid & 63) == 0) atomicMin(&lab_min, lmin_t), atomicMax(&lab_max, lmax_t), atomicMax(&span_max, span_max_t), atomicAdd(&entries, entries_t);
   __syncthreads();
   // Where the times do not descend with the state number, the arcs' first ranks ascend with the arc number -- a tile's
   // arcs are one range of arcs -- because klat_batch_create takes only arcs grouped by ascending source
@@ -1175,6 +1217,11 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
   // first tile's counts: the atomic's trip to memory is not waited for.
   unsigned long long my_at = 0;
   if (tid == 0) my_at = atomicAdd(a.pool_used, (unsigned long long)entries);
+  if (!spans_lds) {  // (workgroup-uniform) a block in which no arc begins takes the next block's first arc
+    if (tid == 0)
+      for (int k = kLnStates / kLnBlock; k >= 0; --k) blk_first[k] = min(blk_first[k], blk_first[k + 1]);
+    __syncthreads();
+  }
   const int longest = span_max;
   // (label - lab_min) and the arc number fit one 32-bit sort key (0xFFFFFFFF stays free for padding), and the
   // label range 30 bits (the folded keys sort as doubles)
@@ -1200,7 +1247,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     // ---- 1. entries per rank from a difference array over the spans, and the buckets' offsets ----
     for (int k = tid; k <= tc; k += NT) lboff[k] = 0;
     if (tid == 0) tile_max = 0, wide_n = 0;
-    auto first_at_least = [&](int rank) {  // first arc whose first rank is >= rank
+    auto first_at_least = [&](int rank) {  // first arc whose first rank is >= rank (spans in LDS)
       int l = 0, h = nA;
       while (l < h) {
         const int mid = (l + h) >> 1;
@@ -1210,15 +1257,30 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
       return l;
     };
     // arcs that can cover a rank of the tile: first rank below the tile's end, and (no arc is longer than
-    // `longest`) above its start less that
-    const int arc_lo = ranged ? first_at_least(c0 - longest + 1) : 0, arc_hi = ranged ? first_at_least(c0 + tc) : nA;
+    // `longest`) above its start less that -- by binary search over the spans in LDS, or to the block of ranks
+    // from the table of first arcs; all arcs where the first ranks do not ascend
+    int arc_lo = 0, arc_hi = nA;
+    if (ranged && spans_lds) arc_lo = first_at_least(c0 - longest + 1), arc_hi = first_at_least(c0 + tc);
+    if (ranged && !spans_lds) arc_lo = blk_first[max(c0 - longest + 1, 0) / kLnBlock], arc_hi = blk_first[(c0 + tc + kLnBlock - 1) / kLnBlock];
     if (c0 == 0 && tid == 0) {
       rec_at = my_at;
       if (my_at + (unsigned long long)entries > (unsigned long long)a.pool_cap) atomicOr(&unfit, 1);
     }
+    // the spans of the tile's arcs in LDS: where they are anyway, or -- a lattice whose spans lie in L2 -- staged behind
+    // the rank times, in the place the spans of a smaller lattice would have (one coalesced trip per tile)
+    uint32_t* stage = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2));
+    const int stage_cap = (int)((sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap) / sizeof(uint32_t)) -
+                          (int)(sizeof(uint16_t) * (kLnStates + 2) / sizeof(uint32_t));
+    if (!spans_lds && arc_hi - arc_lo > stage_cap) {  // (workgroup-uniform; also a larger lattice whose first ranks do not ascend)
+      leave();
+      return;
+    }
+    const uint32_t* tspan = spans_lds ? lspan : stage - arc_lo;  // tspan[i]: the span of arc i, arc_lo <= i < arc_hi
+    if (!spans_lds)
+      for (int i = arc_lo + tid; i < arc_hi; i += NT) stage[i - arc_lo] = gspan[i];
     __syncthreads();
     for (int i = arc_lo + tid; i < arc_hi; i += NT) {
-      const uint32_t sp32 = lspan[i];
+      const uint32_t sp32 = tspan[i];
       const int lo = max((int)(sp32 & 0xFFFFu), c0) - c0, hi = min((int)(sp32 >> 16), c0 + tc) - c0;
       if (hi > lo) {
         atomicAdd(&lboff[lo], 1);
@@ -1266,7 +1328,7 @@ __global__ __launch_bounds__(kFrLeanThreads) void frame_lean_kernel(FrameArgs a,
     FR_LAP(1);
     // ---- 2. every arc drops its number into the buckets of its ranks ----
     for (int i = arc_lo + tid; i < arc_hi; i += NT) {
-      const uint32_t sp32 = lspan[i];
+      const uint32_t sp32 = tspan[i];
       const int lo = max((int)(sp32 & 0xFFFFu), c0) - c0, hi = min((int)(sp32 >> 16), c0 + tc) - c0;
       for (int c = lo; c < hi; c += 4) {  // four cursors at a time: the atomics' round trips overlap
         int at[4];
@@ -1467,13 +1529,17 @@ hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipS
   hipLaunchKernelGGL(frame_kernel, dim3(num_lattices), dim3(kFrThreads), lds, stream, a, span_cap);
   return hipGetLastError();
 }
-// the lean kernel: needs neither scratch_off nor the scratch rows, takes its records from a.pool
-hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream) {
+// the lean kernel: needs neither scratch_off nor the scratch rows, takes its records from a.pool.  big: its second
+// instantiation over the lattices the first one listed (a.redo_list); it lists what it leaves in a.redo2_list
+hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, bool big, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
   static_assert(sizeof(uint16_t) * kLnStates + 2048 * 6 <= sizeof(uint16_t) * kFrLdsEntries, "the states' ranks and the frame bits lie under the buckets");
   const int span_cap = frame_span_cap(max_arcs);
-  const size_t lds = sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2) + sizeof(uint32_t) * (size_t)span_cap;
-  auto lean = a.phase_clock ? &frame_lean_kernel<true> : &frame_lean_kernel<false>;
+  // buckets, rank times, spans; a lattice whose spans lie in L2 has up to kLnStates + 1 rank times where the spans would be
+  const size_t lds = sizeof(uint16_t) * kFrLdsEntries + std::max(sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap,
+                                                                 sizeof(uint16_t) * (kLnStates + 2));
+  auto lean = big ? (a.phase_clock ? &frame_lean_kernel<true, true> : &frame_lean_kernel<true, false>)
+                  : (a.phase_clock ? &frame_lean_kernel<false, true> : &frame_lean_kernel<false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);

@@ -8,8 +8,9 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
 import klat_amd
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 ctx = klat_amd.Ctx(0)
-arrays = klat_amd.synth(20260001, np.full(U, 2000, np.int32), np.full(U, 3, np.int32), host_threads=16)
+arrays = klat_amd.synth(20260001, np.full(U, S, np.int32), np.full(U, 3, np.int32), host_threads=16)
 b = klat_amd.Batch(ctx, arrays, host_threads=16)
 b.forward_backward(1.0, 0.1, 0.0)
 L = klat_amd.lib()
