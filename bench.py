@@ -157,7 +157,7 @@ def median(xs):
     return float(np.median(np.asarray(xs, dtype=np.float64))) if len(xs) else 0.0
 
 
-def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=30, warm=100, wide=0, lanes=0):
+def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=30, warm=100, wide=0, lanes=0, frames=False):
     """sweep / step time of one more batch shape on this GPU (medians over `steps` steps).  A batch
     of few lattices that are far wider than deep runs on the level path (klat_level.hip); for such
     a batch the time through the streams (lanes fixed by the caller) is reported beside it.  (A hundred untimed
@@ -186,6 +186,20 @@ def time_shape(ctx, klat_amd, name, seed, ns, fo, host_threads, steps=30, warm=1
            "sweep_frac": (32.0 * A + 32.0 * S) / (sweep * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "step_frac": (56.0 * A + 48.0 * S) / (step * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "fwd_bwd_totals_agree": ok}
+    if frames:  # frame posteriors (latbin/lattice-to-word-frame-post.cc:93-135) on this shape too: larger lattices than C2's
+        import ctypes as C
+        L = klat_amd.lib()
+        nf = arrays["state_time"][arrays["state_off"][1:] - 1].astype(np.int32)
+        foff = np.zeros(int(nf.sum()) + 1, np.int64)
+        ne, fms, stored, fr = C.c_int64(0), C.c_float(0), C.c_int64(0), []
+        for _ in range(3):
+            klat_amd._check(L.klat_frame_post(b.h, klat_amd._p(nf), klat_amd._p(foff), None, None, C.c_int64(0), C.byref(ne)))
+            klat_amd._check(L.klat_get_accum_timings(b.h, None, C.byref(fms)))
+            fr.append(fms.value)
+        klat_amd._check(L.klat_frame_stored_records(b.h, C.byref(stored)))
+        fr_bytes = 28.0 * A + 4.0 * S + 8.0 * stored.value + 8.0 * int(nf.sum())  # (as in accumulate_leg)
+        out["frame_ms"], out["frame_entries"], out["frame_records_stored"] = median(fr), ne.value, stored.value
+        out["frame_frac"] = fr_bytes / (median(fr) * 1e-3) / 1e9 / HBM_PEAK_GBS
     b.close()
     if info["level_lattices"] and lanes == 0:
         out["level_lattices"] = info["level_lattices"]
@@ -764,7 +778,7 @@ def main():
                 ("one lattice of 20000 states x fanout 3 (the longest of the configs[4] mix on its own)", 20260008,
                  np.full(1, 20000, np.int32), np.full(1, 3, np.int32), 0)):
             try:
-                shapes.append(time_shape(ctx, klat_amd, name, seed, sn, sf, host_threads, wide=wide))
+                shapes.append(time_shape(ctx, klat_amd, name, seed, sn, sf, host_threads, wide=wide, frames=name.startswith("C4/8")))
             except Exception as e:  # a shape that fails must not take the headline with it
                 shapes.append({"workload": name, "error": str(e)[:300]})
         out["shapes"] = shapes
