@@ -1242,8 +1242,17 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
   int nbase = 0;   // bucket entries of the tiles before this one
   int stored = 0;  // records this thread wrote
   int dense = 0;   // (frame, word) entries of its ranks: every frame counts its records, shared or not
-  for (int c0 = 0; c0 < nr; c0 += kLnTile) {
-    const int tc = min(kLnTile, nr - c0);
+  // ranks per tile: kLnTile, or -- spans in L2, a tile's arcs staged in LDS -- as many blocks of kLnBlock ranks as keep
+  // the arcs of a tile (with a block and the longest span before it) inside the stage
+  const int stage_cap = (int)((sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap) / sizeof(uint32_t)) -
+                        (int)(sizeof(uint16_t) * (kLnStates + 2) / sizeof(uint32_t));
+  int tile_ranks = kLnTile;
+  if (!spans_lds && ranged && nr > 0) {
+    const long long fit = (long long)max(stage_cap, 0) * nr / nA - kLnBlock - longest;  // ranks whose arcs fill the stage, less the slack
+    tile_ranks = (int)max((long long)kLnBlock, min((long long)kLnTile, fit / kLnBlock * kLnBlock));
+  }
+  for (int c0 = 0; c0 < nr; c0 += tile_ranks) {
+    const int tc = min(tile_ranks, nr - c0);
     // ---- 1. entries per rank from a difference array over the spans, and the buckets' offsets ----
     for (int k = tid; k <= tc; k += NT) lboff[k] = 0;
     if (tid == 0) tile_max = 0, wide_n = 0;
@@ -1267,27 +1276,31 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
       if (my_at + (unsigned long long)entries > (unsigned long long)a.pool_cap) atomicOr(&unfit, 1);
     }
     // the spans of the tile's arcs in LDS: where they are anyway, or -- a lattice whose spans lie in L2 -- staged behind
-    // the rank times, in the place the spans of a smaller lattice would have (one coalesced trip per tile)
+    // the rank times, in the place the spans of a smaller lattice would have: one coalesced trip per tile as a rule, one
+    // per stage-full of arcs where a tile has more (a larger lattice whose first ranks do not ascend looks at all arcs)
     uint32_t* stage = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2));
-    const int stage_cap = (int)((sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap) / sizeof(uint32_t)) -
-                          (int)(sizeof(uint16_t) * (kLnStates + 2) / sizeof(uint32_t));
-    if (!spans_lds && arc_hi - arc_lo > stage_cap) {  // (workgroup-uniform; also a larger lattice whose first ranks do not ascend)
+    if (!spans_lds && stage_cap < NT) {  // (workgroup-uniform: no stage to speak of)
       leave();
       return;
     }
-    const uint32_t* tspan = spans_lds ? lspan : stage - arc_lo;  // tspan[i]: the span of arc i, arc_lo <= i < arc_hi
-    if (!spans_lds)
-      for (int i = arc_lo + tid; i < arc_hi; i += NT) stage[i - arc_lo] = gspan[i];
-    __syncthreads();
-    for (int i = arc_lo + tid; i < arc_hi; i += NT) {
-      const uint32_t sp32 = tspan[i];
-      const int lo = max((int)(sp32 & 0xFFFFu), c0) - c0, hi = min((int)(sp32 >> 16), c0 + tc) - c0;
-      if (hi > lo) {
-        atomicAdd(&lboff[lo], 1);
-        atomicAdd(&lboff[hi], -1);
+    const int chunk = spans_lds ? max(arc_hi - arc_lo, 1) : stage_cap;  // arcs per trip
+    const bool one_trip = arc_hi - arc_lo <= chunk;
+    for (int cb = arc_lo; cb < arc_hi || cb == arc_lo; cb += chunk) {
+      const int ce = min(cb + chunk, arc_hi);
+      if (!spans_lds)
+        for (int i = cb + tid; i < ce; i += NT) stage[i - cb] = gspan[i];
+      __syncthreads();
+      const uint32_t* tspan = spans_lds ? lspan : stage - cb;  // tspan[i]: the span of arc i, cb <= i < ce
+      for (int i = cb + tid; i < ce; i += NT) {
+        const uint32_t sp32 = tspan[i];
+        const int lo = max((int)(sp32 & 0xFFFFu), c0) - c0, hi = min((int)(sp32 >> 16), c0 + tc) - c0;
+        if (hi > lo) {
+          atomicAdd(&lboff[lo], 1);
+          atomicAdd(&lboff[hi], -1);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     int n = 0;
     {
       constexpr int kCh = kLnTile / NT;  // every thread owns kCh consecutive ranks
@@ -1327,16 +1340,25 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
     uint64_t* rec8 = a.pool + rec_at;
     FR_LAP(1);
     // ---- 2. every arc drops its number into the buckets of its ranks ----
-    for (int i = arc_lo + tid; i < arc_hi; i += NT) {
-      const uint32_t sp32 = tspan[i];
-      const int lo = max((int)(sp32 & 0xFFFFu), c0) - c0, hi = min((int)(sp32 >> 16), c0 + tc) - c0;
-      for (int c = lo; c < hi; c += 4) {  // four cursors at a time: the atomics' round trips overlap
-        int at[4];
+    for (int cb = arc_lo; cb < arc_hi; cb += chunk) {
+      const int ce = min(cb + chunk, arc_hi);
+      if (!one_trip) {  // (workgroup-uniform; else the stage still holds the tile's arcs)
+        __syncthreads();
+        for (int i = cb + tid; i < ce; i += NT) stage[i - cb] = gspan[i];
+        __syncthreads();
+      }
+      const uint32_t* tspan = spans_lds ? lspan : stage - cb;
+      for (int i = cb + tid; i < ce; i += NT) {
+        const uint32_t sp32 = tspan[i];
+        const int lo = max((int)(sp32 & 0xFFFFu), c0) - c0, hi = min((int)(sp32 >> 16), c0 + tc) - c0;
+        for (int c = lo; c < hi; c += 4) {  // four cursors at a time: the atomics' round trips overlap
+          int at[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) at[q] = (c + q < hi) ? atomicAdd(&lcur[c + q], 1) : -1;
+          for (int q = 0; q < 4; ++q) at[q] = (c + q < hi) ? atomicAdd(&lcur[c + q], 1) : -1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (at[q] >= 0) lbucket[at[q]] = (uint16_t)i;
+          for (int q = 0; q < 4; ++q)
+            if (at[q] >= 0) lbucket[at[q]] = (uint16_t)i;
+        }
       }
     }
     __syncthreads();

@@ -377,6 +377,46 @@ def test_frame_post_state_times(ctx, times, frame_mode):
     assert off[-1] == len(labels)
 
 
+def test_frame_post_kernels_agree_on_a_mix(ctx, monkeypatch):
+    """The two instantiations of the lean kernel and the general kernel against one another on a batch too large
+    for the CPU oracle in a test: lattices of 2 .. 9 000 states (the larger ones keep their spans in L2), jittered
+    and tied state times, few labels (every frame folds), frames of 17 .. 40 arcs (a wave each).  Same frames, same
+    labels in the same order up to ties of the float posterior, posteriors within the tolerance of the oracle tests."""
+    rng = np.random.RandomState(5)
+    ns = np.concatenate([rng.randint(2, 600, size=60), rng.randint(2500, 9000, size=12), [1, 2]]).astype(np.int32)
+    fo = rng.choice([2, 3, 4], size=len(ns)).astype(np.int32)
+    arrays = klat_amd.synth(4242, ns, fo)
+    arrays["ilabel"] = (arrays["ilabel"] % 13).astype(np.int32)
+    arrays["olabel"] = arrays["ilabel"].copy()
+    t = arrays["state_time"].copy()
+    for u in range(len(ns)):
+        lo, hi = arrays["state_off"][u], arrays["state_off"][u + 1]
+        if u % 3 == 1:
+            t[lo:hi] = np.maximum(t[lo:hi] + rng.randint(-5, 6, size=hi - lo), 0)
+        elif u % 3 == 2:
+            t[lo:hi] = (t[lo:hi] // 3) * 3
+    arrays["state_time"] = t.astype(np.int32)
+    nframes = [max(0, int(t[arrays["state_off"][u + 1] - 1])) for u in range(len(ns))]
+    got = {}
+    for mode in ("lean", "general"):
+        for k, v in FRAME_MODES[mode].items():
+            monkeypatch.setenv(k, v)
+        b = klat_amd.Batch(ctx, arrays)
+        b.forward_backward(1.0, 0.3, 0.0)
+        got[mode] = b.frame_post(nframes)
+        b.close()
+        for k in FRAME_MODES[mode]:
+            monkeypatch.delenv(k)
+    (o0, l0, p0), (o1, l1, p1) = got["lean"], got["general"]
+    assert np.array_equal(o0, o1) and len(l0) == len(l1) and len(l0) > 100000
+    close = np.isclose(p0, p1, rtol=2e-6, atol=2e-6) | (p0 == p1)
+    assert close.all(), int((~close).sum())
+    diff = np.nonzero(l0 != l1)[0]  # labels may swap only where the float posteriors tie or nearly tie inside a frame
+    for i in diff[:200]:
+        f = np.searchsorted(o0, i, side="right") - 1
+        assert sorted(l0[o0[f]:o0[f + 1]].tolist()) == sorted(l1[o1[f]:o1[f + 1]].tolist()), (int(i), int(f))
+
+
 @pytest.mark.parametrize("width", [40, 200, 700, 5000])
 def test_frame_post_wide_frames(ctx, width):
     """Frames crossed by many arcs: up to 16 entries a frame's thread sorts in LDS, up to 256 in
