@@ -648,11 +648,11 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         for (size_t i = 0; i < cl.size(); ++i)
           for (int32_t g = 0; g < cl[i].num_grps; ++g)
             groups.push_back(ChainGroup{(int32_t)i, cl[i].seg_begin + g * kChainGroup, std::min(kChainGroup, cl[i].num_segs - g * kChainGroup), 0});
-        const int32_t zero[4] = {0, 0, 0, 0};
+        const int32_t zero[5] = {0, 0, 0, 0, 0};
         if ((rc = b->ch_lats.upload(cl.data(), cl.size(), c->stream)) || (rc = b->ch_segs.alloc(nseg)) ||
             (rc = b->ch_qm.alloc(nseg * cc * cc)) || (rc = b->ch_qe.alloc(nseg * cc)) || (rc = b->ch_qfm.alloc(nseg * cc)) ||
             (rc = b->ch_qfe.alloc(nseg * cc)) || (rc = b->ch_bfm.alloc(nseg * cc)) || (rc = b->ch_bfe.alloc(nseg)) ||
-            (rc = b->ch_bbm.alloc(nseg * cc)) || (rc = b->ch_bbe.alloc(nseg)) || (rc = b->ch_status.upload(zero, 4, c->stream)) ||
+            (rc = b->ch_bbm.alloc(nseg * cc)) || (rc = b->ch_bbe.alloc(nseg)) || (rc = b->ch_status.upload(zero, 5, c->stream)) ||
             (rc = b->ch_grps.upload(groups.data(), groups.size(), c->stream)) || (rc = b->ch_gm.alloc(ngrp * cc * cc)) || (rc = b->ch_ge.alloc(ngrp * cc)) ||
             (rc = b->ch_gfm.alloc(ngrp * cc)) || (rc = b->ch_gfe.alloc(ngrp * cc)) || (rc = b->ch_gbfm.alloc(ngrp * cc)) || (rc = b->ch_gbfe.alloc(ngrp)) ||
             (rc = b->ch_gbbm.alloc(ngrp * cc)) || (rc = b->ch_gbbe.alloc(ngrp))) {
@@ -934,7 +934,7 @@ int klat_batch_chain_fallback(klat_batch* b, int32_t* raised) {
   *raised = 0;
   if (b->num_chain == 0 || !b->swept) return KLAT_OK;
   KLAT_HIP(hipSetDevice(b->ctx->device));
-  KLAT_HIP(hipMemcpyAsync(raised, b->ch_status.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
+  KLAT_HIP(hipMemcpyAsync(raised, b->ch_status.p + (b->chain_flag_turn ? 4 : 1), sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   return KLAT_OK;
 }
@@ -1108,7 +1108,7 @@ static void fill_chain_args(klat_batch* b, ChainArgs* out) {
   ca.Gm = b->ch_gm.p, ca.Ge = b->ch_ge.p, ca.Gfm = b->ch_gfm.p, ca.Gfe = b->ch_gfe.p;
   ca.gb_fm = b->ch_gbfm.p, ca.gb_fe = b->ch_gbfe.p, ca.gb_bm = b->ch_gbbm.p, ca.gb_be = b->ch_gbbe.p;
   ca.rescale_iters = b->chain_rescale;
-  ca.flag = b->ch_status.p + 1;
+  ca.flag = b->ch_status.p + (b->chain_flag_turn ? 4 : 1);  // (klat_forward_backward_ex passes the turn on)
   ca.state_off = b->state_off.p;
   ca.alpha = b->alpha.p;
   ca.beta = b->beta.p;
@@ -1184,7 +1184,11 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
     if (b->num_chain > 0) {  // the long lattices, in segments
       const int erc = ensure_chain_records(b, s, sp, false, &chain_ok);
       if (erc != KLAT_OK) return erc;
-      if (chain_ok) fill_chain_args(b, &ca);
+      if (chain_ok) {
+        b->chain_flag_turn ^= 1;  // this sweep's flag was cleared by the one before it, and it clears the next one's
+        fill_chain_args(b, &ca);
+        ca.flag_next = b->ch_status.p + (b->chain_flag_turn ? 1 : 4);
+      }
     }
     // the launches, in this order: the classes' fast sweeps (a few long workgroups each: they take their CUs before
     // the segment path's thousands of waves fill the chip), the segment path on the context's stream, the classes'
@@ -1216,8 +1220,8 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
         // ... and behind the segment path's kernels, on the same stream, the streams its lattices keep: their
         // workgroups leave at once unless it raised its flag (values that do not fit its arithmetic)
         work.push_back(SweepPiece{0, [&](hipStream_t stream) {
-          hipError_t e = hipMemsetAsync(ca.flag, 0, sizeof(int32_t), stream);
-          if (e == hipSuccess) e = launch_chain_sweep(ca, stream);
+          // (its flag was cleared by the sweep before this one: the two flags take turns, no memset between sweeps)
+          hipError_t e = launch_chain_sweep(ca, stream);
           for (const LayoutClass& lc : b->classes) {
             if (!lc.chain || e != hipSuccess) continue;
             SweepArgs fa = class_args(lc);

@@ -97,6 +97,7 @@ struct ChainArgs {
   unsigned long long* dbg = nullptr;  // (KLAT_CHAIN_DEBUG) four words per wave: begin, end (100 MHz), HW_ID, XCC_ID
   size_t dbg_stride = 0;              //   the sweep's waves start here
   int32_t* flag;          // [1] raised when a lattice's values do not fit this arithmetic: the streams sweep them again
+  int32_t* flag_next = nullptr;  // [1] or null: the NEXT sweep's flag, cleared by this one's first kernel (two flags take turns: no memset between sweeps)
   const int64_t* state_off;
   double* alpha; double* beta;  // padded rows (klat_kernels.h)
   const LnTabEntry* ln_table;

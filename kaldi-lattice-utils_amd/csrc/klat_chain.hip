@@ -494,6 +494,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void chain_walk_kernel(ChainArgs a
   double* ring = smem + 2 * kLnTabSize + wave * per_wave;
   double* outbuf = ring + a.W * 64;
   if (threadIdx.x < kLnTabSize) lntab[threadIdx.x] = a.ln_table[threadIdx.x];
+  if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0 && a.flag_next) *a.flag_next = 0;  // (nobody looks at the next sweep's flag during this one)
   __syncthreads();
   const unsigned long long t_begin = a.dbg ? wall_clock64() : 0;
   if (MODE == 0) {

@@ -294,7 +294,8 @@ struct klat_batch {
   size_t chain_records = 0;
   bool chain_trop_ready = false, chain_log_ready = false, chain_log_ok = false;
   klat_scales chain_trop_scales = {1.f, 1.f, 0.f}, chain_log_scales = {1.f, 1.f, 0.f};  // what the records were built for
-  klat::DevBuf<int32_t> ch_status;  // [0] the record pass met a cost that fits no record, [1] the sweep's fall-back flag, [2..3] the largest |cost|
+  klat::DevBuf<int32_t> ch_status;  // [0] the record pass met a cost that fits no record, [1] and [4] the sweep's fall-back flags (they take turns), [2..3] the largest |cost|
+  int chain_flag_turn = 0;          // which of the two the last (or the running) sweep uses
   int32_t chain_rescale = 1;        // ChainArgs::rescale_iters
   float pack_host_ms = 0.0f;  // wall time of klat_batch_create (uploads, host planning, waits included)
   klat::DevBuf<int64_t> lv_stream_off;
