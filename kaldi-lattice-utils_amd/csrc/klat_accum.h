@@ -158,7 +158,7 @@ struct FrameArgs {
   int32_t* redo2_n;
   const LnTabEntry* ln_table;  // [kLnTabSize] (klat_kernels.h), the lean kernel's LogAdd
   uint64_t* pool;             // the lean kernel's records, a lattice's in one piece
-  unsigned long long* pool_used;  // [1] records asked for so far (also by the lattices the pool had no room for)
+  unsigned long long* pool_used;  // [2] records asked for so far (also by the lattices the pool had no room for); those asked for in vain
   int64_t pool_cap;
   const uint64_t** rec_ptr;   // [U] where a lattice's records begin (the pool, or its rows of rec_scratch)
   int64_t* rec_fmt;           // [U] 0: desc(float logp) << 32 | biased label; 1 << 32 | lab_base: the lean kernel's keys

@@ -408,12 +408,22 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     const bool general_only = std::getenv("KLAT_FRAME_GENERAL") != nullptr;  // (tests, comparisons)
     int32_t redo_n = (int32_t)b->U;
     std::vector<int32_t> redo_list;
-    if (!general_only && b->U > 0) {
+    bool lean = !general_only && b->U > 0;
+    int64_t cap = 0;
+    if (lean) {
       const double ratio = std::getenv("KLAT_FRAME_POOL_RATIO") ? std::atof(std::getenv("KLAT_FRAME_POOL_RATIO")) : c->frame_pool_ratio;  // (the variable: tests)
-      const int64_t cap = std::min<int64_t>(((int64_t)1 << 31) - 1, (int64_t)(ratio * (double)b->A) + 4096);
-      if ((rc = st.pool.alloc((size_t)cap))) return rc;
+      cap = std::min<int64_t>(((int64_t)1 << 31) - 1, (int64_t)(ratio * (double)b->A) + 4096);
+      // No room for the pool: the general kernel needs none (it sizes its scratch behind a count pass).  Only the
+      // allocation failed, nothing is running on this call's temporaries: the call is not a failing one.
+      if ((rc = st.pool.alloc((size_t)cap))) {
+        if (rc != KLAT_ERR_OOM) return rc;
+        lean = false;
+        c->pool.failing = false;
+      }
+    }
+    if (lean) {
       if ((rc = st.redo.alloc(2 * (size_t)b->U + 2))) return rc;
-      if ((rc = st.pool_used.alloc(1))) return rc;
+      if ((rc = st.pool_used.alloc(2))) return rc;
       a.pool = st.pool.p;
       a.pool_cap = cap;
       a.pool_used = st.pool_used.p;
@@ -423,26 +433,42 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       a.redo2_n = st.redo.p + 2 * b->U + 1;
       a.ln_table = c->ln_table.p;
       KLAT_HIP(hipMemsetAsync(a.redo_n, 0, 2 * sizeof(int32_t), c->stream));
-      KLAT_HIP(hipMemsetAsync(a.pool_used, 0, sizeof(unsigned long long), c->stream));
+      KLAT_HIP(hipMemsetAsync(a.pool_used, 0, 2 * sizeof(unsigned long long), c->stream));
       KLAT_HIP(launch_frame_lean(a, (int)b->U, max_arcs, false, c->stream));
       if ((rc = print_clock("frame_lean_kernel"))) return rc;
       int32_t first_n = 0;
-      unsigned long long used = 0;
+      unsigned long long used[2] = {0, 0};  // [0] records asked of the pool, [1] those of them the pool had no room for
       KLAT_HIP(hipMemcpyAsync(&first_n, a.redo_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      KLAT_HIP(hipMemcpyAsync(&used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipMemcpyAsync(used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipStreamSynchronize(c->stream));
       redo_n = first_n;
+      unsigned long long need = used[0];
       if (first_n > 0) {  // larger lattices (spans in L2), and one more try for what else did not fit
+        const unsigned long long short_first = used[1];
         KLAT_HIP(launch_frame_lean(a, (int)first_n, max_arcs, true, c->stream));
         if ((rc = print_clock("frame_lean_kernel (second instantiation)"))) return rc;
         KLAT_HIP(hipMemcpyAsync(&redo_n, a.redo2_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        KLAT_HIP(hipMemcpyAsync(&used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+        KLAT_HIP(hipMemcpyAsync(used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
         KLAT_HIP(hipStreamSynchronize(c->stream));
+        // the lattices the first pass turned away for want of room asked again: once is what they need
+        need = used[0] - std::min(used[0], short_first);
       }
-      if ((int64_t)used > cap && b->A > 0) c->frame_pool_ratio = 1.1 * (double)used / (double)b->A;  // the next call's pool holds this batch
+      // The next call's pool: what this batch needed and a tenth, when that is more than it had; otherwise half-way
+      // back towards it, so that one batch of long arcs does not size every later pool of the context -- never
+      // below the starting ratio, never above what an eighth of the device holds (a batch beyond that is listed
+      // and takes the general kernel).
+      if (b->A > 0 && std::getenv("KLAT_FRAME_POOL_RATIO") == nullptr) {
+        const double asked = 1.1 * (double)need / (double)b->A;
+        double next = (int64_t)need > cap ? asked : std::max(asked, 0.5 * (c->frame_pool_ratio + asked));
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError(), total_b = (size_t)256 << 30;
+        next = std::min(next, (double)(total_b / 8 / sizeof(uint64_t)) / (double)b->A);
+        c->frame_pool_ratio = std::max(4.0, next);
+      }
+      const unsigned long long used_total = need;
       if (a.phase_clock)
         std::fprintf(stderr, "frame_lean_kernel: %d of %lld lattices left by the first instantiation, %d to the general kernel; %llu records asked of a pool of %lld\n",
-                     (int)first_n, (long long)b->U, (int)redo_n, used, (long long)cap);
+                     (int)first_n, (long long)b->U, (int)redo_n, used_total, (long long)cap);
       if (redo_n > 0) {
         redo_list.resize((size_t)redo_n);
         KLAT_HIP(hipMemcpyAsync(redo_list.data(), a.redo2_list, sizeof(int32_t) * (size_t)redo_n, hipMemcpyDeviceToHost, c->stream));
@@ -456,7 +482,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       std::vector<int64_t> nexp((size_t)b->U);
       KLAT_HIP(hipMemcpyAsync(nexp.data(), st.num_expansions.p, sizeof(int64_t) * (size_t)b->U, hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipStreamSynchronize(c->stream));
-      std::vector<uint8_t> listed((size_t)b->U, general_only ? 1 : 0);
+      std::vector<uint8_t> listed((size_t)b->U, lean ? 0 : 1);
       for (int32_t u : redo_list) listed[(size_t)u] = 1;
       std::vector<int64_t> off((size_t)b->U + 1, 0);
       for (int64_t u = 0; u < b->U; ++u) {

@@ -966,13 +966,9 @@ int klat_batch_topological_depth(klat_batch* b, int32_t* depth) {
 // The arc posteriors are made when somebody asks for them: klat_forward_backward without
 // KLAT_FB_NO_ARC_POSTERIORS, or klat_get_arc_logpost after a sweep that left them out.  The first pass
 // over a batch allocates `logpost` and builds the one-byte source steps and arc spans of the arcs.
-static int ensure_posterior_tables(klat_batch* b) {
+static int posterior_tables_pass(klat_batch* b, bool* overflow) {
   klat_ctx* c = b->ctx;
   int rc;
-  if (b->logpost.n < (size_t)b->A && (rc = b->logpost.alloc((size_t)b->A))) return rc;
-  if (b->post_prepared) return KLAT_OK;
-  b->post_prepared = true;
-  if (std::getenv("KLAT_NO_SRC_DELTA") != nullptr || b->A == 0) return KLAT_OK;
   DevBuf<int32_t> over;
   if ((rc = b->src_delta.alloc((size_t)b->A)) || (rc = b->arc_span.alloc((size_t)b->A)) || (rc = b->item_src.alloc((size_t)b->num_items)) ||
       (rc = over.alloc(1)))
@@ -995,7 +991,24 @@ static int ensure_posterior_tables(klat_batch* b) {
   }
   KLAT_HIP(hipMemcpyAsync(&h_over, over.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   KLAT_HIP(hipStreamSynchronize(c->stream));
-  if (h_over) b->src_delta.release(), b->arc_span.release(), b->item_src.release();  // a step or an arc above 255 states: the pass reads src and dst themselves
+  *overflow = h_over != 0;
+  return KLAT_OK;
+}
+
+static int ensure_posterior_tables(klat_batch* b) {
+  int rc;
+  if (b->logpost.n < (size_t)b->A && (rc = b->logpost.alloc((size_t)b->A))) return rc;
+  if (b->post_prepared) return KLAT_OK;
+  if (std::getenv("KLAT_NO_SRC_DELTA") == nullptr && b->A > 0) {
+    bool overflow = false;
+    rc = posterior_tables_pass(b, &overflow);
+    // a step or an arc above 255 states: the pass reads src and dst themselves.  A pass that failed (out of memory,
+    // say: klat_ctx_trim and a second try are the caller's answer) leaves no half-built table behind either, and
+    // the batch stays unprepared so that the next call builds them again.
+    if (rc != KLAT_OK || overflow) b->src_delta.release(), b->arc_span.release(), b->item_src.release();
+    if (rc != KLAT_OK) return rc;
+  }
+  b->post_prepared = true;  // only now: the tables are whole, or absent
   return KLAT_OK;
 }
 

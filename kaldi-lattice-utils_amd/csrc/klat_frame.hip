@@ -1273,7 +1273,10 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
     if (ranged && !spans_lds) arc_lo = blk_first[max(c0 - longest + 1, 0) / kLnBlock], arc_hi = blk_first[(c0 + tc + kLnBlock - 1) / kLnBlock];
     if (c0 == 0 && tid == 0) {
       rec_at = my_at;
-      if (my_at + (unsigned long long)entries > (unsigned long long)a.pool_cap) atomicOr(&unfit, 1);
+      if (my_at + (unsigned long long)entries > (unsigned long long)a.pool_cap) {
+        atomicOr(&unfit, 1);
+        atomicAdd(a.pool_used + 1, (unsigned long long)entries);  // asked for in vain (the host does not count it twice)
+      }
     }
     // the spans of the tile's arcs in LDS: where they are anyway, or -- a lattice whose spans lie in L2 -- staged behind
     // the rank times, in the place the spans of a smaller lattice would have: one coalesced trip per tile as a rule, one

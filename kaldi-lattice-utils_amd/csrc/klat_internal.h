@@ -99,8 +99,11 @@ DevPool*& current_pool();
 struct PoolScope {
   DevPool* saved;
   explicit PoolScope(DevPool* p) : saved(current_pool()) { current_pool() = p; }
-  ~PoolScope() {  // (the call's locals are gone by now: a failing call has returned its temporaries through hipFree)
-    if (current_pool()) current_pool()->failing = false;
+  // (the call's locals are gone by now: a failing call has returned its temporaries through hipFree).  Only the
+  // OUTERMOST scope on a pool ends the failing state: an API call that wraps another one on the same context
+  // (klat_batch_create_compact -> klat_batch_create) still holds temporaries the failed call's kernels may be reading.
+  ~PoolScope() {
+    if (current_pool() && current_pool() != saved) current_pool()->failing = false;
     current_pool() = saved;
   }
 };

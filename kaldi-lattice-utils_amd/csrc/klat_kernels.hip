@@ -199,39 +199,40 @@ void fill_ln_table(LnTabEntry* t) {
 // The arcs of a compact descriptor: state s owns the arcs [row[s], row[s + 1]), row = prefix sums of the
 // out-degrees; src = s, dst = s + span.
 __global__ __launch_bounds__(256) void expand_compact_kernel(ExpandArgs a) {
-  __shared__ int sh[4];
-  __shared__ int carry_sh;
+  __shared__ long long sh[4];
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
-  const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
-  int carry = 0;
-  for (int base = 0; base < S; base += 256) {
+  const int S = (int)(a.state_off[u + 1] - s0);
+  const long long A = (long long)(a.arc_off[u + 1] - a0);
+  long long carry = 0;  // 64 bits: no sum of 32-bit degrees wraps round into the lattice's range
+  bool bad = false;
+  for (int base = 0; base < S && !bad; base += 256) {
     const int s = base + tid;
-    const int deg = s < S ? a.out_degree[s0 + s] : 0;
-    int incl = deg;
+    const int deg_in = s < S ? a.out_degree[s0 + s] : 0;
+    const long long deg = deg_in > 0 ? deg_in : 0;
+    long long incl = deg;
     for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d, 64);
+      const long long t = __shfl_up(incl, d, 64);
       if (lane >= d) incl += t;
     }
-    __syncthreads();
+    // a negative degree ends the lattice before anything of this round is written (the barrier's vote is uniform)
+    bad = __syncthreads_or(deg_in < 0) != 0;
     if (lane == 63) sh[wave] = incl;
     __syncthreads();
-    int off = carry, tot = 0;
+    long long off = carry, tot = 0;
     for (int w = 0; w < 4; ++w) {
       if (w < wave) off += sh[w];
       tot += sh[w];
     }
-    const int first = off + incl - deg;
-    if (s < S && deg >= 0 && first + deg <= A)
-      for (int i = first; i < first + deg; ++i) {
+    const long long first = off + incl - deg;
+    if (!bad && s < S && first >= 0 && first + deg <= A)
+      for (long long i = first; i < first + deg; ++i) {
         a.src[a0 + i] = s;
         a.dst[a0 + i] = s + (int)a.span[a0 + i];
       }
     carry += tot;
   }
-  if (tid == 0) carry_sh = carry;
-  __syncthreads();
-  if (tid == 0 && carry_sh != A) atomicCAS(&a.status[0], 0, u + 1);
+  if (tid == 0 && (bad || carry != A)) atomicCAS(&a.status[0], 0, u + 1);
 }
 
 hipError_t launch_expand_compact(const ExpandArgs& a, int num_lattices, hipStream_t stream) {

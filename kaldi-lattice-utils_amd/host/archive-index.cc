@@ -81,7 +81,7 @@ void MappedArchive::ScanNext(ArchiveEntry* e) {
     e->binary = true;
     e->begin = p;
     auto need = [&](size_t n) {
-      if (p + n > size_) bad();
+      if (n > size_ - p) bad();  // (p <= size_ always; no sum that could wrap)
     };
     auto i32 = [&]() -> int32_t {
       need(4);
@@ -175,7 +175,7 @@ bool MappedArchive::ReadFlat(const ArchiveEntry& e, FlatLattice* lat) const {
   const size_t end = e.end;
   auto bad = [&]() { KLAT_ERR("Failed reading lattice for key \"" << e.key << "\""); };
   auto need = [&](size_t n) {
-    if (p + n > end) bad();
+    if (n > end - p) bad();  // (p <= end always; no sum that could wrap)
   };
   auto i32 = [&]() -> int32_t {
     need(4);
@@ -200,10 +200,12 @@ bool MappedArchive::ReadFlat(const ArchiveEntry& e, FlatLattice* lat) const {
   };
   (void)i32();  // magic (the scan saw it)
   const int32_t n1 = i32();
+  if (n1 < 0 || n1 > 1024) bad();  // (the scan's bounds: an entry need not have come through it)
   need((size_t)n1);
   const bool vector_fst = n1 == 6 && std::memcmp(d + p, "vector", 6) == 0;
   p += (size_t)n1;
   const int32_t n2 = i32();
+  if (n2 < 0 || n2 > 1024) bad();
   need((size_t)n2);
   const bool compact = n2 >= 7 && std::memcmp(d + p, "compact", 7) == 0;
   p += (size_t)n2;

@@ -61,3 +61,21 @@ def test_scan_refuses_a_truncated_binary_entry_and_a_pipe(tmp_path):
     assert rc != 0 and "Failed reading lattice" in err
     rc, out, err = _run("klat-archive-scan", "ark:cat %s|" % binary)
     assert rc != 0 and "not a plain file" in err
+
+
+def test_scan_refuses_negative_header_string_lengths(tmp_path):
+    """The fst-type / arc-type strings of an OpenFst header carry int32 lengths: a negative one must end in the
+    reader's error, never in a pointer that walks backwards through the mapping (scanner and flat reader alike)."""
+    arrays, ns, txt, binary = _make(tmp_path)
+    data = bytearray(open(binary, "rb").read())
+    magic = (2125659606).to_bytes(4, "little")
+    at = data.find(magic)
+    assert at > 0
+    for which, off in (("fst type", at + 4), ("arc type", at + 4 + 4 + 6)):  # "vector" is six bytes long
+        broken = bytearray(data)
+        assert which != "fst type" or int.from_bytes(broken[off:off + 4], "little") == 6
+        broken[off:off + 4] = (-1).to_bytes(4, "little", signed=True)
+        path = str(tmp_path / "neg.ark")
+        open(path, "wb").write(broken)
+        rc, out, err = _run("klat-archive-scan", "ark:" + path)
+        assert rc != 0 and "Failed reading lattice" in err, (which, rc, err)

@@ -26,6 +26,13 @@ def ctx():
     c.close()
 
 
+@pytest.fixture
+def ctx_fresh():
+    c = klat_amd.Ctx(0)
+    yield c
+    c.close()
+
+
 def _fmt7(x):
     s = "%.7g" % x
     return "0" if float(s) == 0 else s
@@ -333,6 +340,39 @@ def test_frame_post_synthetic(ctx, scales, frame_mode):
         _check_frames(off, labels, logps, fb, want)
         fb += nframes[u]
     assert off[-1] == len(labels)
+
+
+def test_frame_post_pool_follows_the_batches(ctx_fresh):
+    """The lean kernel's record pool is sized by what the context's earlier batches asked for: a batch of long arcs
+    (thirty ranks an arc: far beyond the four records per arc a new context starts with) goes to the general
+    kernel the first time and through the enlarged pool the second time, and an ordinary batch afterwards brings
+    the pool back down; all four calls give the oracle's posteriors."""
+    rng = np.random.RandomState(5)
+    ns = np.concatenate([[1, 2], rng.randint(100, 500, size=12)]).astype(np.int32)
+    fo = np.full(len(ns), 3, np.int32)
+    plain = klat_amd.synth(20260009, ns, fo)
+    plain["olabel"] = (plain["olabel"] % 7).astype(np.int32)
+    plain["ilabel"] = plain["olabel"].copy()
+    long_arcs = {k: v.copy() for k, v in plain.items()}
+    S_of = np.repeat(ns, np.diff(plain["arc_off"]))
+    src, dst = long_arcs["src"], long_arcs["dst"]
+    far = dst != src + 1  # (the arcs to the next state keep every lattice connected)
+    dst[far] = np.minimum(src[far] + 60, S_of[far] - 1)
+    for arrays in (long_arcs, long_arcs, plain, plain):
+        nframes = [int(arrays["state_time"][arrays["state_off"][u + 1] - 1]) for u in range(len(ns))]
+        b = klat_amd.Batch(ctx_fresh, arrays)
+        b.forward_backward(1.0, 0.2, 0.0)
+        off, labels, logps = b.frame_post(nframes)
+        b.close()
+        fb = 0
+        for u, lat in enumerate(_split(arrays)):
+            sl = orc.scale_and_penalize(lat, 1.0, 0.2, 0.0)
+            alpha, beta, total, _, _ = orc.alphas_betas(sl)
+            t = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
+            want, _ = orc.frame_post(sl, t, nframes[u], alpha, beta, total)
+            _check_frames(off, labels, logps, fb, want)
+            fb += nframes[u]
+        assert off[-1] == len(labels)
 
 
 @pytest.mark.parametrize("times", ["ties", "clipped", "descending", "jitter"])

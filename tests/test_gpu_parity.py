@@ -378,6 +378,23 @@ def test_compact_descriptor_gives_the_same_batch(ctx):
     with pytest.raises(klat_amd.KlatError) as e:
         klat_amd.Batch.from_compact(ctx, bad)
     assert e.value.code == klat_amd.ERR_INVALID_ARG and "lattice 3" in str(e.value)
+    # negative out-degrees: refused before anything is written outside the lattice's own arcs -- also where they
+    # cancel (the sum is right, the rows are not)
+    s5 = int(arrays["state_off"][5])
+    assert ns[5] >= 3
+    for cancels in (False, True):
+        deg = compact["out_degree"].copy()
+        if cancels:
+            deg[s5 + 1] += deg[s5] + 2
+        deg[s5] = -2
+        bad["out_degree"] = deg
+        with pytest.raises(klat_amd.KlatError) as e:
+            klat_amd.Batch.from_compact(ctx, bad)
+        assert e.value.code == klat_amd.ERR_INVALID_ARG and "lattice 5" in str(e.value)
+    good = klat_amd.Batch.from_compact(ctx, compact)  # the context is none the worse for it
+    good.forward_backward(1.0, 0.3, 0.25)
+    assert np.array_equal(good.alpha_beta()[0], ab0[0])
+    good.close()
 
 
 def test_fused_scales_streams_match_the_generic_ones(ctx):
