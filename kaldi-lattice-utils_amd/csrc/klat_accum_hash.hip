@@ -30,6 +30,7 @@
 // of LDS; LOGH = 15: up to 16 384 arcs, 16 per thread, 150 KiB.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <cstdlib>
 #include <stdint.h>
 
@@ -605,11 +606,583 @@ hipError_t launch_hash_one(const AccumArgs& a, const RadixPack& pk, int num_latt
   return hipGetLastError();
 }
 
+
+// ================================================================================================
+// Second form of the same kernel (round 4).  What the first form cost, measured (profiles/r03_accum_sq_counters.txt
+// and its ISA): 3 200 vector instructions per wave for eight arcs a thread, 15 000 lines of code per instantiation
+// (more than the instruction cache two CUs share), 80 registers at two workgroups a CU with 43 of them spilled and
+// every arc's value written to and read from a scratch row: 2.5 x the algorithmic bytes.  This form keeps the
+// algorithm -- hash grouping, fold of the repeated keys in arc order, one bucket pass by value, exact order inside
+// the buckets -- and changes what it costs:
+//   * 512 threads x 12 (or 16) arcs, two workgroups a CU at 128 registers, nothing spilled; per arc the registers
+//     hold the packed key and the value, nothing else survives a phase;
+//   * the hash is computed once per arc from 24-bit pieces (full-rate multiplies) with a 32-bit finaliser; three
+//     rounds of compare-and-swap in flight together, and everything that is not "the slot was free" -- a slot taken
+//     by another key after three tries, a fingerprint that matches -- goes to a QUEUE (the lattice's scratch row)
+//     that the workgroup drains afterwards in one compact loop: the rare paths exist once in the code, not once
+//     per unrolled arc;
+//   * repeated keys are marked per ARC (two bitmaps), so no arc has to remember its slot; a lattice without
+//     repeated keys (BASELINE's synthetic ones) skips the fold and its barriers altogether;
+//   * the values never leave the registers: only the members of repeated keys put theirs in the scratch row, and
+//     an exact tie (two records whose values agree in their upper 50 bits) recomputes the other record's value
+//     from alpha / beta, out of line;
+//   * the per-lattice table is the smallest power of two holding twice the lattice's arcs, the value buckets as
+//     many as fit behind the order words (8 192 for 6 144 arcs: 0.7 records a bucket).
+// Same records, bit for bit (tests/test_gpu_accum.py compares the two forms; KLAT_INDEX_V1=1 selects the first).
+namespace v2 {
+
+constexpr uint32_t kFree = 0xFFFFFFFFu;  // {fingerprint 17 bits | arc 15 bits}: arc 32 767 does not exist
+constexpr int kRounds = 3;               // tries before an arc goes to the queue
+
+__device__ __forceinline__ uint32_t key_hash32(uint64_t key) {
+  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  const uint32_t p0 = lo & 0xFFFFFFu, p1 = ((lo >> 24) | (hi << 8)) & 0xFFFFFFu, p2 = hi >> 16;
+  uint32_t h = __umul24(p0, 0x9E3779u);
+  h += __umul24(p1, 0x85EBCBu);
+  h += __umul24(p2, 0xC2B2AFu);
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= h >> 15;
+  return h;
+}
+
+// What the out-of-line paths need of the lattice: in LDS, written by the workgroup's first thread (they run for a
+// handful of arcs; handed over by value the view cost thirty registers and a stack frame at every call site).
+struct LatView {
+  const int32_t* olabel;  // the lattice's first arc
+  const int32_t* src;
+  const int32_t* dst;
+  const int32_t* ilabel;
+  const float* graph;
+  const float* acoustic;
+  const int32_t* tm;    // the lattice's first state: state_len (position index) or state_time
+  const int32_t* time;  // state_time
+  const double* alpha;  // padded rows
+  const double* beta;
+  const double* vals;   // scratch row: the values of the members of repeated keys (a first arc: the folded sum)
+  const int32_t* include;
+  const int32_t* exclude;
+  double tot;
+  ScaleParams sp;
+  int32_t label_min, time_bits;
+  int32_t num_include, num_exclude;
+  uint32_t dupbit_off;  // byte offset of the bitmap of repeated keys' arcs in the dynamic LDS
+};
+__shared__ LatView lat_view;
+extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+
+template <bool POSITION>
+__device__ __noinline__ uint64_t slow_key(int arc) {
+  const LatView& v = lat_view;
+  const uint64_t l = (uint64_t)(uint32_t)(v.olabel[arc] - v.label_min);
+  const int32_t s = v.src[arc];
+  if (POSITION) return (l << v.time_bits) | (uint64_t)(uint32_t)v.tm[s];
+  return (((l << v.time_bits) | (uint64_t)(uint32_t)v.tm[s]) << v.time_bits) | (uint64_t)(uint32_t)v.tm[v.dst[arc]];
+}
+
+// image (descending order) of the value record `arc` carries: the folded sum of a repeated key, else the arc's own
+__device__ __noinline__ uint64_t slow_image(int arc) {
+  const LatView& v = lat_view;
+  const uint32_t* dupbit = reinterpret_cast<const uint32_t*>(smem2 + v.dupbit_off);
+  if ((dupbit[arc >> 5] >> (arc & 31)) & 1u) return hdesc_key(v.vals[arc]);
+  const int32_t s = v.src[arc], d = v.dst[arc];
+  const bool word = v.sp.penalized ? v.ilabel[arc] != 0 : false;
+  const double thr = v.alpha[s] + v.beta[d] - arc_cost(v.graph[arc], v.acoustic[arc], word, v.sp);
+  return hdesc_key(accum_normalise(thr, v.tot));
+}
+
+__device__ __noinline__ bool filter_keeps(int32_t label) {
+  const LatView& v = lat_view;
+  return v.num_include > 0 ? hin_sorted(v.include, v.num_include, label) : !hin_sorted(v.exclude, v.num_exclude, label);
+}
+
+// exact comparison of two order words with equal upper parts: (logp desc, label, t0, t1) / (logp desc, label, pos)
+// on the full doubles and keys, recomputed from the arcs
+template <bool POSITION>
+__device__ __noinline__ bool tie_less(int ax, int ay) {
+  const uint64_t dx = slow_image(ax), dy = slow_image(ay);
+  if (dx != dy) return dx < dy;
+  return slow_key<POSITION>(ax) < slow_key<POSITION>(ay);
+}
+
+// position of order word `me` in its bucket [lo, hi) where the plain count does not do: a crowded bucket (sorted by
+// the workgroup beforehand: binary search) or one that holds words whose upper parts equal mine
+template <bool POSITION, int RB>
+__device__ __noinline__ int slow_position(const uint64_t* order, int lo, int hi, uint64_t me) {
+  constexpr uint64_t idmask = (1ull << RB) - 1ull;
+  auto less = [&](uint64_t x, uint64_t y) -> bool {
+    return ((x ^ y) & ~idmask) ? x < y : (x != y && tie_less<POSITION>((int)(x & idmask), (int)(y & idmask)));
+  };
+  if (hi - lo > kSerialMax) {
+    int l = lo, h = hi;  // first entry not less than me
+    while (l < h) {
+      const int mid = (l + h) >> 1;
+      if (less(order[mid], me)) l = mid + 1;
+      else h = mid;
+    }
+    return l;
+  }
+  int p = lo;
+  for (int q = lo; q < hi; ++q) p += less(order[q], me) ? 1 : 0;
+  return p;
+}
+
+template <bool POSITION>
+__device__ __forceinline__ Payload payload_of(uint64_t key, int seg_arc, int32_t label_min, int time_bits) {
+  const uint64_t tmask = (1ull << time_bits) - 1ull;
+  Payload q;
+  if (POSITION) {
+    const LatView& v = lat_view;
+    const int32_t label = (int32_t)(uint32_t)(key >> time_bits) + label_min;
+    const int32_t pos = (int32_t)(uint32_t)(key & tmask) + 1;  // 1-based on output
+    q.k1 = ((uint64_t)hbias(label) << 32) | hbias(pos);
+    const int32_t t0 = v.time[v.src[seg_arc]];
+    const int32_t t1 = v.time[v.dst[seg_arc]];
+    q.k2 = ((uint64_t)(uint32_t)t0 << 32) | (uint32_t)t1;
+  } else {
+    const int32_t label = (int32_t)(uint32_t)(key >> (2 * time_bits)) + label_min;
+    const int32_t t0 = (int32_t)(uint32_t)((key >> time_bits) & tmask);
+    const int32_t t1 = (int32_t)(uint32_t)(key & tmask);
+    q.k1 = ((uint64_t)hbias(label) << 32) | hbias(t0);
+    q.k2 = (uint64_t)hbias(t1) << 32;
+  }
+  return q;
+}
+
+struct QEntry {  // 16 B, in the lattice's record row until the records go there
+  uint32_t klo, khi, packed /* fingerprint << 15 | slot to look at next */, arc;
+};
+
+// T threads, P arcs a thread; RB: bits of an arc number.  Dynamic LDS: [0, 4H) table -> order words -> stage;
+// [4H, 4H + H/8) the two arc bitmaps; the value counters at cnt_off (inside the first region where the order words
+// leave room, else behind the bitmaps).
+template <bool POSITION, int T, int P>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int log_b, int lds_bytes) {
+  constexpr int CAP = T * P;
+  constexpr int RB = CAP > 8192 ? 14 : 13;
+  static_assert(CAP <= 16384, "arc numbers take 14 bits");
+  unsigned char* const smem = smem2;
+  const int H = 1 << log_h, B = 1 << log_b;
+  uint32_t* table = reinterpret_cast<uint32_t*>(smem);
+  uint64_t* order = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* dupbit = reinterpret_cast<uint32_t*>(smem + (size_t)H * 4);  // [CAP / 32] arcs of repeated keys
+  uint32_t* headbit = dupbit + H / 64;                                   // [CAP / 32] their first arcs
+  uint32_t* bcnt = reinterpret_cast<uint32_t*>(smem + cnt_off);          // [B / 2] packed 16-bit counters
+  __shared__ int sh[T / 64];
+  __shared__ float sh_lo[T / 64], sh_hi[T / 64];
+  __shared__ int sh_qn, sh_ndl, sh_nbig, sh_big[CAP / kSerialMax + 1];
+
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t a0 = a.arc_off[u], s0 = a.state_off[u];
+  const int n = (int)(a.arc_off[u + 1] - a0);
+  if (n <= a.min_arcs || n > a.max_arcs) return;  // another launch's lattice (workgroup-uniform)
+#define KLAT_STAMP(k)                                                                 \
+  do {                                                                                \
+    if (a.phase_clock && tid == 0) a.phase_clock[(size_t)u * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+  KLAT_STAMP(0);
+  if (n == 0) {
+    if (tid == 0) a.num_records[u] = 0;
+    return;
+  }
+  const int64_t pb = padded_state_base(s0, u);
+  const int64_t row = a.scratch_off[u];
+  double* vals = a.val_scratch + row;
+  const double tot = a.total[u];
+  const int32_t* const l_olabel = a.olabel + a0;
+  const int32_t* const l_src = a.src + a0;
+  const int32_t* const l_dst = a.dst + a0;
+  const int32_t* const l_tm = (POSITION ? a.state_len : a.state_time) + s0;
+  const double* const l_alpha = a.alpha + pb;
+  const double* const l_beta = a.beta + pb;
+  if (tid == 0) {
+    LatView& v = lat_view;
+    v.olabel = l_olabel, v.src = l_src, v.dst = l_dst, v.ilabel = a.ilabel + a0;
+    v.graph = a.graph + a0, v.acoustic = a.acoustic + a0;
+    v.tm = l_tm, v.time = a.state_time + s0;
+    v.alpha = l_alpha, v.beta = l_beta;
+    v.vals = vals;
+    v.include = a.include, v.exclude = a.exclude, v.num_include = a.num_include, v.num_exclude = a.num_exclude;
+    v.tot = tot;
+    v.sp = a.sp;
+    v.label_min = pk.label_min, v.time_bits = pk.time_bits;
+    v.dupbit_off = (uint32_t)H * 4u;
+  }
+  QEntry* queue = reinterpret_cast<QEntry*>(reinterpret_cast<Rec*>(a.rec_scratch) + row);  // (24 B a slot: room for n entries)
+  uint32_t* duplist = reinterpret_cast<uint32_t*>(reinterpret_cast<Payload*>(a.key_scratch) + row);
+  Payload* payload = reinterpret_cast<Payload*>(a.key_scratch) + row;  // by first arc, repeated keys only (after the list is in LDS)
+  Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + row;
+  const int jmax = (n + T - 1) / T;  // rounds of T arcs this lattice has (workgroup-uniform)
+  // the lattice's table: the smallest power of two >= 2 n, 1 024 slots at least
+  int lh = 10;
+  while ((1 << lh) < 2 * n) ++lh;
+  const uint32_t hmask = (1u << lh) - 1u;
+
+  // ---- 1. table and bitmaps cleared; keys and values (loads batched, no branches around them) ----
+  {
+    const uint4 free4 = {kFree, kFree, kFree, kFree};
+    for (int i = tid * 4; i < (1 << lh); i += T * 4) *reinterpret_cast<uint4*>(table + i) = free4;
+    for (int i = tid; i < H / 32; i += T) dupbit[i] = 0;  // (both bitmaps)
+    if (tid == 0) sh_qn = 0, sh_ndl = 0, sh_nbig = 0;
+  }
+  uint64_t key[P];
+  double val[P];
+  uint32_t valid = 0;
+  const bool filtered = (a.num_include | a.num_exclude) != 0;  // workgroup-uniform
+  if (filtered) __syncthreads();  // (the filter reads the lattice's view)
+  constexpr int HALF = P / 2;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half * HALF >= jmax) break;
+    int32_t lab[HALF], t0[HALF], t1[HALF];
+    float gr[HALF], ac[HALF];
+    bool word[HALF];
+#pragma unroll
+    for (int q = 0; q < HALF; ++q) {
+      const int i = min((half * HALF + q) * T + tid, n - 1);
+      lab[q] = l_olabel[i];
+      t0[q] = l_src[i];
+      t1[q] = l_dst[i];
+      gr[q] = a.graph[a0 + i];
+      ac[q] = a.acoustic[a0 + i];
+      word[q] = a.sp.penalized ? a.ilabel[a0 + i] != 0 : false;
+    }
+    double al[HALF], be[HALF];
+#pragma unroll
+    for (int q = 0; q < HALF; ++q) {
+      al[q] = l_alpha[t0[q]];
+      be[q] = l_beta[t1[q]];
+      t0[q] = l_tm[t0[q]];
+      if (!POSITION) t1[q] = l_tm[t1[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < HALF; ++q) {
+      const int j = half * HALF + q;
+      const int i = j * T + tid;
+      // fw[src] + bw[dst] - cost (kwsbin2/lattice-word-index-segment.cc:160-163), the posterior pass's expression
+      val[j] = accum_normalise(al[q] + be[q] - arc_cost(gr[q], ac[q], word[q], a.sp), tot);
+      bool ok = i < n && lab[q] != 0;
+      if (filtered && ok) ok = filter_keeps(lab[q]);
+      const uint64_t l = (uint64_t)(uint32_t)(lab[q] - pk.label_min);
+      key[j] = POSITION ? ((l << pk.time_bits) | (uint64_t)(uint32_t)t0[q])
+                        : ((((l << pk.time_bits) | (uint64_t)(uint32_t)t0[q]) << pk.time_bits) | (uint64_t)(uint32_t)t1[q]);
+      if (ok) valid |= 1u << j;
+    }
+  }
+  __syncthreads();
+  KLAT_STAMP(1);
+
+  // ---- 2. hash grouping: kRounds tries with every compare-and-swap of a round in flight, the rest queued ----
+  {
+    uint32_t packed[P];  // fingerprint << 15 | slot
+    uint32_t pend = valid;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const uint32_t h = key_hash32(key[j]);
+      packed[j] = (h << 15) | (h >> (32 - lh));  // (fingerprint: the hash's low 17 bits; slot: its high bits)
+    }
+    uint32_t stuck = 0;  // a matching fingerprint: the queue looks at the slot (no more tries)
+#pragma unroll
+    for (int round = 0; round < kRounds; ++round) {
+      uint32_t seen[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        seen[j] = kFree;
+        if ((pend & ~stuck) & (1u << j)) seen[j] = atomicCAS(&table[packed[j] & 0x7FFFu], kFree, (packed[j] & ~0x7FFFu) | (uint32_t)(j * T + tid));
+      }
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        if (!((pend & ~stuck) & (1u << j))) continue;
+        if (seen[j] == kFree) pend &= ~(1u << j);                       // inserted: this arc stands for its key
+        else if (((seen[j] ^ packed[j]) >> 15) == 0) stuck |= 1u << j;  // its key, as likely as not
+        else if (round + 1 < kRounds) packed[j] = (packed[j] & ~0x7FFFu) | ((packed[j] + 1) & hmask);  // another key's slot: the next one
+      }
+    }
+    if (pend) {
+      const int mine_n = __popc(pend);
+      int at = atomicAdd(&sh_qn, mine_n);
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        if (!(pend & (1u << j))) continue;
+        const uint4 e = {(uint32_t)key[j], (uint32_t)(key[j] >> 32), packed[j], (uint32_t)(j * T + tid)};
+        *reinterpret_cast<uint4*>(&queue[at++]) = e;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  KLAT_STAMP(2);
+  // the queue: linear probing from the slot an entry names; a fingerprint match is checked against the inserter's
+  // key, and an arc that finds its key present puts itself and the inserter on the list of repeated keys
+  const int qn = sh_qn;
+  for (int e = tid; e < qn; e += T) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(&queue[e]);
+    const uint64_t k = ((uint64_t)raw.y << 32) | raw.x;
+    const uint32_t fp = raw.z >> 15, mine = (raw.z & ~0x7FFFu) | raw.w;
+    uint32_t h = raw.z & 0x7FFFu;
+    for (int probe = 0; probe <= (int)hmask; ++probe) {
+      uint32_t seen = table[h];
+      if (seen == kFree) {
+        seen = atomicCAS(&table[h], kFree, mine);
+        if (seen == kFree) break;  // inserted
+      }
+      if ((seen >> 15) == fp) {
+        const int other = (int)(seen & 0x7FFFu);
+        if (slow_key<POSITION>(other) == k) {
+          const int me = (int)raw.w;
+          atomicOr(&dupbit[me >> 5], 1u << (me & 31));
+          const uint32_t before = atomicOr(&dupbit[other >> 5], 1u << (other & 31));
+          const bool first = !(before & (1u << (other & 31)));
+          const int at = atomicAdd(&sh_ndl, first ? 2 : 1);
+          duplist[at] = ((uint32_t)other << 14) | (uint32_t)me;
+          if (first) duplist[at + 1] = ((uint32_t)other << 14) | (uint32_t)other;
+          break;
+        }
+      }
+      h = (h + 1) & hmask;
+    }
+  }
+  if (qn > 0) {  // workgroup-uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  KLAT_STAMP(3);
+
+  // ---- 3. repeated keys: (inserter | arc) words sorted, every run folded in arc order ----
+  const int ndl = sh_ndl;  // workgroup-uniform
+  uint32_t recmask = valid;  // the arcs that stand for a record: unique keys, plus first arcs of repeated keys
+  uint32_t dupmask = 0;
+  if (ndl > 0) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int i = j * T + tid;
+      if ((valid & (1u << j)) && (dupbit[i >> 5] & (1u << (i & 31)))) {
+        dupmask |= 1u << j;
+        vals[i] = val[j];
+      }
+    }
+    recmask &= ~dupmask;
+    uint32_t* dups = table;  // (the table is dead)
+    for (int p = tid; p < ndl; p += T) dups[p] = duplist[p];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    block_sort_any(T, dups, ndl, [](uint32_t x, uint32_t y) { return x < y; });
+    for (int p = tid; p < ndl; p += T) {
+      const uint32_t w = dups[p];
+      if (!(p == 0 || (dups[p - 1] >> 14) != (w >> 14))) continue;
+      int arc = (int)(w & 0x3FFFu);
+      const int first_arc = arc;
+      double acc = vals[arc], best = acc;
+      int best_arc = arc;
+      for (int q = p + 1; q < ndl && (dups[q] >> 14) == (w >> 14); ++q) {
+        arc = (int)(dups[q] & 0x3FFFu);
+        const double x = vals[arc];
+        acc = hlog_add(acc, x);
+        if (x > best) {  // strict: the first maximum in arc order wins
+          best = x;
+          best_arc = arc;
+        }
+      }
+      vals[first_arc] = acc;  // (runs are disjoint: nobody else reads this arc's own value any more)
+      if (POSITION) payload[first_arc] = payload_of<POSITION>(slow_key<POSITION>(first_arc), best_arc, pk.label_min, pk.time_bits);
+      atomicOr(&headbit[first_arc >> 5], 1u << (first_arc & 31));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int i = j * T + tid;
+      if ((dupmask & (1u << j)) && (headbit[i >> 5] & (1u << (i & 31)))) {
+        recmask |= 1u << j;
+        val[j] = vals[i];  // the folded sum
+      }
+    }
+  }
+  KLAT_STAMP(4);
+
+  // ---- 4. order by (logp desc, key): one bucket pass by value, then the exact order inside every bucket ----
+  // range of the finite values, as floats rounded outwards (any common scale keeps the bucket function monotone)
+  {
+    float flo = INFINITY, fhi = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      if (!(recmask & (1u << j))) continue;
+      const float f = (float)val[j];
+      if (f > -INFINITY && f < INFINITY) flo = fminf(flo, f), fhi = fmaxf(fhi, f);
+    }
+    for (int d = 32; d > 0; d >>= 1) flo = fminf(flo, __shfl_xor(flo, d, 64)), fhi = fmaxf(fhi, __shfl_xor(fhi, d, 64));
+    if (lane == 0) sh_lo[wave] = flo, sh_hi[wave] = fhi;
+    for (int i = tid; i < B / 2; i += T) bcnt[i] = 0;
+  }
+  int m;
+  (void)block_excl_sum(T, __popc(recmask), &m, sh);  // (its barriers also publish the minima / maxima and the cleared counters)
+  float flo = INFINITY, fhi = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w) flo = fminf(flo, sh_lo[w]), fhi = fmaxf(fhi, sh_hi[w]);
+  // one ulp outwards: (float)val rounds to nearest, the true extremes may lie half an ulp beyond
+  const double vmax = (double)fhi + fabs((double)fhi) * 1.2e-7, vspan = vmax - ((double)flo - fabs((double)flo) * 1.2e-7);
+  const float scale = (vspan > 0.0 && vspan < INFINITY) ? (float)(B - 1) / __fsqrt_rn((float)vspan) : 0.0f;
+  uint32_t where[P];  // bucket << 16 | arrival number inside it
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    where[j] = 0;
+    if (recmask & (1u << j)) {
+      int b = B - 1;  // -inf, NaN: behind every finite value (their images order them inside the bucket)
+      if (val[j] > -INFINITY && val[j] < INFINITY) {
+        // monotone in -logp: subtract, clamp, double -> float rounding, correctly rounded float sqrt, multiply, truncate
+        const float t = __fsqrt_rn((float)fmax(vmax - val[j], 0.0)) * scale;
+        b = t >= (float)(B - 1) ? B - 1 : (int)t;
+      } else if (val[j] == INFINITY) {
+        b = 0;
+      }
+      const uint32_t old = atomicAdd(&bcnt[b >> 1], 1u << ((b & 1) * 16));
+      where[j] = ((uint32_t)b << 16) | ((old >> ((b & 1) * 16)) & 0xFFFFu);
+    }
+  }
+  __syncthreads();
+  {  // in-place inclusive scan of the B 16-bit counters: B / T consecutive ones per thread
+    const int per = (B / 2) / T;  // words per thread: 1 .. 8 (2 T <= B <= H / 2, launch_one)
+    uint32_t w[8];
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      w[q] = q < per ? bcnt[tid * per + q] : 0u;
+      sum += (int)(w[q] & 0xFFFFu) + (int)(w[q] >> 16);
+    }
+    int total;
+    int run = block_excl_sum(T, sum, &total, sh);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int lo = run + (int)(w[q] & 0xFFFFu);
+      const int hi = lo + (int)(w[q] >> 16);
+      run = hi;
+      if (q < per) bcnt[tid * per + q] = (uint32_t)lo | ((uint32_t)hi << 16);
+    }
+  }
+  __syncthreads();
+  const uint16_t* bend = reinterpret_cast<const uint16_t*>(bcnt);  // bend[b] = end of bucket b
+  constexpr uint64_t idmask = (1ull << RB) - 1ull;
+  // an order word: the image's upper 64 - RB bits | the arc.  Two words whose upper parts differ are ordered by
+  // them; equal upper parts (values within 2^-38 of one another, or equal) go back to the records themselves.
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    if (recmask & (1u << j)) {
+      const int b = (int)(where[j] >> 16);
+      const int lo = b ? (int)bend[b - 1] : 0;
+      order[lo + (int)(where[j] & 0xFFFFu)] = (hdesc_key(val[j]) & ~idmask) | (uint64_t)(j * T + tid);
+      where[j] = ((uint32_t)lo << 16) | (uint32_t)bend[b];  // the bucket's range from here on
+    }
+  }
+  __syncthreads();
+  KLAT_STAMP(5);
+  // crowded buckets (clustered or tied values) are sorted by the whole workgroup, in place
+  for (int b = tid; b < B; b += T)
+    if ((int)bend[b] - (b ? (int)bend[b - 1] : 0) > kSerialMax) sh_big[atomicAdd(&sh_nbig, 1)] = b;
+  __syncthreads();
+  const int nbig = sh_nbig;  // workgroup-uniform
+  for (int g = 0; g < nbig; ++g) {
+    const int b = sh_big[g];
+    const int lo = b ? (int)bend[b - 1] : 0, hi = (int)bend[b];
+    block_sort_any(T, order + lo, hi - lo, [&](uint64_t x, uint64_t y) -> bool {
+      return ((x ^ y) & ~idmask) ? x < y : (x != y && tie_less<POSITION>((int)(x & idmask), (int)(y & idmask)));
+    });
+  }
+  // every record finds its final position inside its bucket by counting the smaller entries (independent LDS
+  // reads); a crowded bucket, or one with a word whose upper part equals the record's, takes the slow way
+  uint32_t finalpos[(P + 1) / 2];  // two 16-bit positions per word
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    int p = 0;
+    if (recmask & (1u << j)) {
+      const int lo = (int)(where[j] >> 16), hi = (int)(where[j] & 0xFFFFu);
+      const uint64_t me = (hdesc_key(val[j]) & ~idmask) | (uint64_t)(j * T + tid);
+      bool slow = hi - lo > kSerialMax;
+      p = lo;
+      if (!slow)
+        for (int q = lo; q < hi; ++q) {
+          const uint64_t f = order[q];
+          p += f < me ? 1 : 0;
+          slow |= !((f ^ me) & ~idmask) && f != me;
+        }
+      if (slow) p = slow_position<POSITION, RB>(order, lo, hi, me);
+    }
+    if (j & 1) finalpos[j >> 1] |= (uint32_t)p << 16;
+    else finalpos[j >> 1] = (uint32_t)p;
+  }
+  KLAT_STAMP(6);
+
+  // ---- 5. the records at their final positions: through LDS, so that they leave as full lines ----
+  __syncthreads();  // every thread is done with `order` (and with the counters behind it)
+  {
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    const int stage_recs = lds_bytes / (int)sizeof(Rec);
+    uint64_t* stage = reinterpret_cast<uint64_t*>(smem);  // [stage_recs][3]
+    uint64_t* out64 = reinterpret_cast<uint64_t*>(recs);
+    for (int base = 0; base < m; base += stage_recs) {  // (m is workgroup-uniform)
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        if (!(recmask & (1u << j))) continue;
+        const int p = (int)((finalpos[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu) - base;
+        if ((unsigned)p >= (unsigned)stage_recs) continue;
+        const int i = j * T + tid;
+        Payload q;
+        if (POSITION && (dupmask & (1u << j))) q = payload[i];  // (t0, t1) of the first arc attaining the maximum
+        else q = payload_of<POSITION>(key[j], i, pk.label_min, pk.time_bits);
+        stage[p * 3 + 0] = hdesc_key(val[j]);
+        stage[p * 3 + 1] = q.k1;
+        stage[p * 3 + 2] = q.k2;
+      }
+      lds_barrier();
+      const int cnt = min(stage_recs, m - base) * 3;
+      for (int i = tid; i < cnt; i += T) out64[(size_t)base * 3 + i] = stage[i];
+      lds_barrier();
+    }
+  }
+  if (tid == 0) a.num_records[u] = m;
+  KLAT_STAMP(7);
+#undef KLAT_STAMP
+}
+
+template <bool POSITION, int T, int P>
+hipError_t launch_one(const AccumArgs& a, const RadixPack& pk, int num_lattices, int log_h, hipStream_t stream) {
+  const int H = 1 << log_h, cap = T * P;
+  // the value counters: H / 2 of them inside the first region where the order words leave room, else H / 4 behind the bitmaps
+  int cnt_off, log_b;
+  if (8 * cap + H <= 4 * H) {
+    cnt_off = 8 * cap, log_b = log_h - 1;
+  } else {
+    cnt_off = 4 * H + H / 8, log_b = log_h - 2;
+  }
+  while ((1 << log_b) < 2 * T) ++log_b;  // (the scan gives every thread a whole word at least)
+  const int lds = std::max(4 * H + H / 8, cnt_off + 2 * (1 << log_b));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_hash2_kernel<POSITION, T, P>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((index_hash2_kernel<POSITION, T, P>), dim3(num_lattices), dim3(T), lds, stream, a, pk, log_h, cnt_off, log_b, lds);
+  return hipGetLastError();
+}
+
+template <bool POSITION>
+hipError_t launch(const AccumArgs& a, const RadixPack& pk, int num_lattices, int max_arcs, hipStream_t stream) {
+  if (max_arcs <= 512 * 12) return launch_one<POSITION, 512, 12>(a, pk, num_lattices, 14, stream);
+  if (max_arcs <= 512 * 16) return launch_one<POSITION, 512, 16>(a, pk, num_lattices, 14, stream);
+  return launch_one<POSITION, 1024, 16>(a, pk, num_lattices, 15, stream);
+}
+
+}  // namespace v2
+
 }  // namespace
 
 hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots, int max_arcs,
                              hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
+  if (std::getenv("KLAT_INDEX_V1") == nullptr)  // (the first form: comparisons, tests)
+    return position ? v2::launch<true>(a, pk, num_lattices, max_arcs, stream) : v2::launch<false>(a, pk, num_lattices, max_arcs, stream);
   if (log_slots == 14)
     return position ? launch_hash_one<true, 14>(a, pk, num_lattices, max_arcs, stream) : launch_hash_one<false, 14>(a, pk, num_lattices, max_arcs, stream);
   if (log_slots == 15)

@@ -301,6 +301,46 @@ def test_frame_post_word_lattice(ctx, golden_dir):
     assert [int(x) for x in labels[off[9]:off[10]]] == [5]
 
 
+@pytest.mark.parametrize("shape", ["plain", "repeated_keys", "dead_arcs", "filtered"])
+def test_index_kernel_forms_agree(ctx, shape, monkeypatch):
+    """The round-4 form of the hash kernel (queue for everything that is not a free slot, arc bitmaps, values in
+    registers, ties out of line) against the first form (KLAT_INDEX_V1=1): the same records in the same order, bit
+    for bit, segment and position index -- lattices of 1 ... 7 000 arcs (both table classes of the first form, the
+    512 x 12 and 512 x 16 instantiations of the second), keys that repeat in most arcs (few words, many states a
+    time: what real word lattices look like), arcs of infinite cost (records that tie at log-zero) and a label filter."""
+    rng = np.random.RandomState(21)
+    ns = np.concatenate([[1, 2, 3], rng.randint(4, 700, size=14), [2000, 2300]]).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4], size=len(ns)).astype(np.int32)
+    fo[-1] = 3
+    arrays = klat_amd.synth(20260021, ns, fo)
+    inc = exc = None
+    if shape == "repeated_keys":
+        arrays["olabel"] = (arrays["olabel"] % 5).astype(np.int32)
+        arrays["ilabel"] = arrays["olabel"].copy()
+        arrays["state_time"] = (arrays["state_time"] // 6).astype(np.int32)
+    if shape == "dead_arcs":
+        dead = rng.rand(len(arrays["graph"])) < 0.05
+        dead &= arrays["dst"] != arrays["src"] + 1
+        arrays["graph"][dead] = np.inf
+        arrays["acoustic"][dead] = np.inf
+    if shape == "filtered":
+        exc = [int(x) for x in rng.randint(1, 1000, size=300)]
+    state_len = np.concatenate([np.arange(int(n), dtype=np.int32) % 13 for n in ns])
+    got = {}
+    for form in ("v2", "v1"):
+        if form == "v1":
+            monkeypatch.setenv("KLAT_INDEX_V1", "1")
+        b = klat_amd.Batch(ctx, arrays)
+        b.forward_backward(1.0, 0.3, 0.25)
+        got[form] = (b.segment_index(include=inc, exclude=exc), b.position_index(state_len, include=inc, exclude=exc))
+        b.close()
+    for k in (0, 1):
+        (o1, r1), (o2, r2) = got["v1"][k], got["v2"][k]
+        assert np.array_equal(o1, o2)
+        assert r1.tobytes() == r2.tobytes()
+    assert got["v2"][0][0][-1] > 0
+
+
 # the frame kernels: the lean one with the general one behind it (default), the general one alone, and a record
 # pool that holds the first few lattices only (the others go through the count pass and the general kernel)
 FRAME_MODES = {"lean": {}, "general": {"KLAT_FRAME_GENERAL": "1"}, "short_pool": {"KLAT_FRAME_POOL_RATIO": "0.2"}}
