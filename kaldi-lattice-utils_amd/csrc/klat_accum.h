@@ -40,6 +40,7 @@ struct AccumArgs {
   double* val_scratch;   // 8 B per slot: the hash kernel's record values, by record id
   int32_t min_arcs, max_arcs;  // a launch takes the lattices with min_arcs < arcs <= max_arcs
   long long* phase_clock;      // [U][8] or null: s_memtime stamps of the hash kernel's phases (KLAT_ACCUM_PROFILE)
+  const int32_t* lattice_list; // the launch's lattices (workgroup k takes lattice_list[k]) or null: every lattice
 };
 
 }  // namespace klat
@@ -88,6 +89,12 @@ hipError_t launch_range(const RangeArgs& a, hipStream_t stream);
 // max_arcs: the most arcs of a lattice this launch takes (its workgroups are as wide as that lattice needs)
 hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots, int max_arcs,
                              hipStream_t stream);
+// The hash kernel's second form: lattices by size class -- up to kHashClassArcs[c] arcs each, class c's lattices listed
+// in `list` (device memory, `count` of them).
+static const int kHashClasses = 5;
+static const int kHashClassArcs[kHashClasses] = {1536, 3072, 6144, 8192, 16384};
+hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool position, int cls, const int32_t* list, int count,
+                              hipStream_t stream);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
                                OutRecord* out, hipStream_t stream);
 

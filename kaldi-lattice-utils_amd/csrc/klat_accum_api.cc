@@ -34,7 +34,8 @@ int ensure_index_scratch(klat_batch* b) {
   klat_accum_state& st = b->accum;
   if (st.scratch_ready) return KLAT_OK;
   std::vector<int64_t> off(b->U + 1, 0);
-  for (int64_t u = 0; u < b->U; ++u) off[u + 1] = off[u] + next_pow2(b->h_arc_off[u + 1] - b->h_arc_off[u]);
+  // (two slots at least: every row then starts on a 16-byte boundary in each of the three scratch arrays)
+  for (int64_t u = 0; u < b->U; ++u) off[u + 1] = off[u] + std::max<int64_t>(2, next_pow2(b->h_arc_off[u + 1] - b->h_arc_off[u]));
   st.scratch_slots = off[b->U];
   int rc;
   if ((rc = st.scratch_off.upload(off.data(), off.size(), b->ctx->stream))) return rc;
@@ -178,7 +179,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       KLAT_HIP(hipMemsetAsync(d_clock.p, 0, sizeof(long long) * (size_t)b->U * 8, c->stream));
       a.phase_clock = d_clock.p;
     }
-    if (radix) {
+    if (radix && std::getenv("KLAT_INDEX_V1") != nullptr) {  // the kernel's first form (comparisons, tests)
       if (n_small > 0) {
         a.min_arcs = -1, a.max_arcs = kHashMaxArcs / 2;
         KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 14, (int)most_small, c->stream));
@@ -192,6 +193,47 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
         KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
       }
       a.min_arcs = -1, a.max_arcs = 0x7FFFFFFF;
+    } else if (radix) {
+      // Size classes: a lattice runs in the smallest workgroup that holds its arcs (128 threads and 17 KiB of LDS
+      // for 1 536 arcs ... 1 024 threads and 150 KiB for 16 384), every class one launch over its own list of
+      // lattices; a class of fewer than 64 lattices rides with the next larger one that has any.  Above 16 384
+      // arcs: the general kernel.
+      if (!st.classes_ready) {
+        std::vector<int32_t> cls((size_t)b->U);
+        int64_t cnt[kHashClasses + 1] = {0};
+        for (int64_t u = 0; u < b->U; ++u) {
+          const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
+          int k = 0;
+          while (k < kHashClasses && arcs > kHashClassArcs[k]) ++k;
+          cls[(size_t)u] = k;
+          ++cnt[k];
+        }
+        int to[kHashClasses + 1];
+        for (int k = kHashClasses; k >= 0; --k) {
+          to[k] = k;
+          if (k < kHashClasses - 1 && cnt[k] < 64) {
+            int up = k + 1;
+            while (up < kHashClasses && cnt[up] == 0) ++up;
+            if (up < kHashClasses) to[k] = to[up], cnt[to[up]] += cnt[k], cnt[k] = 0;
+          }
+        }
+        st.class_begin[0] = 0;
+        for (int k = 0; k <= kHashClasses; ++k) st.class_begin[k + 1] = st.class_begin[k] + cnt[k];
+        std::vector<int32_t> list((size_t)b->U);
+        int64_t at[kHashClasses + 1];
+        for (int k = 0; k <= kHashClasses; ++k) at[k] = st.class_begin[k];
+        for (int64_t u = 0; u < b->U; ++u) list[(size_t)at[to[cls[(size_t)u]]]++] = (int32_t)u;
+        if ((rc = st.class_list.upload(list.data(), list.size(), c->stream))) return rc;
+        KLAT_HIP(hipStreamSynchronize(c->stream));  // (the list is a local)
+        st.classes_ready = true;
+      }
+      for (int k = 0; k < kHashClasses; ++k)
+        KLAT_HIP(launch_index_hash2(a, pk, position, k, st.class_list.p + st.class_begin[k], (int)(st.class_begin[k + 1] - st.class_begin[k]), c->stream));
+      if (st.class_begin[kHashClasses + 1] > st.class_begin[kHashClasses]) {
+        a.min_arcs = kHashClassArcs[kHashClasses - 1], a.max_arcs = 0x7FFFFFFF;
+        KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
+        a.min_arcs = -1, a.max_arcs = 0x7FFFFFFF;
+      }
     } else {
       KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
     }

@@ -756,8 +756,8 @@ struct QEntry {  // 16 B, in the lattice's record row until the records go there
 // T threads, P arcs a thread; RB: bits of an arc number.  Dynamic LDS: [0, 4H) table -> order words -> stage;
 // [4H, 4H + H/8) the two arc bitmaps; the value counters at cnt_off (inside the first region where the order words
 // leave room, else behind the bitmaps).
-template <bool POSITION, int T, int P>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <bool POSITION, int T, int P, int WPE>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int log_b, int lds_bytes) {
   constexpr int CAP = T * P;
   constexpr int RB = CAP > 8192 ? 14 : 13;
@@ -773,10 +773,10 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   __shared__ float sh_lo[T / 64], sh_hi[T / 64];
   __shared__ int sh_qn, sh_ndl, sh_nbig, sh_big[CAP / kSerialMax + 1];
 
-  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u = a.lattice_list ? a.lattice_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t a0 = a.arc_off[u], s0 = a.state_off[u];
   const int n = (int)(a.arc_off[u + 1] - a0);
-  if (n <= a.min_arcs || n > a.max_arcs) return;  // another launch's lattice (workgroup-uniform)
+  if (n > CAP) return;  // (never: the host lists a class's lattices)
 #define KLAT_STAMP(k)                                                                 \
   do {                                                                                \
     if (a.phase_clock && tid == 0) a.phase_clock[(size_t)u * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
@@ -1069,12 +1069,15 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   constexpr uint64_t idmask = (1ull << RB) - 1ull;
   // an order word: the image's upper 64 - RB bits | the arc.  Two words whose upper parts differ are ordered by
   // them; equal upper parts (values within 2^-38 of one another, or equal) go back to the records themselves.
+  // From here on a record's registers hold the image of its value (what the order words and the record want).
+  uint64_t img[P];
 #pragma unroll
   for (int j = 0; j < P; ++j) {
+    img[j] = hdesc_key(val[j]);
     if (recmask & (1u << j)) {
       const int b = (int)(where[j] >> 16);
       const int lo = b ? (int)bend[b - 1] : 0;
-      order[lo + (int)(where[j] & 0xFFFFu)] = (hdesc_key(val[j]) & ~idmask) | (uint64_t)(j * T + tid);
+      order[lo + (int)(where[j] & 0xFFFFu)] = (img[j] & ~idmask) | (uint64_t)(j * T + tid);
       where[j] = ((uint32_t)lo << 16) | (uint32_t)bend[b];  // the bucket's range from here on
     }
   }
@@ -1100,16 +1103,21 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
     int p = 0;
     if (recmask & (1u << j)) {
       const int lo = (int)(where[j] >> 16), hi = (int)(where[j] & 0xFFFFu);
-      const uint64_t me = (hdesc_key(val[j]) & ~idmask) | (uint64_t)(j * T + tid);
+      // the words below every word with my upper part, and those up to the last such word: mine is the only one
+      // in between unless another record's value agrees with mine in its upper bits
+      const uint64_t floor_w = img[j] & ~idmask, ceil_w = img[j] | idmask;
       bool slow = hi - lo > kSerialMax;
       p = lo;
-      if (!slow)
+      if (!slow) {
+        int upto = 0;
         for (int q = lo; q < hi; ++q) {
           const uint64_t f = order[q];
-          p += f < me ? 1 : 0;
-          slow |= !((f ^ me) & ~idmask) && f != me;
+          p += f < floor_w ? 1 : 0;
+          upto += f <= ceil_w ? 1 : 0;
         }
-      if (slow) p = slow_position<POSITION, RB>(order, lo, hi, me);
+        slow = upto - (p - lo) != 1;
+      }
+      if (slow) p = slow_position<POSITION, RB>(order, lo, hi, floor_w | (uint64_t)(j * T + tid));
     }
     if (j & 1) finalpos[j >> 1] |= (uint32_t)p << 16;
     else finalpos[j >> 1] = (uint32_t)p;
@@ -1120,7 +1128,7 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   __syncthreads();  // every thread is done with `order` (and with the counters behind it)
   {
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    const int stage_recs = lds_bytes / (int)sizeof(Rec);
+    const int stage_recs = lds_bytes / (int)sizeof(Rec) & ~1;  // (even: every pass starts on a 16-byte boundary)
     uint64_t* stage = reinterpret_cast<uint64_t*>(smem);  // [stage_recs][3]
     uint64_t* out64 = reinterpret_cast<uint64_t*>(recs);
     for (int base = 0; base < m; base += stage_recs) {  // (m is workgroup-uniform)
@@ -1133,13 +1141,16 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
         Payload q;
         if (POSITION && (dupmask & (1u << j))) q = payload[i];  // (t0, t1) of the first arc attaining the maximum
         else q = payload_of<POSITION>(key[j], i, pk.label_min, pk.time_bits);
-        stage[p * 3 + 0] = hdesc_key(val[j]);
+        stage[p * 3 + 0] = img[j];
         stage[p * 3 + 1] = q.k1;
         stage[p * 3 + 2] = q.k2;
       }
       lds_barrier();
-      const int cnt = min(stage_recs, m - base) * 3;
-      for (int i = tid; i < cnt; i += T) out64[(size_t)base * 3 + i] = stage[i];
+      const int cnt = min(stage_recs, m - base) * 3;  // 8-byte words; the row starts on a 16-byte boundary and base * 3 is even
+      const uint4* stage4 = reinterpret_cast<const uint4*>(stage);
+      uint4* out4 = reinterpret_cast<uint4*>(out64 + (size_t)base * 3);
+      for (int i = tid; i < cnt / 2; i += T) out4[i] = stage4[i];
+      if ((cnt & 1) && tid == 0) out64[(size_t)base * 3 + cnt - 1] = stage[cnt - 1];
       lds_barrier();
     }
   }
@@ -1148,7 +1159,7 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
 #undef KLAT_STAMP
 }
 
-template <bool POSITION, int T, int P>
+template <bool POSITION, int T, int P, int WPE = 4>
 hipError_t launch_one(const AccumArgs& a, const RadixPack& pk, int num_lattices, int log_h, hipStream_t stream) {
   const int H = 1 << log_h, cap = T * P;
   // the value counters: H / 2 of them inside the first region where the order words leave room, else H / 4 behind the bitmaps
@@ -1160,18 +1171,23 @@ hipError_t launch_one(const AccumArgs& a, const RadixPack& pk, int num_lattices,
   }
   while ((1 << log_b) < 2 * T) ++log_b;  // (the scan gives every thread a whole word at least)
   const int lds = std::max(4 * H + H / 8, cnt_off + 2 * (1 << log_b));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_hash2_kernel<POSITION, T, P>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&index_hash2_kernel<POSITION, T, P, WPE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((index_hash2_kernel<POSITION, T, P>), dim3(num_lattices), dim3(T), lds, stream, a, pk, log_h, cnt_off, log_b, lds);
+  hipLaunchKernelGGL((index_hash2_kernel<POSITION, T, P, WPE>), dim3(num_lattices), dim3(T), lds, stream, a, pk, log_h, cnt_off, log_b, lds);
   return hipGetLastError();
 }
 
 template <bool POSITION>
-hipError_t launch(const AccumArgs& a, const RadixPack& pk, int num_lattices, int max_arcs, hipStream_t stream) {
-  if (max_arcs <= 512 * 12) return launch_one<POSITION, 512, 12>(a, pk, num_lattices, 14, stream);
-  if (max_arcs <= 512 * 16) return launch_one<POSITION, 512, 16>(a, pk, num_lattices, 14, stream);
-  return launch_one<POSITION, 1024, 16>(a, pk, num_lattices, 15, stream);
+hipError_t launch(const AccumArgs& a, const RadixPack& pk, int cls, int count, hipStream_t stream) {
+  switch (cls) {  // kHashClassArcs (klat_accum.h): threads x arcs a thread, table slots
+    case 0: return launch_one<POSITION, 128, 12>(a, pk, count, 12, stream);
+    case 1: return launch_one<POSITION, 256, 12>(a, pk, count, 13, stream);
+    case 2: return launch_one<POSITION, 512, 12>(a, pk, count, 14, stream);
+    case 3: return launch_one<POSITION, 512, 16>(a, pk, count, 14, stream);
+    case 4: return launch_one<POSITION, 1024, 16>(a, pk, count, 15, stream);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace v2
@@ -1181,13 +1197,19 @@ hipError_t launch(const AccumArgs& a, const RadixPack& pk, int num_lattices, int
 hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots, int max_arcs,
                              hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
-  if (std::getenv("KLAT_INDEX_V1") == nullptr)  // (the first form: comparisons, tests)
-    return position ? v2::launch<true>(a, pk, num_lattices, max_arcs, stream) : v2::launch<false>(a, pk, num_lattices, max_arcs, stream);
   if (log_slots == 14)
     return position ? launch_hash_one<true, 14>(a, pk, num_lattices, max_arcs, stream) : launch_hash_one<false, 14>(a, pk, num_lattices, max_arcs, stream);
   if (log_slots == 15)
     return position ? launch_hash_one<true, 15>(a, pk, num_lattices, max_arcs, stream) : launch_hash_one<false, 15>(a, pk, num_lattices, max_arcs, stream);
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool position, int cls, const int32_t* list, int count,
+                              hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  AccumArgs b = a;
+  b.lattice_list = list;
+  return position ? v2::launch<true>(b, pk, cls, count, stream) : v2::launch<false>(b, pk, cls, count, stream);
 }
 
 }  // namespace klat

@@ -212,6 +212,10 @@ struct klat_accum_state {
   klat::DevBuf<unsigned char> key_scratch, rec_scratch;
   klat::DevBuf<double> val_scratch;
   klat::DevBuf<int32_t> num_records, include, exclude, state_len;
+  // the hash kernel's size classes (klat_accum.h): class c's lattices are class_list[class_begin[c] .. class_begin[c + 1])
+  bool classes_ready = false;
+  klat::DevBuf<int32_t> class_list;
+  int64_t class_begin[klat::kHashClasses + 2] = {0};  // (the last class: the lattices the general kernel takes)
 };
 
 struct klat_frame_state {
