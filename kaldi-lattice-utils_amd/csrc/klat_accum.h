@@ -91,8 +91,8 @@ hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_la
                              hipStream_t stream);
 // The hash kernel's second form: lattices by size class -- up to kHashClassArcs[c] arcs each, class c's lattices listed
 // in `list` (device memory, `count` of them).
-static const int kHashClasses = 5;
-static const int kHashClassArcs[kHashClasses] = {1536, 3072, 6144, 8192, 16384};
+static const int kHashClasses = 6;
+static const int kHashClassArcs[kHashClasses] = {1536, 3072, 6144, 8192, 15360, 16384};
 hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool position, int cls, const int32_t* list, int count,
                               hipStream_t stream);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,

@@ -632,7 +632,10 @@ hipError_t launch_hash_one(const AccumArgs& a, const RadixPack& pk, int num_latt
 namespace v2 {
 
 constexpr uint32_t kFree = 0xFFFFFFFFu;  // {fingerprint 17 bits | arc 15 bits}: arc 32 767 does not exist
-constexpr int kRounds = 3;               // tries before an arc goes to the queue
+#ifndef KLAT_IDX_ROUNDS
+#define KLAT_IDX_ROUNDS 3
+#endif
+constexpr int kRounds = KLAT_IDX_ROUNDS;  // tries before an arc goes to the queue
 
 __device__ __forceinline__ uint32_t key_hash32(uint64_t key) {
   const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
@@ -831,9 +834,10 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   uint32_t valid = 0;
   const bool filtered = (a.num_include | a.num_exclude) != 0;  // workgroup-uniform
   if (filtered) __syncthreads();  // (the filter reads the lattice's view)
-  constexpr int HALF = P / 2;
+  constexpr int HALF = P % 6 == 0 ? 6 : P % 5 == 0 ? 5 : 4;  // arcs a thread asks for at a time (what the registers hold beside the keys and values)
+  static_assert(P % HALF == 0, "");
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < P / HALF; ++half) {
     if (half * HALF >= jmax) break;
     int32_t lab[HALF], t0[HALF], t1[HALF];
     float gr[HALF], ac[HALF];
@@ -885,18 +889,25 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
     uint32_t stuck = 0;  // a matching fingerprint: the queue looks at the slot (no more tries)
 #pragma unroll
     for (int round = 0; round < kRounds; ++round) {
-      uint32_t seen[P];
+      constexpr int NB = P <= 12 ? P : P % 8 == 0 ? 8 : 5;  // compare-and-swaps in flight together
+      static_assert(P % NB == 0, "");
 #pragma unroll
-      for (int j = 0; j < P; ++j) {
-        seen[j] = kFree;
-        if ((pend & ~stuck) & (1u << j)) seen[j] = atomicCAS(&table[packed[j] & 0x7FFFu], kFree, (packed[j] & ~0x7FFFu) | (uint32_t)(j * T + tid));
-      }
+      for (int j0 = 0; j0 < P; j0 += NB) {
+        uint32_t seen[NB];
 #pragma unroll
-      for (int j = 0; j < P; ++j) {
-        if (!((pend & ~stuck) & (1u << j))) continue;
-        if (seen[j] == kFree) pend &= ~(1u << j);                       // inserted: this arc stands for its key
-        else if (((seen[j] ^ packed[j]) >> 15) == 0) stuck |= 1u << j;  // its key, as likely as not
-        else if (round + 1 < kRounds) packed[j] = (packed[j] & ~0x7FFFu) | ((packed[j] + 1) & hmask);  // another key's slot: the next one
+        for (int q = 0; q < NB; ++q) {
+          const int j = j0 + q;
+          seen[q] = kFree;
+          if ((pend & ~stuck) & (1u << j)) seen[q] = atomicCAS(&table[packed[j] & 0x7FFFu], kFree, (packed[j] & ~0x7FFFu) | (uint32_t)(j * T + tid));
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int j = j0 + q;
+          if (!((pend & ~stuck) & (1u << j))) continue;
+          if (seen[q] == kFree) pend &= ~(1u << j);                       // inserted: this arc stands for its key
+          else if (((seen[q] ^ packed[j]) >> 15) == 0) stuck |= 1u << j;  // its key, as likely as not
+          else if (round + 1 < kRounds) packed[j] = (packed[j] & ~0x7FFFu) | ((packed[j] + 1) & hmask);  // another key's slot: the next one
+        }
       }
     }
     if (pend) {
@@ -1185,7 +1196,8 @@ hipError_t launch(const AccumArgs& a, const RadixPack& pk, int cls, int count, h
     case 1: return launch_one<POSITION, 256, 12>(a, pk, count, 13, stream);
     case 2: return launch_one<POSITION, 512, 12>(a, pk, count, 14, stream);
     case 3: return launch_one<POSITION, 512, 16>(a, pk, count, 14, stream);
-    case 4: return launch_one<POSITION, 1024, 16>(a, pk, count, 15, stream);
+    case 4: return launch_one<POSITION, 1024, 15>(a, pk, count, 15, stream);
+    case 5: return launch_one<POSITION, 1024, 16>(a, pk, count, 15, stream);
   }
   return hipErrorInvalidValue;
 }
