@@ -813,7 +813,10 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
     v.dupbit_off = (uint32_t)H * 4u;
   }
   QEntry* queue = reinterpret_cast<QEntry*>(reinterpret_cast<Rec*>(a.rec_scratch) + row);  // (24 B a slot: room for n entries)
-  uint32_t* duplist = reinterpret_cast<uint32_t*>(reinterpret_cast<Payload*>(a.key_scratch) + row);
+  // the list of repeated keys' arcs: behind the queue in the record row (16 of a slot's 24 bytes are the queue's),
+  // out of the way of the payloads the fold writes while it reads the list
+  uint32_t* duplist = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(reinterpret_cast<Rec*>(a.rec_scratch) + row) +
+                                                  16 * (size_t)(a.scratch_off[u + 1] - row));
   Payload* payload = reinterpret_cast<Payload*>(a.key_scratch) + row;  // by first arc, repeated keys only (after the list is in LDS)
   Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + row;
   const int jmax = (n + T - 1) / T;  // rounds of T arcs this lattice has (workgroup-uniform)
@@ -976,31 +979,108 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
       }
     }
     recmask &= ~dupmask;
-    uint32_t* dups = table;  // (the table is dead)
-    for (int p = tid; p < ndl; p += T) dups[p] = duplist[p];
+    // The list holds (inserter | arc) words, the inserter's own among them: a counting sort by inserter (the table
+    // is dead: three 16-bit arrays over the arcs take its place) puts every key's arcs side by side, the thread
+    // that meets an inserter's own word orders its few arcs and folds them.  (Sorting the whole list with the
+    // workgroup's bitonic network -- the first form -- took 63 of a lattice's 175 thousand cycles where a fifth of
+    // the arcs repeat a key; it stays for a key with more arcs than one thread should order.)
+    uint32_t* gcnt = table;                                            // [CAP / 2] arcs of an inserter's key, two per word
+    uint32_t* goff = table + CAP / 2;                                  // [CAP / 2] where the next one goes -> the group's end
+    uint16_t* grouped = reinterpret_cast<uint16_t*>(table + CAP);      // [CAP] the arcs, key by key
+    __shared__ int sh_gmax;
+    for (int i = tid; i < CAP / 2; i += T) gcnt[i] = 0;
+    if (tid == 0) sh_gmax = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    block_sort_any(T, dups, ndl, [](uint32_t x, uint32_t y) { return x < y; });
     for (int p = tid; p < ndl; p += T) {
-      const uint32_t w = dups[p];
-      if (!(p == 0 || (dups[p - 1] >> 14) != (w >> 14))) continue;
-      int arc = (int)(w & 0x3FFFu);
-      const int first_arc = arc;
-      double acc = vals[arc], best = acc;
-      int best_arc = arc;
-      for (int q = p + 1; q < ndl && (dups[q] >> 14) == (w >> 14); ++q) {
-        arc = (int)(dups[q] & 0x3FFFu);
-        const double x = vals[arc];
-        acc = hlog_add(acc, x);
-        if (x > best) {  // strict: the first maximum in arc order wins
-          best = x;
-          best_arc = arc;
-        }
+      const uint32_t y = duplist[p] >> 14;
+      atomicAdd(&gcnt[y >> 1], 1u << ((y & 1) * 16));
+    }
+    __syncthreads();
+    {  // exclusive scan of the CAP 16-bit counts, CAP / T consecutive ones a thread
+      constexpr int PERW = (CAP / 2 + T - 1) / T;  // words per thread
+      uint32_t w[PERW];
+      int sum = 0, most = 0;
+#pragma unroll
+      for (int q = 0; q < PERW; ++q) {
+        w[q] = tid * PERW + q < CAP / 2 ? gcnt[tid * PERW + q] : 0u;
+        sum += (int)(w[q] & 0xFFFFu) + (int)(w[q] >> 16);
+        most = max(most, max((int)(w[q] & 0xFFFFu), (int)(w[q] >> 16)));
       }
-      vals[first_arc] = acc;  // (runs are disjoint: nobody else reads this arc's own value any more)
-      if (POSITION) payload[first_arc] = payload_of<POSITION>(slow_key<POSITION>(first_arc), best_arc, pk.label_min, pk.time_bits);
-      atomicOr(&headbit[first_arc >> 5], 1u << (first_arc & 31));
+      if (most > 1) atomicMax(&sh_gmax, most);
+      int total;
+      int run = block_excl_sum(T, sum, &total, sh);
+#pragma unroll
+      for (int q = 0; q < PERW; ++q) {
+        const int lo = run, hi = lo + (int)(w[q] & 0xFFFFu);
+        run = hi + (int)(w[q] >> 16);
+        if (tid * PERW + q < CAP / 2) goff[tid * PERW + q] = (uint32_t)lo | ((uint32_t)hi << 16);
+      }
+    }
+    __syncthreads();
+    const bool serial = sh_gmax <= 64;  // workgroup-uniform
+    if (serial) {
+      for (int p = tid; p < ndl; p += T) {
+        const uint32_t w = duplist[p], y = w >> 14;
+        const uint32_t old = atomicAdd(&goff[y >> 1], 1u << ((y & 1) * 16));
+        grouped[(old >> ((y & 1) * 16)) & 0xFFFFu] = (uint16_t)(w & 0x3FFFu);
+      }
+      __syncthreads();
+      for (int p = tid; p < ndl; p += T) {
+        const uint32_t w = duplist[p], y = w >> 14;
+        if (y != (w & 0x3FFFu)) continue;  // (the inserter's own word: one per key)
+        const int g = (int)((gcnt[y >> 1] >> ((y & 1) * 16)) & 0xFFFFu);
+        const int end = (int)((goff[y >> 1] >> ((y & 1) * 16)) & 0xFFFFu);
+        uint16_t* grp = grouped + (end - g);
+        for (int i = 1; i < g; ++i) {  // insertion sort by arc number (the key's arcs: a handful)
+          const uint16_t x = grp[i];
+          int k = i;
+          while (k > 0 && grp[k - 1] > x) grp[k] = grp[k - 1], --k;
+          grp[k] = x;
+        }
+        int arc = (int)grp[0];
+        const int first_arc = arc;
+        double acc = vals[arc], best = acc;
+        int best_arc = arc;
+        for (int q = 1; q < g; ++q) {
+          arc = (int)grp[q];
+          const double x = vals[arc];
+          acc = hlog_add(acc, x);
+          if (x > best) {  // strict: the first maximum in arc order wins
+            best = x;
+            best_arc = arc;
+          }
+        }
+        vals[first_arc] = acc;  // (keys are disjoint: nobody else reads this arc's own value any more)
+        if (POSITION) payload[first_arc] = payload_of<POSITION>(slow_key<POSITION>(first_arc), best_arc, pk.label_min, pk.time_bits);
+        atomicOr(&headbit[first_arc >> 5], 1u << (first_arc & 31));
+      }
+    } else {
+      uint32_t* dups = table;
+      for (int p = tid; p < ndl; p += T) dups[p] = duplist[p];
+      __syncthreads();
+      block_sort_any(T, dups, ndl, [](uint32_t x, uint32_t y) { return x < y; });
+      for (int p = tid; p < ndl; p += T) {
+        const uint32_t w = dups[p];
+        if (!(p == 0 || (dups[p - 1] >> 14) != (w >> 14))) continue;
+        int arc = (int)(w & 0x3FFFu);
+        const int first_arc = arc;
+        double acc = vals[arc], best = acc;
+        int best_arc = arc;
+        for (int q = p + 1; q < ndl && (dups[q] >> 14) == (w >> 14); ++q) {
+          arc = (int)(dups[q] & 0x3FFFu);
+          const double x = vals[arc];
+          acc = hlog_add(acc, x);
+          if (x > best) {
+            best = x;
+            best_arc = arc;
+          }
+        }
+        vals[first_arc] = acc;
+        if (POSITION) payload[first_arc] = payload_of<POSITION>(slow_key<POSITION>(first_arc), best_arc, pk.label_min, pk.time_bits);
+        atomicOr(&headbit[first_arc >> 5], 1u << (first_arc & 31));
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
