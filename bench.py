@@ -683,6 +683,21 @@ def main():
                                                   "page-locked buffers (klat_host_alloc)", "seconds_per_batch": sec_c, "arcs_per_s": A / sec_c,
                                           "h2d_bytes": int(sum(v.nbytes for v in compact.values())),
                                           "d2h_bytes": int(ppost.nbytes + pab[0].nbytes + pab[1].nbytes)}
+            # the same traffic through ONE call that pipelines the batch in pieces over three streams (upload of piece
+            # k+1 | packing and sweep of piece k | results of piece k-1): klat_forward_backward_host
+            try:
+                pout = {"alpha": pab[0], "beta": pab[1], "total": klat_amd.pinned_empty(U, np.float64), "post": ppost}
+                times = []
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    klat_amd.forward_backward_host(ctx, pin, SCALES, pieces=0, fuse=FUSE, out=pout, host_threads=host_threads)
+                    times.append(time.perf_counter() - t0)
+                sec_p = median(times[1:])
+                out["boundary"]["pipelined"] = {"what": "klat_forward_backward_host: the compact descriptor in, alpha / beta / totals / arc posteriors out, "
+                                                        "page-locked buffers, the batch in pieces over three streams", "seconds_per_batch": sec_p,
+                                                "arcs_per_s": A / sec_p}
+            except Exception as e:
+                out["boundary"]["pipelined"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             del ppost, pab, pin
 
     # ---- the one-shot path of the tools: pack + sweep (+ index) on a fresh batch, device-resident input

@@ -226,6 +226,19 @@ int klat_get_alpha_beta(klat_batch* batch, double* alpha, double* beta);
 int klat_get_totals(klat_batch* batch, double* total, double* tot_fwd, double* tot_bwd);
 int klat_get_arc_logpost(klat_batch* batch, double* logpost /* [A] */);
 
+/* Interface B2 widened to a batch, host to host in ONE call: what
+ *   double ComputeLatticeAlphasAndBetas(const CompactLattice&, bool, vector<double>* alpha, vector<double>* beta)
+ * (latbin/lattice-to-word-frame-post.cc:88-90) gives for one lattice, for every lattice of the descriptor, plus the
+ * arc log-posteriors alpha[src] - cost + beta[dst] - total (:102-104) when asked for.  The lattices are cut into
+ * `pieces` runs of about equal arcs (0: chosen from the batch's size); piece k+1 crosses PCIe while piece k is packed
+ * and swept and piece k-1's results come down, on three streams the context keeps for this call -- a C2 batch takes
+ * 26 ms instead of the 39 ms of create / sweep / fetch one after the other (bench.py `boundary`).  The copies only
+ * run beside one another from and into page-locked memory (klat_host_alloc); ordinary memory works, serially.
+ * Any of alpha, beta [S], total [num_lattices], arc_logpost [A] may be NULL.  Nothing stays on the device. */
+int klat_forward_backward_host(klat_ctx* ctx, const klat_batch_desc_compact* desc, const klat_pack_options* opt,
+                               const klat_scales* scales, int32_t pieces, double* alpha, double* beta, double* total,
+                               double* arc_logpost);
+
 /* ---- tropical twin of the sweep ----
  * Viterbi forward / backward costs (min,+) over the same batch and, from them, ComputeLatticeBeam
  * (latbin/lattice-prune-dyn-beam.cc:27-90) and the decisions of PruneLattice(beam, &clat)

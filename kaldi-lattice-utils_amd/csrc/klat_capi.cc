@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -298,6 +299,8 @@ int klat_ctx_create(int device, klat_ctx** out) {
 
 static void ctx_release(klat_ctx* c) {
   if (c->refs.fetch_sub(1) != 1) return;  // batches (or a communicator) still use its stream
+  for (klat_ctx*& h : c->pipe)
+    if (h) ctx_release(h), h = nullptr;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < klat_ctx::kTimingSlots * 4; ++i)
@@ -835,42 +838,57 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   return KLAT_OK;
 }
 
-int klat_batch_create_compact(klat_ctx* c, const klat_batch_desc_compact* d, const klat_pack_options* opt, klat_batch** out) {
-  if (!c || !d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
-  *out = nullptr;
+// klat_batch_create_compact in two steps: the uploads (asynchronous from page-locked memory: nothing waits here), and
+// everything that does wait for the device (src / dst rebuilt, the ordinary path over device pointers).
+// klat_forward_backward_host asks for the next piece's uploads before it finishes this piece.
+struct CompactUpload {
+  DevBuf<int32_t> deg, label, src, dst, status, time;
+  DevBuf<uint8_t> span;
+  DevBuf<float> graph, acoustic, fg, fa;
+  DevBuf<int64_t> so, ao;
+};
+
+static int compact_check(const klat_batch_desc_compact* d) {
   const int64_t U = d->num_lattices;
   if (U < 0 || (U > 0 && (!d->state_off || !d->arc_off))) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: null offsets");
   const int64_t S = U ? d->state_off[U] : 0, A = U ? d->arc_off[U] : 0;
   if (A > 0 && (!d->span || !d->label || !d->graph || !d->acoustic)) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: null arc arrays");
   if (S > 0 && (!d->out_degree || !d->final_graph || !d->final_acoustic)) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: null state arrays");
-  KLAT_HIP(hipSetDevice(c->device));
+  return KLAT_OK;
+}
+
+static int compact_upload(klat_ctx* c, const klat_batch_desc_compact* d, CompactUpload* up) {
+  const int64_t U = d->num_lattices;
+  const int64_t S = U ? d->state_off[U] : 0, A = U ? d->arc_off[U] : 0;
   PoolScope pool_scope(&c->pool);
-  // the compact arrays go up, src / dst are rebuilt on the device, and the full descriptor -- device
-  // pointers -- takes the ordinary path (its copies are device to device)
-  DevBuf<int32_t> deg, label, src, dst, status, time;
-  DevBuf<uint8_t> span;
-  DevBuf<float> graph, acoustic, fg, fa;
-  const int32_t zero = 0;
+  static const int32_t zero = 0;  // (outlives the asynchronous copy)
   int rc;
-  if ((rc = deg.upload(d->out_degree, (size_t)S, c->stream)) || (rc = span.upload(d->span, (size_t)A, c->stream)) ||
-      (rc = label.upload(d->label, (size_t)A, c->stream)) || (rc = graph.upload(d->graph, (size_t)A, c->stream)) ||
-      (rc = acoustic.upload(d->acoustic, (size_t)A, c->stream)) || (rc = fg.upload(d->final_graph, (size_t)S, c->stream)) ||
-      (rc = fa.upload(d->final_acoustic, (size_t)S, c->stream)) || (rc = src.alloc((size_t)A)) || (rc = dst.alloc((size_t)A)) ||
-      (rc = status.upload(&zero, 1, c->stream)) || (d->state_time && (rc = time.upload(d->state_time, (size_t)S, c->stream))))
+  if ((rc = up->deg.upload(d->out_degree, (size_t)S, c->stream)) || (rc = up->span.upload(d->span, (size_t)A, c->stream)) ||
+      (rc = up->label.upload(d->label, (size_t)A, c->stream)) || (rc = up->graph.upload(d->graph, (size_t)A, c->stream)) ||
+      (rc = up->acoustic.upload(d->acoustic, (size_t)A, c->stream)) || (rc = up->fg.upload(d->final_graph, (size_t)S, c->stream)) ||
+      (rc = up->fa.upload(d->final_acoustic, (size_t)S, c->stream)) || (rc = up->src.alloc((size_t)A)) || (rc = up->dst.alloc((size_t)A)) ||
+      (rc = up->status.upload(&zero, 1, c->stream)) || (d->state_time && (rc = up->time.upload(d->state_time, (size_t)S, c->stream))))
     return rc;
-  DevBuf<int64_t> so, ao;
-  if ((rc = so.upload(d->state_off, (size_t)U + 1, c->stream)) || (rc = ao.upload(d->arc_off, (size_t)U + 1, c->stream))) return rc;
+  if ((rc = up->so.upload(d->state_off, (size_t)U + 1, c->stream)) || (rc = up->ao.upload(d->arc_off, (size_t)U + 1, c->stream))) return rc;
+  return KLAT_OK;
+}
+
+static int compact_finish(klat_ctx* c, const klat_batch_desc_compact* d, CompactUpload* up, const klat_pack_options* opt, klat_batch** out) {
+  const int64_t U = d->num_lattices;
+  PoolScope pool_scope(&c->pool);
+  // src / dst are rebuilt on the device, and the full descriptor -- device pointers -- takes the ordinary path
+  // (its copies are device to device)
   ExpandArgs ea;
-  ea.state_off = so.p;
-  ea.arc_off = ao.p;
-  ea.out_degree = deg.p;
-  ea.span = span.p;
-  ea.src = src.p;
-  ea.dst = dst.p;
-  ea.status = status.p;
+  ea.state_off = up->so.p;
+  ea.arc_off = up->ao.p;
+  ea.out_degree = up->deg.p;
+  ea.span = up->span.p;
+  ea.src = up->src.p;
+  ea.dst = up->dst.p;
+  ea.status = up->status.p;
   KLAT_HIP(launch_expand_compact(ea, (int)U, c->stream));
   int32_t h_status = 0;
-  KLAT_HIP(hipMemcpyAsync(&h_status, status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  KLAT_HIP(hipMemcpyAsync(&h_status, up->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   KLAT_HIP(hipStreamSynchronize(c->stream));
   if (h_status != 0)
     return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: the out-degrees of lattice " + std::to_string(h_status - 1) + " do not add up to its arcs");
@@ -879,16 +897,28 @@ int klat_batch_create_compact(klat_ctx* c, const klat_batch_desc_compact* d, con
   full.num_lattices = d->num_lattices;
   full.state_off = d->state_off;
   full.arc_off = d->arc_off;
-  full.src = src.p;
-  full.dst = dst.p;
-  full.ilabel = label.p;
-  full.olabel = label.p;
-  full.graph = graph.p;
-  full.acoustic = acoustic.p;
-  full.final_graph = fg.p;
-  full.final_acoustic = fa.p;
-  full.state_time = d->state_time ? time.p : nullptr;
+  full.src = up->src.p;
+  full.dst = up->dst.p;
+  full.ilabel = up->label.p;
+  full.olabel = up->label.p;
+  full.graph = up->graph.p;
+  full.acoustic = up->acoustic.p;
+  full.final_graph = up->fg.p;
+  full.final_acoustic = up->fa.p;
+  full.state_time = d->state_time ? up->time.p : nullptr;
   return klat_batch_create(c, &full, opt, out);
+}
+
+int klat_batch_create_compact(klat_ctx* c, const klat_batch_desc_compact* d, const klat_pack_options* opt, klat_batch** out) {
+  if (!c || !d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  int rc = compact_check(d);
+  if (rc != KLAT_OK) return rc;
+  KLAT_HIP(hipSetDevice(c->device));
+  PoolScope pool_scope(&c->pool);  // (outermost: a failing step's temporaries are freed, not recycled, until this call returns)
+  CompactUpload up;
+  if ((rc = compact_upload(c, d, &up)) != KLAT_OK) return rc;
+  return compact_finish(c, d, &up, opt, out);
 }
 
 void klat_batch_destroy(klat_batch* b) {
@@ -1508,11 +1538,8 @@ static int fetch(klat_batch* b, void* host, const void* dev, size_t bytes) {
   return KLAT_OK;
 }
 
-int klat_get_alpha_beta(klat_batch* b, double* alpha, double* beta) {
-  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
-  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
-  KLAT_HIP(hipSetDevice(b->ctx->device));
-  PoolScope pool_scope(&b->ctx->pool);
+// The fetches without their wait (klat_forward_backward_host enqueues a piece's results and goes on to the next piece).
+static int enqueue_alpha_beta(klat_batch* b, double* alpha, double* beta) {
   int rc;
   // the device keeps both arrays padded (one extra slot per lattice): compact, then copy
   if (b->dense.n < (size_t)b->S && (rc = b->dense.alloc((size_t)b->S))) return rc;
@@ -1527,6 +1554,28 @@ int klat_get_alpha_beta(klat_batch* b, double* alpha, double* beta) {
     KLAT_HIP(launch_unpad(ua, b->ctx->stream));
     if ((rc = fetch(b, host, b->dense.p, sizeof(double) * (size_t)b->S))) return rc;
   }
+  return KLAT_OK;
+}
+
+static int enqueue_arc_logpost(klat_batch* b, double* logpost) {
+  int rc;
+  if (!b->have_logpost) {  // the sweep ran with KLAT_FB_NO_ARC_POSTERIORS: the pass runs now
+    if ((rc = ensure_posterior_tables(b))) return rc;
+    PosteriorArgs pa;
+    fill_posterior_args(b, make_scale_params(b->scales), &pa);
+    KLAT_HIP(launch_posterior(pa, b->num_items, b->ctx->stream));
+    b->have_logpost = true;
+  }
+  return fetch(b, logpost, b->logpost.p, sizeof(double) * (size_t)b->A);
+}
+
+int klat_get_alpha_beta(klat_batch* b, double* alpha, double* beta) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  if (!b->swept) return set_error(KLAT_ERR_STATE, "klat_forward_backward has not run on this batch");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
+  int rc;
+  if ((rc = enqueue_alpha_beta(b, alpha, beta))) return rc;
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   return KLAT_OK;
 }
@@ -1550,16 +1599,112 @@ int klat_get_arc_logpost(klat_batch* b, double* logpost) {
   KLAT_HIP(hipSetDevice(b->ctx->device));
   PoolScope pool_scope(&b->ctx->pool);
   int rc;
-  if (!b->have_logpost) {  // the sweep ran with KLAT_FB_NO_ARC_POSTERIORS: the pass runs now
-    if ((rc = ensure_posterior_tables(b))) return rc;
-    PosteriorArgs pa;
-    fill_posterior_args(b, make_scale_params(b->scales), &pa);
-    KLAT_HIP(launch_posterior(pa, b->num_items, b->ctx->stream));
-    b->have_logpost = true;
-  }
-  if ((rc = fetch(b, logpost, b->logpost.p, sizeof(double) * (size_t)b->A))) return rc;
+  if ((rc = enqueue_arc_logpost(b, logpost))) return rc;
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   return KLAT_OK;
+}
+
+// Host lattices in, host results out, the batch in pieces over three contexts' streams (include/klat.h).
+int klat_forward_backward_host(klat_ctx* c, const klat_batch_desc_compact* d, const klat_pack_options* opt, const klat_scales* scales,
+                               int32_t pieces, double* alpha, double* beta, double* total, double* arc_logpost) {
+  if (!c || !d) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
+  const int64_t U = d->num_lattices;
+  if (U < 0 || (U > 0 && (!d->state_off || !d->arc_off))) return set_error(KLAT_ERR_INVALID_ARG, "klat_batch_desc_compact: null offsets");
+  if (U == 0) return KLAT_OK;
+  const int64_t A = d->arc_off[U] - d->arc_off[0];
+  if (pieces <= 0) pieces = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, A / (8 << 20)));  // pieces of eight million arcs or more
+  pieces = (int32_t)std::min<int64_t>(pieces, U);
+  KLAT_HIP(hipSetDevice(c->device));
+  klat_ctx* ctxs[3] = {c, nullptr, nullptr};
+  const int lanes = pieces >= 3 ? 3 : pieces;
+  for (int i = 1; i < lanes; ++i) {
+    if (!c->pipe[i - 1]) {
+      int rc = klat_ctx_create(c->device, &c->pipe[i - 1]);
+      if (rc != KLAT_OK) return rc;
+    }
+    ctxs[i] = c->pipe[i - 1];
+  }
+  const uint32_t flags = arc_logpost ? 0u : KLAT_FB_NO_ARC_POSTERIORS;
+  int rc = compact_check(d);
+  if (rc != KLAT_OK) return rc;
+  klat_batch* live[3] = {nullptr, nullptr, nullptr};
+  struct Piece {
+    int64_t u0 = 0, u1 = 0, s0 = 0, a0 = 0;
+    std::vector<int64_t> so, ao;
+    klat_batch_desc_compact desc;
+    CompactUpload up;
+  };
+  // the pieces end at the lattice boundaries nearest their share of the arcs
+  std::vector<int64_t> cut((size_t)pieces + 1, 0);
+  cut[(size_t)pieces] = U;
+  for (int k = 1; k < pieces; ++k) {
+    const int64_t want = d->arc_off[0] + A * k / pieces;
+    int64_t u = std::lower_bound(d->arc_off + cut[(size_t)k - 1] + 1, d->arc_off + U, want) - d->arc_off;
+    cut[(size_t)k] = std::max(cut[(size_t)k - 1] + 1, std::min<int64_t>(u, U - (pieces - k)));
+  }
+  // a piece's uploads are asked for one piece ahead: they cross PCIe while the piece before is packed and swept
+  auto start = [&](int k, Piece* pc) -> int {
+    const int slot = k % lanes;
+    if (live[slot]) {  // the piece this context carried before: its results are down when its stream is idle
+      klat_batch_destroy(live[slot]);
+      live[slot] = nullptr;
+    }
+    pc->u0 = cut[(size_t)k], pc->u1 = cut[(size_t)k + 1];
+    pc->s0 = d->state_off[pc->u0], pc->a0 = d->arc_off[pc->u0];
+    const int64_t n = pc->u1 - pc->u0;
+    pc->so.resize((size_t)n + 1), pc->ao.resize((size_t)n + 1);
+    for (int64_t i = 0; i <= n; ++i) pc->so[(size_t)i] = d->state_off[pc->u0 + i] - pc->s0, pc->ao[(size_t)i] = d->arc_off[pc->u0 + i] - pc->a0;
+    klat_batch_desc_compact& p = pc->desc;
+    p = *d;
+    p.num_lattices = (int32_t)n;
+    p.state_off = pc->so.data(), p.arc_off = pc->ao.data();
+    p.out_degree = d->out_degree ? d->out_degree + pc->s0 : nullptr;
+    p.span = d->span ? d->span + pc->a0 : nullptr;
+    p.label = d->label ? d->label + pc->a0 : nullptr;
+    p.graph = d->graph ? d->graph + pc->a0 : nullptr;
+    p.acoustic = d->acoustic ? d->acoustic + pc->a0 : nullptr;
+    p.final_graph = d->final_graph ? d->final_graph + pc->s0 : nullptr;
+    p.final_acoustic = d->final_acoustic ? d->final_acoustic + pc->s0 : nullptr;
+    p.state_time = nullptr;  // (no accumulator runs on the pieces)
+    return compact_upload(ctxs[slot], &p, &pc->up);
+  };
+  const bool dbg = std::getenv("KLAT_PIPE_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  std::unique_ptr<Piece> cur(new Piece()), next;
+  rc = start(0, cur.get());
+  for (int k = 0; k < pieces && rc == KLAT_OK; ++k) {
+    const int slot = k % lanes;
+    const double t0 = now();
+    if (k + 1 < pieces) {
+      next.reset(new Piece());
+      if ((rc = start(k + 1, next.get())) != KLAT_OK) break;
+    }
+    const double t1 = now();
+    klat_batch* b = nullptr;
+    {
+      PoolScope pool_scope(&ctxs[slot]->pool);
+      rc = compact_finish(ctxs[slot], &cur->desc, &cur->up, opt, &b);
+    }
+    if (rc != KLAT_OK) break;
+    const double t2 = now();
+    if (dbg) std::fprintf(stderr, "piece %d: at %.2f ms, next piece's uploads asked for in %.2f ms, finish %.2f ms\n", k, t0 - t_begin, t1 - t0, t2 - t1);
+    live[slot] = b;
+    if ((rc = klat_forward_backward_ex(b, scales, flags)) != KLAT_OK) break;
+    {
+      PoolScope pool_scope(&b->ctx->pool);
+      if ((rc = enqueue_alpha_beta(b, alpha ? alpha + cur->s0 : nullptr, beta ? beta + cur->s0 : nullptr)) != KLAT_OK) break;
+      if (arc_logpost && (rc = enqueue_arc_logpost(b, arc_logpost + cur->a0)) != KLAT_OK) break;
+      if ((rc = fetch(b, total ? total + cur->u0 : nullptr, b->total.p, sizeof(double) * (size_t)(cur->u1 - cur->u0))) != KLAT_OK) break;
+    }
+    cur = std::move(next);
+  }
+  if (rc != KLAT_OK)  // uploads of a piece that never ran may still be in flight on its stream
+    for (int i = 0; i < lanes; ++i) (void)hipStreamSynchronize(ctxs[i]->stream);
+  cur.reset(), next.reset();
+  for (klat_batch*& b : live)
+    if (b) klat_batch_destroy(b), b = nullptr;  // (waits for the piece's stream)
+  return rc;
 }
 
 /* ---- host-only view of the packed streams (no device needed; used by the CPU-side tests

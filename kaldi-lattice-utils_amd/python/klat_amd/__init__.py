@@ -158,6 +158,35 @@ def pinned_copy(a):
     return out
 
 
+def forward_backward_host(ctx, compact, scales=(1.0, 1.0, 0.0), pieces=0, want_post=True, fuse=False, out=None, host_threads=0):
+    """klat_forward_backward_host: compact host arrays in, host alpha / beta / total (/ arc posteriors) out, the batch
+    pipelined in pieces.  `out`: dict of preallocated arrays (alpha, beta, total, post), e.g. page-locked ones."""
+    d, keep = BatchDescCompact(), {}
+    d.num_lattices = len(compact["state_off"]) - 1
+    for name, dt in COMPACT_FIELDS:
+        a = compact.get(name)
+        if a is None:
+            setattr(d, name, None)
+            continue
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep[name] = a
+        setattr(d, name, a.ctypes.data)
+    U = d.num_lattices
+    S = int(keep["state_off"][-1]) if U else 0
+    A = int(keep["arc_off"][-1]) if U else 0
+    out = dict(out or {})
+    out.setdefault("alpha", np.empty(S, np.float64))
+    out.setdefault("beta", np.empty(S, np.float64))
+    out.setdefault("total", np.empty(U, np.float64))
+    if want_post:
+        out.setdefault("post", np.empty(A, np.float64))
+    sc = Scales(*scales)
+    opt = PackOptions(0, 0, host_threads, C.cast(C.pointer(sc), C.c_void_p) if fuse else None)
+    _check(lib().klat_forward_backward_host(ctx.h, C.byref(d), C.byref(opt), C.byref(sc), C.c_int32(pieces), _p(out["alpha"]), _p(out["beta"]),
+                                            _p(out["total"]), _p(out["post"]) if want_post else None))
+    return out
+
+
 def device_count():
     n = C.c_int(0)
     rc = lib().klat_device_count(C.byref(n))

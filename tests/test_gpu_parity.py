@@ -397,6 +397,37 @@ def test_compact_descriptor_gives_the_same_batch(ctx):
     good.close()
 
 
+@pytest.mark.parametrize("pieces", [1, 2, 5, 0])
+def test_host_to_host_call_gives_the_batch_calls_results(ctx, pieces):
+    """klat_forward_backward_host -- interface B2 (ComputeLatticeAlphasAndBetas, latbin/lattice-to-word-frame-post.cc:88-90)
+    for a whole batch in one call, the batch cut into pieces that cross PCIe, are swept and come back side by side --
+    must give what create / sweep / fetch give on the whole batch, and what the oracle gives: the cut falls between
+    lattices, every lattice keeps its own arithmetic (a piece may choose other lanes per lattice than the whole
+    batch: sums in another order, 1e-9).  Page-locked and ordinary result buffers; with and without arc posteriors."""
+    rng = np.random.RandomState(5)
+    ns = np.concatenate([[1, 2], rng.randint(2, 600, size=40), [3000]]).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4, 6], size=len(ns)).astype(np.int32)
+    arrays = klat_amd.synth(991, ns, fo)
+    compact = klat_amd.compact_arrays(arrays)
+    scales = (1.0, 0.3, 0.25)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(*scales)
+    want_ab, want_tot, want_post = b.alpha_beta(), b.totals()[0], b.arc_logpost()
+    b.close()
+    S, A, U = int(arrays["state_off"][-1]), int(arrays["arc_off"][-1]), len(ns)
+    pinned = {"alpha": klat_amd.pinned_empty(S, np.float64), "beta": klat_amd.pinned_empty(S, np.float64),
+              "total": klat_amd.pinned_empty(U, np.float64), "post": klat_amd.pinned_empty(A, np.float64)}
+    for out, fuse in ((pinned, False), (None, True)):
+        got = klat_amd.forward_backward_host(ctx, compact, scales, pieces=pieces, fuse=fuse, out=out)
+        _check(got["alpha"], want_ab[0], 1e-9), _check(got["beta"], want_ab[1], 1e-9)
+        _check(got["total"], want_tot, 1e-9), _check(got["post"], want_post, 1e-9)
+    wa, wb, wt, wpost = _oracle_batch(arrays, *scales)
+    _check(pinned["alpha"], wa, 1e-8), _check(pinned["beta"], wb, 1e-8), _check(pinned["total"], wt, 1e-8), _check(pinned["post"], wpost, 1e-8)
+    got = klat_amd.forward_backward_host(ctx, compact, scales, pieces=pieces, want_post=False)
+    _check(got["alpha"], want_ab[0], 1e-9), _check(got["total"], want_tot, 1e-9)
+    assert "post" not in got
+
+
 def test_fused_scales_streams_match_the_generic_ones(ctx):
     """klat_pack_options.fuse_scales: the packer applies ScaleLattice / AddWordInsPen and the stream holds a
     term's cost as a float plus a 16-bit residual (10-byte slots, a sixth less for the sweep to read).  The
