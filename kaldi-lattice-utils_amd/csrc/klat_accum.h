@@ -70,10 +70,9 @@ struct OutRecord {  // == klat_segment_record / klat_position_record (24 B)
 
 hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hipStream_t stream);
 
-// Hash path (klat_accum_hash.hip): lattices of at most kHashMaxArcs arcs whose index keys pack
+// Hash path (klat_accum_hash.hip): lattices of at most kHashClassArcs[kHashClasses - 1] arcs whose index keys pack
 // into total_bits <= 62 bits -- (label - label_min) in label_bits, times / positions in time_bits
 // each.  The ranges come from range_kernel over the batch.
-static const int kHashMaxArcs = 16384;  // 2^14 table slots up to 8192 arcs, 2^15 above
 struct RadixPack {
   int32_t label_min;
   int32_t label_bits, time_bits, total_bits;
@@ -86,11 +85,8 @@ struct RangeArgs {
   int32_t* out;              // [4]: label min, label max, time max, length max
 };
 hipError_t launch_range(const RangeArgs& a, hipStream_t stream);
-// max_arcs: the most arcs of a lattice this launch takes (its workgroups are as wide as that lattice needs)
-hipError_t launch_index_hash(const AccumArgs& a, const RadixPack& pk, int num_lattices, bool position, int log_slots, int max_arcs,
-                             hipStream_t stream);
-// The hash kernel's second form: lattices by size class -- up to kHashClassArcs[c] arcs each, class c's lattices listed
-// in `list` (device memory, `count` of them).
+// The hash kernel's lattices by size class -- up to kHashClassArcs[c] arcs each, class c's lattices listed in `list`
+// (device memory, `count` of them).
 static const int kHashClasses = 6;
 static const int kHashClassArcs[kHashClasses] = {1536, 3072, 6144, 8192, 15360, 16384};
 hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool position, int cls, const int32_t* list, int count,

@@ -135,14 +135,9 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     // table of 2^14 slots up to 8192 arcs, 2^15 above), the others the general kernel
     bool radix = std::getenv("KLAT_INDEX_BITONIC") == nullptr;  // (test hook: force the general kernel)
     RadixPack pk = {0, 0, 0, 0};
-    int64_t n_small = 0, n_medium = 0, n_large = 0, most_small = 0, most_medium = 0;
-    for (int64_t u = 0; u < b->U; ++u) {
-      const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
-      if (arcs <= kHashMaxArcs / 2) most_small = std::max(most_small, arcs);
-      else if (arcs < kHashMaxArcs) most_medium = std::max(most_medium, arcs);
-      (arcs <= kHashMaxArcs / 2 ? n_small : arcs < kHashMaxArcs ? n_medium : n_large)++;  // (16 384 arcs exactly: a table entry {fingerprint all ones, arc 16 383} would equal the empty marker)
-    }
-    radix = radix && n_small + n_medium > 0 && b->A > 0;
+    int64_t n_hash = 0;  // lattices the hash kernel takes
+    for (int64_t u = 0; u < b->U; ++u) n_hash += b->h_arc_off[u + 1] - b->h_arc_off[u] <= kHashClassArcs[kHashClasses - 1] ? 1 : 0;
+    radix = radix && n_hash > 0 && b->A > 0;
     st.cached_mode = st.dense_mode = 0;
     if (!st.ev[0]) {
       KLAT_HIP(hipEventCreate(&st.ev[0]));
@@ -179,21 +174,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       KLAT_HIP(hipMemsetAsync(d_clock.p, 0, sizeof(long long) * (size_t)b->U * 8, c->stream));
       a.phase_clock = d_clock.p;
     }
-    if (radix && std::getenv("KLAT_INDEX_V1") != nullptr) {  // the kernel's first form (comparisons, tests)
-      if (n_small > 0) {
-        a.min_arcs = -1, a.max_arcs = kHashMaxArcs / 2;
-        KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 14, (int)most_small, c->stream));
-      }
-      if (n_medium > 0) {
-        a.min_arcs = kHashMaxArcs / 2, a.max_arcs = kHashMaxArcs - 1;
-        KLAT_HIP(launch_index_hash(a, pk, (int)b->U, position, 15, (int)most_medium, c->stream));
-      }
-      if (n_large > 0) {
-        a.min_arcs = kHashMaxArcs - 1, a.max_arcs = 0x7FFFFFFF;
-        KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
-      }
-      a.min_arcs = -1, a.max_arcs = 0x7FFFFFFF;
-    } else if (radix) {
+    if (radix) {
       // Size classes: a lattice runs in the smallest workgroup that holds its arcs (128 threads and 17 KiB of LDS
       // for 1 536 arcs ... 1 024 threads and 150 KiB for 16 384), every class one launch over its own list of
       // lattices; a class of fewer than 64 lattices rides with the next larger one that has any.  Above 16 384

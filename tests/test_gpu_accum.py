@@ -302,23 +302,24 @@ def test_frame_post_word_lattice(ctx, golden_dir):
 
 
 @pytest.mark.parametrize("shape", ["plain", "repeated_keys", "crowded_keys", "dead_arcs", "filtered"])
-def test_index_kernel_forms_agree(ctx, shape, monkeypatch):
-    """The round-4 form of the hash kernel (queue for everything that is not a free slot, arc bitmaps, values in
-    registers, ties out of line) against the first form (KLAT_INDEX_V1=1): the same records in the same order, bit
-    for bit, segment and position index -- lattices of 1 ... 7 000 arcs (both table classes of the first form, the
-    512 x 12 and 512 x 16 instantiations of the second), keys that repeat in most arcs (few words, many states a
-    time: what real word lattices look like), arcs of infinite cost (records that tie at log-zero) and a label filter."""
+def test_index_kernel_shapes(ctx, shape):
+    """The hash kernel's size classes and rare paths against the oracle, segment and position index: lattices of
+    1 ... 7 000 arcs (the 128-, 256- and 512-thread classes, 12 and 16 arcs a thread), keys that repeat in most arcs
+    (few words, many states a time: what real word lattices look like -- the counting sort by inserter, one thread
+    folding a key's arcs in arc order), hundreds of arcs a key (the fold's bitonic path), arcs of infinite cost
+    (records that tie at log-zero: the out-of-line exact comparisons and a crowded last bucket) and a label filter.
+    Keys and order exact (kwsbin2/lattice-word-index-segment.cc:98-126, -position.cc:102-127), logp to 1e-9."""
     rng = np.random.RandomState(21)
     ns = np.concatenate([[1, 2, 3], rng.randint(4, 700, size=14), [2000, 2300]]).astype(np.int32)
     fo = rng.choice([1, 2, 3, 4], size=len(ns)).astype(np.int32)
     fo[-1] = 3
     arrays = klat_amd.synth(20260021, ns, fo)
-    inc = exc = None
+    flt = {}
     if shape == "repeated_keys":
         arrays["olabel"] = (arrays["olabel"] % 5).astype(np.int32)
         arrays["ilabel"] = arrays["olabel"].copy()
         arrays["state_time"] = (arrays["state_time"] // 6).astype(np.int32)
-    if shape == "crowded_keys":  # hundreds of arcs a key: the fold's bitonic path instead of one thread per key
+    if shape == "crowded_keys":
         arrays["olabel"] = (arrays["olabel"] % 2).astype(np.int32)
         arrays["ilabel"] = arrays["olabel"].copy()
         arrays["state_time"] = (arrays["state_time"] // 400).astype(np.int32)
@@ -328,21 +329,36 @@ def test_index_kernel_forms_agree(ctx, shape, monkeypatch):
         arrays["graph"][dead] = np.inf
         arrays["acoustic"][dead] = np.inf
     if shape == "filtered":
-        exc = [int(x) for x in rng.randint(1, 1000, size=300)]
-    state_len = np.concatenate([np.arange(int(n), dtype=np.int32) % 13 for n in ns])
-    got = {}
-    for form in ("v2", "v1"):
-        if form == "v1":
-            monkeypatch.setenv("KLAT_INDEX_V1", "1")
-        b = klat_amd.Batch(ctx, arrays)
-        b.forward_backward(1.0, 0.3, 0.25)
-        got[form] = (b.segment_index(include=inc, exclude=exc), b.position_index(state_len, include=inc, exclude=exc))
-        b.close()
-    for k in (0, 1):
-        (o1, r1), (o2, r2) = got["v1"][k], got["v2"][k]
-        assert np.array_equal(o1, o2)
-        assert r1.tobytes() == r2.tobytes()
-    assert got["v2"][0][0][-1] > 0
+        flt = {"exclude": [int(x) for x in rng.randint(1, 1000, size=300)]}
+    # (any per-state integer serves as a length here; the state's own number keeps the maxima of a key's arcs apart:
+    # arcs of one word thirteen states apart on the best path carry the same likelihood to the last bits)
+    state_len = np.concatenate([np.arange(int(n), dtype=np.int32) for n in ns])
+    scales = (1.0, 0.3, 0.25)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(*scales)
+    (soff, srec), (poff, prec) = b.segment_index(**flt), b.position_index(state_len, **flt)
+    b.close()
+    assert soff[-1] > 0
+    for u, lat in enumerate(_split(arrays)):
+        s0, s1 = int(arrays["state_off"][u]), int(arrays["state_off"][u + 1])
+        sl = orc.scale_and_penalize(lat, *scales)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        want = orc.segment_index(sl, arrays["state_time"][s0:s1], alpha, beta, total, **flt)
+        got = [(int(r["label"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in srec[soff[u]:soff[u + 1]]]
+        _check_sorted_records(got, want, 3, tol=1e-9)
+        want = orc.position_index(sl, arrays["state_time"][s0:s1], state_len[s0:s1], alpha, beta, total, **flt)
+        got = [(int(r["label"]), int(r["pos"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in prec[poff[u]:poff[u + 1]]]
+        assert len(got) == len(want)
+        gk = {g[:2]: g for g in got}
+        assert len(gk) == len(got)
+        for w in want:  # (t0, t1) is payload: the first arc attaining the maximum, strict '>' (-position.cc:178)
+            g = gk[w[:2]]
+            assert g[4] == w[4] or abs(g[4] - w[4]) <= 1e-9
+            assert g[2:4] == w[2:4]
+        for x, y in zip(got[:-1], got[1:]):
+            assert x[4] >= y[4] - 1e-9 or x[4] == y[4]
+            if x[4] == y[4]:
+                assert x[:2] < y[:2]
 
 
 # the frame kernels: the lean one with the general one behind it (default), the general one alone, and a record
