@@ -48,7 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-TRAFFIC_PROFILE = os.path.join("profiles", "r03_hbm_traffic.json")  # PMC passes of this round's kernels
+TRAFFIC_PROFILE = os.path.join("profiles", "r04_hbm_traffic.json")  # PMC passes of this round's kernels
 SCALES = (1.0, 0.1, 0.0)
 FUSE = SCALES  # klat_pack_options.fuse_scales of every batch of the run (--no-fuse: None): 10-byte stream slots
 
@@ -499,6 +499,7 @@ def main():
     ap.add_argument("--no-shapes", action="store_true")
     ap.add_argument("--no-accumulate", action="store_true")
     ap.add_argument("--no-one-shot", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the host-in / host-out legs (profiles: their pieces' launches carry the step's kernel names)")
     ap.add_argument("--no-fuse", action="store_true", help="generic 12-byte stream slots (the scales stay kernel arguments)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg on BASELINE configs[3]")
     ap.add_argument("--strong-lattices", type=int, default=C4["lattices"], help="lattices of the strong-scaling list (default: configs[3] whole)")
@@ -652,7 +653,7 @@ def main():
     # arrays + stream packing) -> sweep -> fetch, serial on this context; never `value`.  Twice: the full
     # descriptor into pageable result arrays (what round 2 measured), and the compact descriptor
     # (klat_batch_desc_compact: 13 B per arc up instead of 28) into page-locked result buffers.
-    if rank == 0:
+    if rank == 0 and not args.no_boundary:
         def boundary(make_batch, post, ab):
             times = []
             for _ in range(4):
