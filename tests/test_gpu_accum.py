@@ -361,6 +361,42 @@ def test_index_kernel_shapes(ctx, shape):
                 assert x[:2] < y[:2]
 
 
+@pytest.mark.parametrize("shape", ["C2", "C4"])
+def test_segment_index_full_size_properties(ctx, shape):
+    """The segment index at BASELINE's sizes -- configs[1] whole (10 000 lattices x 2 000 states: the 512 x 12 class)
+    and 2 000 lattices of configs[3]'s shape (5 000 states, 14 997 arcs: the 1 024 x 15 class) -- through what does
+    not depend on the size: one record per distinct (lattice, label, t0, t1) of the word arcs, no more and no fewer;
+    every lattice's records in descending order of logp, equal values by ascending key
+    (kwsbin2/lattice-word-index-segment.cc:98-126); and folding keeps the mass: the records' exp(logp) add up to the word
+    arcs' posteriors, lattice by lattice (LogAdd of a key's arcs, :165-171)."""
+    U, S = (10000, 2000) if shape == "C2" else (2000, 5000)
+    arrays = klat_amd.synth(20260001 if shape == "C2" else 20260003, np.full(U, S, np.int32), np.full(U, 3, np.int32))
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.1, 0.0)
+    post = b.arc_logpost()
+    off, rec = b.segment_index()
+    b.close()
+    lat_of_arc = np.repeat(np.arange(U, dtype=np.int64), np.diff(arrays["arc_off"]))
+    word = arrays["olabel"] != 0
+    gsrc = arrays["src"].astype(np.int64) + arrays["state_off"][lat_of_arc]
+    gdst = arrays["dst"].astype(np.int64) + arrays["state_off"][lat_of_arc]
+    t0, t1 = arrays["state_time"][gsrc].astype(np.int64), arrays["state_time"][gdst].astype(np.int64)
+    assert int(t1.max()) < (1 << 15) and int(arrays["olabel"].max()) < (1 << 11) and U < (1 << 14)
+    key = (((lat_of_arc << 11 | arrays["olabel"].astype(np.int64)) << 15 | t0) << 15 | t1)[word]
+    want_keys = np.unique(key)
+    lat_of_rec = np.repeat(np.arange(U, dtype=np.int64), np.diff(off))
+    got_keys = ((lat_of_rec << 11 | rec["label"].astype(np.int64)) << 15 | rec["t0"].astype(np.int64)) << 15 | rec["t1"].astype(np.int64)
+    assert len(got_keys) == len(want_keys) and np.array_equal(np.sort(got_keys), want_keys)
+    lp = rec["logp"]
+    inside = lat_of_rec[1:] == lat_of_rec[:-1]
+    assert np.all(lp[:-1][inside] >= lp[1:][inside])
+    tie = inside & (lp[:-1] == lp[1:])
+    assert np.all(got_keys[:-1][tie] < got_keys[1:][tie])
+    mass_arcs = np.bincount(lat_of_arc[word], weights=np.exp(post[word]), minlength=U)
+    mass_recs = np.bincount(lat_of_rec, weights=np.exp(lp), minlength=U)
+    assert np.max(np.abs(mass_arcs - mass_recs) / np.maximum(mass_arcs, 1e-300)) < 1e-9
+
+
 # the frame kernels: the lean one with the general one behind it (default), the general one alone, and a record
 # pool that holds the first few lattices only (the others go through the count pass and the general kernel)
 FRAME_MODES = {"lean": {}, "general": {"KLAT_FRAME_GENERAL": "1"}, "short_pool": {"KLAT_FRAME_POOL_RATIO": "0.2"}}
