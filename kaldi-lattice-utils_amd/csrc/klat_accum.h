@@ -160,6 +160,7 @@ struct FrameArgs {
   int32_t* redo2_list;        // [U], [1]: what the lean kernel's second instantiation (over redo_list) leaves in its turn
   int32_t* redo2_n;
   const LnTabEntry* ln_table;  // [kLnTabSize] (klat_kernels.h), the lean kernel's LogAdd
+  const int32_t* lattice_list; // the lean kernel's first instantiation: workgroup k takes lattice_list[k] (null: lattice k)
   uint64_t* pool;             // the lean kernel's records, a lattice's in one piece
   unsigned long long* pool_used;  // [2] records asked for so far (also by the lattices the pool had no room for); those asked for in vain
   int64_t pool_cap;
@@ -169,7 +170,13 @@ struct FrameArgs {
 
 hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t stream);
 hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream);
-hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, bool big, hipStream_t stream);
+// The lean kernel's size classes: class c takes the lattices of at most kFrameClassArcs[c] arcs and kFrameClassStates[c]
+// states (workgroups of 128 / 256 / 512 threads with 16 / 32 / 64 KiB of LDS), listed in a.lattice_list; the last class
+// whatever is left.  big: the second instantiation over a.redo_list.
+static const int kFrameClasses = 3;
+static const int kFrameClassArcs[kFrameClasses] = {1536, 3072, 0x7FFFFFFF};
+static const int kFrameClassStates[kFrameClasses] = {1024, 2048, 0x7FFFFFFF};
+hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, bool big, int size_class, hipStream_t stream);
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
                                const int64_t* frame_base, int64_t* frame_off, int32_t* labels, float* logps,
                                hipStream_t stream);

@@ -457,7 +457,42 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       a.ln_table = c->ln_table.p;
       KLAT_HIP(hipMemsetAsync(a.redo_n, 0, 2 * sizeof(int32_t), c->stream));
       KLAT_HIP(hipMemsetAsync(a.pool_used, 0, 2 * sizeof(unsigned long long), c->stream));
-      KLAT_HIP(launch_frame_lean(a, (int)b->U, max_arcs, false, c->stream));
+      // size classes: a lattice runs in the smallest workgroup that holds it, every class one launch over its own list
+      // (a class of fewer than 64 lattices rides with the next larger one)
+      if (!st.classes_ready) {
+        std::vector<int32_t> cls((size_t)b->U);
+        int64_t cnt[kFrameClasses] = {0};
+        for (int64_t u = 0; u < b->U; ++u) {
+          const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u], states = b->h_state_off[u + 1] - b->h_state_off[u];
+          int k = 0;
+          while (k < kFrameClasses - 1 && (arcs > kFrameClassArcs[k] || states > kFrameClassStates[k])) ++k;
+          cls[(size_t)u] = k;
+          ++cnt[k];
+        }
+        int to[kFrameClasses];
+        for (int k = kFrameClasses - 1; k >= 0; --k) {
+          to[k] = k;
+          if (k < kFrameClasses - 1 && cnt[k] < 64) to[k] = to[k + 1], cnt[to[k + 1]] += cnt[k], cnt[k] = 0;
+        }
+        st.class_begin[0] = 0;
+        for (int k = 0; k < kFrameClasses; ++k) st.class_begin[k + 1] = st.class_begin[k] + cnt[k], st.class_max_arcs[k] = 0;
+        std::vector<int32_t> list((size_t)b->U);
+        int64_t at[kFrameClasses];
+        for (int k = 0; k < kFrameClasses; ++k) at[k] = st.class_begin[k];
+        for (int64_t u = 0; u < b->U; ++u) {
+          const int k = to[cls[(size_t)u]];
+          list[(size_t)at[k]++] = (int32_t)u;
+          st.class_max_arcs[k] = (int32_t)std::max<int64_t>(st.class_max_arcs[k], std::min<int64_t>(b->h_arc_off[u + 1] - b->h_arc_off[u], 1 << 30));
+        }
+        if ((rc = st.class_list.upload(list.data(), list.size(), c->stream))) return rc;
+        KLAT_HIP(hipStreamSynchronize(c->stream));  // (the list is a local)
+        st.classes_ready = true;
+      }
+      for (int k = 0; k < kFrameClasses; ++k) {
+        a.lattice_list = st.class_list.p + st.class_begin[k];
+        KLAT_HIP(launch_frame_lean(a, (int)(st.class_begin[k + 1] - st.class_begin[k]), st.class_max_arcs[k], false, k, c->stream));
+      }
+      a.lattice_list = nullptr;
       if ((rc = print_clock("frame_lean_kernel"))) return rc;
       int32_t first_n = 0;
       unsigned long long used[2] = {0, 0};  // [0] records asked of the pool, [1] those of them the pool had no room for
@@ -468,7 +503,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       unsigned long long need = used[0];
       if (first_n > 0) {  // larger lattices (spans in L2), and one more try for what else did not fit
         const unsigned long long short_first = used[1];
-        KLAT_HIP(launch_frame_lean(a, (int)first_n, max_arcs, true, c->stream));
+        KLAT_HIP(launch_frame_lean(a, (int)first_n, max_arcs, true, 0, c->stream));
         if ((rc = print_clock("frame_lean_kernel (second instantiation)"))) return rc;
         KLAT_HIP(hipMemcpyAsync(&redo_n, a.redo2_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         KLAT_HIP(hipMemcpyAsync(used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));

@@ -986,17 +986,24 @@ static constexpr int kLnWideList = 32;  // such ranks per tile
 // BIG: the instantiation for the lattices the first one lists (spans in L2, up to kLnStates states; whatever else did
 // not fit is tried once more and listed for the general kernel); the first one keeps the shorter code of a lattice
 // whose spans stay in LDS.
-template <bool BIG, bool CLOCK>
-__global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
-  constexpr int NT = kFrLeanThreads;
+// SC: the size class -- threads, bucket entries, states and ranks per tile are 1 / SC of the full-size kernel's, so a
+// lattice of a few hundred states runs in 128 threads with 16 KiB of LDS and eight such workgroups share a CU (80 000
+// lattices of 125 states took 3.25 ms in 512-thread workgroups, two a CU).  The host lists every class's lattices.
+template <bool BIG, bool CLOCK, int SC>
+__global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
+  static_assert(!BIG || SC == 1, "the second instantiation is full size");
+  constexpr int NT = kFrLeanThreads / SC;
+  constexpr int kEntries = kFrLdsEntries / SC;    // bucket entries of a tile in LDS
+  constexpr int kStatesLds = kLnStatesLds / SC;   // states of a lattice whose spans stay in LDS
+  constexpr int kTile = kLnTile / SC;             // ranks per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
-  uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kFrLdsEntries]: a tile's buckets as arc numbers
+  uint16_t* lbucket = reinterpret_cast<uint16_t*>(fr_smem);  // [kEntries]: a tile's buckets as arc numbers
   uint16_t* lrank = lbucket;                                 // [S]: rank of every state, during the arc pass only
-  // [kLnStatesLds + 2], or into the spans' place for a lattice whose spans lie in L2: the time of rank r; rtime[nr] = T
-  uint16_t* rtime = reinterpret_cast<uint16_t*>(fr_smem + sizeof(uint16_t) * kFrLdsEntries);
-  uint32_t* lspan = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kFrLdsEntries + kLnStatesLds + 2));  // [span_cap]: rank(src) | rank(dst) << 16
-  __shared__ int lboff[kLnTile + 1];  // first bucket entry of every rank of the tile
-  __shared__ int lcur[kLnTile];       // scatter cursors
+  // [kStatesLds + 2], or into the spans' place for a lattice whose spans lie in L2: the time of rank r; rtime[nr] = T
+  uint16_t* rtime = reinterpret_cast<uint16_t*>(fr_smem + sizeof(uint16_t) * kEntries);
+  uint32_t* lspan = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kEntries + kStatesLds + 2));  // [span_cap]: rank(src) | rank(dst) << 16
+  __shared__ int lboff[kTile + 1];  // first bucket entry of every rank of the tile
+  __shared__ int lcur[kTile];       // scatter cursors
   __shared__ int sh[2 * NT / 64];
   __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, sum_stored, sum_dense, descending;
   __shared__ int wide_rank[kLnWideList];
@@ -1004,7 +1011,7 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
   __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
   if (BIG && (int)blockIdx.x >= *a.redo_n) return;
-  const int u = BIG ? a.redo_list[blockIdx.x] : (int)blockIdx.x;
+  const int u = BIG ? a.redo_list[blockIdx.x] : (a.lattice_list ? a.lattice_list[blockIdx.x] : (int)blockIdx.x);
   const int tid = threadIdx.x;
   if (tid < kLnTabSize) lntab[tid] = a.ln_table[tid];  // (barriers follow before its first use)
   const int64_t a0 = a.arc_off[u];
@@ -1023,13 +1030,13 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
       else a.redo_list[atomicAdd(a.redo_n, 1)] = u;
     }
   };
-  if (nA > 65535 || S > kLnStates || T > 65535 || (!BIG && (nA > span_cap || S > kLnStatesLds))) {
+  if (nA > 65535 || S > kLnStates || T > 65535 || (!BIG && (nA > span_cap || S > kStatesLds))) {
     leave();
     return;
   }
   // the spans of the arcs in LDS (two 16-bit ranks each), or -- more arcs or states than fit -- in the back half of
   // the lattice's scratch rows (L2): the tiles then read them a batch per thread, and the rank times take their place
-  const bool spans_lds = BIG ? (nA <= span_cap && S <= kLnStatesLds) : true;  // workgroup-uniform
+  const bool spans_lds = BIG ? (nA <= span_cap && S <= kStatesLds) : true;  // workgroup-uniform
   uint32_t* gspan = reinterpret_cast<uint32_t*>(xs + nA);
   if (nA == 0) {  // nothing crosses any frame (and the unconditional loads below read the lattice's first arc)
     for (int f = tid; f < T; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
@@ -1078,7 +1085,7 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
     }
     if (tid == 0) rtime[nr] = (uint16_t)T, num_ranks = nr;
     __syncthreads();
-    if (descending) {  // (workgroup-uniform)
+    if (SC == 1 && descending) {  // (workgroup-uniform; a smaller class has no room for the frame bits and leaves the lattice to the second instantiation)
       // any order of the times: a bit per frame that some state sits at, ranks by counting the bits below
       uint32_t* bits = reinterpret_cast<uint32_t*>(lrank + kLnStates);   // [2048]: frames 0 .. 65535 (behind the ranks, under the buckets)
       uint16_t* wpre = reinterpret_cast<uint16_t*>(bits + 2048);         // [2048]: bits set in the words before this one
@@ -1109,10 +1116,14 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
       __syncthreads();
     }
   };
-  if (!BIG || S <= kLnStatesLds)  // (workgroup-uniform)
-    rank_pass(std::integral_constant<int, kLnStatesLds / NT>());
+  if (!BIG || S <= kStatesLds)  // (workgroup-uniform)
+    rank_pass(std::integral_constant<int, kStatesLds / NT>());
   else
     rank_pass(std::integral_constant<int, kLnStates / NT>());
+  if (SC > 1 && descending) {  // (workgroup-uniform)
+    leave();
+    return;
+  }
   // descending times: the arcs' first ranks need not ascend with the arc number, every tile looks at all arcs
   const bool ranged = descending == 0;
   const int nr = num_ranks;
@@ -1124,7 +1135,7 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
   // for all of them).
   for (int base = 0; base < (BIG ? nA : 1); base += 2 * kLnBatch * NT) {
     int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0, entries_t = 0;  // (reduced at the end of the trip: nothing of a thread's lives across trips)
-    static_assert(2 * kLnBatch * NT >= kFrLdsSpans, "one trip covers the arcs of a lattice whose spans stay in LDS");
+    static_assert(2 * kLnBatch * NT >= kFrLdsSpans / SC, "one trip covers the arcs of a lattice whose spans stay in LDS");
     int il[2][kLnBatch], t0[2][kLnBatch], t1[2][kLnBatch];
     float gr[2][kLnBatch], ac4[2][kLnBatch];
     double xq[2][kLnBatch];
@@ -1242,14 +1253,14 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
   int nbase = 0;   // bucket entries of the tiles before this one
   int stored = 0;  // records this thread wrote
   int dense = 0;   // (frame, word) entries of its ranks: every frame counts its records, shared or not
-  // ranks per tile: kLnTile, or -- spans in L2, a tile's arcs staged in LDS -- as many blocks of kLnBlock ranks as keep
+  // ranks per tile: kTile, or -- spans in L2, a tile's arcs staged in LDS -- as many blocks of kLnBlock ranks as keep
   // the arcs of a tile (with a block and the longest span before it) inside the stage
-  const int stage_cap = (int)((sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap) / sizeof(uint32_t)) -
+  const int stage_cap = (int)((sizeof(uint16_t) * (kStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap) / sizeof(uint32_t)) -
                         (int)(sizeof(uint16_t) * (kLnStates + 2) / sizeof(uint32_t));
-  int tile_ranks = kLnTile;
+  int tile_ranks = kTile;
   if (!spans_lds && ranged && nr > 0) {
     const long long fit = (long long)max(stage_cap, 0) * nr / nA - kLnBlock - longest;  // ranks whose arcs fill the stage, less the slack
-    tile_ranks = (int)max((long long)kLnBlock, min((long long)kLnTile, fit / kLnBlock * kLnBlock));
+    tile_ranks = (int)max((long long)kLnBlock, min((long long)kTile, fit / kLnBlock * kLnBlock));
   }
   for (int c0 = 0; c0 < nr; c0 += tile_ranks) {
     const int tc = min(tile_ranks, nr - c0);
@@ -1281,7 +1292,7 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
     // the spans of the tile's arcs in LDS: where they are anyway, or -- a lattice whose spans lie in L2 -- staged behind
     // the rank times, in the place the spans of a smaller lattice would have: one coalesced trip per tile as a rule, one
     // per stage-full of arcs where a tile has more (a larger lattice whose first ranks do not ascend looks at all arcs)
-    uint32_t* stage = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kFrLdsEntries + kLnStates + 2));
+    uint32_t* stage = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kEntries + kLnStates + 2));
     if (!spans_lds && stage_cap < NT) {  // (workgroup-uniform: no stage to speak of)
       leave();
       return;
@@ -1306,7 +1317,7 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
     }
     int n = 0;
     {
-      constexpr int kCh = kLnTile / NT;  // every thread owns kCh consecutive ranks
+      constexpr int kCh = kTile / NT;  // every thread owns kCh consecutive ranks
       int dl[kCh], sum_d = 0;
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
@@ -1336,7 +1347,7 @@ __global__ __launch_bounds__(kFrLeanThreads, BIG ? 4 : 1) void frame_lean_kernel
       if ((tid & 63) == 0) atomicMax(&tile_max, cmax);
     }
     __syncthreads();
-    if (tile_max > kLnWideMax || n > kFrLdsEntries || unfit) {  // workgroup-uniform
+    if (tile_max > kLnWideMax || n > kEntries || unfit) {  // workgroup-uniform
       leave();
       return;
     }
@@ -1556,19 +1567,27 @@ hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipS
 }
 // the lean kernel: needs neither scratch_off nor the scratch rows, takes its records from a.pool.  big: its second
 // instantiation over the lattices the first one listed (a.redo_list); it lists what it leaves in a.redo2_list
-hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, bool big, hipStream_t stream) {
-  if (num_lattices <= 0) return hipSuccess;
-  static_assert(sizeof(uint16_t) * kLnStates + 2048 * 6 <= sizeof(uint16_t) * kFrLdsEntries, "the states' ranks and the frame bits lie under the buckets");
-  const int span_cap = frame_span_cap(max_arcs);
+template <bool BIG, int SC>
+static hipError_t launch_frame_lean_class(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream) {
+  const int span_cap = std::min(frame_span_cap(max_arcs), kFrLdsSpans / SC);
   // buckets, rank times, spans; a lattice whose spans lie in L2 has up to kLnStates + 1 rank times where the spans would be
-  const size_t lds = sizeof(uint16_t) * kFrLdsEntries + std::max(sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap,
-                                                                 sizeof(uint16_t) * (kLnStates + 2));
-  auto lean = big ? (a.phase_clock ? &frame_lean_kernel<true, true> : &frame_lean_kernel<true, false>)
-                  : (a.phase_clock ? &frame_lean_kernel<false, true> : &frame_lean_kernel<false, false>);
+  size_t lds = sizeof(uint16_t) * (kFrLdsEntries / SC) + sizeof(uint16_t) * (kLnStatesLds / SC + 2) + sizeof(uint32_t) * (size_t)span_cap;
+  if (BIG) lds = std::max(lds, sizeof(uint16_t) * kFrLdsEntries + sizeof(uint16_t) * (kLnStates + 2));
+  auto lean = a.phase_clock ? &frame_lean_kernel<BIG, true, SC> : &frame_lean_kernel<BIG, false, SC>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);
+  hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads / SC), lds, stream, a, span_cap);
   return hipGetLastError();
+}
+hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, bool big, int size_class, hipStream_t stream) {
+  if (num_lattices <= 0) return hipSuccess;
+  static_assert(sizeof(uint16_t) * kLnStates + 2048 * 6 <= sizeof(uint16_t) * kFrLdsEntries, "the states' ranks and the frame bits lie under the buckets");
+  if (big) return launch_frame_lean_class<true, 1>(a, num_lattices, max_arcs, stream);
+  switch (size_class) {  // kFrameClassArcs / kFrameClassStates (klat_accum.h)
+    case 0: return launch_frame_lean_class<false, 4>(a, num_lattices, max_arcs, stream);
+    case 1: return launch_frame_lean_class<false, 2>(a, num_lattices, max_arcs, stream);
+    default: return launch_frame_lean_class<false, 1>(a, num_lattices, max_arcs, stream);
+  }
 }
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
                                const int64_t* frame_base, int64_t* frame_off, int32_t* labels, float* logps,

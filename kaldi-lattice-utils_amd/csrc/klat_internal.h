@@ -234,6 +234,11 @@ struct klat_frame_state {
   klat::DevBuf<unsigned long long> pool_used;
   klat::DevBuf<const uint64_t*> rec_ptr;   // [U] where every lattice's records begin
   klat::DevBuf<int64_t> rec_fmt;           // [U] their format (klat_accum.h)
+  // the lean kernel's size classes: class c's lattices are class_list[class_begin[c] .. class_begin[c + 1])
+  bool classes_ready = false;
+  klat::DevBuf<int32_t> class_list;
+  int64_t class_begin[klat::kFrameClasses + 1] = {0};
+  int32_t class_max_arcs[klat::kFrameClasses] = {0};
 };
 
 struct klat_batch {
