@@ -9,6 +9,13 @@
 
 namespace klat {
 
+// What one workgroup of the hash kernel takes: a lattice whole (begin 0, end = its arcs, slot -1), or one PIECE of a
+// lattice of more than 16 384 arcs -- the arcs [begin, end) of lattice u, cut where the time (the length, for the
+// position index) of the arcs' source states changes, so that no key repeats across pieces (index_slice_kernel).
+struct IndexItem {
+  int32_t u, begin, end, slot;
+};
+
 struct AccumArgs {
   const int64_t* state_off;
   const int64_t* arc_off;
@@ -40,7 +47,14 @@ struct AccumArgs {
   double* val_scratch;   // 8 B per slot: the hash kernel's record values, by record id
   int32_t min_arcs, max_arcs;  // a launch takes the lattices with min_arcs < arcs <= max_arcs
   long long* phase_clock;      // [U][8] or null: s_memtime stamps of the hash kernel's phases (KLAT_ACCUM_PROFILE)
-  const int32_t* lattice_list; // the launch's lattices (workgroup k takes lattice_list[k]) or null: every lattice
+  const IndexItem* items;      // the hash kernel's launch: workgroup k takes items[k]
+  // long lattices in pieces: lattice u's pieces are piece_items[piece_first[u] .. + piece_count[u]) (piece_count[u] = 0: the
+  // lattice was not cut), piece k's records lie at its `begin` in the lattice's record row, item_records[k] of them;
+  // the gather merges the pieces' sorted runs
+  IndexItem* piece_items;
+  const int32_t* piece_first;  // [U] (-1: not a long lattice)
+  int32_t* piece_count;        // [U]
+  int32_t* item_records;       // [number of piece slots]
 };
 
 }  // namespace klat
@@ -85,12 +99,18 @@ struct RangeArgs {
   int32_t* out;              // [4]: label min, label max, time max, length max
 };
 hipError_t launch_range(const RangeArgs& a, hipStream_t stream);
-// The hash kernel's lattices by size class -- up to kHashClassArcs[c] arcs each, class c's lattices listed in `list`
+// The hash kernel's lattices by size class -- up to kHashClassArcs[c] arcs each, class c's work items in `items`
 // (device memory, `count` of them).
 static const int kHashClasses = 6;
 static const int kHashClassArcs[kHashClasses] = {1536, 3072, 6144, 8192, 15360, 16384};
-hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool position, int cls, const int32_t* list, int count,
+hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool position, int cls, const IndexItem* items, int count,
                               hipStream_t stream);
+// Lattices of more than kHashClassArcs[last] arcs: pieces of at most kPieceStride + kPieceWindow arcs, cut at a change of the
+// source states' time within kPieceWindow arcs before every multiple of kPieceStride.  `long_list`: the lattices (device),
+// whose piece slots (a.piece_first, ceil(arcs / kPieceStride) each) the kernel fills; a lattice whose times descend
+// somewhere, or that has no change of time inside a window, keeps piece_count 0 and takes the general kernel.
+static const int kPieceStride = 13312, kPieceWindow = 2048;
+hipError_t launch_index_slice(const AccumArgs& a, bool position, const int32_t* long_list, int count, hipStream_t stream);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
                                OutRecord* out, hipStream_t stream);
 

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
   const int64_t s0 = a.state_off[u];
   const int64_t pb = padded_state_base(s0, u);
   const int nA = (int)(a1 - a0);
-  if (nA <= a.min_arcs || nA > a.max_arcs) return;  // the radix kernel's lattice (workgroup-uniform)
+  if (nA <= a.min_arcs || nA > a.max_arcs) return;  // the hash kernel's lattice (workgroup-uniform)
+  if (a.piece_count && a.piece_count[u] > 0) return;  // a long lattice the hash kernel took in pieces
   Key* keys = reinterpret_cast<Key*>(a.key_scratch) + a.scratch_off[u];
   Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + a.scratch_off[u];
   const int cap = (int)(a.scratch_off[u + 1] - a.scratch_off[u]);  // power of two >= nA (or 0)
@@ -301,25 +302,62 @@ __global__ __launch_bounds__(kAccThreads) void index_kernel(AccumArgs a) {
 // from num_records).  Output record = {int32 f0,f1,f2,f3; double logp} (24 B):
 //   segment : label, t0, t1, 0        position : label, pos, t0, t1
 template <bool POSITION>
+__device__ __forceinline__ OutRecord decode_record(const Rec& r) {
+  OutRecord w;
+  w.logp = desc_unkey(r.k0);
+  w.f0 = unbias((uint32_t)(r.k1 >> 32));
+  w.f1 = unbias((uint32_t)r.k1);
+  if (POSITION) {
+    w.f2 = (int32_t)(uint32_t)(r.k2 >> 32);
+    w.f3 = (int32_t)(uint32_t)r.k2;
+  } else {
+    w.f2 = unbias((uint32_t)(r.k2 >> 32));
+    w.f3 = 0;
+  }
+  return w;
+}
+
+// A lattice the hash kernel took in pieces left one sorted run per piece: a record's place in the lattice's order is
+// its place in its own run plus, for every other run, the records there that come before it -- (k0, k1[, k2]) compared
+// as the kernels' sorts compare them (the position index's k2 is payload; its keys differ in k1).  No key occurs in two
+// pieces, so no two records compare equal.
+template <bool POSITION>
 __global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const int64_t* record_off, OutRecord* out) {
   const int u = blockIdx.x;
   const Rec* recs = reinterpret_cast<const Rec*>(a.rec_scratch) + a.scratch_off[u];
   const int64_t o = record_off[u];
   const int m = (int)(record_off[u + 1] - o);
-  for (int i = threadIdx.x; i < m; i += 256) {
-    const Rec r = recs[i];
-    OutRecord w;
-    w.logp = desc_unkey(r.k0);
-    w.f0 = unbias((uint32_t)(r.k1 >> 32));
-    w.f1 = unbias((uint32_t)r.k1);
-    if (POSITION) {
-      w.f2 = (int32_t)(uint32_t)(r.k2 >> 32);
-      w.f3 = (int32_t)(uint32_t)r.k2;
-    } else {
-      w.f2 = unbias((uint32_t)(r.k2 >> 32));
-      w.f3 = 0;
+  const int pieces = a.piece_count ? a.piece_count[u] : 0;
+  if (pieces == 0) {
+    for (int i = threadIdx.x; i < m; i += 256) out[o + i] = decode_record<POSITION>(recs[i]);
+    return;
+  }
+  const IndexItem* its = a.piece_items + a.piece_first[u];
+  for (int p = 0; p < pieces; ++p) {
+    const Rec* mine = recs + its[p].begin;
+    const int mp = a.item_records[its[p].slot];
+    for (int j = threadIdx.x; j < mp; j += 256) {
+      const Rec r = mine[j];
+      int pos = j;
+      for (int q = 0; q < pieces; ++q) {
+        if (q == p) continue;
+        const Rec* other = recs + its[q].begin;
+        int lo = 0, hi = a.item_records[its[q].slot];  // first record of run q that does not come before r
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const uint64_t k0 = other[mid].k0;
+          bool before = k0 < r.k0;
+          if (k0 == r.k0) {
+            const uint64_t k1 = other[mid].k1;
+            before = k1 < r.k1 || (!POSITION && k1 == r.k1 && other[mid].k2 < r.k2);
+          }
+          if (before) lo = mid + 1;
+          else hi = mid;
+        }
+        pos += lo;
+      }
+      out[o + pos] = decode_record<POSITION>(r);
     }
-    out[o + i] = w;
   }
 }
 

@@ -106,6 +106,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
   a.min_arcs = -1;
   a.max_arcs = 0x7FFFFFFF;
   a.num_records = st.num_records.p;
+  if (st.pieces_live) a.piece_first = st.piece_first.p, a.piece_count = st.piece_count.p, a.item_records = st.item_records.p, a.piece_items = st.piece_items.p;
   {
     // sort tile: big enough for the largest lattice's keys if that fits 128 KiB of LDS
     int64_t max_arcs = 0;
@@ -135,9 +136,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
     // table of 2^14 slots up to 8192 arcs, 2^15 above), the others the general kernel
     bool radix = std::getenv("KLAT_INDEX_BITONIC") == nullptr;  // (test hook: force the general kernel)
     RadixPack pk = {0, 0, 0, 0};
-    int64_t n_hash = 0;  // lattices the hash kernel takes
-    for (int64_t u = 0; u < b->U; ++u) n_hash += b->h_arc_off[u + 1] - b->h_arc_off[u] <= kHashClassArcs[kHashClasses - 1] ? 1 : 0;
-    radix = radix && n_hash > 0 && b->A > 0;
+    radix = radix && b->A > 0;  // (lattices of up to 16 384 arcs whole, longer ones in pieces where they can be cut)
     st.cached_mode = st.dense_mode = 0;
     if (!st.ev[0]) {
       KLAT_HIP(hipEventCreate(&st.ev[0]));
@@ -199,23 +198,48 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
           }
         }
         st.class_begin[0] = 0;
-        for (int k = 0; k <= kHashClasses; ++k) st.class_begin[k + 1] = st.class_begin[k] + cnt[k];
-        std::vector<int32_t> list((size_t)b->U);
-        int64_t at[kHashClasses + 1];
-        for (int k = 0; k <= kHashClasses; ++k) at[k] = st.class_begin[k];
-        for (int64_t u = 0; u < b->U; ++u) list[(size_t)at[to[cls[(size_t)u]]]++] = (int32_t)u;
-        if ((rc = st.class_list.upload(list.data(), list.size(), c->stream))) return rc;
-        KLAT_HIP(hipStreamSynchronize(c->stream));  // (the list is a local)
+        for (int k = 0; k < kHashClasses; ++k) st.class_begin[k + 1] = st.class_begin[k] + cnt[k];
+        std::vector<IndexItem> items((size_t)st.class_begin[kHashClasses]);
+        std::vector<int32_t> longs, first((size_t)b->U, -1);
+        int64_t at[kHashClasses], slots = 0;
+        for (int k = 0; k < kHashClasses; ++k) at[k] = st.class_begin[k];
+        for (int64_t u = 0; u < b->U; ++u) {
+          const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
+          if (cls[(size_t)u] == kHashClasses) {  // a long lattice: piece slots for the slicing to fill
+            if (arcs < ((int64_t)1 << 30)) {
+              longs.push_back((int32_t)u);
+              first[(size_t)u] = (int32_t)slots;
+              slots += (arcs + kPieceStride - 1) / kPieceStride;
+            }
+            continue;
+          }
+          items[(size_t)at[to[cls[(size_t)u]]]++] = IndexItem{(int32_t)u, 0, (int32_t)arcs, -1};
+        }
+        st.num_long = (int64_t)longs.size(), st.num_piece_slots = slots;
+        if ((rc = st.class_items.upload(items.data(), items.size(), c->stream))) return rc;
+        if ((rc = st.long_list.upload(longs.data(), longs.size(), c->stream))) return rc;
+        if ((rc = st.piece_first.upload(first.data(), first.size(), c->stream))) return rc;
+        if ((rc = st.piece_count.alloc((size_t)b->U)) || (rc = st.item_records.alloc((size_t)slots)) || (rc = st.piece_items.alloc((size_t)slots))) return rc;
+        KLAT_HIP(hipStreamSynchronize(c->stream));  // (the lists are locals)
         st.classes_ready = true;
       }
+      a.piece_first = st.piece_first.p, a.piece_count = st.piece_count.p, a.item_records = st.item_records.p, a.piece_items = st.piece_items.p;
+      st.pieces_live = true;
+      KLAT_HIP(hipMemsetAsync(st.piece_count.p, 0, sizeof(int32_t) * (size_t)b->U, c->stream));
       for (int k = 0; k < kHashClasses; ++k)
-        KLAT_HIP(launch_index_hash2(a, pk, position, k, st.class_list.p + st.class_begin[k], (int)(st.class_begin[k + 1] - st.class_begin[k]), c->stream));
-      if (st.class_begin[kHashClasses + 1] > st.class_begin[kHashClasses]) {
+        KLAT_HIP(launch_index_hash2(a, pk, position, k, st.class_items.p + st.class_begin[k], (int)(st.class_begin[k + 1] - st.class_begin[k]), c->stream));
+      if (st.num_long > 0) {
+        // long lattices: cut where the source states' time changes, the pieces through the two largest classes' kernel
+        // (a piece has at most kPieceStride + kPieceWindow = 15 360 arcs), what could not be cut through the general kernel
+        KLAT_HIP(launch_index_slice(a, position, st.long_list.p, (int)st.num_long, c->stream));
+        KLAT_HIP(launch_index_hash2(a, pk, position, kHashClasses - 2, st.piece_items.p, (int)st.num_piece_slots, c->stream));
         a.min_arcs = kHashClassArcs[kHashClasses - 1], a.max_arcs = 0x7FFFFFFF;
         KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
         a.min_arcs = -1, a.max_arcs = 0x7FFFFFFF;
       }
     } else {
+      st.pieces_live = false;  // (every lattice through the general kernel: whole)
+      a.piece_first = nullptr, a.piece_count = nullptr, a.item_records = nullptr, a.piece_items = nullptr;
       KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
     }
     KLAT_HIP(hipEventRecord(st.ev[1], c->stream));

@@ -294,21 +294,23 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   __shared__ float sh_lo[T / 64], sh_hi[T / 64];
   __shared__ int sh_qn, sh_ndl, sh_nbig, sh_big[CAP / kSerialMax + 1];
 
-  const int u = a.lattice_list ? a.lattice_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t a0 = a.arc_off[u], s0 = a.state_off[u];
-  const int n = (int)(a.arc_off[u + 1] - a0);
-  if (n > CAP) return;  // (never: the host lists a class's lattices)
+  const IndexItem item = a.items[blockIdx.x];
+  if (item.u < 0) return;  // (a piece slot the slicing left empty)
+  const int u = item.u, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t a0 = a.arc_off[u] + item.begin, s0 = a.state_off[u];
+  const int n = item.end - item.begin;
+  if (n > CAP) return;  // (never: the host lists a class's lattices, the pieces fit the largest classes)
 #define KLAT_STAMP(k)                                                                 \
   do {                                                                                \
     if (a.phase_clock && tid == 0) a.phase_clock[(size_t)u * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
   } while (0)
   KLAT_STAMP(0);
-  if (n == 0) {
+  if (n == 0) {  // (an empty lattice: pieces are never empty)
     if (tid == 0) a.num_records[u] = 0;
     return;
   }
   const int64_t pb = padded_state_base(s0, u);
-  const int64_t row = a.scratch_off[u];
+  const int64_t row = a.scratch_off[u] + item.begin;  // (the scratch rows hold a slot per arc: a piece has its arcs' slots)
   double* vals = a.val_scratch + row;
   const double tot = a.total[u];
   const int32_t* const l_olabel = a.olabel + a0;
@@ -334,7 +336,7 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   // the list of repeated keys' arcs: behind the queue in the record row (16 of a slot's 24 bytes are the queue's),
   // out of the way of the payloads the fold writes while it reads the list
   uint32_t* duplist = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(reinterpret_cast<Rec*>(a.rec_scratch) + row) +
-                                                  16 * (size_t)(a.scratch_off[u + 1] - row));
+                                                  16 * (size_t)n);
   Payload* payload = reinterpret_cast<Payload*>(a.key_scratch) + row;  // by first arc, repeated keys only (after the list is in LDS)
   Rec* recs = reinterpret_cast<Rec*>(a.rec_scratch) + row;
   const int jmax = (n + T - 1) / T;  // rounds of T arcs this lattice has (workgroup-uniform)
@@ -763,7 +765,14 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
       lds_barrier();
     }
   }
-  if (tid == 0) a.num_records[u] = m;
+  if (tid == 0) {
+    if (item.slot < 0) {
+      a.num_records[u] = m;
+    } else {  // a piece: its own count for the merge, the lattice's sum for the record offsets
+      a.item_records[item.slot] = m;
+      atomicAdd(&a.num_records[u], m);
+    }
+  }
   KLAT_STAMP(7);
 #undef KLAT_STAMP
 }
@@ -802,11 +811,67 @@ hipError_t launch(const AccumArgs& a, const RadixPack& pk, int cls, int count, h
 
 }  // namespace
 
-hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool position, int cls, const int32_t* list, int count,
+// Pieces of a long lattice (klat_accum.h): one workgroup per lattice.  A wave looks for boundary k = the last arc at or
+// before k * kPieceStride whose source state's time differs from its predecessor's, 64 arcs at a time.
+template <bool POSITION>
+__global__ __launch_bounds__(256) void index_slice_kernel(AccumArgs a, const int32_t* long_list) {
+  __shared__ int bad;
+  const int u = long_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t a0 = a.arc_off[u], s0 = a.state_off[u];
+  const int n = (int)(a.arc_off[u + 1] - a0);
+  const int32_t* src = a.src + a0;
+  const int32_t* tm = (POSITION ? a.state_len : a.state_time) + s0;
+  const int first = a.piece_first[u], pieces = (n + kPieceStride - 1) / kPieceStride;
+  IndexItem* items = a.piece_items + first;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  // keys repeat only among arcs whose source states share their time: with times that never descend along the arcs, a
+  // cut where the time changes separates the keys
+  int descends = 0;
+  for (int i = tid + 1; i < n; i += 256) descends |= tm[src[i]] < tm[src[i - 1]] ? 1 : 0;
+  if (descends) bad = 1;
+  for (int k = 1 + wave; k < pieces; k += 4) {  // (wave-uniform)
+    const int target = k * kPieceStride;  // < n
+    int cut = -1;
+    for (int back = 0; back < kPieceWindow && cut < 0; back += 64) {
+      const int i = target - back - lane;  // >= kPieceStride - kPieceWindow > 0
+      const unsigned long long changes = __ballot(tm[src[i]] != tm[src[i - 1]]);
+      if (changes) cut = target - back - (__ffsll((long long)changes) - 1);
+    }
+    if (cut < 0) bad = 1;
+    if (lane == 0) items[k].begin = cut;
+  }
+  if (tid == 0) items[0].begin = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const bool ok = bad == 0;
+  int mine[4] = {0, 0, 0, 0};  // the ends of this thread's pieces, read before anything is rewritten
+  for (int k = tid, q = 0; k < pieces && q < 4; k += 256, ++q) mine[q] = k + 1 < pieces ? items[k + 1].begin : n;
+  __syncthreads();
+  for (int k = tid, q = 0; k < pieces; k += 256, ++q) {
+    IndexItem it;
+    it.u = ok ? u : -1, it.begin = items[k].begin, it.end = mine[q < 4 ? q : 3], it.slot = first + k;
+    items[k] = it;
+    a.item_records[first + k] = 0;
+  }
+  if (tid == 0) a.piece_count[u] = ok ? pieces : 0, a.num_records[u] = 0;
+}
+
+hipError_t launch_index_slice(const AccumArgs& a, bool position, const int32_t* long_list, int count, hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  if (position)
+    hipLaunchKernelGGL(index_slice_kernel<true>, dim3(count), dim3(256), 0, stream, a, long_list);
+  else
+    hipLaunchKernelGGL(index_slice_kernel<false>, dim3(count), dim3(256), 0, stream, a, long_list);
+  return hipGetLastError();
+}
+
+hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool position, int cls, const IndexItem* items, int count,
                               hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   AccumArgs b = a;
-  b.lattice_list = list;
+  b.items = items;
   return position ? launch<true>(b, pk, cls, count, stream) : launch<false>(b, pk, cls, count, stream);
 }
 

@@ -217,8 +217,14 @@ struct klat_accum_state {
   klat::DevBuf<int32_t> num_records, include, exclude, state_len;
   // the hash kernel's size classes (klat_accum.h): class c's lattices are class_list[class_begin[c] .. class_begin[c + 1])
   bool classes_ready = false;
-  klat::DevBuf<int32_t> class_list;
-  int64_t class_begin[klat::kHashClasses + 2] = {0};  // (the last class: the lattices the general kernel takes)
+  klat::DevBuf<klat::IndexItem> class_items;
+  int64_t class_begin[klat::kHashClasses + 1] = {0};
+  // lattices of more than kHashClassArcs[last] arcs: cut into pieces on the device (index_slice_kernel), a piece a work
+  // item of the largest classes; what could not be cut takes the general kernel
+  int64_t num_long = 0, num_piece_slots = 0;
+  bool pieces_live = false;  // the last sizing call went through the hash kernel (piece_count is current)
+  klat::DevBuf<int32_t> long_list, piece_first, piece_count, item_records;
+  klat::DevBuf<klat::IndexItem> piece_items;
 };
 
 struct klat_frame_state {

@@ -361,6 +361,48 @@ def test_index_kernel_shapes(ctx, shape):
                 assert x[:2] < y[:2]
 
 
+@pytest.mark.parametrize("shape", ["plain", "repeated_keys", "long_ties", "descending"])
+def test_index_of_long_lattices(ctx, shape):
+    """Lattices of more than 16 384 arcs: the hash kernel takes them in pieces cut where the source states' time (the
+    length, for the position index) changes -- no key repeats across such a cut -- and the gather merges the pieces'
+    sorted runs.  20 000 and 60 000 arcs beside short lattices, against the oracle; keys that repeat (several states a
+    time: the cuts must find the changes); a stretch of 3 000 arcs of one time (no cut inside a window: that lattice takes
+    the general kernel) and times that descend somewhere (likewise): every path gives the oracle's records."""
+    ns = np.array([150, 6700, 40, 10000, 900], np.int32)
+    fo = np.array([3, 3, 2, 6, 4], np.int32)
+    arrays = klat_amd.synth(20260031, ns, fo)
+    if shape == "repeated_keys":
+        arrays["olabel"] = (arrays["olabel"] % 5).astype(np.int32)
+        arrays["ilabel"] = arrays["olabel"].copy()
+        arrays["state_time"] = (arrays["state_time"] // 6).astype(np.int32)
+    if shape == "long_ties":
+        t = arrays["state_time"].copy()
+        s0 = int(arrays["state_off"][3])
+        t[s0 + 2000:s0 + 2600] = t[s0 + 2000]  # 600 states x 6 arcs of one time around the first cut of the 60 000-arc lattice
+        arrays["state_time"] = t
+    if shape == "descending":
+        t = arrays["state_time"].copy()
+        s0 = int(arrays["state_off"][1])
+        t[s0 + 3000], t[s0 + 3001] = t[s0 + 3001], t[s0 + 3000]
+        arrays["state_time"] = t
+    state_len = np.concatenate([np.arange(int(n), dtype=np.int32) // 3 for n in ns])
+    scales = (1.0, 0.3, 0.25)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(*scales)
+    (soff, srec), (poff, prec) = b.segment_index(), b.position_index(state_len)
+    b.close()
+    for u, lat in enumerate(_split(arrays)):
+        s0, s1 = int(arrays["state_off"][u]), int(arrays["state_off"][u + 1])
+        sl = orc.scale_and_penalize(lat, *scales)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        want = orc.segment_index(sl, arrays["state_time"][s0:s1], alpha, beta, total)
+        got = [(int(r["label"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in srec[soff[u]:soff[u + 1]]]
+        _check_sorted_records(got, want, 3, tol=1e-9)
+        want = orc.position_index(sl, arrays["state_time"][s0:s1], state_len[s0:s1], alpha, beta, total)
+        got = [(int(r["label"]), int(r["pos"]), float(r["logp"])) for r in prec[poff[u]:poff[u + 1]]]
+        _check_sorted_records(got, [(w[0], w[1], w[4]) for w in want], 2, tol=1e-9)
+
+
 @pytest.mark.parametrize("shape", ["C2", "C4"])
 def test_segment_index_full_size_properties(ctx, shape):
     """The segment index at BASELINE's sizes -- configs[1] whole (10 000 lattices x 2 000 states: the 512 x 12 class)
