@@ -150,6 +150,16 @@ __host__ __device__ inline int64_t frame_sort_slots(int64_t num_arcs) {
   return p;
 }
 
+// A piece of a lattice too long for the lean frame kernel (more than 8 192 states, 65 535 arcs or 65 535 frames): the frames
+// [f0, f1) and everything that can cross them -- the states [s_lo, s_hi) (the piece's own and as many before and behind
+// them as the lattice's longest arc spans), the arcs [a_lo, a_hi) leaving the states before the own ones' end.  The times
+// of a piece are the lattice's, clipped to the window: an arc that crosses a cut is counted in both pieces, in each for
+// the frames of that piece (frame_slice_kernel, klat_frame.hip).
+struct FrameItem {
+  int32_t u, s_lo, s_hi, a_lo, a_hi, f0, f1, lab_base;
+  int64_t scratch;  // the piece's rows in piece_scratch (16 B per arc)
+};
+
 struct FrameArgs {
   const int64_t* state_off;
   const int64_t* arc_off;
@@ -181,6 +191,16 @@ struct FrameArgs {
   int32_t* redo2_n;
   const LnTabEntry* ln_table;  // [kLnTabSize] (klat_kernels.h), the lean kernel's LogAdd
   const int32_t* lattice_list; // the lean kernel's first instantiation: workgroup k takes lattice_list[k] (null: lattice k)
+  int32_t* listed;             // [U] 1: the lattice is on redo_list / redo2_list already (a lattice's pieces list it once)
+  int32_t* dense;              // [U] the lattices with more than twelve entries a rank: the dense pass's (klat_frame.hip), ...
+  int32_t* dense_n;            // [1] ... and their number
+  int32_t* piece_dense;        // [piece slots] the same for a piece
+  // long lattices in pieces (FrameItem): slots [piece_first[u], + ceil(states / kFramePieceStates)), filled by the slicing
+  FrameItem* piece_items;
+  const int32_t* piece_first;  // [U]
+  FrameArc* piece_scratch;     // the pieces' arc rows (x and span), taken with piece_scratch_used
+  unsigned long long* piece_scratch_used;
+  int64_t piece_scratch_cap;
   uint64_t* pool;             // the lean kernel's records, a lattice's in one piece
   unsigned long long* pool_used;  // [2] records asked for so far (also by the lattices the pool had no room for); those asked for in vain
   int64_t pool_cap;
@@ -197,6 +217,14 @@ static const int kFrameClasses = 3;
 static const int kFrameClassArcs[kFrameClasses] = {1536, 3072, 0x7FFFFFFF};
 static const int kFrameClassStates[kFrameClasses] = {1024, 2048, 0x7FFFFFFF};
 hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, bool big, int size_class, hipStream_t stream);
+// Long lattices: pieces of kFramePieceStates own states (the cut moved up to kFramePieceWindow states forward, to where the
+// time changes) through the lean kernel's second instantiation; a lattice whose times descend somewhere along its states,
+// whose longest arc spans more than kFramePieceWindow states or that has no change of time inside a window is listed for
+// the general kernel.
+static const int kFramePieceStates = 6144, kFramePieceWindow = 1024;
+hipError_t launch_frame_slice(const FrameArgs& a, const int32_t* long_list, int count, hipStream_t stream);
+hipError_t launch_frame_lean_pieces(const FrameArgs& a, int num_slots, hipStream_t stream);
+hipError_t launch_frame_lean_dense(const FrameArgs& a, int num_lattices, int num_slots, hipStream_t stream);
 hipError_t launch_frame_gather(const FrameArgs& a, int num_lattices, const int64_t* entry_off,
                                const int64_t* frame_base, int64_t* frame_off, int32_t* labels, float* logps,
                                hipStream_t stream);

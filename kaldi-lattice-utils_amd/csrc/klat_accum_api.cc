@@ -470,7 +470,14 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     }
     if (lean) {
       if ((rc = st.redo.alloc(2 * (size_t)b->U + 2))) return rc;
-      if ((rc = st.pool_used.alloc(2))) return rc;
+      if ((rc = st.pool_used.alloc(3))) return rc;  // records asked for, asked for in vain; the pieces' arc rows taken
+      if ((rc = st.listed.alloc((size_t)b->U))) return rc;
+      a.listed = st.listed.p;
+      KLAT_HIP(hipMemsetAsync(a.listed, 0, sizeof(int32_t) * (size_t)b->U, c->stream));
+      if ((rc = st.dense.alloc((size_t)b->U + 1))) return rc;
+      a.dense = st.dense.p;
+      a.dense_n = st.dense.p + b->U;
+      KLAT_HIP(hipMemsetAsync(a.dense_n, 0, sizeof(int32_t), c->stream));
       a.pool = st.pool.p;
       a.pool_cap = cap;
       a.pool_used = st.pool_used.p;
@@ -480,19 +487,34 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       a.redo2_n = st.redo.p + 2 * b->U + 1;
       a.ln_table = c->ln_table.p;
       KLAT_HIP(hipMemsetAsync(a.redo_n, 0, 2 * sizeof(int32_t), c->stream));
-      KLAT_HIP(hipMemsetAsync(a.pool_used, 0, 2 * sizeof(unsigned long long), c->stream));
+      KLAT_HIP(hipMemsetAsync(a.pool_used, 0, 3 * sizeof(unsigned long long), c->stream));
       // size classes: a lattice runs in the smallest workgroup that holds it, every class one launch over its own list
       // (a class of fewer than 64 lattices rides with the next larger one)
       if (!st.classes_ready) {
-        std::vector<int32_t> cls((size_t)b->U);
-        int64_t cnt[kFrameClasses] = {0};
+        std::vector<int32_t> cls((size_t)b->U), longs, pfirst((size_t)b->U, -1);
+        int64_t cnt[kFrameClasses] = {0}, slots = 0, long_arcs = 0;
         for (int64_t u = 0; u < b->U; ++u) {
           const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u], states = b->h_state_off[u + 1] - b->h_state_off[u];
+          // too long for the lean kernel (8 192 states or 65 535 arcs): in pieces (frame_slice_kernel)
+          if ((states > 8192 || arcs > 65535) && arcs < ((int64_t)1 << 30) && states < ((int64_t)1 << 30)) {
+            cls[(size_t)u] = -1;
+            longs.push_back((int32_t)u);
+            pfirst[(size_t)u] = (int32_t)slots;
+            slots += (states + kFramePieceStates - 1) / kFramePieceStates;
+            long_arcs += arcs;
+            continue;
+          }
           int k = 0;
           while (k < kFrameClasses - 1 && (arcs > kFrameClassArcs[k] || states > kFrameClassStates[k])) ++k;
           cls[(size_t)u] = k;
           ++cnt[k];
         }
+        st.num_long = (int64_t)longs.size(), st.num_piece_slots = slots;
+        st.piece_scratch_cap = long_arcs + long_arcs / 2 + 65536;
+        if ((rc = st.long_list.upload(longs.data(), longs.size(), c->stream))) return rc;
+        if ((rc = st.piece_first.upload(pfirst.data(), pfirst.size(), c->stream))) return rc;
+        if ((rc = st.piece_items.alloc((size_t)slots))) return rc;
+        if (slots > 0 && (rc = st.piece_scratch.alloc((size_t)st.piece_scratch_cap))) return rc;
         int to[kFrameClasses];
         for (int k = kFrameClasses - 1; k >= 0; --k) {
           to[k] = k;
@@ -504,6 +526,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
         int64_t at[kFrameClasses];
         for (int k = 0; k < kFrameClasses; ++k) at[k] = st.class_begin[k];
         for (int64_t u = 0; u < b->U; ++u) {
+          if (cls[(size_t)u] < 0) continue;
           const int k = to[cls[(size_t)u]];
           list[(size_t)at[k]++] = (int32_t)u;
           st.class_max_arcs[k] = (int32_t)std::max<int64_t>(st.class_max_arcs[k], std::min<int64_t>(b->h_arc_off[u + 1] - b->h_arc_off[u], 1 << 30));
@@ -517,18 +540,34 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
         KLAT_HIP(launch_frame_lean(a, (int)(st.class_begin[k + 1] - st.class_begin[k]), st.class_max_arcs[k], false, k, c->stream));
       }
       a.lattice_list = nullptr;
+      if (st.num_long > 0) {  // long lattices: sliced on the device, the pieces through the second instantiation
+        a.piece_items = st.piece_items.p, a.piece_first = st.piece_first.p, a.piece_scratch = st.piece_scratch.p;
+        a.piece_scratch_used = st.pool_used.p + 2, a.piece_scratch_cap = st.piece_scratch_cap;
+        if ((rc = st.piece_dense.alloc((size_t)st.num_piece_slots))) return rc;
+        a.piece_dense = st.piece_dense.p;
+        KLAT_HIP(hipMemsetAsync(a.piece_dense, 0, sizeof(int32_t) * (size_t)st.num_piece_slots, c->stream));
+        KLAT_HIP(launch_frame_slice(a, st.long_list.p, (int)st.num_long, c->stream));
+        KLAT_HIP(launch_frame_lean_pieces(a, (int)st.num_piece_slots, c->stream));
+      }
       if ((rc = print_clock("frame_lean_kernel"))) return rc;
-      int32_t first_n = 0;
+      int32_t first_n = 0, dense_n = 0;
       unsigned long long used[2] = {0, 0};  // [0] records asked of the pool, [1] those of them the pool had no room for
       KLAT_HIP(hipMemcpyAsync(&first_n, a.redo_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      KLAT_HIP(hipMemcpyAsync(&dense_n, a.dense_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipMemcpyAsync(used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipStreamSynchronize(c->stream));
       redo_n = first_n;
       unsigned long long need = used[0];
+      const unsigned long long short_first = used[1];
       if (first_n > 0) {  // larger lattices (spans in L2), and one more try for what else did not fit
-        const unsigned long long short_first = used[1];
         KLAT_HIP(launch_frame_lean(a, (int)first_n, max_arcs, true, 0, c->stream));
         if ((rc = print_clock("frame_lean_kernel (second instantiation)"))) return rc;
+      }
+      // the lattices and pieces marked dense (more than twelve entries a rank): thirty-two registers a rank
+      // (the second instantiation, still running, may list up to first_n more)
+      if (first_n > 0 || dense_n > 0 || st.num_long > 0) {  // (a batch the first instantiation finished has nothing more to wait for)
+        KLAT_HIP(launch_frame_lean_dense(a, (int)std::min<int64_t>(b->U, (int64_t)dense_n + first_n), st.num_long > 0 ? (int)st.num_piece_slots : 0, c->stream));
+        if ((rc = print_clock("frame_lean_kernel (dense pass)"))) return rc;
         KLAT_HIP(hipMemcpyAsync(&redo_n, a.redo2_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         KLAT_HIP(hipMemcpyAsync(used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
         KLAT_HIP(hipStreamSynchronize(c->stream));

@@ -317,8 +317,8 @@ __device__ __forceinline__ void fr_sort_regs(uint64_t (&k)[kFrRegs], double (&v)
 }
 
 // The same network over 32-bit keys without payload: a compare-exchange is v_min_u32 + v_max_u32.
-template <int N, int SIZE, int STRIDE>
-__device__ __forceinline__ void fr_sort32_stage(uint32_t (&k)[kFrRegs]) {
+template <int N, int SIZE, int STRIDE, int R = kFrRegs>
+__device__ __forceinline__ void fr_sort32_stage(uint32_t (&k)[R]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const int l = i ^ STRIDE;
@@ -329,20 +329,20 @@ __device__ __forceinline__ void fr_sort32_stage(uint32_t (&k)[kFrRegs]) {
       k[l] = up ? hi : lo;
     }
   }
-  if constexpr (STRIDE > 1) fr_sort32_stage<N, SIZE, STRIDE / 2>(k);
+  if constexpr (STRIDE > 1) fr_sort32_stage<N, SIZE, STRIDE / 2, R>(k);
 }
-template <int N, int SIZE>
-__device__ __forceinline__ void fr_sort32_sizes(uint32_t (&k)[kFrRegs]) {
-  fr_sort32_stage<N, SIZE, SIZE / 2>(k);
-  if constexpr (SIZE < N) fr_sort32_sizes<N, SIZE * 2>(k);
+template <int N, int SIZE, int R = kFrRegs>
+__device__ __forceinline__ void fr_sort32_sizes(uint32_t (&k)[R]) {
+  fr_sort32_stage<N, SIZE, SIZE / 2, R>(k);
+  if constexpr (SIZE < N) fr_sort32_sizes<N, SIZE * 2, R>(k);
 }
 
 // The same network over keys that are positive finite doubles as bit patterns (top two bits clear):
 // their order as doubles is their order as integers, and a compare-exchange is v_min_f64 + v_max_f64
 // instead of a 64-bit compare and four selects.  (Bare instructions: fmin / fmax would first quiet
 // signalling NaNs, which these patterns never are.)
-template <int N, int SIZE, int STRIDE>
-__device__ __forceinline__ void fr_sortd_stage(double (&k)[kFrRegs]) {
+template <int N, int SIZE, int STRIDE, int R = kFrRegs>
+__device__ __forceinline__ void fr_sortd_stage(double (&k)[R]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const int l = i ^ STRIDE;
@@ -355,12 +355,12 @@ __device__ __forceinline__ void fr_sortd_stage(double (&k)[kFrRegs]) {
       k[l] = up ? hi : lo;
     }
   }
-  if constexpr (STRIDE > 1) fr_sortd_stage<N, SIZE, STRIDE / 2>(k);
+  if constexpr (STRIDE > 1) fr_sortd_stage<N, SIZE, STRIDE / 2, R>(k);
 }
-template <int N, int SIZE>
-__device__ __forceinline__ void fr_sortd_sizes(double (&k)[kFrRegs]) {
-  fr_sortd_stage<N, SIZE, SIZE / 2>(k);
-  if constexpr (SIZE < N) fr_sortd_sizes<N, SIZE * 2>(k);
+template <int N, int SIZE, int R = kFrRegs>
+__device__ __forceinline__ void fr_sortd_sizes(double (&k)[R]) {
+  fr_sortd_stage<N, SIZE, SIZE / 2, R>(k);
+  if constexpr (SIZE < N) fr_sortd_sizes<N, SIZE * 2, R>(k);
 }
 
 // Sixteen keys by the 60-comparator network of ten layers (the bitonic network above takes 80; checked over all
@@ -981,7 +981,6 @@ static constexpr int kLnBlock = 128;       // ranks per entry of the table of fi
 static constexpr int kLnTile = 1024;    // ranks per tile
 static constexpr int kLnBatch = 6;      // arcs per thread and round of the arc pass
 static constexpr int kLnWideMax = 64;   // a rank with more than kFrRegs entries and at most this many is folded by a whole wave
-static constexpr int kLnWideList = 32;  // such ranks per tile
 
 // BIG: the instantiation for the lattices the first one lists (spans in L2, up to kLnStates states; whatever else did
 // not fit is tried once more and listed for the general kernel); the first one keeps the shorter code of a lattice
@@ -989,9 +988,17 @@ static constexpr int kLnWideList = 32;  // such ranks per tile
 // SC: the size class -- threads, bucket entries, states and ranks per tile are 1 / SC of the full-size kernel's, so a
 // lattice of a few hundred states runs in 128 threads with 16 KiB of LDS and eight such workgroups share a CU (80 000
 // lattices of 125 states took 3.25 ms in 512-thread workgroups, two a CU).  The host lists every class's lattices.
-template <bool BIG, bool CLOCK, int SC>
-__global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
+// PIECES: the second instantiation over the pieces of long lattices (FrameItem, klat_accum.h) instead of a list of lattices.
+// R: bucket entries a rank's thread sorts in registers.  Sixteen serve lattices whose frames hold ten arcs or so
+// (BASELINE's fanout 3); a lattice with more than twelve entries a rank on average is LISTED (a.dense; a piece: marked in
+// a.piece_dense) and left to the instantiation with thirty-two (DENSE), which
+// pays for its registers with half the waves -- a wave per rank of more than sixteen entries, the only other way this
+// kernel has, costs forty times a thread per rank.
+template <bool BIG, bool CLOCK, int SC, bool PIECES = false, int R = kFrRegs, bool DENSE = false>
+__global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
+  static_assert(!DENSE || (BIG && R == 2 * kFrRegs), "the dense pass is the second instantiation with thirty-two registers a rank");
   static_assert(!BIG || SC == 1, "the second instantiation is full size");
+  static_assert(!PIECES || BIG, "pieces take the second instantiation");
   constexpr int NT = kFrLeanThreads / SC;
   constexpr int kEntries = kFrLdsEntries / SC;    // bucket entries of a tile in LDS
   constexpr int kStatesLds = kLnStatesLds / SC;   // states of a lattice whose spans stay in LDS
@@ -1006,26 +1013,38 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
   __shared__ int lcur[kTile];       // scatter cursors
   __shared__ int sh[2 * NT / 64];
   __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, sum_stored, sum_dense, descending;
-  __shared__ int wide_rank[kLnWideList];
+  // the tile's ranks of more than kFrRegs entries: every one of them where a lattice's frames hold twenty arcs and more
+  // (fanout four, six: a wave per rank is forty times the work of a thread per rank, and a tenth of the general kernel's)
+  __shared__ uint16_t wide_rank[kTile];
   __shared__ int blk_first[kLnStates / kLnBlock + 2];  // first arc whose first rank lies in or behind block b of kLnBlock ranks
   __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
-  if (BIG && (int)blockIdx.x >= *a.redo_n) return;
-  const int u = BIG ? a.redo_list[blockIdx.x] : (a.lattice_list ? a.lattice_list[blockIdx.x] : (int)blockIdx.x);
+  if (BIG && !PIECES && !DENSE && (int)blockIdx.x >= *a.redo_n) return;
+  FrameItem item = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (PIECES) {
+    item = a.piece_items[blockIdx.x];
+    if (item.u < 0) return;  // (a slot the slicing left empty)
+    if (DENSE && !a.piece_dense[blockIdx.x]) return;
+  }
+  if (DENSE && !PIECES && (int)blockIdx.x >= *a.dense_n) return;
+  const int u = PIECES ? item.u : DENSE ? a.dense[blockIdx.x] : BIG ? a.redo_list[blockIdx.x] : (a.lattice_list ? a.lattice_list[blockIdx.x] : (int)blockIdx.x);
   const int tid = threadIdx.x;
   if (tid < kLnTabSize) lntab[tid] = a.ln_table[tid];  // (barriers follow before its first use)
-  const int64_t a0 = a.arc_off[u];
-  const int nA = (int)(a.arc_off[u + 1] - a0);
-  const int64_t s0 = a.state_off[u];
-  const int S = (int)(a.state_off[u + 1] - s0);
-  const int64_t pb = padded_state_base(s0, u);
+  // a piece: its arcs, its states (numbered from s_lo), its frames (counted from f0)
+  const int s_lo = PIECES ? item.s_lo : 0, f_lo = PIECES ? item.f0 : 0;
+  const int64_t a0 = a.arc_off[u] + (PIECES ? item.a_lo : 0);
+  const int nA = PIECES ? item.a_hi - item.a_lo : (int)(a.arc_off[u + 1] - a0);
+  const int64_t s0 = a.state_off[u] + s_lo;
+  const int S = PIECES ? item.s_hi - item.s_lo : (int)(a.state_off[u + 1] - s0);
+  const int64_t pb = padded_state_base(a.state_off[u], u) + s_lo;
   const double tot = a.total[u];
-  const int T = a.num_frames[u];
-  double* xs = reinterpret_cast<double*>(a.arc_info + a0);  // x of every arc (the front half of the lattice's rows)
-  const int64_t fbase = a.frame_base[u];
+  const int T = PIECES ? item.f1 - item.f0 : a.num_frames[u];
+  // x of every arc (the front half of the lattice's rows; a piece has rows of its own: pieces share the arcs that cross a cut)
+  double* xs = reinterpret_cast<double*>(PIECES ? a.piece_scratch + item.scratch : a.arc_info + a0);
+  const int64_t fbase = a.frame_base[u] + f_lo;
   const ScaleParams sp = a.sp;
-  auto leave = [&]() {  // (workgroup-uniform)
-    if (tid == 0) {
+  auto leave = [&]() {  // (workgroup-uniform; a lattice is listed once, whichever of its pieces leaves first)
+    if (tid == 0 && (atomicOr(&a.listed[u], BIG ? 2 : 1) & (BIG ? 2 : 1)) == 0) {
       if (BIG) a.redo2_list[atomicAdd(a.redo2_n, 1)] = u;
       else a.redo_list[atomicAdd(a.redo_n, 1)] = u;
     }
@@ -1040,7 +1059,7 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
   uint32_t* gspan = reinterpret_cast<uint32_t*>(xs + nA);
   if (nA == 0) {  // nothing crosses any frame (and the unconditional loads below read the lattice's first arc)
     for (int f = tid; f < T; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
-    if (tid == 0) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = a.pool, a.rec_fmt[u] = 0;
+    if (tid == 0 && !PIECES) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = a.pool, a.rec_fmt[u] = 0;
     return;
   }
   long long clk[6] = {0, 0, 0, 0, 0, 0};  // spans, counts, scatter, (unused), frames, (unused)
@@ -1060,12 +1079,12 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
     constexpr int kSt = decltype(per_thread)::value;
     int tm[kSt], fl[kSt], mine = 0;
     const int sfirst = tid * kSt;
-    int prev = (sfirst > 0 && sfirst <= S) ? min(max(a.state_time[s0 + sfirst - 1], 0), T) : -1;
+    int prev = (sfirst > 0 && sfirst <= S) ? min(max(a.state_time[s0 + sfirst - 1] - f_lo, 0), T) : -1;
     bool descends = false;
 #pragma unroll
     for (int q = 0; q < kSt; ++q) {
       const int s = sfirst + q;
-      tm[q] = (s < S) ? min(max(a.state_time[s0 + s], 0), T) : T;
+      tm[q] = (s < S) ? min(max(a.state_time[s0 + s] - f_lo, 0), T) : T;
       descends |= s < S && tm[q] < prev;
       fl[q] = (s < S && tm[q] > prev && tm[q] < T) ? 1 : 0;  // the first state of a time below T: a rank
       prev = (s < S) ? tm[q] : prev;
@@ -1146,8 +1165,8 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
       for (int q = 0; q < kLnBatch; ++q) {
         const int i = min(base + (h * kLnBatch + q) * NT + tid, last);
         il[h][q] = a.ilabel[a0 + i];
-        t0[h][q] = a.src[a0 + i];
-        t1[h][q] = a.dst[a0 + i];
+        t0[h][q] = a.src[a0 + i] - s_lo;
+        t1[h][q] = a.dst[a0 + i] - s_lo;
         gr[h][q] = a.graph[a0 + i];
         ac4[h][q] = a.acoustic[a0 + i];
       }
@@ -1226,6 +1245,13 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
   // nothing has to count the entries before this kernel); a pool that is short leaves the lattice to the general
   // kernel, and the caller learns from pool_used what the next call needs.  Asked for here, looked at behind the
   // first tile's counts: the atomic's trip to memory is not waited for.
+  if (R == kFrRegs && num_ranks > 0 && (long long)entries > 12LL * num_ranks) {  // (workgroup-uniform) crowded frames: the dense pass's
+    if (tid == 0) {
+      if (PIECES) a.piece_dense[blockIdx.x] = 1;
+      else a.dense[atomicAdd(a.dense_n, 1)] = u;
+    }
+    return;
+  }
   unsigned long long my_at = 0;
   if (tid == 0) my_at = atomicAdd(a.pool_used, (unsigned long long)entries);
   if (!spans_lds) {  // (workgroup-uniform) a block in which no arc begins takes the next block's first arc
@@ -1238,10 +1264,10 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
   // label range 30 bits (the folded keys sort as doubles)
   int abits = 1;
   while ((1 << abits) < nA) ++abits;
-  const int lab_base = lab_min;
+  const int lab_base = PIECES ? item.lab_base : lab_min;  // (a lattice's pieces share the lattice's: their records are decoded alike)
   const bool keys_fit = lab_max < lab_min ||
-                        ((uint64_t)((int64_t)lab_max - (int64_t)lab_min) < ((1ull << (32 - abits)) - 1ull) &&
-                         (int64_t)lab_max - (int64_t)lab_min < ((int64_t)1 << 30));
+                        ((uint64_t)((int64_t)lab_max - (int64_t)lab_base) < ((1ull << (32 - abits)) - 1ull) &&
+                         (int64_t)lab_max - (int64_t)lab_base < ((int64_t)1 << 30));
   if (unfit || !keys_fit) {
     leave();
     return;
@@ -1261,6 +1287,14 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
   if (!spans_lds && ranged && nr > 0) {
     const long long fit = (long long)max(stage_cap, 0) * nr / nA - kLnBlock - longest;  // ranks whose arcs fill the stage, less the slack
     tile_ranks = (int)max((long long)kLnBlock, min((long long)kTile, fit / kLnBlock * kLnBlock));
+  }
+  // ... and as many as keep a tile's bucket entries inside their LDS: a lattice whose frames hold thirty arcs each (fanout
+  // six, arcs a few states long) fills the buckets with a quarter of a full tile's ranks -- tiles of the average rank's
+  // entries and a third; a tile that overflows all the same leaves the lattice to the next kernel
+  if (nr > 0 && kTile > kLnBlock) {
+    const long long per_rank = ((long long)entries + nr - 1) / nr;
+    const long long fit = (long long)kEntries * 3 / 4 / max(per_rank, 1LL);
+    tile_ranks = (int)max((long long)min(kLnBlock, kTile), min((long long)tile_ranks, fit / kLnBlock * kLnBlock));
   }
   for (int c0 = 0; c0 < nr; c0 += tile_ranks) {
     const int tc = min(tile_ranks, nr - c0);
@@ -1351,7 +1385,6 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
       leave();
       return;
     }
-    uint64_t* rec8 = a.pool + rec_at;
     FR_LAP(1);
     // ---- 2. every arc drops its number into the buckets of its ranks ----
     for (int cb = arc_lo; cb < arc_hi; cb += chunk) {
@@ -1382,53 +1415,58 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
       const int k = r0 + tid;
       const int lo = (k < tc) ? lboff[k] : 0;
       const int w_all = (k < tc) ? lboff[k + 1] - lo : 0;
-      const bool wide = w_all > kFrRegs;  // (rare: left to a whole wave below; its slots are reserved here)
+      const bool wide = w_all > R;  // (rare: left to a whole wave below; its slots are reserved here)
       const int w = wide ? 0 : w_all;
       int mk = 0;
       // (every load below is unconditional: a load inside a branch waits for its data before the branch
       // closes, and sixteen gathers would take sixteen trips to L2 one after the other.  The slots beyond
       // the bucket all read the lattice's first arc: one more request per instruction, not one per lane)
-      uint32_t k32[kFrRegs];
+      uint32_t k32[R];
 #pragma unroll
-      for (int j = 0; j < kFrRegs; ++j) k32[j] = (uint32_t)lbucket[lo + j];  // (beyond the buckets lies rtime: read, not used)
+      for (int j = 0; j < R; ++j) k32[j] = (uint32_t)lbucket[lo + j];  // (beyond the buckets lies rtime: read, not used)
 #pragma unroll
-      for (int j = 0; j < kFrRegs; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
+      for (int j = 0; j < R; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
 #pragma unroll
-      for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? k32[j] : 0u;
+      for (int j = 0; j < R; ++j) k32[j] = (j < w) ? k32[j] : 0u;
       // (gathers served by L2; 32-bit byte offsets from the lattice's first arc: one address register each)
       const char* lab_row = reinterpret_cast<const char*>(a.ilabel + a0);
       const char* x_row = reinterpret_cast<const char*>(xs);
       {
-        int32_t lab[kFrRegs];
+        int32_t lab[R];
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) lab[j] = *reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2));
+        for (int j = 0; j < R; ++j) lab[j] = *reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2));
         // sort keys (label - lab_base | arc number) in 32 bits: a compare-exchange is two instructions and no
         // payload moves; x is fetched by arc number after the sort
 #pragma unroll
-        for (int j = 0; j < kFrRegs; ++j) k32[j] = (j < w) ? (k32[j] | ((uint32_t)(lab[j] - lab_base) << abits)) : 0xFFFFFFFFu;
+        for (int j = 0; j < R; ++j) k32[j] = (j < w) ? (k32[j] | ((uint32_t)(lab[j] - lab_base) << abits)) : 0xFFFFFFFFu;
       }
       const bool narrow = __all(w <= 8);  // wave-uniform: the 8-wide network is enough
-      if (narrow)
-        fr_sort32_sizes<8, 2>(k32);
-      else
+      const bool medium = R > 16 && __all(w <= 16);
+      if (narrow) {
+        fr_sort32_sizes<8, 2, R>(k32);
+      } else if constexpr (R == 16) {
         fr_sort16_net(k32, FrCeU32());
-      double ex[kFrRegs];
+      } else {
+        if (medium) fr_sort32_sizes<16, 2, R>(k32);
+        else fr_sort32_sizes<R, 2, R>(k32);
+      }
+      double ex[R];
 #pragma unroll
-      for (int j = 0; j < kFrRegs; ++j) ex[j] = *reinterpret_cast<const double*>(x_row + ((j < w ? k32[j] & amask : 0u) << 3));
+      for (int j = 0; j < R; ++j) ex[j] = *reinterpret_cast<const double*>(x_row + ((j < w ? k32[j] & amask : 0u) << 3));
       // fold on the sort keys themselves, the runs of one word in arc order: the key of a run is emitted at its
       // last entry as the positive finite double desc(float logp) << 30 | label - lab_base (sorted by v_min_f64 /
       // v_max_f64), the other entries turn into padding
-      double dk[kFrRegs];
+      double dk[R];
       double acc = ex[0];
 #pragma unroll
-      for (int j = 1; j <= kFrRegs; ++j) {
+      for (int j = 1; j <= R; ++j) {
         const uint32_t lab = k32[j - 1] >> abits;
-        const bool cont = j < kFrRegs && j < w && (k32[j < kFrRegs ? j : 0] >> abits) == lab;
+        const bool cont = j < R && j < w && (k32[j < R ? j : 0] >> abits) == lab;
         const bool emit = !cont && j - 1 < w;
         const uint64_t key = ((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab;  // BaseFloat narrowing of :126
         dk[j - 1] = __longlong_as_double((long long)(emit ? key : 0x7FEFFFFFFFFFFFFFull));
         mk += emit ? 1 : 0;
-        if (j < kFrRegs) {
+        if (j < R) {
           double next = ex[j];
           if (__any(cont)) {  // (skipped unless some frame of the wave has two arcs of one word here)
             const double folded = fr_log_add_fast(acc, ex[j], lntab);
@@ -1437,17 +1475,21 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
           acc = next;
         }
       }
-      if (narrow)
-        fr_sortd_sizes<8, 2>(dk);
-      else
+      if (narrow) {
+        fr_sortd_sizes<8, 2, R>(dk);
+      } else if constexpr (R == 16) {
         fr_sort16_net(dk, FrCeF64());
+      } else {
+        if (medium) fr_sortd_sizes<16, 2, R>(dk);
+        else fr_sortd_sizes<R, 2, R>(dk);
+      }
       const int frame = (k < tc) ? (int)rtime[c0 + k] : 0, run = (k < tc) ? (int)rtime[c0 + k + 1] - frame : 0;
       // the records of a rank go where its bucket's entries would (the lattice's piece of the pool has a slot per
       // entry, and a rank has at most as many records as entries): no scan places them, the waves do not meet here
-      const int dst = nbase + lo;
+      const int dst = (int)rec_at + nbase + lo;  // (counted from the pool's start: a lattice's pieces take their records where they find room)
       if (wide) {
         const int slot = atomicAdd(&wide_n, 1);
-        if (slot < kLnWideList) wide_rank[slot] = k;
+        wide_rank[slot] = (uint16_t)k;
       }
       // 8 bytes per record -- the sort key itself, desc(float logp) << 30 | label - lab_base (rec_fmt tells the gather
       // kernel) -- written ONCE per rank; every frame names its records by (first record, count), so the frames up
@@ -1457,24 +1499,20 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
         a.frame_src[fbase + frame + r] = dst;
       }
 #pragma unroll
-      for (int j = 0; j < kFrRegs; ++j)
-        if (j < mk) rec8[dst + j] = (uint64_t)__double_as_longlong(dk[j]);
+      for (int j = 0; j < R; ++j)
+        if (j < mk) a.pool[dst + j] = (uint64_t)__double_as_longlong(dk[j]);
       dense += mk * run;
       stored += mk;
     }
     __syncthreads();
-    // ---- 3w. the ranks with more than kFrRegs entries, a wave each: one lane per entry, both sorts as bitonic
+    // ---- 3w. the ranks with more than R entries, a wave each: one lane per entry, both sorts as bitonic
     // networks across the lanes, the fold entry by entry in arc order ----
-    if (wide_n > kLnWideList) {  // workgroup-uniform
-      leave();
-      return;
-    }
     for (int wi = tid >> 6; wi < wide_n; wi += NT / 64) {  // (wave-uniform)
       const int lane = tid & 63;
       const int k = wide_rank[wi];
-      const int lo = lboff[k], w = lboff[k + 1] - lo;  // kFrRegs < w <= kLnWideMax
-      const int dst = nbase + lo;
-      const int m = fr_lean_wide_rank(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, rec8 + dst);
+      const int lo = lboff[k], w = lboff[k + 1] - lo;  // R < w <= kLnWideMax
+      const int dst = (int)rec_at + nbase + lo;
+      const int m = fr_lean_wide_rank(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst);
       const int frame = (int)rtime[c0 + k], run = (int)rtime[c0 + k + 1] - frame;
       for (int r = lane; r < run; r += 64) {
         a.frame_count[fbase + frame + r] = m;
@@ -1490,7 +1528,9 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG ? 4 : 1) void frame_lean_k
   if ((tid & 63) == 0) atomicAdd(&sum_stored, stored), atomicAdd(&sum_dense, dense);
   __syncthreads();
   if (tid == 0) {
-    a.num_records[u] = sum_dense, a.num_stored[u] = sum_stored, a.rec_ptr[u] = a.pool + (nr > 0 ? rec_at : 0ull);
+    if (PIECES) atomicAdd(&a.num_records[u], sum_dense), atomicAdd(&a.num_stored[u], sum_stored);  // (zeroed by the slicing)
+    else a.num_records[u] = sum_dense, a.num_stored[u] = sum_stored;
+    a.rec_ptr[u] = a.pool;
     a.rec_fmt[u] = ((int64_t)1 << 32) | (int64_t)(uint32_t)lab_base;  // the records are the sort keys themselves
   }
   if (CLOCK && a.phase_clock && tid == 0)
@@ -1567,6 +1607,131 @@ hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipS
 }
 // the lean kernel: needs neither scratch_off nor the scratch rows, takes its records from a.pool.  big: its second
 // instantiation over the lattices the first one listed (a.redo_list); it lists what it leaves in a.redo2_list
+// Pieces of a long lattice (FrameItem, klat_accum.h): one workgroup per lattice.
+__global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int32_t* long_list) {
+  constexpr int kMaxPieces = 1024;
+  __shared__ int bad, longest, lab_min, own_lo[kMaxPieces + 1];
+  const int u = long_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t a0 = a.arc_off[u], s0 = a.state_off[u];
+  const int nA = (int)(a.arc_off[u + 1] - a0), S = (int)(a.state_off[u + 1] - s0);
+  const int T = a.num_frames[u];
+  const int32_t* src = a.src + a0;
+  const int32_t* dst = a.dst + a0;
+  const int32_t* tm = a.state_time + s0;
+  const int first = a.piece_first[u], pieces = (S + kFramePieceStates - 1) / kFramePieceStates;
+  FrameItem* items = a.piece_items + first;
+  if (tid == 0) bad = pieces > kMaxPieces ? 1 : 0, longest = 0, lab_min = 0x7FFFFFFF;
+  __syncthreads();
+  // a cut between two states separates the frames only if the times never descend along the states
+  int descends = 0, span = 0, lmin = 0x7FFFFFFF;
+  for (int s = tid + 1; s < S; s += 256) descends |= tm[s] < tm[s - 1] ? 1 : 0;
+  for (int i = tid; i < nA; i += 256) {
+    span = max(span, dst[i] - src[i]);
+    const int l = a.ilabel[a0 + i];
+    if (l != 0) lmin = min(lmin, l);
+  }
+  for (int d = 32; d > 0; d >>= 1) span = max(span, __shfl_xor(span, d, 64)), lmin = min(lmin, __shfl_xor(lmin, d, 64));
+  if (lane == 0) atomicMax(&longest, span), atomicMin(&lab_min, lmin);
+  if (descends) bad = 1;
+  // the first state of piece k: the first at or behind k * kFramePieceStates whose time exceeds its predecessor's
+  for (int k = 1 + wave; k < pieces && k <= kMaxPieces; k += 4) {  // (wave-uniform)
+    const int target = k * kFramePieceStates;  // < S
+    int cut = -1;
+    for (int ahead = 0; ahead < kFramePieceWindow && cut < 0; ahead += 64) {
+      const int s = target + ahead + lane;
+      const unsigned long long changes = __ballot(s < S && tm[s] > tm[s - 1]);
+      if (changes) cut = target + ahead + (__ffsll((long long)changes) - 1);
+    }
+    if (cut < 0) bad = 1;
+    if (lane == 0) own_lo[k] = cut;
+  }
+  if (tid == 0) own_lo[0] = 0, own_lo[pieces <= kMaxPieces ? pieces : 0] = S;
+  __syncthreads();
+  const int L = longest;
+  if (L > kFramePieceWindow) bad = 1;
+  __syncthreads();
+  auto first_arc_from = [&](int state) {  // first arc whose source is `state` or later (the arcs are grouped by ascending source)
+    int lo = 0, hi = nA;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (src[mid] < state) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  };
+  FrameItem mine[4];
+  int nmine = 0;
+  if (!bad)
+    for (int k = tid; k < pieces && nmine < 4; k += 256) {
+      FrameItem it;
+      const int lo = own_lo[k], hi = own_lo[k + 1];
+      it.u = u;
+      it.s_lo = max(lo - L, 0), it.s_hi = min(hi + L, S);
+      it.a_lo = first_arc_from(it.s_lo), it.a_hi = first_arc_from(hi);
+      it.f0 = k == 0 ? 0 : min(max(tm[lo], 0), T);
+      it.f1 = hi >= S ? T : min(max(tm[hi], 0), T);
+      it.lab_base = lab_min;
+      const int arcs = it.a_hi - it.a_lo;
+      if (arcs > 65535 || it.s_hi - it.s_lo > kLnStates || it.f1 - it.f0 > 65535) bad = 1;
+      const unsigned long long at = atomicAdd(a.piece_scratch_used, (unsigned long long)arcs);
+      if (at + (unsigned long long)arcs > (unsigned long long)a.piece_scratch_cap) bad = 1;
+      it.scratch = (int64_t)at;
+      mine[nmine++] = it;
+    }
+  __syncthreads();
+  const bool ok = bad == 0;  // (set by plain stores of 1 from any thread: read behind the barrier)
+  for (int k = tid, q = 0; k < pieces; k += 256, ++q) {
+    FrameItem it = {-1, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok && q < 4) it = mine[q];
+    items[k] = it;
+  }
+  if (tid == 0) {
+    if (ok) {
+      a.num_records[u] = 0, a.num_stored[u] = 0;
+    } else if ((atomicOr(&a.listed[u], 2) & 2) == 0) {  // the general kernel's
+      a.redo2_list[atomicAdd(a.redo2_n, 1)] = u;
+    }
+  }
+}
+
+hipError_t launch_frame_slice(const FrameArgs& a, const int32_t* long_list, int count, hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(frame_slice_kernel, dim3(count), dim3(256), 0, stream, a, long_list);
+  return hipGetLastError();
+}
+
+// The dense pass (thirty-two registers a rank) over the listed lattices (at most num_lattices of them) and the marked pieces.
+hipError_t launch_frame_lean_dense(const FrameArgs& a, int num_lattices, int num_slots, hipStream_t stream) {
+  const int span_cap = kFrLdsSpans;
+  const size_t lds = std::max(sizeof(uint16_t) * kFrLdsEntries + sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap,
+                              sizeof(uint16_t) * kFrLdsEntries + sizeof(uint16_t) * (kLnStates + 2));
+  if (num_lattices > 0) {
+    auto lean = a.phase_clock ? &frame_lean_kernel<true, true, 1, false, 2 * kFrRegs, true> : &frame_lean_kernel<true, false, 1, false, 2 * kFrRegs, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);
+  }
+  if (num_slots > 0) {
+    auto lean = a.phase_clock ? &frame_lean_kernel<true, true, 1, true, 2 * kFrRegs, true> : &frame_lean_kernel<true, false, 1, true, 2 * kFrRegs, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lean, dim3(num_slots), dim3(kFrLeanThreads), lds, stream, a, span_cap);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_frame_lean_pieces(const FrameArgs& a, int num_slots, hipStream_t stream) {
+  if (num_slots <= 0) return hipSuccess;
+  const int span_cap = kFrLdsSpans;
+  const size_t lds = std::max(sizeof(uint16_t) * kFrLdsEntries + sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap,
+                              sizeof(uint16_t) * kFrLdsEntries + sizeof(uint16_t) * (kLnStates + 2));
+  auto lean = a.phase_clock ? &frame_lean_kernel<true, true, 1, true> : &frame_lean_kernel<true, false, 1, true>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lean, dim3(num_slots), dim3(kFrLeanThreads), lds, stream, a, span_cap);
+  return hipGetLastError();
+}
+
 template <bool BIG, int SC>
 static hipError_t launch_frame_lean_class(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream) {
   const int span_cap = std::min(frame_span_cap(max_arcs), kFrLdsSpans / SC);

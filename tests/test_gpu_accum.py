@@ -513,6 +513,45 @@ def test_frame_post_pool_follows_the_batches(ctx_fresh):
         assert off[-1] == len(labels)
 
 
+@pytest.mark.parametrize("shape", ["plain", "few_words", "descending", "long_arc"])
+def test_frame_post_of_long_lattices(ctx, shape):
+    """Lattices beyond the lean kernel's 8 192 states or 65 535 arcs are cut into pieces of ~6 144 states on the device --
+    a piece owns the frames between two cuts and takes every arc that can cross them, its times clipped to the window --
+    and the pieces run through the lean kernel's second instantiation: 9 000 states x 3 (27 000 arcs) and 12 000 states x 6
+    (72 000 arcs) beside short lattices, against the oracle frame by frame; few distinct words (every frame folds); times
+    that descend somewhere and an arc longer than a piece's margin (those lattices take the general kernel)."""
+    ns = np.array([150, 9000, 40, 12000, 900], np.int32)
+    fo = np.array([3, 3, 2, 6, 4], np.int32)
+    arrays = klat_amd.synth(20260041, ns, fo)
+    if shape == "few_words":
+        arrays["olabel"] = (arrays["olabel"] % 4).astype(np.int32)
+        arrays["ilabel"] = arrays["olabel"].copy()
+    if shape == "descending":
+        t = arrays["state_time"].copy()
+        s0 = int(arrays["state_off"][1])
+        t[s0 + 7000], t[s0 + 7001] = t[s0 + 7001], t[s0 + 7000]
+        arrays["state_time"] = t
+    if shape == "long_arc":
+        a0 = int(arrays["arc_off"][3])
+        k = a0 + int(np.argmax((arrays["src"][a0:] == 5000) & (arrays["dst"][a0:] != 5001)))
+        arrays["dst"][k] = 7000  # spans 2 000 states: more than a piece's margin of 1 024
+    scales = (1.0, 0.2, 0.0)
+    nframes = [int(arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]].max()) for u in range(len(ns))]
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(*scales)
+    off, labels, logps = b.frame_post(nframes)
+    b.close()
+    fb = 0
+    for u, lat in enumerate(_split(arrays)):
+        sl = orc.scale_and_penalize(lat, *scales)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        t = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
+        want, _ = orc.frame_post(sl, t, nframes[u], alpha, beta, total)
+        _check_frames(off, labels, logps, fb, want)
+        fb += nframes[u]
+    assert off[-1] == len(labels)
+
+
 @pytest.mark.parametrize("times", ["ties", "clipped", "descending", "jitter"])
 def test_frame_post_state_times(ctx, times, frame_mode):
     """The lean kernel works over the distinct state times: states that share a time share a rank, times beyond
