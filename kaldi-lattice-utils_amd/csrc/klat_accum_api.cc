@@ -469,25 +469,23 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       }
     }
     if (lean) {
-      if ((rc = st.redo.alloc(2 * (size_t)b->U + 2))) return rc;
-      if ((rc = st.pool_used.alloc(3))) return rc;  // records asked for, asked for in vain; the pieces' arc rows taken
-      if ((rc = st.listed.alloc((size_t)b->U))) return rc;
-      a.listed = st.listed.p;
-      KLAT_HIP(hipMemsetAsync(a.listed, 0, sizeof(int32_t) * (size_t)b->U, c->stream));
-      if ((rc = st.dense.alloc((size_t)b->U + 1))) return rc;
+      if ((rc = st.redo.alloc(2 * (size_t)b->U))) return rc;
+      // the call's counters and flags in one block (one clearing, one copy back): records asked of the pool / asked for in
+      // vain / the pieces' arc rows taken; lattices listed for the second instantiation / for the general kernel / for the
+      // dense pass; a flag per lattice (on a list already)
+      if ((rc = st.pool_used.alloc(5 + ((size_t)b->U + 1) / 2))) return rc;
+      if ((rc = st.dense.alloc((size_t)b->U))) return rc;
+      int32_t* counters = reinterpret_cast<int32_t*>(st.pool_used.p + 3);
+      a.pool_used = st.pool_used.p;
+      a.redo_n = counters, a.redo2_n = counters + 1, a.dense_n = counters + 2;
+      a.listed = reinterpret_cast<int32_t*>(st.pool_used.p + 5);
       a.dense = st.dense.p;
-      a.dense_n = st.dense.p + b->U;
-      KLAT_HIP(hipMemsetAsync(a.dense_n, 0, sizeof(int32_t), c->stream));
       a.pool = st.pool.p;
       a.pool_cap = cap;
-      a.pool_used = st.pool_used.p;
       a.redo_list = st.redo.p;
-      a.redo_n = st.redo.p + 2 * b->U;
       a.redo2_list = st.redo.p + b->U;
-      a.redo2_n = st.redo.p + 2 * b->U + 1;
       a.ln_table = c->ln_table.p;
-      KLAT_HIP(hipMemsetAsync(a.redo_n, 0, 2 * sizeof(int32_t), c->stream));
-      KLAT_HIP(hipMemsetAsync(a.pool_used, 0, 3 * sizeof(unsigned long long), c->stream));
+      KLAT_HIP(hipMemsetAsync(st.pool_used.p, 0, sizeof(unsigned long long) * (5 + ((size_t)b->U + 1) / 2), c->stream));
       // size classes: a lattice runs in the smallest workgroup that holds it, every class one launch over its own list
       // (a class of fewer than 64 lattices rides with the next larger one)
       if (!st.classes_ready) {
@@ -550,13 +548,15 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
         KLAT_HIP(launch_frame_lean_pieces(a, (int)st.num_piece_slots, c->stream));
       }
       if ((rc = print_clock("frame_lean_kernel"))) return rc;
-      int32_t first_n = 0, dense_n = 0;
-      unsigned long long used[2] = {0, 0};  // [0] records asked of the pool, [1] those of them the pool had no room for
-      KLAT_HIP(hipMemcpyAsync(&first_n, a.redo_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      KLAT_HIP(hipMemcpyAsync(&dense_n, a.dense_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      KLAT_HIP(hipMemcpyAsync(used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+      struct {
+        unsigned long long used[3];  // [0] records asked of the pool, [1] those of them the pool had no room for
+        int32_t first_n, general_n, dense_n, pad;
+      } back = {{0, 0, 0}, 0, 0, 0, 0};
+      KLAT_HIP(hipMemcpyAsync(&back, st.pool_used.p, sizeof(back), hipMemcpyDeviceToHost, c->stream));
       KLAT_HIP(hipStreamSynchronize(c->stream));
-      redo_n = first_n;
+      const int32_t first_n = back.first_n, dense_n = back.dense_n;
+      unsigned long long used[2] = {back.used[0], back.used[1]};
+      redo_n = st.num_long > 0 ? back.general_n : 0;  // (so far only the slicing lists for the general kernel)
       unsigned long long need = used[0];
       const unsigned long long short_first = used[1];
       if (first_n > 0) {  // larger lattices (spans in L2), and one more try for what else did not fit
@@ -568,9 +568,9 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       if (first_n > 0 || dense_n > 0 || st.num_long > 0) {  // (a batch the first instantiation finished has nothing more to wait for)
         KLAT_HIP(launch_frame_lean_dense(a, (int)std::min<int64_t>(b->U, (int64_t)dense_n + first_n), st.num_long > 0 ? (int)st.num_piece_slots : 0, c->stream));
         if ((rc = print_clock("frame_lean_kernel (dense pass)"))) return rc;
-        KLAT_HIP(hipMemcpyAsync(&redo_n, a.redo2_n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        KLAT_HIP(hipMemcpyAsync(used, a.pool_used, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+        KLAT_HIP(hipMemcpyAsync(&back, st.pool_used.p, sizeof(back), hipMemcpyDeviceToHost, c->stream));
         KLAT_HIP(hipStreamSynchronize(c->stream));
+        redo_n = back.general_n, used[0] = back.used[0], used[1] = back.used[1];
         // the lattices the first pass turned away for want of room asked again: once is what they need
         need = used[0] - std::min(used[0], short_first);
       }

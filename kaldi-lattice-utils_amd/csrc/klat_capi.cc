@@ -65,7 +65,7 @@ static int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
     for (const SweepPiece& w : work) KLAT_HIP(w.launch(c->stream));
     return KLAT_OK;
   }
-  if (!c->fork_ev) {
+  if (!c->fork_ev) {  // (a helper context of klat_forward_backward_host: made without them, below)
     KLAT_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     for (int i = 0; i < klat_ctx::kSideStreams; ++i) {
       KLAT_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
@@ -255,7 +255,10 @@ void klat_host_free(void* ptr) {
   if (ptr) (void)hipHostFree(ptr);
 }
 
-int klat_ctx_create(int device, klat_ctx** out) {
+static int ctx_create(int device, klat_ctx** out, bool side_streams);
+int klat_ctx_create(int device, klat_ctx** out) { return ctx_create(device, out, true); }
+
+static int ctx_create(int device, klat_ctx** out, bool side_streams) {
   // The pieces of a skewed batch's sweep run on four streams at once (run_side_by_side).  The HIP runtime maps a
   // process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) when it starts.  The default is the right
   // number for a process whose only streams are this context's (measured on the C5/8 shard, segment path on: 1.04 ms
@@ -282,6 +285,19 @@ int klat_ctx_create(int device, klat_ctx** out) {
     delete c;
     return hip_fail(e, "hipStreamCreate");
   }
+  // The side streams of a skewed batch's sweep, created WITH the context's stream: the runtime deals its streams onto
+  // the hardware queues in the order they are created, so four streams made together sit on four queues whatever else
+  // the process creates in between.  (Made on first use they landed wherever the count stood then: after the bench's
+  // host-to-host leg had created and destroyed six streams, the C5/8 shard's sweep took 1.07 - 1.15 ms instead of 0.94.)
+  // (The helper contexts of klat_forward_backward_host go without: the call's three main streams should sit on three queues.)
+  if (side_streams && hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) (void)hipGetLastError(), c->fork_ev = nullptr;
+  for (int i = 0; c->fork_ev && i < klat_ctx::kSideStreams; ++i)
+    if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      klat_ctx_destroy(c);
+      return set_error(KLAT_ERR_HIP, "side stream creation failed");
+    }
   // (the timing events of the ring are created when a step first uses their slot)
   {
     std::vector<LnTabEntry> tab((size_t)kLnTabSize);
@@ -1615,14 +1631,18 @@ int klat_forward_backward_host(klat_ctx* c, const klat_batch_desc_compact* d, co
   if (pieces <= 0) pieces = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, A / (8 << 20)));  // pieces of eight million arcs or more
   pieces = (int32_t)std::min<int64_t>(pieces, U);
   KLAT_HIP(hipSetDevice(c->device));
+  // Three helper contexts made together on first use, the caller's own stream left out: the runtime deals streams onto
+  // its hardware queues in the order they are created, and three made in a row sit on three queues -- with the caller's
+  // stream as one of the three the call took 32 - 35 ms instead of 28 in three of four process set-ups (with and without
+  // PyTorch in the process, four or eight hardware queues: tools/host_pipe_probe.py), two streams instead of three 31.6.
   klat_ctx* ctxs[3] = {c, nullptr, nullptr};
   const int lanes = pieces >= 3 ? 3 : pieces;
-  for (int i = 1; i < lanes; ++i) {
-    if (!c->pipe[i - 1]) {
-      int rc = klat_ctx_create(c->device, &c->pipe[i - 1]);
+  for (int i = 0; lanes > 1 && i < lanes; ++i) {
+    if (!c->pipe[i]) {
+      int rc = ctx_create(c->device, &c->pipe[i], false);
       if (rc != KLAT_OK) return rc;
     }
-    ctxs[i] = c->pipe[i - 1];
+    ctxs[i] = c->pipe[i];
   }
   const uint32_t flags = arc_logpost ? 0u : KLAT_FB_NO_ARC_POSTERIORS;
   int rc = compact_check(d);

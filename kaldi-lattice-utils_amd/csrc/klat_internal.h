@@ -194,9 +194,9 @@ struct klat_ctx {
   hipEvent_t fork_ev = nullptr, join_ev[kSideStreams] = {nullptr, nullptr, nullptr};
   klat::DevBuf<klat::LnTabEntry> ln_table;  // table behind the sweep's natural log
   klat::DevPool pool;                       // recycled device blocks of this context's batches
-  // klat_forward_backward_host pipelines the pieces of a batch over this context and two more (streams and pools
-  // of their own), created when the call first runs and gone with this context
-  klat_ctx* pipe[2] = {nullptr, nullptr};
+  // klat_forward_backward_host pipelines the pieces of a batch over three helper contexts (streams and pools of their
+  // own), created when the call first runs and gone with this context
+  klat_ctx* pipe[3] = {nullptr, nullptr, nullptr};
 };
 
 // device scratch + cached result of the accumulate stage (klat_accum_api.cc)
