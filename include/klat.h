@@ -232,7 +232,7 @@ int klat_get_arc_logpost(klat_batch* batch, double* logpost /* [A] */);
  * arc log-posteriors alpha[src] - cost + beta[dst] - total (:102-104) when asked for.  The lattices are cut into
  * `pieces` runs of about equal arcs (0: chosen from the batch's size); piece k+1 crosses PCIe while piece k is packed
  * and swept and piece k-1's results come down, on three helper streams the context keeps for this call -- a C2 batch takes
- * 26 ms instead of the 39 ms of create / sweep / fetch one after the other (bench.py `boundary`).  The copies only
+ * 28 ms instead of the 39 ms of create / sweep / fetch one after the other (bench.py `boundary`).  The copies only
  * run beside one another from and into page-locked memory (klat_host_alloc); ordinary memory works, serially.
  * Any of alpha, beta [S], total [num_lattices], arc_logpost [A] may be NULL.  Nothing stays on the device. */
 int klat_forward_backward_host(klat_ctx* ctx, const klat_batch_desc_compact* desc, const klat_pack_options* opt,
