@@ -111,8 +111,9 @@ hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool posi
 // somewhere, or that has no change of time inside a window, keeps piece_count 0 and takes the general kernel.
 static const int kPieceStride = 13312, kPieceWindow = 2048;
 hipError_t launch_index_slice(const AccumArgs& a, bool position, const int32_t* long_list, int count, hipStream_t stream);
-hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
-                               OutRecord* out, hipStream_t stream);
+int64_t index_gather_chunks(const int64_t* record_off_host, int num_lattices);
+hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off, const int64_t* record_off_host,
+                               void* chunk_buf, OutRecord* out, hipStream_t stream);
 
 // Utterance index (klat_utt.hip): one item = up to 64 query words of one lattice.
 struct UttItem {

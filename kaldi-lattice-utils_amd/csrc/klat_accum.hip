@@ -19,6 +19,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "klat_accum.h"
 
 namespace klat {
@@ -321,43 +323,92 @@ __device__ __forceinline__ OutRecord decode_record(const Rec& r) {
 // its place in its own run plus, for every other run, the records there that come before it -- (k0, k1[, k2]) compared
 // as the kernels' sorts compare them (the position index's k2 is payload; its keys differ in k1).  No key occurs in two
 // pieces, so no two records compare equal.
+//
+// One workgroup per CHUNK of kGatherChunk records (a lattice of 120 000 records: thirty workgroups, not one).  The search
+// in another run has two levels: the k0 of every 64th record of every run sits in LDS (a piece has at most 15 360
+// records: 240 samples), eight steps there name a block of 64 records, six steps with the full comparison in that block
+// touch a dozen cache lines that the wave's neighbours -- whose records lie next to this one in their own run -- want too.
+// (Plain binary searches from one workgroup per lattice took 20 ms for the configs[4]-shaped mix's 36 M records.)
+static constexpr int kGatherChunk = 4096, kGatherRuns = 16, kGatherSamples = 256;
+struct GatherChunk {
+  int32_t u, first;  // records [first, first + kGatherChunk) of lattice u, in the order of its runs
+};
+
 template <bool POSITION>
-__global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const int64_t* record_off, OutRecord* out) {
-  const int u = blockIdx.x;
+__device__ __forceinline__ bool rec_before(const Rec& x, const Rec& r) {
+  if (x.k0 != r.k0) return x.k0 < r.k0;
+  return x.k1 < r.k1 || (!POSITION && x.k1 == r.k1 && x.k2 < r.k2);
+}
+
+template <bool POSITION>
+__global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const int64_t* record_off, const GatherChunk* chunks, OutRecord* out) {
+  __shared__ uint64_t samp[kGatherRuns][kGatherSamples];
+  __shared__ int run_begin[kGatherRuns], run_n[kGatherRuns], run_first[kGatherRuns + 1];
+  const GatherChunk ch = chunks[blockIdx.x];
+  const int u = ch.u, tid = threadIdx.x;
   const Rec* recs = reinterpret_cast<const Rec*>(a.rec_scratch) + a.scratch_off[u];
   const int64_t o = record_off[u];
   const int m = (int)(record_off[u + 1] - o);
+  const int last = min(ch.first + kGatherChunk, m);
   const int pieces = a.piece_count ? a.piece_count[u] : 0;
   if (pieces == 0) {
-    for (int i = threadIdx.x; i < m; i += 256) out[o + i] = decode_record<POSITION>(recs[i]);
+    for (int i = ch.first + tid; i < last; i += 256) out[o + i] = decode_record<POSITION>(recs[i]);
     return;
   }
   const IndexItem* its = a.piece_items + a.piece_first[u];
-  for (int p = 0; p < pieces; ++p) {
-    const Rec* mine = recs + its[p].begin;
-    const int mp = a.item_records[its[p].slot];
-    for (int j = threadIdx.x; j < mp; j += 256) {
-      const Rec r = mine[j];
-      int pos = j;
-      for (int q = 0; q < pieces; ++q) {
-        if (q == p) continue;
-        const Rec* other = recs + its[q].begin;
-        int lo = 0, hi = a.item_records[its[q].slot];  // first record of run q that does not come before r
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          const uint64_t k0 = other[mid].k0;
-          bool before = k0 < r.k0;
-          if (k0 == r.k0) {
-            const uint64_t k1 = other[mid].k1;
-            before = k1 < r.k1 || (!POSITION && k1 == r.k1 && other[mid].k2 < r.k2);
-          }
-          if (before) lo = mid + 1;
-          else hi = mid;
-        }
-        pos += lo;
-      }
-      out[o + pos] = decode_record<POSITION>(r);
+  const bool sampled = pieces <= kGatherRuns;  // (workgroup-uniform; beyond that: plain binary searches)
+  if (sampled) {
+    if (tid < pieces) run_begin[tid] = its[tid].begin, run_n[tid] = a.item_records[its[tid].slot];
+    __syncthreads();
+    if (tid == 0) {
+      int at = 0;
+      for (int q = 0; q < pieces; ++q) run_first[q] = at, at += run_n[q];
+      run_first[pieces] = at;
     }
+    for (int q = 0; q < pieces; ++q)
+      for (int i = tid; i * 64 < run_n[q] && i < kGatherSamples; i += 256) samp[q][i] = recs[run_begin[q] + i * 64].k0;
+    __syncthreads();
+  }
+  for (int f = ch.first + tid; f < last; f += 256) {
+    // the record's run and its place there
+    int p = 0, j = f;
+    if (sampled) {
+      while (p + 1 < pieces && f >= run_first[p + 1]) ++p;
+      j = f - run_first[p];
+    } else {
+      while (j >= a.item_records[its[p].slot]) j -= a.item_records[its[p].slot], ++p;
+    }
+    const Rec r = recs[(sampled ? run_begin[p] : its[p].begin) + j];
+    int pos = j;
+    for (int q = 0; q < pieces; ++q) {
+      if (q == p) continue;
+      const Rec* other = recs + (sampled ? run_begin[q] : its[q].begin);
+      int lo = 0, hi = sampled ? run_n[q] : a.item_records[its[q].slot];
+      if (sampled && hi <= 64 * kGatherSamples) {
+        // the block: samples strictly below r.k0 lie before the answer's block, samples above r.k0 behind it
+        const int ns = (hi + 63) >> 6;
+        int sl = 0, sh = ns;  // first sample not below r.k0
+        while (sl < sh) {
+          const int mid = (sl + sh) >> 1;
+          if (samp[q][mid] < r.k0) sl = mid + 1;
+          else sh = mid;
+        }
+        int tl = sl, th = ns;  // first sample above r.k0
+        while (tl < th) {
+          const int mid = (tl + th) >> 1;
+          if (samp[q][mid] <= r.k0) tl = mid + 1;
+          else th = mid;
+        }
+        lo = max(sl - 1, 0) * 64, hi = min(hi, tl * 64);
+      }
+      while (lo < hi) {  // first record of run q that does not come before r
+        const int mid = (lo + hi) >> 1;
+        if (rec_before<POSITION>(other[mid], r)) lo = mid + 1;
+        else hi = mid;
+      }
+      pos += lo;
+    }
+    out[o + pos] = decode_record<POSITION>(r);
   }
 }
 
@@ -424,13 +475,28 @@ hipError_t launch_index(const AccumArgs& a, int num_lattices, bool position, hip
   return hipGetLastError();
 }
 
-hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off,
-                               OutRecord* out, hipStream_t stream) {
+// record_off_host: the offsets on the host (the chunk list is built from them); chunk_buf: device room for the list, at
+// least index_gather_chunks(record_off_host, num_lattices) entries of 8 bytes
+int64_t index_gather_chunks(const int64_t* record_off_host, int num_lattices) {
+  int64_t n = 0;
+  for (int u = 0; u < num_lattices; ++u) n += (record_off_host[u + 1] - record_off_host[u] + kGatherChunk - 1) / kGatherChunk;
+  return n;
+}
+hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off, const int64_t* record_off_host,
+                               void* chunk_buf, OutRecord* out, hipStream_t stream) {
   if (num_lattices <= 0) return hipSuccess;
+  std::vector<GatherChunk> chunks;
+  for (int u = 0; u < num_lattices; ++u)
+    for (int64_t f = 0; f < record_off_host[u + 1] - record_off_host[u]; f += kGatherChunk) chunks.push_back(GatherChunk{u, (int32_t)f});
+  if (chunks.empty()) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(chunk_buf, chunks.data(), sizeof(GatherChunk) * chunks.size(), hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(stream);  // (the list is a local)
+  if (e != hipSuccess) return e;
   if (position)
-    hipLaunchKernelGGL(index_gather_kernel<true>, dim3(num_lattices), dim3(256), 0, stream, a, record_off, out);
+    hipLaunchKernelGGL(index_gather_kernel<true>, dim3((unsigned)chunks.size()), dim3(256), 0, stream, a, record_off, static_cast<const GatherChunk*>(chunk_buf), out);
   else
-    hipLaunchKernelGGL(index_gather_kernel<false>, dim3(num_lattices), dim3(256), 0, stream, a, record_off, out);
+    hipLaunchKernelGGL(index_gather_kernel<false>, dim3((unsigned)chunks.size()), dim3(256), 0, stream, a, record_off, static_cast<const GatherChunk*>(chunk_buf), out);
   return hipGetLastError();
 }
 

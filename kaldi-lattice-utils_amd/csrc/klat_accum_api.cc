@@ -58,7 +58,9 @@ int gather_dense(klat_batch* b, const AccumArgs& a, bool position) {
   int rc;
   if ((rc = st.d_record_off.upload(st.record_off.data(), st.record_off.size(), c->stream))) return rc;
   if ((rc = st.dense.alloc((size_t)total))) return rc;
-  KLAT_HIP(launch_index_gather(a, (int)b->U, position, st.d_record_off.p, st.dense.p, c->stream));
+  DevBuf<int64_t> chunk_buf;  // (8-byte entries)
+  if ((rc = chunk_buf.alloc((size_t)index_gather_chunks(st.record_off.data(), (int)b->U)))) return rc;
+  KLAT_HIP(launch_index_gather(a, (int)b->U, position, st.d_record_off.p, st.record_off.data(), chunk_buf.p, st.dense.p, c->stream));
   KLAT_HIP(hipStreamSynchronize(c->stream));  // record_off was read from pageable host memory
   st.dense_mode = st.cached_mode;
   return KLAT_OK;

@@ -32,3 +32,7 @@ for _ in range(3):
     klat_amd._check(L.klat_frame_post(b.h, klat_amd._p(nf), klat_amd._p(foff), None, None, C.c_int64(0), C.byref(ne)))
     klat_amd._check(L.klat_get_accum_timings(b.h, None, C.byref(ms)))
     print("frame posteriors: %.3f ms, %d entries, %.1f G arcs/s" % (ms.value, ne.value, b.A / ms.value / 1e6), flush=True)
+import time
+for _ in range(2):
+    t0 = time.perf_counter(); off, rec = b.segment_index(); t1 = time.perf_counter()
+    print("segment index incl. the fetch (gather / merge of the pieces' runs + %.0f MB to the host): %.1f ms" % (rec.nbytes / 1e6, (t1 - t0) * 1e3), flush=True)
