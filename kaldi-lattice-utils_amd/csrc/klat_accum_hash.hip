@@ -51,6 +51,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <stdint.h>
 
@@ -345,12 +346,31 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   while ((1 << lh) < 2 * n) ++lh;
   const uint32_t hmask = (1u << lh) - 1u;
 
-  // ---- 1. table and bitmaps cleared; keys and values (loads batched, no branches around them) ----
-  {
+  // ---- 1. keys and values (loads batched, no branches around them); table and bitmaps cleared ----
+  // A whole lattice whose states' alpha / beta / times (20 bytes a state) fit the table's LDS has them STAGED there first:
+  // the arcs' ends then look them up in LDS instead of gathering them from memory -- per group of arcs one trip to memory
+  // instead of two, and no 64-address gathers (one 1 024-thread workgroup a CU has nothing to hide them behind: the
+  // 14 997-arc class spent 74 of its 212 thousand ticks in this phase).  The table is cleared afterwards.
+  const int S_all = (int)(a.state_off[u + 1] - s0);
+  // (Only the 1 024-thread classes: with two and more workgroups a CU the neighbours hide the gathers, and the second
+  // barrier and the rows' trip through LDS cost the smaller classes 2 - 7 %.)
+  const bool staged = T == 1024 && item.slot < 0 && (size_t)S_all * 20 <= (size_t)H * 4;  // (workgroup-uniform; a piece's states are a range this kernel does not know)
+  double* const st_alpha = reinterpret_cast<double*>(smem);
+  double* const st_beta = st_alpha + S_all;
+  int32_t* const st_tm = reinterpret_cast<int32_t*>(st_beta + S_all);
+  auto clear_table = [&]() {
     const uint4 free4 = {kFree, kFree, kFree, kFree};
     for (int i = tid * 4; i < (1 << lh); i += T * 4) *reinterpret_cast<uint4*>(table + i) = free4;
+  };
+  {
     for (int i = tid; i < H / 32; i += T) dupbit[i] = 0;  // (both bitmaps)
     if (tid == 0) sh_qn = 0, sh_ndl = 0, sh_nbig = 0;
+    if (staged) {
+      for (int s = tid; s < S_all; s += T) st_alpha[s] = l_alpha[s], st_beta[s] = l_beta[s], st_tm[s] = l_tm[s];
+      __syncthreads();
+    } else {
+      clear_table();
+    }
   }
   uint64_t key[P];
   double val[P];
@@ -359,43 +379,53 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   if (filtered) __syncthreads();  // (the filter reads the lattice's view)
   constexpr int HALF = P % 6 == 0 ? 6 : P % 5 == 0 ? 5 : 4;  // arcs a thread asks for at a time (what the registers hold beside the keys and values)
   static_assert(P % HALF == 0, "");
+  auto arc_pass = [&](auto from_lds) {
+    constexpr bool LDS = decltype(from_lds)::value;
 #pragma unroll
-  for (int half = 0; half < P / HALF; ++half) {
-    if (half * HALF >= jmax) break;
-    int32_t lab[HALF], t0[HALF], t1[HALF];
-    float gr[HALF], ac[HALF];
-    bool word[HALF];
+    for (int half = 0; half < P / HALF; ++half) {
+      if (half * HALF >= jmax) break;
+      int32_t lab[HALF], t0[HALF], t1[HALF];
+      float gr[HALF], ac[HALF];
+      bool word[HALF];
 #pragma unroll
-    for (int q = 0; q < HALF; ++q) {
-      const int i = min((half * HALF + q) * T + tid, n - 1);
-      lab[q] = l_olabel[i];
-      t0[q] = l_src[i];
-      t1[q] = l_dst[i];
-      gr[q] = a.graph[a0 + i];
-      ac[q] = a.acoustic[a0 + i];
-      word[q] = a.sp.penalized ? a.ilabel[a0 + i] != 0 : false;
+      for (int q = 0; q < HALF; ++q) {
+        const int i = min((half * HALF + q) * T + tid, n - 1);
+        lab[q] = l_olabel[i];
+        t0[q] = l_src[i];
+        t1[q] = l_dst[i];
+        gr[q] = a.graph[a0 + i];
+        ac[q] = a.acoustic[a0 + i];
+        word[q] = a.sp.penalized ? a.ilabel[a0 + i] != 0 : false;
+      }
+      double al[HALF], be[HALF];
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) {
+        al[q] = LDS ? st_alpha[t0[q]] : l_alpha[t0[q]];
+        be[q] = LDS ? st_beta[t1[q]] : l_beta[t1[q]];
+        t0[q] = LDS ? st_tm[t0[q]] : l_tm[t0[q]];
+        if (!POSITION) t1[q] = LDS ? st_tm[t1[q]] : l_tm[t1[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) {
+        const int j = half * HALF + q;
+        const int i = j * T + tid;
+        // fw[src] + bw[dst] - cost (kwsbin2/lattice-word-index-segment.cc:160-163), the posterior pass's expression
+        val[j] = accum_normalise(al[q] + be[q] - arc_cost(gr[q], ac[q], word[q], a.sp), tot);
+        bool ok = i < n && lab[q] != 0;
+        if (filtered && ok) ok = filter_keeps(lab[q]);
+        const uint64_t l = (uint64_t)(uint32_t)(lab[q] - pk.label_min);
+        key[j] = POSITION ? ((l << pk.time_bits) | (uint64_t)(uint32_t)t0[q])
+                          : ((((l << pk.time_bits) | (uint64_t)(uint32_t)t0[q]) << pk.time_bits) | (uint64_t)(uint32_t)t1[q]);
+        if (ok) valid |= 1u << j;
+      }
     }
-    double al[HALF], be[HALF];
-#pragma unroll
-    for (int q = 0; q < HALF; ++q) {
-      al[q] = l_alpha[t0[q]];
-      be[q] = l_beta[t1[q]];
-      t0[q] = l_tm[t0[q]];
-      if (!POSITION) t1[q] = l_tm[t1[q]];
-    }
-#pragma unroll
-    for (int q = 0; q < HALF; ++q) {
-      const int j = half * HALF + q;
-      const int i = j * T + tid;
-      // fw[src] + bw[dst] - cost (kwsbin2/lattice-word-index-segment.cc:160-163), the posterior pass's expression
-      val[j] = accum_normalise(al[q] + be[q] - arc_cost(gr[q], ac[q], word[q], a.sp), tot);
-      bool ok = i < n && lab[q] != 0;
-      if (filtered && ok) ok = filter_keeps(lab[q]);
-      const uint64_t l = (uint64_t)(uint32_t)(lab[q] - pk.label_min);
-      key[j] = POSITION ? ((l << pk.time_bits) | (uint64_t)(uint32_t)t0[q])
-                        : ((((l << pk.time_bits) | (uint64_t)(uint32_t)t0[q]) << pk.time_bits) | (uint64_t)(uint32_t)t1[q]);
-      if (ok) valid |= 1u << j;
-    }
+  };
+  if (T == 1024 && staged) {
+    if constexpr (T == 1024) arc_pass(std::true_type());
+    __syncthreads();  // (every thread is done with the staged rows: the table takes their place)
+    clear_table();
+  } else {
+    arc_pass(std::false_type());
   }
   __syncthreads();
   KLAT_STAMP(1);
