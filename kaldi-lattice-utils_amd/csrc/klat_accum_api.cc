@@ -208,7 +208,7 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
         for (int64_t u = 0; u < b->U; ++u) {
           const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
           if (cls[(size_t)u] == kHashClasses) {  // a long lattice: piece slots for the slicing to fill
-            if (arcs < ((int64_t)1 << 30)) {
+            if (arcs <= (int64_t)1024 * kPieceStride) {  // (the slicing kernel keeps a thread's pieces in four registers: 1 024 pieces a lattice; beyond: the general kernel)
               longs.push_back((int32_t)u);
               first[(size_t)u] = (int32_t)slots;
               slots += (arcs + kPieceStride - 1) / kPieceStride;
