@@ -36,6 +36,7 @@ struct LevelPlanArgs {
   const int32_t* out_begin;  // [S + 2 per lattice] first out-arc of every state (the count pass's row table)
   int32_t* depth;       // [U] number of levels, or -1: not for this path
   int32_t* records;     // [U] records per direction (sum over the levels of ceil(states / 64))
+  const int32_t* status;  // [2] the count pass's verdict: non-zero, a lattice of the batch is malformed and nothing is planned
 };
 
 // Writes the level streams of the lattices on the level path (after level_plan_kernel).
