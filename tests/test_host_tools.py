@@ -514,6 +514,45 @@ def test_tools_on_a_multi_lattice_archive(tmp_path):
 
 
 @pytest.mark.gpu
+def test_tools_on_a_long_lattice(tmp_path):
+    """A 9 000-state lattice (26 997 arcs) between two short ones, through the tools: the segment index takes it in pieces
+    (more than 16 384 arcs: cut where the source states' time changes, the pieces' sorted runs merged when the records are
+    fetched), the frame posteriors in pieces of ~6 144 states (more than 8 192 states).  Order, keys and values against
+    the oracle; the same records with one rank per process group member (--devices is exercised in test_gpu_dist.py)."""
+    ns = np.array([40, 9000, 25], np.int32)
+    fo = np.array([2, 3, 3], np.int32)
+    arrays = klat_amd.synth(20260051, ns, fo)
+    txt = str(tmp_path / "in.txt")
+    _write_text_archive(txt, arrays, ns)
+    args = ["--acoustic-scale=0.2"]
+    rc, out, err = run("lattice-word-index-segment", *args, "ark:" + txt, "ark,t:-")
+    assert rc == 0, err
+    lines = out.decode().strip("\n").split("\n")
+    rc, pout, err = run("lattice-to-word-frame-post", *args, "ark:" + txt, "ark,t:-")
+    assert rc == 0, err
+    plines = pout.decode().strip("\n").split("\n")
+    lats = latfmt.read_text_archive(txt)
+    assert [l.key for l in lats] == ["utt%07d" % u for u in range(3)] and len(lines) == 3 and len(plines) == 3
+    for u, lat in enumerate(lats):
+        sl = orc.scale_and_penalize(lat, 1.0, 0.2, 0.0)
+        times, T, _ = orc.state_times(sl)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        want = orc.segment_index(sl, times, alpha, beta, total)
+        key, got = latfmt.parse_tuple_line(lines[u], 3)
+        assert key == lat.key and len(got) == len(want)
+        wk = {w[:3]: w[3] for w in want}
+        assert all(g[:3] in wk and abs(g[3] - wk[g[:3]]) < 1e-5 for g in got)
+        assert all(x[3] >= y[3] for x, y in zip(got[:-1], got[1:]))  # (as printed: seven significant digits)
+        wantf, _ = orc.frame_post(sl, times, T, alpha, beta, total)
+        key, frames = latfmt.parse_posterior_line(plines[u])
+        assert key == lat.key and len(frames) == T
+        for f, w in zip(frames, wantf):
+            assert sorted(l for l, _ in f) == sorted(int(l) for l, _ in w)
+            wd = {int(l): float(p) for l, p in w}
+            assert all(abs(p - wd[l]) < 1e-5 * max(1.0, abs(wd[l])) for l, p in f)
+
+
+@pytest.mark.gpu
 def test_prune_dyn_beam_tool_on_a_skewed_mix(tmp_path):
     """BASELINE configs[4], first half, through the tool: lattice-prune-dyn-beam over a skewed mix
     (sizes log-uniform in [200, 6 000] states, fanout in {2,3,4,6}; one Viterbi sweep of the whole
