@@ -490,7 +490,20 @@ __global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, i
 // order like their bit patterns.
 __global__ __launch_bounds__(kT) void pack_maxcost_kernel(PackDevArgs a, int64_t num_arcs, int64_t num_states) {
   double m = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < num_arcs; i += (int64_t)gridDim.x * kT) {
+  // four arcs a lane and load (the arrays start on 256-byte boundaries), the last few one by one
+  const int64_t quads = num_arcs / 4;
+  for (int64_t q = (int64_t)blockIdx.x * kT + threadIdx.x; q < quads; q += (int64_t)gridDim.x * kT) {
+    const float4 g = reinterpret_cast<const float4*>(a.graph)[q], ac = reinterpret_cast<const float4*>(a.acoustic)[q];
+    int4 w = {0, 0, 0, 0};
+    if (a.fsp.penalized) w = reinterpret_cast<const int4*>(a.ilabel)[q];
+    const double c0 = fabs(arc_cost(g.x, ac.x, w.x != 0, a.fsp)), c1 = fabs(arc_cost(g.y, ac.y, w.y != 0, a.fsp));
+    const double c2 = fabs(arc_cost(g.z, ac.z, w.z != 0, a.fsp)), c3 = fabs(arc_cost(g.w, ac.w, w.w != 0, a.fsp));
+    if (c0 < 1.0e30) m = fmax(m, c0);
+    if (c1 < 1.0e30) m = fmax(m, c1);
+    if (c2 < 1.0e30) m = fmax(m, c2);
+    if (c3 < 1.0e30) m = fmax(m, c3);
+  }
+  for (int64_t i = quads * 4 + (int64_t)blockIdx.x * kT + threadIdx.x; i < num_arcs; i += (int64_t)gridDim.x * kT) {
     const double c = fabs(arc_cost(a.graph[i], a.acoustic[i], a.fsp.penalized ? a.ilabel[i] != 0 : false, a.fsp));
     if (c < 1.0e30) m = fmax(m, c);
   }
