@@ -56,6 +56,7 @@
 #include <stdint.h>
 
 #include "klat_accum.h"
+#include "klat_slice.h"
 
 namespace klat {
 
@@ -841,11 +842,13 @@ hipError_t launch(const AccumArgs& a, const RadixPack& pk, int cls, int count, h
 
 }  // namespace
 
-// Pieces of a long lattice (klat_accum.h): one workgroup per lattice.  A wave looks for boundary k = the last arc at or
-// before k * kPieceStride whose source state's time differs from its predecessor's, 64 arcs at a time.
+// Pieces of a long lattice (klat_accum.h): one workgroup per lattice.  Keys repeat only among arcs whose source states
+// share their time, so a cut is good where every arc before it has an earlier source time than every arc behind it
+// (klat_slice.h); a wave looks for boundary k = the last such place at or before k * kPieceStride.
 template <bool POSITION>
 __global__ __launch_bounds__(256) void index_slice_kernel(AccumArgs a, const int32_t* long_list) {
   __shared__ int bad;
+  __shared__ int32_t before[kSliceBlocks + 1], from[kSliceBlocks + 1];
   const int u = long_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t a0 = a.arc_off[u], s0 = a.state_off[u];
   const int n = (int)(a.arc_off[u + 1] - a0);
@@ -853,21 +856,13 @@ __global__ __launch_bounds__(256) void index_slice_kernel(AccumArgs a, const int
   const int32_t* tm = (POSITION ? a.state_len : a.state_time) + s0;
   const int first = a.piece_first[u], pieces = (n + kPieceStride - 1) / kPieceStride;
   IndexItem* items = a.piece_items + first;
-  if (tid == 0) bad = 0;
+  auto time_of = [&](int i) { return tm[src[i]]; };
+  if (tid == 0) bad = n > 64 * kSliceBlocks ? 1 : 0;
   __syncthreads();
-  // keys repeat only among arcs whose source states share their time: with times that never descend along the arcs, a
-  // cut where the time changes separates the keys
-  int descends = 0;
-  for (int i = tid + 1; i < n; i += 256) descends |= tm[src[i]] < tm[src[i - 1]] ? 1 : 0;
-  if (descends) bad = 1;
-  for (int k = 1 + wave; k < pieces; k += 4) {  // (wave-uniform)
+  if (!bad) slice_prepare(n, time_of, before, from);  // (workgroup-uniform)
+  for (int k = 1 + wave; !bad && k < pieces; k += 4) {  // (wave-uniform)
     const int target = k * kPieceStride;  // < n
-    int cut = -1;
-    for (int back = 0; back < kPieceWindow && cut < 0; back += 64) {
-      const int i = target - back - lane;  // >= kPieceStride - kPieceWindow > 0
-      const unsigned long long changes = __ballot(tm[src[i]] != tm[src[i - 1]]);
-      if (changes) cut = target - back - (__ffsll((long long)changes) - 1);
-    }
+    const int cut = slice_find(n, time_of, before, from, target - kPieceWindow + 1, target, true);
     if (cut < 0) bad = 1;
     if (lane == 0) items[k].begin = cut;
   }

@@ -35,6 +35,7 @@
 #include <stdint.h>
 
 #include "klat_accum.h"
+#include "klat_slice.h"
 #include "klat_math.h"
 
 namespace klat {
@@ -1610,7 +1611,8 @@ hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipS
 // Pieces of a long lattice (FrameItem, klat_accum.h): one workgroup per lattice.
 __global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int32_t* long_list) {
   constexpr int kMaxPieces = 1024;
-  __shared__ int bad, longest, lab_min, own_lo[kMaxPieces + 1];
+  __shared__ int bad, longest, lab_min, own_lo[kMaxPieces + 1], own_t[kMaxPieces + 1];  // a piece's first own state, its window's first frame
+  __shared__ int32_t before[kSliceBlocks + 1], from[kSliceBlocks + 1];
   const int u = long_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t a0 = a.arc_off[u], s0 = a.state_off[u];
   const int nA = (int)(a.arc_off[u + 1] - a0), S = (int)(a.state_off[u + 1] - s0);
@@ -1620,11 +1622,12 @@ __global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int
   const int32_t* tm = a.state_time + s0;
   const int first = a.piece_first[u], pieces = (S + kFramePieceStates - 1) / kFramePieceStates;
   FrameItem* items = a.piece_items + first;
-  if (tid == 0) bad = pieces > kMaxPieces ? 1 : 0, longest = 0, lab_min = 0x7FFFFFFF;
+  if (tid == 0) bad = (pieces > kMaxPieces || S > 64 * kSliceBlocks) ? 1 : 0, longest = 0, lab_min = 0x7FFFFFFF;
   __syncthreads();
-  // a cut between two states separates the frames only if the times never descend along the states
-  int descends = 0, span = 0, lmin = 0x7FFFFFFF;
-  for (int s = tid + 1; s < S; s += 256) descends |= tm[s] < tm[s - 1] ? 1 : 0;
+  // a cut between two states separates the frames where every state before it is earlier than every state behind it
+  // (klat_slice.h: times that descend here and there still leave such places)
+  auto time_of = [&](int s) { return tm[s]; };
+  int span = 0, lmin = 0x7FFFFFFF;
   for (int i = tid; i < nA; i += 256) {
     span = max(span, dst[i] - src[i]);
     const int l = a.ilabel[a0 + i];
@@ -1632,18 +1635,14 @@ __global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int
   }
   for (int d = 32; d > 0; d >>= 1) span = max(span, __shfl_xor(span, d, 64)), lmin = min(lmin, __shfl_xor(lmin, d, 64));
   if (lane == 0) atomicMax(&longest, span), atomicMin(&lab_min, lmin);
-  if (descends) bad = 1;
-  // the first state of piece k: the first at or behind k * kFramePieceStates whose time exceeds its predecessor's
-  for (int k = 1 + wave; k < pieces && k <= kMaxPieces; k += 4) {  // (wave-uniform)
+  if (!bad) slice_prepare(S, time_of, before, from);  // (workgroup-uniform)
+  // the first state of piece k: the first good cut at or behind k * kFramePieceStates
+  for (int k = 1 + wave; !bad && k < pieces; k += 4) {  // (wave-uniform)
     const int target = k * kFramePieceStates;  // < S
-    int cut = -1;
-    for (int ahead = 0; ahead < kFramePieceWindow && cut < 0; ahead += 64) {
-      const int s = target + ahead + lane;
-      const unsigned long long changes = __ballot(s < S && tm[s] > tm[s - 1]);
-      if (changes) cut = target + ahead + (__ffsll((long long)changes) - 1);
-    }
+    int32_t earliest = 0;  // the earliest time of a state from the cut on: where the piece's window begins
+    const int cut = slice_find(S, time_of, before, from, target, min(target + kFramePieceWindow - 1, S - 1), false, &earliest);
     if (cut < 0) bad = 1;
-    if (lane == 0) own_lo[k] = cut;
+    if (lane == 0) own_lo[k] = cut, own_t[k] = earliest;
   }
   if (tid == 0) own_lo[0] = 0, own_lo[pieces <= kMaxPieces ? pieces : 0] = S;
   __syncthreads();
@@ -1668,8 +1667,8 @@ __global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int
       it.u = u;
       it.s_lo = max(lo - L, 0), it.s_hi = min(hi + L, S);
       it.a_lo = first_arc_from(it.s_lo), it.a_hi = first_arc_from(hi);
-      it.f0 = k == 0 ? 0 : min(max(tm[lo], 0), T);
-      it.f1 = hi >= S ? T : min(max(tm[hi], 0), T);
+      it.f0 = k == 0 ? 0 : min(max(own_t[k], 0), T);
+      it.f1 = hi >= S ? T : min(max(own_t[k + 1], 0), T);
       it.lab_base = lab_min;
       const int arcs = it.a_hi - it.a_lo;
       if (arcs > 65535 || it.s_hi - it.s_lo > kLnStates || it.f1 - it.f0 > 65535) bad = 1;

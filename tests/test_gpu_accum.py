@@ -361,13 +361,14 @@ def test_index_kernel_shapes(ctx, shape):
                 assert x[:2] < y[:2]
 
 
-@pytest.mark.parametrize("shape", ["plain", "repeated_keys", "long_ties", "descending"])
+@pytest.mark.parametrize("shape", ["plain", "repeated_keys", "long_ties", "descending", "disorder"])
 def test_index_of_long_lattices(ctx, shape):
     """Lattices of more than 16 384 arcs: the hash kernel takes them in pieces cut where the source states' time (the
     length, for the position index) changes -- no key repeats across such a cut -- and the gather merges the pieces'
     sorted runs.  20 000 and 60 000 arcs beside short lattices, against the oracle; keys that repeat (several states a
     time: the cuts must find the changes); a stretch of 3 000 arcs of one time (no cut inside a window: that lattice takes
-    the general kernel) and times that descend somewhere (likewise): every path gives the oracle's records."""
+    the general kernel), two neighbouring states out of order (still cut: every arc before a cut is earlier than every arc
+    behind it) and a late state early in the lattice (no cut for 9 000 states: the general kernel): the oracle's records."""
     ns = np.array([150, 6700, 40, 10000, 900], np.int32)
     fo = np.array([3, 3, 2, 6, 4], np.int32)
     arrays = klat_amd.synth(20260031, ns, fo)
@@ -380,10 +381,15 @@ def test_index_of_long_lattices(ctx, shape):
         s0 = int(arrays["state_off"][3])
         t[s0 + 2000:s0 + 2600] = t[s0 + 2000]  # 600 states x 6 arcs of one time around the first cut of the 60 000-arc lattice
         arrays["state_time"] = t
-    if shape == "descending":
+    if shape == "descending":  # two neighbours out of order: a cut is still good wherever all before lie below all behind
         t = arrays["state_time"].copy()
         s0 = int(arrays["state_off"][1])
         t[s0 + 3000], t[s0 + 3001] = t[s0 + 3001], t[s0 + 3000]
+        arrays["state_time"] = t
+    if shape == "disorder":  # a late state early on: nothing before state 9 000 of the 60 000-arc lattice can be cut
+        t = arrays["state_time"].copy()
+        s0 = int(arrays["state_off"][3])
+        t[s0 + 10] = t[s0 + 9000]
         arrays["state_time"] = t
     state_len = np.concatenate([np.arange(int(n), dtype=np.int32) // 3 for n in ns])
     scales = (1.0, 0.3, 0.25)
@@ -513,7 +519,7 @@ def test_frame_post_pool_follows_the_batches(ctx_fresh):
         assert off[-1] == len(labels)
 
 
-@pytest.mark.parametrize("shape", ["plain", "few_words", "descending", "long_arc"])
+@pytest.mark.parametrize("shape", ["plain", "few_words", "descending", "disorder", "long_arc"])
 def test_frame_post_of_long_lattices(ctx, shape):
     """Lattices beyond the lean kernel's 8 192 states or 65 535 arcs are cut into pieces of ~6 144 states on the device --
     a piece owns the frames between two cuts and takes every arc that can cross them, its times clipped to the window --
@@ -530,6 +536,11 @@ def test_frame_post_of_long_lattices(ctx, shape):
         t = arrays["state_time"].copy()
         s0 = int(arrays["state_off"][1])
         t[s0 + 7000], t[s0 + 7001] = t[s0 + 7001], t[s0 + 7000]
+        arrays["state_time"] = t
+    if shape == "disorder":  # a late state early on: no cut before state 11 000 of the 12 000-state lattice
+        t = arrays["state_time"].copy()
+        s0 = int(arrays["state_off"][3])
+        t[s0 + 10] = t[s0 + 11000]
         arrays["state_time"] = t
     if shape == "long_arc":
         a0 = int(arrays["arc_off"][3])
