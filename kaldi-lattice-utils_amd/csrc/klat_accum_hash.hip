@@ -846,7 +846,7 @@ hipError_t launch(const AccumArgs& a, const RadixPack& pk, int cls, int count, h
 // share their time, so a cut is good where every arc before it has an earlier source time than every arc behind it
 // (klat_slice.h); a wave looks for boundary k = the last such place at or before k * kPieceStride.
 template <bool POSITION>
-__global__ __launch_bounds__(256) void index_slice_kernel(AccumArgs a, const int32_t* long_list) {
+__global__ __launch_bounds__(1024) void index_slice_kernel(AccumArgs a, const int32_t* long_list) {
   __shared__ int bad;
   __shared__ int32_t before[kSliceBlocks + 1], from[kSliceBlocks + 1];
   const int u = long_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256) void index_slice_kernel(AccumArgs a, const int
   if (tid == 0) bad = n > 64 * kSliceBlocks ? 1 : 0;
   __syncthreads();
   if (!bad) slice_prepare(n, time_of, before, from);  // (workgroup-uniform)
-  for (int k = 1 + wave; !bad && k < pieces; k += 4) {  // (wave-uniform)
+  for (int k = 1 + wave; !bad && k < pieces; k += 16) {  // (wave-uniform)
     const int target = k * kPieceStride;  // < n
     const int cut = slice_find(n, time_of, before, from, target - kPieceWindow + 1, target, true);
     if (cut < 0) bad = 1;
@@ -871,14 +871,13 @@ __global__ __launch_bounds__(256) void index_slice_kernel(AccumArgs a, const int
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const bool ok = bad == 0;
-  int mine[4] = {0, 0, 0, 0};  // the ends of this thread's pieces, read before anything is rewritten
-  for (int k = tid, q = 0; k < pieces && q < 4; k += 256, ++q) mine[q] = k + 1 < pieces ? items[k + 1].begin : n;
+  const int mine = tid + 1 < pieces ? items[tid + 1].begin : n;  // the end of this thread's piece (at most 1 024 pieces: klat_accum_api.cc), read before anything is rewritten
   __syncthreads();
-  for (int k = tid, q = 0; k < pieces; k += 256, ++q) {
+  if (tid < pieces) {
     IndexItem it;
-    it.u = ok ? u : -1, it.begin = items[k].begin, it.end = mine[q < 4 ? q : 3], it.slot = first + k;
-    items[k] = it;
-    a.item_records[first + k] = 0;
+    it.u = ok ? u : -1, it.begin = items[tid].begin, it.end = mine, it.slot = first + tid;
+    items[tid] = it;
+    a.item_records[first + tid] = 0;
   }
   if (tid == 0) a.piece_count[u] = ok ? pieces : 0, a.num_records[u] = 0;
 }
@@ -886,9 +885,9 @@ __global__ __launch_bounds__(256) void index_slice_kernel(AccumArgs a, const int
 hipError_t launch_index_slice(const AccumArgs& a, bool position, const int32_t* long_list, int count, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   if (position)
-    hipLaunchKernelGGL(index_slice_kernel<true>, dim3(count), dim3(256), 0, stream, a, long_list);
+    hipLaunchKernelGGL(index_slice_kernel<true>, dim3(count), dim3(1024), 0, stream, a, long_list);
   else
-    hipLaunchKernelGGL(index_slice_kernel<false>, dim3(count), dim3(256), 0, stream, a, long_list);
+    hipLaunchKernelGGL(index_slice_kernel<false>, dim3(count), dim3(1024), 0, stream, a, long_list);
   return hipGetLastError();
 }
 

@@ -1609,7 +1609,7 @@ hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipS
 // the lean kernel: needs neither scratch_off nor the scratch rows, takes its records from a.pool.  big: its second
 // instantiation over the lattices the first one listed (a.redo_list); it lists what it leaves in a.redo2_list
 // Pieces of a long lattice (FrameItem, klat_accum.h): one workgroup per lattice.
-__global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int32_t* long_list) {
+__global__ __launch_bounds__(1024) void frame_slice_kernel(FrameArgs a, const int32_t* long_list) {
   constexpr int kMaxPieces = 1024;
   __shared__ int bad, longest, lab_min, own_lo[kMaxPieces + 1], own_t[kMaxPieces + 1];  // a piece's first own state, its window's first frame
   __shared__ int32_t before[kSliceBlocks + 1], from[kSliceBlocks + 1];
@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int
   // (klat_slice.h: times that descend here and there still leave such places)
   auto time_of = [&](int s) { return tm[s]; };
   int span = 0, lmin = 0x7FFFFFFF;
-  for (int i = tid; i < nA; i += 256) {
+  for (int i = tid; i < nA; i += 1024) {
     span = max(span, dst[i] - src[i]);
     const int l = a.ilabel[a0 + i];
     if (l != 0) lmin = min(lmin, l);
@@ -1637,7 +1637,7 @@ __global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int
   if (lane == 0) atomicMax(&longest, span), atomicMin(&lab_min, lmin);
   if (!bad) slice_prepare(S, time_of, before, from);  // (workgroup-uniform)
   // the first state of piece k: the first good cut at or behind k * kFramePieceStates
-  for (int k = 1 + wave; !bad && k < pieces; k += 4) {  // (wave-uniform)
+  for (int k = 1 + wave; !bad && k < pieces; k += 16) {  // (wave-uniform)
     const int target = k * kFramePieceStates;  // < S
     int32_t earliest = 0;  // the earliest time of a state from the cut on: where the piece's window begins
     const int cut = slice_find(S, time_of, before, from, target, min(target + kFramePieceWindow - 1, S - 1), false, &earliest);
@@ -1658,31 +1658,29 @@ __global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int
     }
     return lo;
   };
-  FrameItem mine[4];
-  int nmine = 0;
-  if (!bad)
-    for (int k = tid; k < pieces && nmine < 4; k += 256) {
-      FrameItem it;
-      const int lo = own_lo[k], hi = own_lo[k + 1];
-      it.u = u;
-      it.s_lo = max(lo - L, 0), it.s_hi = min(hi + L, S);
-      it.a_lo = first_arc_from(it.s_lo), it.a_hi = first_arc_from(hi);
-      it.f0 = k == 0 ? 0 : min(max(own_t[k], 0), T);
-      it.f1 = hi >= S ? T : min(max(own_t[k + 1], 0), T);
-      it.lab_base = lab_min;
-      const int arcs = it.a_hi - it.a_lo;
-      if (arcs > 65535 || it.s_hi - it.s_lo > kLnStates || it.f1 - it.f0 > 65535) bad = 1;
-      const unsigned long long at = atomicAdd(a.piece_scratch_used, (unsigned long long)arcs);
-      if (at + (unsigned long long)arcs > (unsigned long long)a.piece_scratch_cap) bad = 1;
-      it.scratch = (int64_t)at;
-      mine[nmine++] = it;
-    }
+  FrameItem mine = {-1, 0, 0, 0, 0, 0, 0, 0, 0};  // (at most kMaxPieces = 1 024 pieces: one a thread)
+  if (!bad && tid < pieces) {
+    const int k = tid;
+    FrameItem it;
+    const int lo = own_lo[k], hi = own_lo[k + 1];
+    it.u = u;
+    it.s_lo = max(lo - L, 0), it.s_hi = min(hi + L, S);
+    it.a_lo = first_arc_from(it.s_lo), it.a_hi = first_arc_from(hi);
+    it.f0 = k == 0 ? 0 : min(max(own_t[k], 0), T);
+    it.f1 = hi >= S ? T : min(max(own_t[k + 1], 0), T);
+    it.lab_base = lab_min;
+    const int arcs = it.a_hi - it.a_lo;
+    if (arcs > 65535 || it.s_hi - it.s_lo > kLnStates || it.f1 - it.f0 > 65535) bad = 1;
+    const unsigned long long at = atomicAdd(a.piece_scratch_used, (unsigned long long)arcs);
+    if (at + (unsigned long long)arcs > (unsigned long long)a.piece_scratch_cap) bad = 1;
+    it.scratch = (int64_t)at;
+    mine = it;
+  }
   __syncthreads();
   const bool ok = bad == 0;  // (set by plain stores of 1 from any thread: read behind the barrier)
-  for (int k = tid, q = 0; k < pieces; k += 256, ++q) {
-    FrameItem it = {-1, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (ok && q < 4) it = mine[q];
-    items[k] = it;
+  if (tid < pieces) {
+    if (!ok) mine.u = -1;
+    items[tid] = mine;
   }
   if (tid == 0) {
     if (ok) {
@@ -1695,7 +1693,7 @@ __global__ __launch_bounds__(256) void frame_slice_kernel(FrameArgs a, const int
 
 hipError_t launch_frame_slice(const FrameArgs& a, const int32_t* long_list, int count, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(frame_slice_kernel, dim3(count), dim3(256), 0, stream, a, long_list);
+  hipLaunchKernelGGL(frame_slice_kernel, dim3(count), dim3(1024), 0, stream, a, long_list);
   return hipGetLastError();
 }
 

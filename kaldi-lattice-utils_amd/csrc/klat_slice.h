@@ -23,24 +23,53 @@ template <class TimeOf>
 __device__ __forceinline__ void slice_prepare(int n, TimeOf t, int32_t* before, int32_t* from) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const int nb = (n + 63) >> 6;
-  for (int b = wave; b < nb; b += waves) {  // (wave-uniform)
-    const int i = b * 64 + lane;
-    const int32_t v = i < n ? t(i) : 0;
-    int32_t hi = i < n ? v : (int32_t)0x80000000, lo = i < n ? v : 0x7FFFFFFF;
-    for (int d = 32; d > 0; d >>= 1) hi = max(hi, __shfl_xor(hi, d, 64)), lo = min(lo, __shfl_xor(lo, d, 64));
-    if (lane == 0) before[b] = hi, from[b] = lo;  // (the block's own extremes for now)
+  for (int b0 = wave * 8; b0 < nb; b0 += waves * 8) {  // (wave-uniform; eight blocks' loads in flight together: t() is two dependent loads)
+    int32_t v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = (b0 + q) * 64 + lane;
+      v[q] = i < n ? t(i) : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = (b0 + q) * 64 + lane;
+      int32_t hi = i < n ? v[q] : (int32_t)0x80000000, lo = i < n ? v[q] : 0x7FFFFFFF;
+      for (int d = 32; d > 0; d >>= 1) hi = max(hi, __shfl_xor(hi, d, 64)), lo = min(lo, __shfl_xor(lo, d, 64));
+      if (lane == 0 && b0 + q < nb) before[b0 + q] = hi, from[b0 + q] = lo;  // (the block's own extremes for now)
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  // the maxima before every block, the minima from every block on: one wave each, 64 blocks a step
+  if (wave == 0) {
     int32_t run = (int32_t)0x80000000;
-    for (int b = 0; b < nb; ++b) {
-      const int32_t own = before[b];
-      before[b] = run;
-      run = max(run, own);
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+      const int b = b0 + lane;
+      const int32_t own = b < nb ? before[b] : (int32_t)0x80000000;
+      int32_t up = own;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_up(up, d, 64);
+        if (lane >= d) up = max(up, o);
+      }
+      int32_t excl = __shfl_up(up, 1, 64);
+      excl = lane == 0 ? run : max(run, excl);
+      if (b < nb) before[b] = excl;
+      run = max(run, __shfl(up, 63, 64));
     }
-    run = 0x7FFFFFFF;
-    from[nb] = run;
-    for (int b = nb - 1; b >= 0; --b) run = min(run, from[b]), from[b] = run;
+  } else if (wave == 1 || waves == 1) {
+    int32_t run = 0x7FFFFFFF;
+    if (lane == 0) from[nb] = run;
+    for (int b1 = nb; b1 > 0; b1 -= 64) {  // blocks [b1 - 64, b1), lane l takes block b1 - 1 - l
+      const int b = b1 - 1 - lane;
+      const int32_t own = b >= 0 ? from[b] : 0x7FFFFFFF;
+      int32_t dn = own;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_up(dn, d, 64);
+        if (lane >= d) dn = min(dn, o);
+      }
+      dn = min(dn, run);
+      if (b >= 0) from[b] = dn;
+      run = __shfl(dn, 63, 64);
+    }
   }
   __syncthreads();
 }
