@@ -923,36 +923,46 @@ __device__ __noinline__ int fr_lean_wide_rank(const uint16_t* bucket /* LDS */, 
                                           int lab_base, int abits, const LnTabEntry* lntab /* LDS */, uint64_t* out) {
   const int lane = threadIdx.x & 63;
   uint32_t key = 0xFFFFFFFFu;
-  double x = 0.0;
   if (lane < w) {
     const int arc = (int)bucket[lane];
     key = (uint32_t)arc | ((uint32_t)(labels[arc] - lab_base) << abits);
-    x = xs[arc];
   }
+  // (the keys alone go through the network -- every stage is a trip through the LDS crossbar per 32 bits --, x is fetched
+  // by arc number afterwards, as the thread-per-rank path does)
   for (int size = 2; size <= 64; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       const uint32_t okey = (uint32_t)__shfl_xor((int)key, stride, 64);
-      const double ox = __shfl_xor(x, stride, 64);
       const bool up = (lane & size) == 0, lower = (lane & stride) == 0;
-      const bool take = (okey < key) == (up == lower);  // the lower lane of an ascending pair keeps the smaller key (keys are distinct; padding sorts last)
-      if (okey != key && take) key = okey, x = ox;
+      key = (up == lower) ? min(key, okey) : max(key, okey);  // the lower lane of an ascending pair keeps the smaller key (padding sorts last)
     }
-  // entry by entry (wave-uniform trips): a run of one word is folded in arc order, its key emitted into lane m
-  double outk = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
-  int m = 0;
-  double acc = __shfl(x, 0, 64);
-  uint32_t lab = (uint32_t)__shfl((int)key, 0, 64) >> abits;
-  for (int j = 1; j <= w; ++j) {
-    const uint32_t lj = j < w ? (uint32_t)__shfl((int)key, j, 64) >> abits : 0xFFFFFFFFu;
-    const double xj = __shfl(x, j < w ? j : 0, 64);
-    if (lj == lab) {
-      acc = fr_log_add_fast(acc, xj, lntab);
-    } else {
-      if (lane == m) outk = __longlong_as_double((long long)(((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab));  // BaseFloat narrowing of :126
-      ++m;
-      acc = xj, lab = lj;
-    }
+  const double x = lane < w ? xs[key & ((1u << abits) - 1u)] : 0.0;
+  // The runs of one word, folded in arc order with every lane at work: a lane knows where its run begins (a prefix
+  // maximum over the lanes that open one) and hence its place in it; step s folds the s-th entry of every run into the sum
+  // its left neighbour holds -- as many steps as the longest run is long (two or three as a rule: walking the rank entry by
+  // entry, one wave-uniform trip per entry, was most of this function's time).  The last lane of a run emits the record's
+  // key, the others padding: the sort below brings the records to the front.
+  const uint32_t lab = key >> abits;
+  const uint32_t lab_left = (uint32_t)__shfl_up((int)lab, 1, 64);
+  const bool opens = lane < w && (lane == 0 || lab_left != lab);
+  int start = opens ? lane : -1;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(start, d, 64);
+    if (lane >= d) start = max(start, o);
   }
+  const int pos = lane < w ? lane - start : 0;
+  int longest = pos;
+  for (int d = 32; d > 0; d >>= 1) longest = max(longest, __shfl_xor(longest, d, 64));
+  double acc = x;
+  for (int s = 1; s <= longest; ++s) {  // (wave-uniform trips)
+    const double left = __shfl_up(acc, 1, 64);
+    const double folded = fr_log_add_fast(left, x, lntab);
+    if (pos == s) acc = folded;
+  }
+  const bool opens_right = __shfl_down((int)opens, 1, 64) != 0;
+  const bool closes = lane < w && (lane == w - 1 || opens_right);
+  const int m = __popcll(__ballot(closes));
+  double outk = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
+  if (closes) outk = __longlong_as_double((long long)(((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab));  // BaseFloat narrowing of :126
   for (int size = 2; size <= 64; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       const double o = __shfl_xor(outk, stride, 64);
