@@ -231,9 +231,10 @@ __device__ __noinline__ bool tie_less(int ax, int ay) {
 // position of order word `me` in its bucket [lo, hi) where the plain count does not do: a crowded bucket (sorted by
 // the workgroup beforehand: binary search) or one that holds words whose upper parts equal mine
 template <bool POSITION, int RB>
-__device__ __noinline__ int slow_position(const uint64_t* order, int lo, int hi, uint64_t me) {
+__device__ __noinline__ int slow_position(const uint64_t* order, int lo, int hi, uint64_t me, bool plain) {
   constexpr uint64_t idmask = (1ull << RB) - 1ull;
-  auto less = [&](uint64_t x, uint64_t y) -> bool {
+  auto less = [&](uint64_t x, uint64_t y) -> bool {  // (plain: the last bucket's words are the records' keys themselves)
+    if (plain) return x < y;
     return ((x ^ y) & ~idmask) ? x < y : (x != y && tie_less<POSITION>((int)(x & idmask), (int)(y & idmask)));
   };
   if (hi - lo > kSerialMax) {
@@ -668,19 +669,26 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   for (int w = 0; w < T / 64; ++w) flo = fminf(flo, sh_lo[w]), fhi = fmaxf(fhi, sh_hi[w]);
   // one ulp outwards: (float)val rounds to nearest, the true extremes may lie half an ulp beyond
   const double vmax = (double)fhi + fabs((double)fhi) * 1.2e-7, vspan = vmax - ((double)flo - fabs((double)flo) * 1.2e-7);
-  const float scale = (vspan > 0.0 && vspan < INFINITY) ? (float)(B - 1) / __fsqrt_rn((float)vspan) : 0.0f;
+  const float scale = (vspan > 0.0 && vspan < INFINITY) ? (float)(B - 2) / __fsqrt_rn((float)vspan) : 0.0f;
   uint32_t where[P];  // bucket << 16 | arrival number inside it
+  uint32_t zeromask = 0;  // records of the last bucket (log-zero)
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     where[j] = 0;
     if (recmask & (1u << j)) {
-      int b = B - 1;  // -inf, NaN: behind every finite value (their images order them inside the bucket)
+      // Log-zero (an arc on no complete path; NaN with it) has the LAST bucket to itself: such records all tie, the
+      // reference orders them by their keys alone -- and the keys, unique as they are, are that bucket's order words:
+      // plain 64-bit compares in LDS where value ties would recompute both records from memory (1 % of dead arcs made
+      // this kernel six times slower, 20 % twenty-four times).
+      int b = B - 1;
       if (val[j] > -INFINITY && val[j] < INFINITY) {
         // monotone in -logp: subtract, clamp, double -> float rounding, correctly rounded float sqrt, multiply, truncate
         const float t = __fsqrt_rn((float)fmax(vmax - val[j], 0.0)) * scale;
-        b = t >= (float)(B - 1) ? B - 1 : (int)t;
+        b = t >= (float)(B - 2) ? B - 2 : (int)t;
       } else if (val[j] == INFINITY) {
         b = 0;
+      } else {
+        zeromask |= 1u << j;
       }
       const uint32_t old = atomicAdd(&bcnt[b >> 1], 1u << ((b & 1) * 16));
       where[j] = ((uint32_t)b << 16) | ((old >> ((b & 1) * 16)) & 0xFFFFu);
@@ -719,7 +727,7 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
     if (recmask & (1u << j)) {
       const int b = (int)(where[j] >> 16);
       const int lo = b ? (int)bend[b - 1] : 0;
-      order[lo + (int)(where[j] & 0xFFFFu)] = (img[j] & ~idmask) | (uint64_t)(j * T + tid);
+      order[lo + (int)(where[j] & 0xFFFFu)] = (zeromask & (1u << j)) ? key[j] : ((img[j] & ~idmask) | (uint64_t)(j * T + tid));
       where[j] = ((uint32_t)lo << 16) | (uint32_t)bend[b];  // the bucket's range from here on
     }
   }
@@ -733,9 +741,12 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   for (int g = 0; g < nbig; ++g) {
     const int b = sh_big[g];
     const int lo = b ? (int)bend[b - 1] : 0, hi = (int)bend[b];
-    block_sort_any(T, order + lo, hi - lo, [&](uint64_t x, uint64_t y) -> bool {
-      return ((x ^ y) & ~idmask) ? x < y : (x != y && tie_less<POSITION>((int)(x & idmask), (int)(y & idmask)));
-    });
+    if (b == B - 1)  // (workgroup-uniform) the keys of the log-zero records
+      block_sort_any(T, order + lo, hi - lo, [](uint64_t x, uint64_t y) -> bool { return x < y; });
+    else
+      block_sort_any(T, order + lo, hi - lo, [&](uint64_t x, uint64_t y) -> bool {
+        return ((x ^ y) & ~idmask) ? x < y : (x != y && tie_less<POSITION>((int)(x & idmask), (int)(y & idmask)));
+      });
   }
   // every record finds its final position inside its bucket by counting the smaller entries (independent LDS
   // reads); a crowded bucket, or one with a word whose upper part equals the record's, takes the slow way
@@ -743,7 +754,7 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     int p = 0;
-    if (recmask & (1u << j)) {
+    if ((recmask & ~zeromask) & (1u << j)) {
       const int lo = (int)(where[j] >> 16), hi = (int)(where[j] & 0xFFFFu);
       // the words below every word with my upper part, and those up to the last such word: mine is the only one
       // in between unless another record's value agrees with mine in its upper bits
@@ -759,10 +770,24 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
         }
         slow = upto - (p - lo) != 1;
       }
-      if (slow) p = slow_position<POSITION, RB>(order, lo, hi, floor_w | (uint64_t)(j * T + tid));
+      if (slow) p = slow_position<POSITION, RB>(order, lo, hi, floor_w | (uint64_t)(j * T + tid), false);
     }
     if (j & 1) finalpos[j >> 1] |= (uint32_t)p << 16;
     else finalpos[j >> 1] = (uint32_t)p;
+  }
+  if (zeromask) {  // the log-zero records, apart (no lane of most waves has any): their words are their keys
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      if (!(zeromask & (1u << j))) continue;
+      const int lo = (int)(where[j] >> 16), hi = (int)(where[j] & 0xFFFFu);
+      int p = lo;
+      if (hi - lo > kSerialMax) {
+        p = slow_position<POSITION, RB>(order, lo, hi, key[j], true);
+      } else {
+        for (int q = lo; q < hi; ++q) p += order[q] < key[j] ? 1 : 0;
+      }
+      finalpos[j >> 1] = (finalpos[j >> 1] & ~(0xFFFFu << ((j & 1) * 16))) | ((uint32_t)p << ((j & 1) * 16));
+    }
   }
   KLAT_STAMP(6);
 
