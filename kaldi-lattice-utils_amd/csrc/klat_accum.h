@@ -184,8 +184,8 @@ struct FrameArgs {
   ScaleParams sp;
   long long* phase_clock;   // [U][8] or null: shader cycles of the frame kernel's phases (KLAT_ACCUM_PROFILE)
   const int64_t* frame_base;  // [U+1] first frame of every lattice in the batch-wide frame numbering
-  int32_t* frame_count;       // [sum of num_frames] records per frame
-  int32_t* frame_src;         // [sum of num_frames] first record of the frame in the lattice's record rows
+  int2* frame_ref;            // [sum of num_frames] x: records of the frame, y: the first of them in the lattice's record rows
+                              // (one word pair: a frame's two numbers are one store, and the stores of a wave one run of lines)
   int32_t* redo_list;         // [U] or null: the lattices the lean kernel leaves to the general one, ...
   int32_t* redo_n;            // [1] ... and their number
   int32_t* redo2_list;        // [U], [1]: what the lean kernel's second instantiation (over redo_list) leaves in its turn

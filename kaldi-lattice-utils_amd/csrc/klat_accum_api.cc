@@ -407,11 +407,9 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
     }
     if ((rc = st.num_frames.upload(num_frames, (size_t)b->U, c->stream))) return rc;
     if ((rc = st.d_frame_base.upload(st.frame_base.data(), st.frame_base.size(), c->stream))) return rc;
-    if ((rc = st.frame_count.alloc((size_t)st.frame_base[b->U]))) return rc;
-    if ((rc = st.frame_src.alloc((size_t)st.frame_base[b->U]))) return rc;
+    if ((rc = st.frame_ref.alloc((size_t)st.frame_base[b->U]))) return rc;
     a.frame_base = st.d_frame_base.p;
-    a.frame_count = st.frame_count.p;
-    a.frame_src = st.frame_src.p;
+    a.frame_ref = st.frame_ref.p;
     if ((rc = st.arc_scratch.alloc((size_t)b->A * sizeof(FrameArc)))) return rc;
     if ((rc = st.num_expansions.alloc((size_t)b->U))) return rc;
     if ((rc = st.num_records.alloc((size_t)b->U))) return rc;
@@ -649,8 +647,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
   a.rec_ptr = st.rec_ptr.p;
   a.rec_fmt = st.rec_fmt.p;
   a.frame_base = st.d_frame_base.p;
-  a.frame_count = st.frame_count.p;
-  a.frame_src = st.frame_src.p;
+  a.frame_ref = st.frame_ref.p;
   DevBuf<int64_t> d_eoff, d_fbase, d_foff;
   DevBuf<int32_t> d_lab;
   DevBuf<float> d_lp;

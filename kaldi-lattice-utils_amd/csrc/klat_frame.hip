@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
   FKey* tmp = recs + ((a.scratch_off[u + 1] - a.scratch_off[u]) - frame_sort_slots(nA));
 
   if (nA == 0) {  // nothing crosses any frame (and the unconditional gathers of the frames phase read the lattice's first arc)
-    for (int f = tid; f < T; f += kFrThreads) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
+    for (int f = tid; f < T; f += kFrThreads) a.frame_ref[fbase + f] = make_int2(0, 0);
     if (tid == 0) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = rec8, a.rec_fmt[u] = 0;
     return;
   }
@@ -893,8 +893,7 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
       // changed frame; every frame names its records by (first record, count), so the unchanged frames
       // that follow share them, and the gather kernel expands the runs into the dense output
       for (int r = 0; r < run; ++r) {
-        a.frame_count[fbase + f0 + frame + r] = mk;
-        a.frame_src[fbase + f0 + frame + r] = dst;
+        a.frame_ref[fbase + f0 + frame + r] = make_int2(mk, dst);
       }
       if (in_regs) {
 #pragma unroll
@@ -1069,7 +1068,7 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) v
   const bool spans_lds = BIG ? (nA <= span_cap && S <= kStatesLds) : true;  // workgroup-uniform
   uint32_t* gspan = reinterpret_cast<uint32_t*>(xs + nA);
   if (nA == 0) {  // nothing crosses any frame (and the unconditional loads below read the lattice's first arc)
-    for (int f = tid; f < T; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
+    for (int f = tid; f < T; f += NT) a.frame_ref[fbase + f] = make_int2(0, 0);
     if (tid == 0 && !PIECES) a.num_records[u] = 0, a.num_stored[u] = 0, a.rec_ptr[u] = a.pool, a.rec_fmt[u] = 0;
     return;
   }
@@ -1285,7 +1284,7 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) v
   }
   const uint32_t amask = (1u << abits) - 1u;
   // the frames before the first rank hold nothing
-  for (int f = tid, first = (nr > 0) ? (int)rtime[0] : T; f < first; f += NT) a.frame_count[fbase + f] = 0, a.frame_src[fbase + f] = 0;
+  for (int f = tid, first = (nr > 0) ? (int)rtime[0] : T; f < first; f += NT) a.frame_ref[fbase + f] = make_int2(0, 0);
   FR_LAP(0);
   int nbase = 0;   // bucket entries of the tiles before this one
   int stored = 0;  // records this thread wrote
@@ -1504,14 +1503,22 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) v
       }
       // 8 bytes per record -- the sort key itself, desc(float logp) << 30 | label - lab_base (rec_fmt tells the gather
       // kernel) -- written ONCE per rank; every frame names its records by (first record, count), so the frames up
-      // to the next rank share them, and the gather kernel expands the runs into the dense output
-      for (int r = 0; r < (wide ? 0 : run); ++r) {
-        a.frame_count[fbase + frame + r] = mk;
-        a.frame_src[fbase + frame + r] = dst;
-      }
+      // to the next rank share them, and the gather kernel expands the runs into the dense output.
+      // What the stores of this pass cost is the NUMBER of their requests, one per lane and instruction where the lanes'
+      // addresses lie in different lines: a rank's records go two to a store (190 M records one by one on C2), and the
+      // frames' words are written behind the tile's ranks, a lane per frame (lcur, free since the scatter, keeps every
+      // rank's number of records until then)
+      if (k < tc && !wide) lcur[k] = mk;
+      struct __attribute__((packed, aligned(8))) RecordPair {
+        uint64_t first, second;
+      };
 #pragma unroll
-      for (int j = 0; j < R; ++j)
-        if (j < mk) a.pool[dst + j] = (uint64_t)__double_as_longlong(dk[j]);
+      for (int j = 0; j < R; j += 2) {
+        if (j + 1 < mk)
+          *reinterpret_cast<RecordPair*>(a.pool + dst + j) = RecordPair{(uint64_t)__double_as_longlong(dk[j]), (uint64_t)__double_as_longlong(dk[j + 1])};
+        else if (j < mk)
+          a.pool[dst + j] = (uint64_t)__double_as_longlong(dk[j]);
+      }
       dense += mk * run;
       stored += mk;
     }
@@ -1524,12 +1531,19 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) v
       const int lo = lboff[k], w = lboff[k + 1] - lo;  // R < w <= kLnWideMax
       const int dst = (int)rec_at + nbase + lo;
       const int m = fr_lean_wide_rank(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst);
-      const int frame = (int)rtime[c0 + k], run = (int)rtime[c0 + k + 1] - frame;
-      for (int r = lane; r < run; r += 64) {
-        a.frame_count[fbase + frame + r] = m;
-        a.frame_src[fbase + frame + r] = dst;
-      }
-      if (lane == 0) dense += m * run, stored += m;
+      const int run = (int)rtime[c0 + k + 1] - (int)rtime[c0 + k];
+      if (lane == 0) lcur[k] = m, dense += m * run, stored += m;
+    }
+    if (wide_n > 0) __syncthreads();  // (workgroup-uniform; the thread path's counts lie behind the barrier above)
+    // ---- 4. the frames of the tile's ranks, one run of frames: a thread per frame finds the frame's rank among the rank
+    // times and writes its two words (records, first record) -- whole lines, where a thread per rank wrote every frame
+    // of its rank one by one ----
+    for (int f = (int)rtime[c0] + tid, f_end = (int)rtime[c0 + tc]; f < f_end; f += NT) {
+      int j = 0;
+#pragma unroll
+      for (int step = kTile / 2; step > 0; step >>= 1)
+        if (j + step < tc && (int)rtime[c0 + j + step] <= f) j += step;
+      a.frame_ref[fbase + f] = make_int2(lcur[j], (int)rec_at + nbase + lboff[j]);
     }
     nbase += n;
     __syncthreads();
@@ -1567,8 +1581,8 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(FrameArgs a, const in
   int carry = 0;
   for (int base = 0; base < T; base += 256) {
     const int k = base + (int)threadIdx.x;
-    const int c = k < T ? a.frame_count[fb + k] : 0;
-    const int src = k < T ? a.frame_src[fb + k] : 0;
+    const int2 ref = k < T ? a.frame_ref[fb + k] : make_int2(0, 0);
+    const int c = ref.x, src = ref.y;
     int tot;
     const int ex = fr_block_scan(c, &tot, sh);  // entries of this block's frames before frame k
     if (k < T) frame_off[fb + k] = o + carry + ex;

@@ -232,7 +232,8 @@ struct klat_frame_state {
   hipEvent_t ev[2] = {nullptr, nullptr};  // around the frame kernels of the last sizing call
   std::vector<int64_t> frame_base, entry_off;
   klat::DevBuf<int64_t> scratch_off, num_expansions;
-  klat::DevBuf<int32_t> num_frames, num_records, num_stored, frame_count, frame_src, redo;
+  klat::DevBuf<int32_t> num_frames, num_records, num_stored, redo;
+  klat::DevBuf<int2> frame_ref;
   int64_t stored_records = 0;  // records the last run stored (the (frame, word) entries share them)
   klat::DevBuf<int64_t> d_frame_base;
   klat::DevBuf<unsigned char> key_scratch, rec_scratch, arc_scratch;
