@@ -211,7 +211,7 @@ __device__ int fr_block_scan(int v, int* total, int* sh /* [NT/64] */) {
 }
 
 // the same for two ints per thread at once (one pair of barriers)
-template <int NT = kFrThreads>
+template <int NT = kFrThreads, bool TAIL = true>
 __device__ int2 fr_block_scan2(int v, int w, int* total_v, int* total_w, int* sh /* [2 * NT/64] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int iv = v, iw = w;
@@ -226,7 +226,7 @@ __device__ int2 fr_block_scan2(int v, int w, int* total_v, int* total_w, int* sh
     if (k < wave) pv += sh[k], pw += sh[NT / 64 + k];
     tv += sh[k], tw += sh[NT / 64 + k];
   }
-  __syncthreads();
+  if (TAIL) __syncthreads();
   *total_v = tv, *total_w = tw;
   return make_int2(pv + iv - v, pw + iw - w);
 }
@@ -378,6 +378,31 @@ __device__ __forceinline__ void fr_sort16_net(T (&k)[kFrRegs], CE ce) {
   ce(k[2], k[4]); ce(k[3], k[6]); ce(k[9], k[12]); ce(k[11], k[13]);
   ce(k[3], k[5]); ce(k[6], k[8]); ce(k[7], k[9]); ce(k[10], k[12]);
   ce(k[3], k[4]); ce(k[5], k[6]); ce(k[7], k[8]); ce(k[9], k[10]); ce(k[11], k[12]);
+  ce(k[6], k[7]); ce(k[8], k[9]);
+}
+// The same for eight keys (Batcher's odd-even merge: 19 comparators) and for twelve (the network above without the
+// comparators that touch the lines 12 ... 15 -- those lines hold padding, which no comparator moves down -- and without
+// those that then compare nothing that can be out of order: 40).  Both checked like the one above.
+template <class T, class CE>
+__device__ __forceinline__ void fr_sort8_net(T (&k)[8], CE ce) {
+  ce(k[0], k[1]); ce(k[2], k[3]); ce(k[4], k[5]); ce(k[6], k[7]);
+  ce(k[0], k[2]); ce(k[1], k[3]); ce(k[4], k[6]); ce(k[5], k[7]);
+  ce(k[1], k[2]); ce(k[5], k[6]);
+  ce(k[0], k[4]); ce(k[1], k[5]); ce(k[2], k[6]); ce(k[3], k[7]);
+  ce(k[2], k[4]); ce(k[3], k[5]);
+  ce(k[1], k[2]); ce(k[3], k[4]); ce(k[5], k[6]);
+}
+template <class T, class CE>
+__device__ __forceinline__ void fr_sort12_net(T (&k)[12], CE ce) {
+  ce(k[4], k[8]); ce(k[5], k[6]); ce(k[7], k[11]); ce(k[9], k[10]);
+  ce(k[0], k[5]); ce(k[1], k[7]); ce(k[2], k[9]); ce(k[3], k[4]); ce(k[6], k[8]); ce(k[10], k[11]);
+  ce(k[0], k[1]); ce(k[2], k[3]); ce(k[4], k[5]); ce(k[7], k[9]);
+  ce(k[0], k[2]); ce(k[1], k[3]); ce(k[4], k[10]); ce(k[5], k[11]); ce(k[6], k[7]); ce(k[8], k[9]);
+  ce(k[1], k[2]); ce(k[4], k[6]); ce(k[5], k[7]); ce(k[8], k[10]); ce(k[9], k[11]);
+  ce(k[1], k[4]); ce(k[2], k[6]); ce(k[5], k[8]); ce(k[7], k[10]);
+  ce(k[2], k[4]); ce(k[3], k[6]); ce(k[7], k[9]);
+  ce(k[3], k[5]); ce(k[6], k[8]); ce(k[9], k[10]);
+  ce(k[3], k[4]); ce(k[5], k[6]); ce(k[7], k[8]);
   ce(k[6], k[7]); ce(k[8], k[9]);
 }
 struct FrCeU32 {
@@ -1021,11 +1046,17 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) v
   uint32_t* lspan = reinterpret_cast<uint32_t*>(fr_smem + sizeof(uint16_t) * (kEntries + kStatesLds + 2));  // [span_cap]: rank(src) | rank(dst) << 16
   __shared__ int lboff[kTile + 1];  // first bucket entry of every rank of the tile
   __shared__ int lcur[kTile];       // scatter cursors
-  __shared__ int sh[2 * NT / 64];
+  __shared__ int sh[3 * NT / 64];
   __shared__ int tile_max, lab_min, lab_max, span_max, unfit, num_ranks, entries, wide_n, sum_stored, sum_dense, descending;
   // the tile's ranks of more than kFrRegs entries: every one of them where a lattice's frames hold twenty arcs and more
   // (fanout four, six: a wave per rank is forty times the work of a thread per rank, and a tenth of the general kernel's)
   __shared__ uint16_t wide_rank[kTile];
+  // the tile's ranks in the order the threads take them: those of at most kW0 entries first, those of at most kW1 next,
+  // the others last (each in ascending order) -- a wave sorts as many registers as its largest bucket needs, and on
+  // lattices whose frames hold ten arcs or so (one rank in four has eight entries or fewer, all but one in thirty twelve
+  // or fewer) a wave of consecutive ranks nearly always held one of more than twelve
+  __shared__ uint16_t order[kTile];
+  constexpr int kW0 = R == kFrRegs ? 8 : 16, kW1 = R == kFrRegs ? 12 : R;
   __shared__ int blk_first[kLnStates / kLnBlock + 2];  // first arc whose first rank lies in or behind block b of kLnBlock ranks
   __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
@@ -1379,11 +1410,22 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) v
         cmax = max(cmax, dl[q]);
         sum_c += dl[q];
       }
-      int off = fr_block_scan<NT, false>(sum_c, &n, sh + NT / 64);
+      int narrow_c = 0;  // its ranks of at most kW0 entries | those of kW0 + 1 ... kW1 << 16
+#pragma unroll
+      for (int q = 0; q < kCh; ++q)
+        if (tid * kCh + q < tc) narrow_c += dl[q] <= kW0 ? 1 : dl[q] <= kW1 ? 0x10000 : 0;
+      int narrow_n;
+      const int2 before = fr_block_scan2<NT, false>(sum_c, narrow_c, &n, &narrow_n, sh + NT / 64);
+      int off = before.x;
+      int at0 = before.y & 0xFFFF, at1 = (narrow_n & 0xFFFF) + (before.y >> 16);
+      int at2 = (narrow_n & 0xFFFF) + (narrow_n >> 16) + min(tid * kCh, tc) - (before.y & 0xFFFF) - (before.y >> 16);
 #pragma unroll
       for (int q = 0; q < kCh; ++q) {
         const int k = tid * kCh + q;
-        if (k < tc) lboff[k] = off, lcur[k] = off;
+        if (k < tc) {
+          lboff[k] = off, lcur[k] = off;
+          order[dl[q] <= kW0 ? at0++ : dl[q] <= kW1 ? at1++ : at2++] = (uint16_t)k;
+        }
         off += dl[q];
       }
       if (tid == 0) lboff[tc] = n;
@@ -1422,105 +1464,102 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) v
     FR_LAP(2);
     // ---- 3. one thread per rank, NT at a time: sort by (word, arc), fold, sort by (logp desc, word), place ----
     for (int r0 = 0; r0 < tc; r0 += NT) {
-      const int k = r0 + tid;
+      const int k = (r0 + tid < tc) ? (int)order[r0 + tid] : tc;
       const int lo = (k < tc) ? lboff[k] : 0;
       const int w_all = (k < tc) ? lboff[k + 1] - lo : 0;
       const bool wide = w_all > R;  // (rare: left to a whole wave below; its slots are reserved here)
       const int w = wide ? 0 : w_all;
-      int mk = 0;
-      // (every load below is unconditional: a load inside a branch waits for its data before the branch
-      // closes, and sixteen gathers would take sixteen trips to L2 one after the other.  The slots beyond
-      // the bucket all read the lattice's first arc: one more request per instruction, not one per lane)
-      uint32_t k32[R];
-#pragma unroll
-      for (int j = 0; j < R; ++j) k32[j] = (uint32_t)lbucket[lo + j];  // (beyond the buckets lies rtime: read, not used)
-#pragma unroll
-      for (int j = 0; j < R; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
-#pragma unroll
-      for (int j = 0; j < R; ++j) k32[j] = (j < w) ? k32[j] : 0u;
-      // (gathers served by L2; 32-bit byte offsets from the lattice's first arc: one address register each)
-      const char* lab_row = reinterpret_cast<const char*>(a.ilabel + a0);
-      const char* x_row = reinterpret_cast<const char*>(xs);
-      {
-        int32_t lab[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) lab[j] = *reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2));
-        // sort keys (label - lab_base | arc number) in 32 bits: a compare-exchange is two instructions and no
-        // payload moves; x is fetched by arc number after the sort
-#pragma unroll
-        for (int j = 0; j < R; ++j) k32[j] = (j < w) ? (k32[j] | ((uint32_t)(lab[j] - lab_base) << abits)) : 0xFFFFFFFFu;
-      }
-      const bool narrow = __all(w <= 8);  // wave-uniform: the 8-wide network is enough
-      const bool medium = R > 16 && __all(w <= 16);
-      if (narrow) {
-        fr_sort32_sizes<8, 2, R>(k32);
-      } else if constexpr (R == 16) {
-        fr_sort16_net(k32, FrCeU32());
-      } else {
-        if (medium) fr_sort32_sizes<16, 2, R>(k32);
-        else fr_sort32_sizes<R, 2, R>(k32);
-      }
-      double ex[R];
-#pragma unroll
-      for (int j = 0; j < R; ++j) ex[j] = *reinterpret_cast<const double*>(x_row + ((j < w ? k32[j] & amask : 0u) << 3));
-      // fold on the sort keys themselves, the runs of one word in arc order: the key of a run is emitted at its
-      // last entry as the positive finite double desc(float logp) << 30 | label - lab_base (sorted by v_min_f64 /
-      // v_max_f64), the other entries turn into padding
-      double dk[R];
-      double acc = ex[0];
-#pragma unroll
-      for (int j = 1; j <= R; ++j) {
-        const uint32_t lab = k32[j - 1] >> abits;
-        const bool cont = j < R && j < w && (k32[j < R ? j : 0] >> abits) == lab;
-        const bool emit = !cont && j - 1 < w;
-        const uint64_t key = ((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab;  // BaseFloat narrowing of :126
-        dk[j - 1] = __longlong_as_double((long long)(emit ? key : 0x7FEFFFFFFFFFFFFFull));
-        mk += emit ? 1 : 0;
-        if (j < R) {
-          double next = ex[j];
-          if (__any(cont)) {  // (skipped unless some frame of the wave has two arcs of one word here)
-            const double folded = fr_log_add_fast(acc, ex[j], lntab);
-            next = cont ? folded : next;
-          }
-          acc = next;
+      // W: the registers this wave sorts -- no bucket of its ranks holds more entries
+      auto rank_round = [&](auto width) {
+        constexpr int W = decltype(width)::value;
+        int mk = 0;
+        // (every load below is unconditional: a load inside a branch waits for its data before the branch
+        // closes, and sixteen gathers would take sixteen trips to L2 one after the other.  The slots beyond
+        // the bucket all read the lattice's first arc: one more request per instruction, not one per lane)
+        uint32_t k32[W];
+  #pragma unroll
+        for (int j = 0; j < W; ++j) k32[j] = (uint32_t)lbucket[lo + j];  // (beyond the buckets lies rtime: read, not used)
+  #pragma unroll
+        for (int j = 0; j < W; ++j) asm volatile("" : "+v"(k32[j]));  // (the reads stay outside the selects)
+  #pragma unroll
+        for (int j = 0; j < W; ++j) k32[j] = (j < w) ? k32[j] : 0u;
+        // (gathers served by L2; 32-bit byte offsets from the lattice's first arc: one address register each)
+        const char* lab_row = reinterpret_cast<const char*>(a.ilabel + a0);
+        const char* x_row = reinterpret_cast<const char*>(xs);
+        {
+          int32_t lab[W];
+  #pragma unroll
+          for (int j = 0; j < W; ++j) lab[j] = *reinterpret_cast<const int32_t*>(lab_row + (k32[j] << 2));
+          // sort keys (label - lab_base | arc number) in 32 bits: a compare-exchange is two instructions and no
+          // payload moves; x is fetched by arc number after the sort
+  #pragma unroll
+          for (int j = 0; j < W; ++j) k32[j] = (j < w) ? (k32[j] | ((uint32_t)(lab[j] - lab_base) << abits)) : 0xFFFFFFFFu;
         }
-      }
-      if (narrow) {
-        fr_sortd_sizes<8, 2, R>(dk);
-      } else if constexpr (R == 16) {
-        fr_sort16_net(dk, FrCeF64());
-      } else {
-        if (medium) fr_sortd_sizes<16, 2, R>(dk);
-        else fr_sortd_sizes<R, 2, R>(dk);
-      }
-      const int frame = (k < tc) ? (int)rtime[c0 + k] : 0, run = (k < tc) ? (int)rtime[c0 + k + 1] - frame : 0;
-      // the records of a rank go where its bucket's entries would (the lattice's piece of the pool has a slot per
-      // entry, and a rank has at most as many records as entries): no scan places them, the waves do not meet here
-      const int dst = (int)rec_at + nbase + lo;  // (counted from the pool's start: a lattice's pieces take their records where they find room)
+        if constexpr (W == 8) fr_sort8_net(k32, FrCeU32());
+        else if constexpr (W == 12) fr_sort12_net(k32, FrCeU32());
+        else if constexpr (W == 16) fr_sort16_net(k32, FrCeU32());
+        else fr_sort32_sizes<W, 2, W>(k32);
+        double ex[W];
+  #pragma unroll
+        for (int j = 0; j < W; ++j) ex[j] = *reinterpret_cast<const double*>(x_row + ((j < w ? k32[j] & amask : 0u) << 3));
+        // fold on the sort keys themselves, the runs of one word in arc order: the key of a run is emitted at its
+        // last entry as the positive finite double desc(float logp) << 30 | label - lab_base (sorted by v_min_f64 /
+        // v_max_f64), the other entries turn into padding
+        double dk[W];
+        double acc = ex[0];
+  #pragma unroll
+        for (int j = 1; j <= W; ++j) {
+          const uint32_t lab = k32[j - 1] >> abits;
+          const bool cont = j < W && j < w && (k32[j < W ? j : 0] >> abits) == lab;
+          const bool emit = !cont && j - 1 < w;
+          const uint64_t key = ((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab;  // BaseFloat narrowing of :126
+          dk[j - 1] = __longlong_as_double((long long)(emit ? key : 0x7FEFFFFFFFFFFFFFull));
+          mk += emit ? 1 : 0;
+          if (j < W) {
+            double next = ex[j];
+            if (__any(cont)) {  // (skipped unless some frame of the wave has two arcs of one word here)
+              const double folded = fr_log_add_fast(acc, ex[j], lntab);
+              next = cont ? folded : next;
+            }
+            acc = next;
+          }
+        }
+        if constexpr (W == 8) fr_sort8_net(dk, FrCeF64());
+        else if constexpr (W == 12) fr_sort12_net(dk, FrCeF64());
+        else if constexpr (W == 16) fr_sort16_net(dk, FrCeF64());
+        else fr_sortd_sizes<W, 2, W>(dk);
+        const int frame = (k < tc) ? (int)rtime[c0 + k] : 0, run = (k < tc) ? (int)rtime[c0 + k + 1] - frame : 0;
+        // the records of a rank go where its bucket's entries would (the lattice's piece of the pool has a slot per
+        // entry, and a rank has at most as many records as entries): no scan places them, the waves do not meet here
+        const int dst = (int)rec_at + nbase + lo;  // (counted from the pool's start: a lattice's pieces take their records where they find room)
+        // 8 bytes per record -- the sort key itself, desc(float logp) << 30 | label - lab_base (rec_fmt tells the gather
+        // kernel) -- written ONCE per rank; every frame names its records by (first record, count), so the frames up
+        // to the next rank share them, and the gather kernel expands the runs into the dense output.
+        // What the stores of this pass cost is the NUMBER of their requests, one per lane and instruction where the lanes'
+        // addresses lie in different lines: a rank's records go two to a store (190 M records one by one on C2), and the
+        // frames' words are written behind the tile's ranks, a lane per frame (lcur, free since the scatter, keeps every
+        // rank's number of records until then)
+        if (k < tc && !wide) lcur[k] = mk;
+        struct __attribute__((packed, aligned(8))) RecordPair {
+          uint64_t first, second;
+        };
+  #pragma unroll
+        for (int j = 0; j < W; j += 2) {
+          if (j + 1 < mk)
+            *reinterpret_cast<RecordPair*>(a.pool + dst + j) = RecordPair{(uint64_t)__double_as_longlong(dk[j]), (uint64_t)__double_as_longlong(dk[j + 1])};
+          else if (j < mk)
+            a.pool[dst + j] = (uint64_t)__double_as_longlong(dk[j]);
+        }
+        dense += mk * run;
+        stored += mk;
+      };
+      if (__all(w <= kW0)) rank_round(std::integral_constant<int, kW0>());  // (wave-uniform)
+      else if (kW1 < R && __all(w <= kW1)) rank_round(std::integral_constant<int, kW1>());
+      else rank_round(std::integral_constant<int, R>());
       if (wide) {
         const int slot = atomicAdd(&wide_n, 1);
         wide_rank[slot] = (uint16_t)k;
       }
-      // 8 bytes per record -- the sort key itself, desc(float logp) << 30 | label - lab_base (rec_fmt tells the gather
-      // kernel) -- written ONCE per rank; every frame names its records by (first record, count), so the frames up
-      // to the next rank share them, and the gather kernel expands the runs into the dense output.
-      // What the stores of this pass cost is the NUMBER of their requests, one per lane and instruction where the lanes'
-      // addresses lie in different lines: a rank's records go two to a store (190 M records one by one on C2), and the
-      // frames' words are written behind the tile's ranks, a lane per frame (lcur, free since the scatter, keeps every
-      // rank's number of records until then)
-      if (k < tc && !wide) lcur[k] = mk;
-      struct __attribute__((packed, aligned(8))) RecordPair {
-        uint64_t first, second;
-      };
-#pragma unroll
-      for (int j = 0; j < R; j += 2) {
-        if (j + 1 < mk)
-          *reinterpret_cast<RecordPair*>(a.pool + dst + j) = RecordPair{(uint64_t)__double_as_longlong(dk[j]), (uint64_t)__double_as_longlong(dk[j + 1])};
-        else if (j < mk)
-          a.pool[dst + j] = (uint64_t)__double_as_longlong(dk[j]);
-      }
-      dense += mk * run;
-      stored += mk;
     }
     __syncthreads();
     // ---- 3w. the ranks with more than R entries, a wave each: one lane per entry, both sorts as bitonic

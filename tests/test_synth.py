@@ -141,16 +141,18 @@ def test_generated_lattices_are_topsorted_connected_and_timed(w):
         assert depth < ns[1] // 4
 
 
-def test_sixteen_key_sorting_network_sorts():
-    """The 60-comparator network of csrc/klat_frame.hip (fr_sort16_net) over all 2^16 zero-one inputs: by the
-    zero-one principle it sorts everything.  (tools/sort_net_check.py is the same check as a script.)"""
+@pytest.mark.parametrize("n,count", [(16, 60), (12, 40), (8, 19)])
+def test_sorting_networks_sort(n, count):
+    """The comparator networks of csrc/klat_frame.hip (fr_sort16_net, fr_sort12_net, fr_sort8_net) over all 2^n
+    zero-one inputs: by the zero-one principle they sort everything.  (tools/sort_net_check.py is the same check as a
+    script.)"""
     import re
     src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kaldi-lattice-utils_amd", "csrc", "klat_frame.hip")).read()
-    body = src[src.index("void fr_sort16_net"):]
+    body = src[src.index("void fr_sort%d_net" % n):]
     body = body[:body.index("\n}\n")]
     ces = [(int(a), int(b)) for a, b in re.findall(r"ce\(k\[(\d+)\], k\[(\d+)\]\)", body)]
-    assert len(ces) == 60
-    x = ((np.arange(1 << 16)[:, None] >> np.arange(16)) & 1).astype(np.int8)
+    assert len(ces) == count and all(a < b < n for a, b in ces)
+    x = ((np.arange(1 << n)[:, None] >> np.arange(n)) & 1).astype(np.int8)
     for a, b in ces:
         lo, hi = np.minimum(x[:, a], x[:, b]), np.maximum(x[:, a], x[:, b])
         x[:, a], x[:, b] = lo, hi
