@@ -1030,7 +1030,7 @@ static constexpr int kLnWideMax = 64;   // a rank with more than kFrRegs entries
 // pays for its registers with half the waves -- a wave per rank of more than sixteen entries, the only other way this
 // kernel has, costs forty times a thread per rank.
 template <bool BIG, bool CLOCK, int SC, bool PIECES = false, int R = kFrRegs, bool DENSE = false>
-__global__ __launch_bounds__(kFrLeanThreads / SC, BIG && R == kFrRegs ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
+__global__ __launch_bounds__(kFrLeanThreads / SC, (BIG || CLOCK) && R == kFrRegs ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
   static_assert(!DENSE || (BIG && R == 2 * kFrRegs), "the dense pass is the second instantiation with thirty-two registers a rank");
   static_assert(!BIG || SC == 1, "the second instantiation is full size");
   static_assert(!PIECES || BIG, "pieces take the second instantiation");
