@@ -405,6 +405,45 @@ __device__ __forceinline__ void fr_sort12_net(T (&k)[12], CE ce) {
   ce(k[3], k[4]); ce(k[5], k[6]); ce(k[7], k[8]);
   ce(k[6], k[7]); ce(k[8], k[9]);
 }
+// Twenty-four and thirty-two keys (the dense pass): Batcher's merge exchange (Knuth 5.2.2 M, which sorts any number of
+// keys): 127 and 191 comparators, where the bitonic network takes 240 for thirty-two and has no form for twenty-four.
+// (tools/sort_net_check.py: the first over all 2^24 zero-one inputs, the second over a sample of them.)
+template <class T, class CE>
+__device__ __forceinline__ void fr_sort24_net(T (&k)[24], CE ce) {
+  ce(k[0], k[16]); ce(k[1], k[17]); ce(k[2], k[18]); ce(k[3], k[19]); ce(k[4], k[20]); ce(k[5], k[21]); ce(k[6], k[22]); ce(k[7], k[23]);
+  ce(k[0], k[8]); ce(k[1], k[9]); ce(k[2], k[10]); ce(k[3], k[11]); ce(k[4], k[12]); ce(k[5], k[13]); ce(k[6], k[14]); ce(k[7], k[15]);
+  ce(k[8], k[16]); ce(k[9], k[17]); ce(k[10], k[18]); ce(k[11], k[19]); ce(k[12], k[20]); ce(k[13], k[21]); ce(k[14], k[22]); ce(k[15], k[23]); ce(k[0], k[4]); ce(k[1], k[5]); ce(k[2], k[6]); ce(k[3], k[7]);
+  ce(k[8], k[12]); ce(k[9], k[13]); ce(k[10], k[14]); ce(k[11], k[15]); ce(k[16], k[20]); ce(k[17], k[21]); ce(k[18], k[22]); ce(k[19], k[23]); ce(k[0], k[2]); ce(k[1], k[3]);
+  ce(k[4], k[16]); ce(k[5], k[17]); ce(k[6], k[18]); ce(k[7], k[19]); ce(k[20], k[22]); ce(k[21], k[23]); ce(k[0], k[1]);
+  ce(k[4], k[8]); ce(k[5], k[9]); ce(k[6], k[10]); ce(k[7], k[11]); ce(k[12], k[16]); ce(k[13], k[17]); ce(k[14], k[18]); ce(k[15], k[19]); ce(k[22], k[23]);
+  ce(k[4], k[6]); ce(k[5], k[7]); ce(k[8], k[10]); ce(k[9], k[11]); ce(k[12], k[14]); ce(k[13], k[15]); ce(k[16], k[18]); ce(k[17], k[19]);
+  ce(k[2], k[16]); ce(k[3], k[17]); ce(k[6], k[20]); ce(k[7], k[21]);
+  ce(k[2], k[8]); ce(k[3], k[9]); ce(k[6], k[12]); ce(k[7], k[13]); ce(k[10], k[16]); ce(k[11], k[17]); ce(k[14], k[20]); ce(k[15], k[21]);
+  ce(k[2], k[4]); ce(k[3], k[5]); ce(k[6], k[8]); ce(k[7], k[9]); ce(k[10], k[12]); ce(k[11], k[13]); ce(k[14], k[16]); ce(k[15], k[17]); ce(k[18], k[20]); ce(k[19], k[21]);
+  ce(k[2], k[3]); ce(k[4], k[5]); ce(k[6], k[7]); ce(k[8], k[9]); ce(k[10], k[11]); ce(k[12], k[13]); ce(k[14], k[15]); ce(k[16], k[17]); ce(k[18], k[19]); ce(k[20], k[21]);
+  ce(k[1], k[16]); ce(k[3], k[18]); ce(k[5], k[20]); ce(k[7], k[22]);
+  ce(k[1], k[8]); ce(k[3], k[10]); ce(k[5], k[12]); ce(k[7], k[14]); ce(k[9], k[16]); ce(k[11], k[18]); ce(k[13], k[20]); ce(k[15], k[22]);
+  ce(k[1], k[4]); ce(k[3], k[6]); ce(k[5], k[8]); ce(k[7], k[10]); ce(k[9], k[12]); ce(k[11], k[14]); ce(k[13], k[16]); ce(k[15], k[18]); ce(k[17], k[20]); ce(k[19], k[22]);
+  ce(k[1], k[2]); ce(k[3], k[4]); ce(k[5], k[6]); ce(k[7], k[8]); ce(k[9], k[10]); ce(k[11], k[12]); ce(k[13], k[14]); ce(k[15], k[16]); ce(k[17], k[18]); ce(k[19], k[20]); ce(k[21], k[22]);
+}
+template <class T, class CE>
+__device__ __forceinline__ void fr_sort32_net(T (&k)[32], CE ce) {
+  ce(k[0], k[16]); ce(k[1], k[17]); ce(k[2], k[18]); ce(k[3], k[19]); ce(k[4], k[20]); ce(k[5], k[21]); ce(k[6], k[22]); ce(k[7], k[23]); ce(k[8], k[24]); ce(k[9], k[25]); ce(k[10], k[26]); ce(k[11], k[27]); ce(k[12], k[28]); ce(k[13], k[29]); ce(k[14], k[30]); ce(k[15], k[31]);
+  ce(k[0], k[8]); ce(k[1], k[9]); ce(k[2], k[10]); ce(k[3], k[11]); ce(k[4], k[12]); ce(k[5], k[13]); ce(k[6], k[14]); ce(k[7], k[15]); ce(k[16], k[24]); ce(k[17], k[25]); ce(k[18], k[26]); ce(k[19], k[27]); ce(k[20], k[28]); ce(k[21], k[29]); ce(k[22], k[30]); ce(k[23], k[31]);
+  ce(k[8], k[16]); ce(k[9], k[17]); ce(k[10], k[18]); ce(k[11], k[19]); ce(k[12], k[20]); ce(k[13], k[21]); ce(k[14], k[22]); ce(k[15], k[23]); ce(k[0], k[4]); ce(k[1], k[5]); ce(k[2], k[6]); ce(k[3], k[7]); ce(k[24], k[28]); ce(k[25], k[29]); ce(k[26], k[30]); ce(k[27], k[31]);
+  ce(k[8], k[12]); ce(k[9], k[13]); ce(k[10], k[14]); ce(k[11], k[15]); ce(k[16], k[20]); ce(k[17], k[21]); ce(k[18], k[22]); ce(k[19], k[23]); ce(k[0], k[2]); ce(k[1], k[3]); ce(k[28], k[30]); ce(k[29], k[31]);
+  ce(k[4], k[16]); ce(k[5], k[17]); ce(k[6], k[18]); ce(k[7], k[19]); ce(k[12], k[24]); ce(k[13], k[25]); ce(k[14], k[26]); ce(k[15], k[27]); ce(k[0], k[1]); ce(k[30], k[31]);
+  ce(k[4], k[8]); ce(k[5], k[9]); ce(k[6], k[10]); ce(k[7], k[11]); ce(k[12], k[16]); ce(k[13], k[17]); ce(k[14], k[18]); ce(k[15], k[19]); ce(k[20], k[24]); ce(k[21], k[25]); ce(k[22], k[26]); ce(k[23], k[27]);
+  ce(k[4], k[6]); ce(k[5], k[7]); ce(k[8], k[10]); ce(k[9], k[11]); ce(k[12], k[14]); ce(k[13], k[15]); ce(k[16], k[18]); ce(k[17], k[19]); ce(k[20], k[22]); ce(k[21], k[23]); ce(k[24], k[26]); ce(k[25], k[27]);
+  ce(k[2], k[16]); ce(k[3], k[17]); ce(k[6], k[20]); ce(k[7], k[21]); ce(k[10], k[24]); ce(k[11], k[25]); ce(k[14], k[28]); ce(k[15], k[29]);
+  ce(k[2], k[8]); ce(k[3], k[9]); ce(k[6], k[12]); ce(k[7], k[13]); ce(k[10], k[16]); ce(k[11], k[17]); ce(k[14], k[20]); ce(k[15], k[21]); ce(k[18], k[24]); ce(k[19], k[25]); ce(k[22], k[28]); ce(k[23], k[29]);
+  ce(k[2], k[4]); ce(k[3], k[5]); ce(k[6], k[8]); ce(k[7], k[9]); ce(k[10], k[12]); ce(k[11], k[13]); ce(k[14], k[16]); ce(k[15], k[17]); ce(k[18], k[20]); ce(k[19], k[21]); ce(k[22], k[24]); ce(k[23], k[25]); ce(k[26], k[28]); ce(k[27], k[29]);
+  ce(k[2], k[3]); ce(k[4], k[5]); ce(k[6], k[7]); ce(k[8], k[9]); ce(k[10], k[11]); ce(k[12], k[13]); ce(k[14], k[15]); ce(k[16], k[17]); ce(k[18], k[19]); ce(k[20], k[21]); ce(k[22], k[23]); ce(k[24], k[25]); ce(k[26], k[27]); ce(k[28], k[29]);
+  ce(k[1], k[16]); ce(k[3], k[18]); ce(k[5], k[20]); ce(k[7], k[22]); ce(k[9], k[24]); ce(k[11], k[26]); ce(k[13], k[28]); ce(k[15], k[30]);
+  ce(k[1], k[8]); ce(k[3], k[10]); ce(k[5], k[12]); ce(k[7], k[14]); ce(k[9], k[16]); ce(k[11], k[18]); ce(k[13], k[20]); ce(k[15], k[22]); ce(k[17], k[24]); ce(k[19], k[26]); ce(k[21], k[28]); ce(k[23], k[30]);
+  ce(k[1], k[4]); ce(k[3], k[6]); ce(k[5], k[8]); ce(k[7], k[10]); ce(k[9], k[12]); ce(k[11], k[14]); ce(k[13], k[16]); ce(k[15], k[18]); ce(k[17], k[20]); ce(k[19], k[22]); ce(k[21], k[24]); ce(k[23], k[26]); ce(k[25], k[28]); ce(k[27], k[30]);
+  ce(k[1], k[2]); ce(k[3], k[4]); ce(k[5], k[6]); ce(k[7], k[8]); ce(k[9], k[10]); ce(k[11], k[12]); ce(k[13], k[14]); ce(k[15], k[16]); ce(k[17], k[18]); ce(k[19], k[20]); ce(k[21], k[22]); ce(k[23], k[24]); ce(k[25], k[26]); ce(k[27], k[28]); ce(k[29], k[30]);
+}
 struct FrCeU32 {
   __device__ __forceinline__ void operator()(uint32_t& lo, uint32_t& hi) const {
     const uint32_t a = min(lo, hi), b = max(lo, hi);
@@ -1056,7 +1095,7 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, (BIG || CLOCK) && R == kFrRegs
   // lattices whose frames hold ten arcs or so (one rank in four has eight entries or fewer, all but one in thirty twelve
   // or fewer) a wave of consecutive ranks nearly always held one of more than twelve
   __shared__ uint16_t order[kTile];
-  constexpr int kW0 = R == kFrRegs ? 8 : 16, kW1 = R == kFrRegs ? 12 : R;
+  constexpr int kW0 = R == kFrRegs ? 8 : 16, kW1 = R == kFrRegs ? 12 : 24;
   __shared__ int blk_first[kLnStates / kLnBlock + 2];  // first arc whose first rank lies in or behind block b of kLnBlock ranks
   __shared__ unsigned long long rec_at;
   __shared__ LnTabEntry lntab[kLnTabSize];
@@ -1498,6 +1537,8 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, (BIG || CLOCK) && R == kFrRegs
         if constexpr (W == 8) fr_sort8_net(k32, FrCeU32());
         else if constexpr (W == 12) fr_sort12_net(k32, FrCeU32());
         else if constexpr (W == 16) fr_sort16_net(k32, FrCeU32());
+        else if constexpr (W == 24) fr_sort24_net(k32, FrCeU32());
+        else if constexpr (W == 32) fr_sort32_net(k32, FrCeU32());
         else fr_sort32_sizes<W, 2, W>(k32);
         double ex[W];
   #pragma unroll
@@ -1527,6 +1568,8 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, (BIG || CLOCK) && R == kFrRegs
         if constexpr (W == 8) fr_sort8_net(dk, FrCeF64());
         else if constexpr (W == 12) fr_sort12_net(dk, FrCeF64());
         else if constexpr (W == 16) fr_sort16_net(dk, FrCeF64());
+        else if constexpr (W == 24) fr_sort24_net(dk, FrCeF64());
+        else if constexpr (W == 32) fr_sort32_net(dk, FrCeF64());
         else fr_sortd_sizes<W, 2, W>(dk);
         const int frame = (k < tc) ? (int)rtime[c0 + k] : 0, run = (k < tc) ? (int)rtime[c0 + k + 1] - frame : 0;
         // the records of a rank go where its bucket's entries would (the lattice's piece of the pool has a slot per
