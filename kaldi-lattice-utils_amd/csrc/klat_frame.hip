@@ -1068,12 +1068,15 @@ static constexpr int kLnWideMax = 64;   // a rank with more than kFrRegs entries
 // a.piece_dense) and left to the instantiation with thirty-two (DENSE), which
 // pays for its registers with half the waves -- a wave per rank of more than sixteen entries, the only other way this
 // kernel has, costs forty times a thread per rank.
-template <bool BIG, bool CLOCK, int SC, bool PIECES = false, int R = kFrRegs, bool DENSE = false>
-__global__ __launch_bounds__(kFrLeanThreads / SC, (BIG || CLOCK) && R == kFrRegs ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
+template <bool BIG, bool CLOCK, int SC, bool PIECES = false, int R = kFrRegs, int DENSE = 0>
+__global__ __launch_bounds__(kFrLeanThreads / SC / (DENSE == 2 ? 2 : 1), (BIG || CLOCK) && R == kFrRegs ? 4 : 1) void frame_lean_kernel(FrameArgs a, int span_cap) {
   static_assert(!DENSE || (BIG && R == 2 * kFrRegs), "the dense pass is the second instantiation with thirty-two registers a rank");
   static_assert(!BIG || SC == 1, "the second instantiation is full size");
   static_assert(!PIECES || BIG, "pieces take the second instantiation");
-  constexpr int NT = kFrLeanThreads / SC;
+  // (the dense pass: thirty-two registers a rank leave two waves a SIMD, one workgroup of 512 a CU.  DENSE == 2: two
+  // workgroups of 256 instead, two lattices whose phases overlap -- a fifth faster where the pass has lattices for four
+  // rounds of that and more, slower where it has few: the host chooses)
+  constexpr int NT = kFrLeanThreads / SC / (DENSE == 2 ? 2 : 1);
   constexpr int kEntries = kFrLdsEntries / SC;    // bucket entries of a tile in LDS
   constexpr int kStatesLds = kLnStatesLds / SC;   // states of a lattice whose spans stay in LDS
   constexpr int kTile = kLnTile / SC;             // ranks per tile
@@ -1234,7 +1237,7 @@ __global__ __launch_bounds__(kFrLeanThreads / SC, (BIG || CLOCK) && R == kFrRegs
   // for all of them).
   for (int base = 0; base < (BIG ? nA : 1); base += 2 * kLnBatch * NT) {
     int lmin_t = 0x7FFFFFFF, lmax_t = (int)0x80000000, span_max_t = 0, entries_t = 0;  // (reduced at the end of the trip: nothing of a thread's lives across trips)
-    static_assert(2 * kLnBatch * NT >= kFrLdsSpans / SC, "one trip covers the arcs of a lattice whose spans stay in LDS");
+    static_assert(BIG || 2 * kLnBatch * NT >= kFrLdsSpans / SC, "one trip covers the arcs of a lattice whose spans stay in LDS");
     int il[2][kLnBatch], t0[2][kLnBatch], t1[2][kLnBatch];
     float gr[2][kLnBatch], ac4[2][kLnBatch];
     double xq[2][kLnBatch];
@@ -1808,14 +1811,19 @@ hipError_t launch_frame_lean_dense(const FrameArgs& a, int num_lattices, int num
   const int span_cap = kFrLdsSpans;
   const size_t lds = std::max(sizeof(uint16_t) * kFrLdsEntries + sizeof(uint16_t) * (kLnStatesLds + 2) + sizeof(uint32_t) * (size_t)span_cap,
                               sizeof(uint16_t) * kFrLdsEntries + sizeof(uint16_t) * (kLnStates + 2));
-  if (num_lattices > 0) {
-    auto lean = a.phase_clock ? &frame_lean_kernel<true, true, 1, false, 2 * kFrRegs, true> : &frame_lean_kernel<true, false, 1, false, 2 * kFrRegs, true>;
+  if (num_lattices >= 2048) {  // (eight lattices a CU and more)
+    auto lean = a.phase_clock ? &frame_lean_kernel<true, true, 1, false, 2 * kFrRegs, 2> : &frame_lean_kernel<true, false, 1, false, 2 * kFrRegs, 2>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads / 2), lds, stream, a, span_cap);
+  } else if (num_lattices > 0) {
+    auto lean = a.phase_clock ? &frame_lean_kernel<true, true, 1, false, 2 * kFrRegs, 1> : &frame_lean_kernel<true, false, 1, false, 2 * kFrRegs, 1>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lean, dim3(num_lattices), dim3(kFrLeanThreads), lds, stream, a, span_cap);
   }
-  if (num_slots > 0) {
-    auto lean = a.phase_clock ? &frame_lean_kernel<true, true, 1, true, 2 * kFrRegs, true> : &frame_lean_kernel<true, false, 1, true, 2 * kFrRegs, true>;
+  if (num_slots > 0) {  // (how many of the pieces are dense only the device knows: workgroups of 512)
+    auto lean = a.phase_clock ? &frame_lean_kernel<true, true, 1, true, 2 * kFrRegs, 1> : &frame_lean_kernel<true, false, 1, true, 2 * kFrRegs, 1>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lean, dim3(num_slots), dim3(kFrLeanThreads), lds, stream, a, span_cap);
