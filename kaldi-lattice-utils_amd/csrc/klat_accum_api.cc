@@ -228,17 +228,28 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       a.piece_first = st.piece_first.p, a.piece_count = st.piece_count.p, a.item_records = st.item_records.p, a.piece_items = st.piece_items.p;
       st.pieces_live = true;
       KLAT_HIP(hipMemsetAsync(st.piece_count.p, 0, sizeof(int32_t) * (size_t)b->U, c->stream));
-      for (int k = 0; k < kHashClasses; ++k)
-        KLAT_HIP(launch_index_hash2(a, pk, position, k, st.class_items.p + st.class_begin[k], (int)(st.class_begin[k + 1] - st.class_begin[k]), c->stream));
+      // A batch of one size has one class, one launch.  A mixed one has up to eight, most of them with fewer workgroups
+      // than the device holds (a class of 142 lattices takes as long as one of its lattices): the long lattices' chain
+      // (slicing, pieces, general kernel) on the context's stream, the classes on side streams, largest first.
+      std::vector<SweepPiece> work;
+      AccumArgs long_args = a;
       if (st.num_long > 0) {
         // long lattices: cut where the source states' time changes, the pieces through the two largest classes' kernel
         // (a piece has at most kPieceStride + kPieceWindow = 15 360 arcs), what could not be cut through the general kernel
-        KLAT_HIP(launch_index_slice(a, position, st.long_list.p, (int)st.num_long, c->stream));
-        KLAT_HIP(launch_index_hash2(a, pk, position, kHashClasses - 2, st.piece_items.p, (int)st.num_piece_slots, c->stream));
-        a.min_arcs = kHashClassArcs[kHashClasses - 1], a.max_arcs = 0x7FFFFFFF;
-        KLAT_HIP(launch_index(a, (int)b->U, position, c->stream));
-        a.min_arcs = -1, a.max_arcs = 0x7FFFFFFF;
+        long_args.min_arcs = kHashClassArcs[kHashClasses - 1], long_args.max_arcs = 0x7FFFFFFF;
+        work.push_back(SweepPiece{0, [&](hipStream_t s) {
+                                    hipError_t e = launch_index_slice(a, position, st.long_list.p, (int)st.num_long, s);
+                                    if (e == hipSuccess) e = launch_index_hash2(a, pk, position, kHashClasses - 2, st.piece_items.p, (int)st.num_piece_slots, s);
+                                    if (e == hipSuccess) e = launch_index(long_args, (int)b->U, position, s);
+                                    return e;
+                                  }});
       }
+      for (int k = kHashClasses - 1, slot = work.empty() ? 0 : 1; k >= 0; --k) {
+        const int count = (int)(st.class_begin[k + 1] - st.class_begin[k]);
+        if (count <= 0) continue;
+        work.push_back(SweepPiece{slot++, [&, k, count](hipStream_t s) { return launch_index_hash2(a, pk, position, k, st.class_items.p + st.class_begin[k], count, s); }});
+      }
+      if ((rc = run_side_by_side(c, work))) return rc;
     } else {
       st.pieces_live = false;  // (every lattice through the general kernel: whole)
       a.piece_first = nullptr, a.piece_count = nullptr, a.item_records = nullptr, a.piece_items = nullptr;
@@ -533,19 +544,33 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
         KLAT_HIP(hipStreamSynchronize(c->stream));  // (the list is a local)
         st.classes_ready = true;
       }
-      for (int k = 0; k < kFrameClasses; ++k) {
-        a.lattice_list = st.class_list.p + st.class_begin[k];
-        KLAT_HIP(launch_frame_lean(a, (int)(st.class_begin[k + 1] - st.class_begin[k]), st.class_max_arcs[k], false, k, c->stream));
-      }
-      a.lattice_list = nullptr;
       if (st.num_long > 0) {  // long lattices: sliced on the device, the pieces through the second instantiation
         a.piece_items = st.piece_items.p, a.piece_first = st.piece_first.p, a.piece_scratch = st.piece_scratch.p;
         a.piece_scratch_used = st.pool_used.p + 2, a.piece_scratch_cap = st.piece_scratch_cap;
         if ((rc = st.piece_dense.alloc((size_t)st.num_piece_slots))) return rc;
         a.piece_dense = st.piece_dense.p;
         KLAT_HIP(hipMemsetAsync(a.piece_dense, 0, sizeof(int32_t) * (size_t)st.num_piece_slots, c->stream));
-        KLAT_HIP(launch_frame_slice(a, st.long_list.p, (int)st.num_long, c->stream));
-        KLAT_HIP(launch_frame_lean_pieces(a, (int)st.num_piece_slots, c->stream));
+      }
+      {
+        // the long lattices' chain on the context's stream, the size classes beside it on side streams, largest first (a
+        // mixed batch's classes have fewer workgroups than the device holds; a batch of one size has one launch)
+        std::vector<SweepPiece> work;
+        if (st.num_long > 0)
+          work.push_back(SweepPiece{0, [&](hipStream_t s) {
+                                      hipError_t e = launch_frame_slice(a, st.long_list.p, (int)st.num_long, s);
+                                      if (e == hipSuccess) e = launch_frame_lean_pieces(a, (int)st.num_piece_slots, s);
+                                      return e;
+                                    }});
+        for (int k = kFrameClasses - 1, slot = work.empty() ? 0 : 1; k >= 0; --k) {
+          const int count = (int)(st.class_begin[k + 1] - st.class_begin[k]);
+          if (count <= 0) continue;
+          work.push_back(SweepPiece{slot++, [&, k, count](hipStream_t s) {
+                                      FrameArgs ak = a;
+                                      ak.lattice_list = st.class_list.p + st.class_begin[k];
+                                      return launch_frame_lean(ak, count, st.class_max_arcs[k], false, k, s);
+                                    }});
+        }
+        if ((rc = run_side_by_side(c, work))) return rc;
       }
       if ((rc = print_clock("frame_lean_kernel"))) return rc;
       struct {

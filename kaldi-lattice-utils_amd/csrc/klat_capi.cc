@@ -54,10 +54,6 @@ using namespace klat;
 // may take several pieces: a class's fast sweep goes out FIRST, before the eight launches of the segment path
 // (a launch is ~10 us of host time, and a class that started 200 us late finished 200 us late), its exact
 // sweep after them.
-struct SweepPiece {
-  int slot;
-  std::function<hipError_t(hipStream_t)> launch;
-};
 static int ensure_side_streams(klat_ctx* c) {
   if (c->fork_ev) return KLAT_OK;  // (a helper context of klat_forward_backward_host is made without them)
   KLAT_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
@@ -67,7 +63,7 @@ static int ensure_side_streams(klat_ctx* c) {
   }
   return KLAT_OK;
 }
-static int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
+int klat::run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work) {
   int most = 0;
   for (const SweepPiece& w : work) most = std::max(most, w.slot);
   if (most == 0) {

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -170,6 +171,14 @@ struct DevBuf {
     return KLAT_OK;
   }
 };
+
+// Launches side by side (klat_capi.cc): the first on the context's stream, the others on side streams that fork from it
+// and join it again.  A piece names its stream (0: the context's; 1 ..: a side stream) and is launched in list order.
+struct SweepPiece {
+  int slot;
+  std::function<hipError_t(hipStream_t)> launch;
+};
+int run_side_by_side(klat_ctx* c, const std::vector<SweepPiece>& work);
 
 }  // namespace klat
 
