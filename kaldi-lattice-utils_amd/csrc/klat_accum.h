@@ -213,10 +213,12 @@ hipError_t launch_frame_count(const FrameArgs& a, int num_lattices, hipStream_t 
 hipError_t launch_frame(const FrameArgs& a, int num_lattices, int max_arcs, hipStream_t stream);
 // The lean kernel's size classes: class c takes the lattices of at most kFrameClassArcs[c] arcs and kFrameClassStates[c]
 // states (workgroups of 128 / 256 / 512 threads with 16 / 32 / 64 KiB of LDS), listed in a.lattice_list; the last class
-// whatever is left.  big: the second instantiation over a.redo_list.
-static const int kFrameClasses = 3;
-static const int kFrameClassArcs[kFrameClasses] = {1536, 3072, 0x7FFFFFFF};
-static const int kFrameClassStates[kFrameClasses] = {1024, 2048, 0x7FFFFFFF};
+// whatever is left: the lattices whose spans do not fit LDS, which the host hands to the second instantiation at once
+// (listed in a.redo_list, their number in a.redo_n) instead of to the first, which would only list them.  big: the second
+// instantiation over a.redo_list.
+static const int kFrameClasses = 4;
+static const int kFrameClassArcs[kFrameClasses] = {1536, 3072, 6144, 0x7FFFFFFF};
+static const int kFrameClassStates[kFrameClasses] = {1024, 2048, 4096, 0x7FFFFFFF};
 hipError_t launch_frame_lean(const FrameArgs& a, int num_lattices, int max_arcs, bool big, int size_class, hipStream_t stream);
 // Long lattices: pieces of kFramePieceStates own states (the cut moved up to kFramePieceWindow states forward, to where the
 // time changes) through the lean kernel's second instantiation; a lattice whose times descend somewhere along its states,

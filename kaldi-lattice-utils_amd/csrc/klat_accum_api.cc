@@ -541,6 +541,8 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
           st.class_max_arcs[k] = (int32_t)std::max<int64_t>(st.class_max_arcs[k], std::min<int64_t>(b->h_arc_off[u + 1] - b->h_arc_off[u], 1 << 30));
         }
         if ((rc = st.class_list.upload(list.data(), list.size(), c->stream))) return rc;
+        const int32_t big_n = (int32_t)(st.class_begin[kFrameClasses] - st.class_begin[kFrameClasses - 1]);
+        if ((rc = st.big_n.upload(&big_n, 1, c->stream))) return rc;
         KLAT_HIP(hipStreamSynchronize(c->stream));  // (the list is a local)
         st.classes_ready = true;
       }
@@ -566,6 +568,10 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
           if (count <= 0) continue;
           work.push_back(SweepPiece{slot++, [&, k, count](hipStream_t s) {
                                       FrameArgs ak = a;
+                                      if (k == kFrameClasses - 1) {  // (spans in L2: the second instantiation, over this list)
+                                        ak.redo_list = st.class_list.p + st.class_begin[k], ak.redo_n = st.big_n.p;
+                                        return launch_frame_lean(ak, count, st.class_max_arcs[k], true, 0, s);
+                                      }
                                       ak.lattice_list = st.class_list.p + st.class_begin[k];
                                       return launch_frame_lean(ak, count, st.class_max_arcs[k], false, k, s);
                                     }});
@@ -581,7 +587,7 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       KLAT_HIP(hipStreamSynchronize(c->stream));
       const int32_t first_n = back.first_n, dense_n = back.dense_n;
       unsigned long long used[2] = {back.used[0], back.used[1]};
-      redo_n = st.num_long > 0 ? back.general_n : 0;  // (so far only the slicing lists for the general kernel)
+      redo_n = back.general_n;  // (so far the slicing and the last class list for the general kernel)
       unsigned long long need = used[0];
       const unsigned long long short_first = used[1];
       if (first_n > 0) {  // larger lattices (spans in L2), and one more try for what else did not fit
@@ -591,7 +597,13 @@ int klat_frame_post(klat_batch* b, const int32_t* num_frames, int64_t* frame_off
       // the lattices and pieces marked dense (more than twelve entries a rank): thirty-two registers a rank
       // (the second instantiation, still running, may list up to first_n more)
       if (first_n > 0 || dense_n > 0 || st.num_long > 0) {  // (a batch the first instantiation finished has nothing more to wait for)
-        KLAT_HIP(launch_frame_lean_dense(a, (int)std::min<int64_t>(b->U, (int64_t)dense_n + first_n), st.num_long > 0 ? (int)st.num_piece_slots : 0, c->stream));
+        {  // (the dense lattices and the dense pieces side by side: either has a workgroup a CU, and a few rounds of them)
+          const int dense_lattices = (int)std::min<int64_t>(b->U, (int64_t)dense_n + first_n), dense_slots = st.num_long > 0 ? (int)st.num_piece_slots : 0;
+          std::vector<SweepPiece> work;
+          if (dense_slots > 0) work.push_back(SweepPiece{0, [&, dense_slots](hipStream_t s) { return launch_frame_lean_dense(a, 0, dense_slots, s); }});
+          if (dense_lattices > 0) work.push_back(SweepPiece{(int)work.size(), [&, dense_lattices](hipStream_t s) { return launch_frame_lean_dense(a, dense_lattices, 0, s); }});
+          if ((rc = run_side_by_side(c, work))) return rc;
+        }
         if ((rc = print_clock("frame_lean_kernel (dense pass)"))) return rc;
         KLAT_HIP(hipMemcpyAsync(&back, st.pool_used.p, sizeof(back), hipMemcpyDeviceToHost, c->stream));
         KLAT_HIP(hipStreamSynchronize(c->stream));

@@ -252,7 +252,7 @@ struct klat_frame_state {
   klat::DevBuf<int64_t> rec_fmt;           // [U] their format (klat_accum.h)
   // the lean kernel's size classes: class c's lattices are class_list[class_begin[c] .. class_begin[c + 1])
   bool classes_ready = false;
-  klat::DevBuf<int32_t> class_list, listed, dense, piece_dense;
+  klat::DevBuf<int32_t> class_list, listed, dense, piece_dense, big_n;  // big_n: one word, the last class's size
   // lattices too long for the lean kernel, sliced on the device (frame_slice_kernel)
   int64_t num_long = 0, num_piece_slots = 0, piece_scratch_cap = 0;
   klat::DevBuf<int32_t> long_list, piece_first;
