@@ -982,60 +982,150 @@ __global__ __launch_bounds__(kFrThreads) void frame_kernel(FrameArgs a, int span
 // A rank of the lean kernel with more than kFrRegs (and at most 64) entries, by one wave: one lane per entry, both
 // sorts as bitonic networks across the lanes, the fold entry by entry in arc order; returns the records written.
 // (Rare, and kept out of line: inlined, its registers would be the lean kernel's.)
+// The value of lane (l ^ STRIDE), without a trip through the LDS crossbar (ds_bpermute: ~100 cycles each, and a bitonic
+// network over a wave is 21 of them one after the other): quad permutes for 1 and 2, a pair of row shifts under
+// complementary bank masks for 4 and 8 (a bank is four lanes: the banks whose lanes have the stride's bit clear read
+// upwards, the others downwards), and gfx950's v_permlane16_swap / v_permlane32_swap for 16 and 32 (both operands the
+// value itself: the two results hold every row's / half's neighbour).
+template <int STRIDE>
+__device__ __forceinline__ uint32_t fr_lane_xor(uint32_t v, int lane) {
+  static_assert(STRIDE == 1 || STRIDE == 2 || STRIDE == 4 || STRIDE == 8 || STRIDE == 16 || STRIDE == 32, "a power of two below the wave");
+  if constexpr (STRIDE == 1) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm:[1,0,3,2]
+  } else if constexpr (STRIDE == 2) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm:[2,3,0,1]
+  } else if constexpr (STRIDE == 4) {
+    const int up = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);   // row_shl:4 into banks 0, 2
+    return (uint32_t)__builtin_amdgcn_update_dpp(up, (int)v, 0x114, 0xF, 0xA, false);  // row_shr:4 into banks 1, 3
+  } else if constexpr (STRIDE == 8) {
+    const int up = __builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xF, 0x3, false);   // row_shl:8 into banks 0, 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(up, (int)v, 0x118, 0xF, 0xC, false);  // row_shr:8 into banks 2, 3
+  } else if constexpr (STRIDE == 16) {
+    const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (lane & 16) ? p[0] : p[1];
+  } else {
+    const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? p[0] : p[1];
+  }
+}
+template <int STRIDE>
+__device__ __forceinline__ double fr_lane_xor(double v, int lane) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = fr_lane_xor<STRIDE>((uint32_t)b, lane), hi = fr_lane_xor<STRIDE>((uint32_t)(b >> 32), lane);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// Bitonic network over 64 * NR keys, NR a lane (key[r] of lane l is element r * 64 + l), ascending; pick(a, b, take_min)
+// is the comparator.  Strides below 64 pair lanes of one register, the stride of 64 pairs a lane's own two registers.
+template <int NR, int SIZE, int STRIDE, class T, class Pick>
+__device__ __forceinline__ void fr_wave_sort_stage(T (&key)[NR], int lane, Pick pick) {
+  if constexpr (STRIDE == 64) {
+    static_assert(NR == 2 && SIZE == 128, "the last merge of two registers a lane");
+    const T lo = pick(key[0], key[1], true), hi = pick(key[0], key[1], false);
+    key[0] = lo, key[1] = hi;
+  } else {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const T other = fr_lane_xor<STRIDE>(key[r], lane);
+      const bool up = ((lane | (r << 6)) & SIZE) == 0, lower = (lane & STRIDE) == 0;
+      key[r] = pick(key[r], other, up == lower);  // the lower lane of an ascending pair keeps the smaller key (padding sorts last)
+    }
+  }
+  if constexpr (STRIDE > 1) fr_wave_sort_stage<NR, SIZE, STRIDE / 2>(key, lane, pick);
+}
+template <int NR, int SIZE, class T, class Pick>
+__device__ __forceinline__ void fr_wave_sort_sizes(T (&key)[NR], int lane, Pick pick) {
+  fr_wave_sort_stage<NR, SIZE, SIZE / 2>(key, lane, pick);
+  if constexpr (SIZE < 64 * NR) fr_wave_sort_sizes<NR, SIZE * 2>(key, lane, pick);
+}
+
+// A rank of more than R and at most 64 * NR entries, by a whole wave: NR entries a lane (entry r * 64 + l in register r of
+// lane l), both sorts as networks across the lanes.
+template <int NR>
 __device__ __noinline__ int fr_lean_wide_rank(const uint16_t* bucket /* LDS */, int w, const int32_t* labels, const double* xs,
                                           int lab_base, int abits, const LnTabEntry* lntab /* LDS */, uint64_t* out) {
   const int lane = threadIdx.x & 63;
-  uint32_t key = 0xFFFFFFFFu;
-  if (lane < w) {
-    const int arc = (int)bucket[lane];
-    key = (uint32_t)arc | ((uint32_t)(labels[arc] - lab_base) << abits);
-  }
-  // (the keys alone go through the network -- every stage is a trip through the LDS crossbar per 32 bits --, x is fetched
-  // by arc number afterwards, as the thread-per-rank path does)
-  for (int size = 2; size <= 64; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const uint32_t okey = (uint32_t)__shfl_xor((int)key, stride, 64);
-      const bool up = (lane & size) == 0, lower = (lane & stride) == 0;
-      key = (up == lower) ? min(key, okey) : max(key, okey);  // the lower lane of an ascending pair keeps the smaller key (padding sorts last)
+  uint32_t key[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    key[r] = 0xFFFFFFFFu;
+    if (r * 64 + lane < w) {
+      const int arc = (int)bucket[r * 64 + lane];
+      key[r] = (uint32_t)arc | ((uint32_t)(labels[arc] - lab_base) << abits);
     }
-  const double x = lane < w ? xs[key & ((1u << abits) - 1u)] : 0.0;
-  // The runs of one word, folded in arc order with every lane at work: a lane knows where its run begins (a prefix
-  // maximum over the lanes that open one) and hence its place in it; step s folds the s-th entry of every run into the sum
+  }
+  // (the keys alone go through the network, x is fetched by arc number afterwards, as the thread-per-rank path does)
+  fr_wave_sort_sizes<NR, 2>(key, lane, [](uint32_t a, uint32_t b, bool take_min) { return take_min ? min(a, b) : max(a, b); });
+  double x[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) x[r] = r * 64 + lane < w ? xs[key[r] & ((1u << abits) - 1u)] : 0.0;
+  // The runs of one word, folded in arc order with every lane at work: an entry knows where its run begins (a prefix
+  // maximum over the entries that open one) and hence its place in it; step s folds the s-th entry of every run into the sum
   // its left neighbour holds -- as many steps as the longest run is long (two or three as a rule: walking the rank entry by
-  // entry, one wave-uniform trip per entry, was most of this function's time).  The last lane of a run emits the record's
-  // key, the others padding: the sort below brings the records to the front.
-  const uint32_t lab = key >> abits;
-  const uint32_t lab_left = (uint32_t)__shfl_up((int)lab, 1, 64);
-  const bool opens = lane < w && (lane == 0 || lab_left != lab);
-  int start = opens ? lane : -1;
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(start, d, 64);
-    if (lane >= d) start = max(start, o);
-  }
-  const int pos = lane < w ? lane - start : 0;
-  int longest = pos;
-  for (int d = 32; d > 0; d >>= 1) longest = max(longest, __shfl_xor(longest, d, 64));
-  double acc = x;
-  for (int s = 1; s <= longest; ++s) {  // (wave-uniform trips)
-    const double left = __shfl_up(acc, 1, 64);
-    const double folded = fr_log_add_fast(left, x, lntab);
-    if (pos == s) acc = folded;
-  }
-  const bool opens_right = __shfl_down((int)opens, 1, 64) != 0;
-  const bool closes = lane < w && (lane == w - 1 || opens_right);
-  const int m = __popcll(__ballot(closes));
-  double outk = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
-  if (closes) outk = __longlong_as_double((long long)(((uint64_t)fr_desc_key((float)acc) << 30) | (uint64_t)lab));  // BaseFloat narrowing of :126
-  for (int size = 2; size <= 64; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const double o = __shfl_xor(outk, stride, 64);
-      const bool up = (lane & size) == 0, lower = (lane & stride) == 0;
-      const bool take_min = up == lower;
-      outk = take_min ? fmin(outk, o) : fmax(outk, o);
+  // entry, one wave-uniform trip per entry, was most of this function's time).  The last entry of a run emits the record's
+  // key, the others padding: the sort below brings the records to the front.  (Entry 64's left neighbour is lane 63's
+  // first register.)
+  uint32_t lab[NR];
+  bool opens[NR];
+  int start[NR], pos[NR], longest = 0, carry = -1;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    lab[r] = key[r] >> abits;
+    uint32_t lab_left = (uint32_t)__shfl_up((int)lab[r], 1, 64);
+    if (r > 0) {
+      const uint32_t across = (uint32_t)__shfl((int)lab[r - 1], 63, 64);
+      lab_left = lane == 0 ? across : lab_left;
     }
-  if (lane < m) {
-    out[lane] = (uint64_t)__double_as_longlong(outk);
+    const int e = r * 64 + lane;
+    opens[r] = e < w && (e == 0 || lab_left != lab[r]);
+    start[r] = opens[r] ? e : -1;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(start[r], d, 64);
+      if (lane >= d) start[r] = max(start[r], o);
+    }
+    start[r] = max(start[r], carry);
+    carry = __shfl(start[r], 63, 64);
+    pos[r] = e < w ? e - start[r] : 0;
+    longest = max(longest, pos[r]);
   }
+  for (int d = 32; d > 0; d >>= 1) longest = max(longest, __shfl_xor(longest, d, 64));
+  double acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = x[r];
+  for (int s = 1; s <= longest; ++s) {  // (wave-uniform trips)
+    double left[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      left[r] = __shfl_up(acc[r], 1, 64);
+      if (r > 0) {
+        const double across = __shfl(acc[r - 1], 63, 64);
+        left[r] = lane == 0 ? across : left[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const double folded = fr_log_add_fast(left[r], x[r], lntab);
+      if (pos[r] == s) acc[r] = folded;
+    }
+  }
+  int m = 0;
+  double outk[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    bool opens_right = __shfl_down((int)opens[r], 1, 64) != 0;
+    if (r + 1 < NR) {
+      const bool across = __shfl((int)opens[r + 1 < NR ? r + 1 : r], 0, 64) != 0;
+      opens_right = lane == 63 ? across : opens_right;
+    }
+    const int e = r * 64 + lane;
+    const bool closes = e < w && (e == w - 1 || opens_right);
+    m += __popcll(__ballot(closes));
+    outk[r] = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
+    if (closes) outk[r] = __longlong_as_double((long long)(((uint64_t)fr_desc_key((float)acc[r]) << 30) | (uint64_t)lab[r]));  // BaseFloat narrowing of :126
+  }
+  fr_wave_sort_sizes<NR, 2>(outk, lane, [](double a, double b, bool take_min) { return take_min ? fmin(a, b) : fmax(a, b); });
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+    if (r * 64 + lane < m) out[r * 64 + lane] = (uint64_t)__double_as_longlong(outk[r]);
   return m;
 }
 
@@ -1054,7 +1144,7 @@ static constexpr int kLnStatesLds = 4096;  // ... and of a lattice whose spans s
 static constexpr int kLnBlock = 128;       // ranks per entry of the table of first arcs (lattices whose spans lie in L2)
 static constexpr int kLnTile = 1024;    // ranks per tile
 static constexpr int kLnBatch = 6;      // arcs per thread and round of the arc pass
-static constexpr int kLnWideMax = 64;   // a rank with more than kFrRegs entries and at most this many is folded by a whole wave
+static constexpr int kLnWideMax = 128;  // a rank with more than kFrRegs entries and at most this many is folded by a whole wave (one or two entries a lane)
 
 // BIG: the instantiation for the lattices the first one lists (spans in L2, up to kLnStates states; whatever else did
 // not fit is tried once more and listed for the general kernel); the first one keeps the shorter code of a lattice
@@ -1615,7 +1705,8 @@ __global__ __launch_bounds__(kFrLeanThreads / SC / (DENSE == 2 ? 2 : 1), (BIG ||
       const int k = wide_rank[wi];
       const int lo = lboff[k], w = lboff[k + 1] - lo;  // R < w <= kLnWideMax
       const int dst = (int)rec_at + nbase + lo;
-      const int m = fr_lean_wide_rank(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst);
+      const int m = w <= 64 ? fr_lean_wide_rank<1>(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst)  // (wave-uniform)
+                            : fr_lean_wide_rank<2>(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst);
       const int run = (int)rtime[c0 + k + 1] - (int)rtime[c0 + k];
       if (lane == 0) lcur[k] = m, dense += m * run, stored += m;
     }
