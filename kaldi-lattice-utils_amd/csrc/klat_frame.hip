@@ -1015,13 +1015,18 @@ __device__ __forceinline__ double fr_lane_xor(double v, int lane) {
   return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 // Bitonic network over 64 * NR keys, NR a lane (key[r] of lane l is element r * 64 + l), ascending; pick(a, b, take_min)
-// is the comparator.  Strides below 64 pair lanes of one register, the stride of 64 pairs a lane's own two registers.
+// is the comparator.  Strides below 64 pair lanes of one register, those of 64 and more a lane's own registers.
 template <int NR, int SIZE, int STRIDE, class T, class Pick>
 __device__ __forceinline__ void fr_wave_sort_stage(T (&key)[NR], int lane, Pick pick) {
-  if constexpr (STRIDE == 64) {
-    static_assert(NR == 2 && SIZE == 128, "the last merge of two registers a lane");
-    const T lo = pick(key[0], key[1], true), hi = pick(key[0], key[1], false);
-    key[0] = lo, key[1] = hi;
+  if constexpr (STRIDE >= 64) {  // a lane's own registers r and r + STRIDE / 64
+    constexpr int RS = STRIDE / 64;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if ((r & RS) == 0) {
+        const bool up = ((r << 6) & SIZE) == 0;
+        const T lo = pick(key[r], key[r | RS], true), hi = pick(key[r], key[r | RS], false);
+        key[r] = up ? lo : hi, key[r | RS] = up ? hi : lo;
+      }
   } else {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -1144,7 +1149,7 @@ static constexpr int kLnStatesLds = 4096;  // ... and of a lattice whose spans s
 static constexpr int kLnBlock = 128;       // ranks per entry of the table of first arcs (lattices whose spans lie in L2)
 static constexpr int kLnTile = 1024;    // ranks per tile
 static constexpr int kLnBatch = 6;      // arcs per thread and round of the arc pass
-static constexpr int kLnWideMax = 128;  // a rank with more than kFrRegs entries and at most this many is folded by a whole wave (one or two entries a lane)
+static constexpr int kLnWideMax = 256;  // a rank with more than kFrRegs entries and at most this many is folded by a whole wave (one, two or four entries a lane)
 
 // BIG: the instantiation for the lattices the first one lists (spans in L2, up to kLnStates states; whatever else did
 // not fit is tried once more and listed for the general kernel); the first one keeps the shorter code of a lattice
@@ -1467,7 +1472,7 @@ __global__ __launch_bounds__(kFrLeanThreads / SC / (DENSE == 2 ? 2 : 1), (BIG ||
   if (nr > 0 && kTile > kLnBlock) {
     const long long per_rank = ((long long)entries + nr - 1) / nr;
     const long long fit = (long long)kEntries * 3 / 4 / max(per_rank, 1LL);
-    tile_ranks = (int)max((long long)min(kLnBlock, kTile), min((long long)tile_ranks, fit / kLnBlock * kLnBlock));
+    tile_ranks = (int)max(32LL, min((long long)tile_ranks, fit >= kLnBlock ? fit / kLnBlock * kLnBlock : fit / 32 * 32));  // (frames of a hundred arcs: tiles of 96 ranks, 64, 32)
   }
   for (int c0 = 0; c0 < nr; c0 += tile_ranks) {
     const int tc = min(tile_ranks, nr - c0);
@@ -1705,8 +1710,9 @@ __global__ __launch_bounds__(kFrLeanThreads / SC / (DENSE == 2 ? 2 : 1), (BIG ||
       const int k = wide_rank[wi];
       const int lo = lboff[k], w = lboff[k + 1] - lo;  // R < w <= kLnWideMax
       const int dst = (int)rec_at + nbase + lo;
-      const int m = w <= 64 ? fr_lean_wide_rank<1>(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst)  // (wave-uniform)
-                            : fr_lean_wide_rank<2>(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst);
+      const int m = w <= 64    ? fr_lean_wide_rank<1>(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst)  // (wave-uniform)
+                    : w <= 128 ? fr_lean_wide_rank<2>(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst)
+                               : fr_lean_wide_rank<4>(lbucket + lo, w, a.ilabel + a0, xs, lab_base, abits, lntab, a.pool + dst);
       const int run = (int)rtime[c0 + k + 1] - (int)rtime[c0 + k];
       if (lane == 0) lcur[k] = m, dense += m * run, stored += m;
     }

@@ -645,11 +645,11 @@ def test_frame_post_kernels_agree_on_a_mix(ctx, monkeypatch):
         assert sorted(l0[o0[f]:o0[f + 1]].tolist()) == sorted(l1[o1[f]:o1[f + 1]].tolist()), (int(i), int(f))
 
 
-@pytest.mark.parametrize("width", [40, 100, 128, 135, 200, 700, 5000])
+@pytest.mark.parametrize("width", [40, 100, 128, 135, 200, 256, 270, 700, 5000])
 def test_frame_post_wide_frames(ctx, width):
     """Frames crossed by many arcs.  The lean kernel: up to 16 (dense pass: 32) entries in a thread's registers, up to 64
-    one a lane of a wave, up to 128 two a lane (100, 128, 135: runs of one word cross from a lane's first register into the
-    next lane's second).  Beyond that the general kernel: up to 256 in place, above that the whole workgroup sorts the
+    one a lane of a wave, up to 128 two and up to 256 four a lane (100 ... 270: runs of one word cross from lane 63's
+    register into lane 0's next).  Beyond that the general kernel: up to 256 in place, above that the whole workgroup sorts the
     frame's bucket (700: through the LDS tile; 5000: beyond it).  Labels repeat inside a frame, so runs get folded; some
     arcs are dead."""
     rng = np.random.RandomState(width)

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
 import klat_amd
 ctx = klat_amd.Ctx(0)
 L = klat_amd.lib()
-for fan in [int(x) for x in sys.argv[1:]] or (3, 6, 8, 12, 16):
+for fan in [int(x) for x in sys.argv[1:]] or (3, 6, 8, 12, 16, 24, 32):
     U = 24000 // fan
     arrays = klat_amd.synth(20260061, np.full(U, 1000, np.int32), np.full(U, fan, np.int32), host_threads=16)
     b = klat_amd.Batch(ctx, arrays, host_threads=16)
