@@ -486,6 +486,40 @@ def test_frame_post_synthetic(ctx, scales, frame_mode):
     assert off[-1] == len(labels)
 
 
+@pytest.mark.parametrize("words", [7, 400])
+def test_frame_post_of_dense_lattices(ctx, words):
+    """Lattices whose frames hold from a few to two hundred arcs (fanout 1 ... 40), of few distinct words (runs to fold in
+    every frame, across a wave's lanes and registers) or of many: the thread-per-rank path with 8 / 12 / 16 registers, the
+    dense pass with 16 / 24 / 32, the wave path with one, two and four entries a lane, and tiles of fewer than 128 ranks --
+    every lattice against the oracle (latbin/lattice-to-word-frame-post.cc:93-135)."""
+    rng = np.random.RandomState(words)
+    fo = np.array([1, 2, 3, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 3, 6, 12, 24, 40], np.int32)
+    ns = np.concatenate([rng.randint(40, 200, size=13), [900, 700, 500, 300, 250]]).astype(np.int32)
+    arrays = klat_amd.synth(20260070 + words, ns, fo)
+    arrays["olabel"] = (1 + arrays["olabel"] % words).astype(np.int32)
+    arrays["olabel"][rng.rand(len(arrays["olabel"])) < 0.04] = 0  # epsilon arcs cross no frame
+    arrays["ilabel"] = arrays["olabel"].copy()
+    dead = rng.rand(len(arrays["graph"])) < 0.02
+    dead &= arrays["dst"] != arrays["src"] + 1  # (keep every lattice connected)
+    arrays["graph"][dead] = np.inf
+    arrays["acoustic"][dead] = np.inf
+    lats = _split(arrays)
+    nframes = [int(arrays["state_time"][arrays["state_off"][u + 1] - 1]) for u in range(len(ns))]
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.3, 0.1)
+    off, labels, logps = b.frame_post(nframes)
+    b.close()
+    fb, densest = 0, 0
+    for u, lat in enumerate(lats):
+        sl = orc.scale_and_penalize(lat, 1.0, 0.3, 0.1)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        t = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
+        want, mis = orc.frame_post(sl, t, nframes[u], alpha, beta, total)
+        _check_frames(off, labels, logps, fb, want)
+        fb += nframes[u]
+    assert off[-1] == len(labels)
+
+
 def test_frame_post_pool_follows_the_batches(ctx_fresh):
     """The lean kernel's record pool is sized by what the context's earlier batches asked for: a batch of long arcs
     (thirty ranks an arc: far beyond the four records per arc a new context starts with) goes to the general
