@@ -230,12 +230,17 @@ __device__ __noinline__ bool tie_less(int ax, int ay) {
 
 // position of order word `me` in its bucket [lo, hi) where the plain count does not do: a crowded bucket (sorted by
 // the workgroup beforehand: binary search) or one that holds words whose upper parts equal mine
+// (my_image, my_key: the calling record's own full image and key -- it has them in registers; only the other record of a
+// tie is recomputed from memory)
 template <bool POSITION, int RB>
-__device__ __noinline__ int slow_position(const uint64_t* order, int lo, int hi, uint64_t me, bool plain) {
+__device__ __noinline__ int slow_position(const uint64_t* order, int lo, int hi, uint64_t me, bool plain, uint64_t my_image, uint64_t my_key) {
   constexpr uint64_t idmask = (1ull << RB) - 1ull;
-  auto less = [&](uint64_t x, uint64_t y) -> bool {  // (plain: the last bucket's words are the records' keys themselves)
+  auto less = [&](uint64_t x, uint64_t y) -> bool {  // y == me.  (plain: the last bucket's words are the records' keys themselves)
     if (plain) return x < y;
-    return ((x ^ y) & ~idmask) ? x < y : (x != y && tie_less<POSITION>((int)(x & idmask), (int)(y & idmask)));
+    if ((x ^ y) & ~idmask) return x < y;
+    if (x == y) return false;
+    const uint64_t dx = slow_image((int)(x & idmask));
+    return dx != my_image ? dx < my_image : slow_key<POSITION>((int)(x & idmask)) < my_key;
   };
   if (hi - lo > kSerialMax) {
     int l = lo, h = hi;  // first entry not less than me
@@ -770,7 +775,7 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
         }
         slow = upto - (p - lo) != 1;
       }
-      if (slow) p = slow_position<POSITION, RB>(order, lo, hi, floor_w | (uint64_t)(j * T + tid), false);
+      if (slow) p = slow_position<POSITION, RB>(order, lo, hi, floor_w | (uint64_t)(j * T + tid), false, img[j], key[j]);
     }
     if (j & 1) finalpos[j >> 1] |= (uint32_t)p << 16;
     else finalpos[j >> 1] = (uint32_t)p;
@@ -782,7 +787,7 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
       const int lo = (int)(where[j] >> 16), hi = (int)(where[j] & 0xFFFFu);
       int p = lo;
       if (hi - lo > kSerialMax) {
-        p = slow_position<POSITION, RB>(order, lo, hi, key[j], true);
+        p = slow_position<POSITION, RB>(order, lo, hi, key[j], true, 0, 0);
       } else {
         for (int q = lo; q < hi; ++q) p += order[q] < key[j] ? 1 : 0;
       }
