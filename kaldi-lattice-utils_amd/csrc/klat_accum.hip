@@ -324,14 +324,17 @@ __device__ __forceinline__ OutRecord decode_record(const Rec& r) {
 // as the kernels' sorts compare them (the position index's k2 is payload; its keys differ in k1).  No key occurs in two
 // pieces, so no two records compare equal.
 //
-// One workgroup per CHUNK of kGatherChunk records (a lattice of 120 000 records: thirty workgroups, not one).  The search
-// in another run has two levels: the k0 of every 64th record of every run sits in LDS (a piece has at most 15 360
-// records: 240 samples), eight steps there name a block of 64 records, six steps with the full comparison in that block
-// touch a dozen cache lines that the wave's neighbours -- whose records lie next to this one in their own run -- want too.
-// (Plain binary searches from one workgroup per lattice took 20 ms for the configs[4]-shaped mix's 36 M records.)
-static constexpr int kGatherChunk = 4096, kGatherRuns = 16, kGatherSamples = 256;
+// One workgroup per BAND of the lattice's output (a lattice of 120 000 records: thirty workgroups, not one): the records
+// that lie between two boundary records -- every (n / bands)-th record of the lattice's longest run -- in ALL runs.  A
+// band is one range of every run (a binary search of either boundary, 2 x runs of them a workgroup) and ONE range of the
+// output, which the workgroup writes whole: a record's place is its band's first place plus its place in its own range
+// plus the records before it in the other runs' ranges (searches over a few hundred values, which the workgroup keeps in LDS).
+// (Chunks of the INPUT instead, every record searching the whole of every other run from samples in LDS, scattered 24-byte
+// records over the lattice's whole output from thirty workgroups on eight L2s: lines reached memory in pieces, and the
+// configs[4]-shaped mix's 36 M records took 2.2 ms; plain binary searches from one workgroup per lattice 20 ms.)
+static constexpr int kGatherChunk = 4096, kGatherRuns = 16, kGatherBand = 6144;  // (a band's values in LDS: 48 KB)
 struct GatherChunk {
-  int32_t u, first;  // records [first, first + kGatherChunk) of lattice u, in the order of its runs
+  int32_t u, first;  // band first / kGatherChunk of lattice u (a lattice in one run: its records [first, first + kGatherChunk))
 };
 
 template <bool POSITION>
@@ -339,11 +342,21 @@ __device__ __forceinline__ bool rec_before(const Rec& x, const Rec& r) {
   if (x.k0 != r.k0) return x.k0 < r.k0;
   return x.k1 < r.k1 || (!POSITION && x.k1 == r.k1 && x.k2 < r.k2);
 }
+// first record of run[lo .. hi) that does not come before r
+template <bool POSITION>
+__device__ __forceinline__ int rec_lower_bound(const Rec* run, int lo, int hi, const Rec& r) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (rec_before<POSITION>(run[mid], r)) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
 
 template <bool POSITION>
 __global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const int64_t* record_off, const GatherChunk* chunks, OutRecord* out) {
-  __shared__ uint64_t samp[kGatherRuns][kGatherSamples];
-  __shared__ int run_begin[kGatherRuns], run_n[kGatherRuns], run_first[kGatherRuns + 1];
+  __shared__ int run_begin[kGatherRuns], run_n[kGatherRuns], band_lo[kGatherRuns], band_hi[kGatherRuns], band_at[kGatherRuns + 1];
+  __shared__ uint64_t band_k0[kGatherBand];
   const GatherChunk ch = chunks[blockIdx.x];
   const int u = ch.u, tid = threadIdx.x;
   const Rec* recs = reinterpret_cast<const Rec*>(a.rec_scratch) + a.scratch_off[u];
@@ -356,57 +369,77 @@ __global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const in
     return;
   }
   const IndexItem* its = a.piece_items + a.piece_first[u];
-  const bool sampled = pieces <= kGatherRuns;  // (workgroup-uniform; beyond that: plain binary searches)
-  if (sampled) {
-    if (tid < pieces) run_begin[tid] = its[tid].begin, run_n[tid] = a.item_records[its[tid].slot];
-    __syncthreads();
-    if (tid == 0) {
-      int at = 0;
-      for (int q = 0; q < pieces; ++q) run_first[q] = at, at += run_n[q];
-      run_first[pieces] = at;
+  if (pieces > kGatherRuns) {  // (workgroup-uniform; a lattice of more than 200 000 arcs) a chunk of the input, plain binary searches
+    for (int f = ch.first + tid; f < last; f += 256) {
+      int p = 0, j = f;
+      while (j >= a.item_records[its[p].slot]) j -= a.item_records[its[p].slot], ++p;
+      const Rec r = recs[its[p].begin + j];
+      int pos = j;
+      for (int q = 0; q < pieces; ++q)
+        if (q != p) pos += rec_lower_bound<POSITION>(recs + its[q].begin, 0, a.item_records[its[q].slot], r);
+      out[o + pos] = decode_record<POSITION>(r);
     }
-    for (int q = 0; q < pieces; ++q)
-      for (int i = tid; i * 64 < run_n[q] && i < kGatherSamples; i += 256) samp[q][i] = recs[run_begin[q] + i * 64].k0;
+    return;
+  }
+  if (tid < pieces) run_begin[tid] = its[tid].begin, run_n[tid] = a.item_records[its[tid].slot];
+  __syncthreads();
+  // the band's two boundary records, from the longest run; its range in every run (threads 0 .. 2 * pieces - 1)
+  const int bands = (m + kGatherChunk - 1) / kGatherChunk, c = ch.first / kGatherChunk;
+  int longest = 0;
+  for (int q = 1; q < pieces; ++q)
+    if (run_n[q] > run_n[longest]) longest = q;
+  if (tid < 2 * pieces) {
+    const int q = tid >> 1, side = tid & 1, edge = c + side;  // edge 0: before everything; edge `bands`: behind everything
+    int at = edge == 0 ? 0 : run_n[q];
+    if (edge > 0 && edge < bands) {
+      const int b = (int)((int64_t)edge * run_n[longest] / bands);
+      at = q == longest ? b : rec_lower_bound<POSITION>(recs + run_begin[q], 0, run_n[q], recs[run_begin[longest] + b]);
+    }
+    if (side) band_hi[q] = at;
+    else band_lo[q] = at;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int at = 0;
+    for (int q = 0; q < pieces; ++q) band_at[q] = at, at += band_hi[q] - band_lo[q];
+    band_at[pieces] = at;
+  }
+  __syncthreads();
+  int first_place = 0;  // the band's first place in the output: the records before it in every run
+  for (int q = 0; q < pieces; ++q) first_place += band_lo[q];
+  const int count = band_at[pieces];
+  // the values (k0) of the band's records in LDS, run after run: the searches read those; two records of equal value
+  // (rare: different runs hold different keys) are compared in full, from memory
+  const bool staged = count <= kGatherBand;  // (workgroup-uniform; a band far larger than the others: the searches go to memory)
+  if (staged) {
+    for (int f = tid; f < count; f += 256) {
+      int p = 0;
+      while (f >= band_at[p + 1]) ++p;
+      band_k0[f] = recs[run_begin[p] + band_lo[p] + f - band_at[p]].k0;
+    }
     __syncthreads();
   }
-  for (int f = ch.first + tid; f < last; f += 256) {
-    // the record's run and its place there
-    int p = 0, j = f;
-    if (sampled) {
-      while (p + 1 < pieces && f >= run_first[p + 1]) ++p;
-      j = f - run_first[p];
-    } else {
-      while (j >= a.item_records[its[p].slot]) j -= a.item_records[its[p].slot], ++p;
-    }
-    const Rec r = recs[(sampled ? run_begin[p] : its[p].begin) + j];
-    int pos = j;
+  for (int f = tid; f < count; f += 256) {
+    int p = 0;
+    while (f >= band_at[p + 1]) ++p;
+    const int j = band_lo[p] + f - band_at[p];
+    const Rec r = recs[run_begin[p] + j];
+    int pos = first_place + (j - band_lo[p]);
     for (int q = 0; q < pieces; ++q) {
       if (q == p) continue;
-      const Rec* other = recs + (sampled ? run_begin[q] : its[q].begin);
-      int lo = 0, hi = sampled ? run_n[q] : a.item_records[its[q].slot];
-      if (sampled && hi <= 64 * kGatherSamples) {
-        // the block: samples strictly below r.k0 lie before the answer's block, samples above r.k0 behind it
-        const int ns = (hi + 63) >> 6;
-        int sl = 0, sh = ns;  // first sample not below r.k0
-        while (sl < sh) {
-          const int mid = (sl + sh) >> 1;
-          if (samp[q][mid] < r.k0) sl = mid + 1;
-          else sh = mid;
-        }
-        int tl = sl, th = ns;  // first sample above r.k0
-        while (tl < th) {
-          const int mid = (tl + th) >> 1;
-          if (samp[q][mid] <= r.k0) tl = mid + 1;
-          else th = mid;
-        }
-        lo = max(sl - 1, 0) * 64, hi = min(hi, tl * 64);
+      if (!staged) {
+        pos += rec_lower_bound<POSITION>(recs + run_begin[q], band_lo[q], band_hi[q], r) - band_lo[q];
+        continue;
       }
-      while (lo < hi) {  // first record of run q that does not come before r
+      int lo = band_at[q], hi = band_at[q + 1];  // first value of the run's range not below r's
+      while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (rec_before<POSITION>(other[mid], r)) lo = mid + 1;
+        if (band_k0[mid] < r.k0) lo = mid + 1;
         else hi = mid;
       }
-      pos += lo;
+      pos += lo - band_at[q];
+      for (int e = lo; e < band_at[q + 1] && band_k0[e] == r.k0; ++e)  // (equal values: the keys decide)
+        pos += rec_before<POSITION>(recs[run_begin[q] + band_lo[q] + e - band_at[q]], r) ? 1 : 0;
     }
     out[o + pos] = decode_record<POSITION>(r);
   }
