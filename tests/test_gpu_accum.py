@@ -520,6 +520,32 @@ def test_frame_post_of_dense_lattices(ctx, words):
     assert off[-1] == len(labels)
 
 
+def test_frame_post_of_many_dense_lattices(ctx):
+    """A batch whose dense pass has more than 2 048 lattices takes that pass in workgroups of 256 threads (two lattices a
+    CU; a smaller batch: one workgroup of 512): every fortieth lattice against the oracle."""
+    rng = np.random.RandomState(11)
+    U = 2400
+    ns = rng.randint(30, 70, size=U).astype(np.int32)
+    fo = rng.choice([6, 8, 10], size=U).astype(np.int32)
+    arrays = klat_amd.synth(20260081, ns, fo)
+    arrays["olabel"] = (1 + arrays["olabel"] % 50).astype(np.int32)
+    arrays["ilabel"] = arrays["olabel"].copy()
+    lats = _split(arrays)
+    nframes = [int(arrays["state_time"][arrays["state_off"][u + 1] - 1]) for u in range(U)]
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.2, 0.0)
+    off, labels, logps = b.frame_post(nframes)
+    b.close()
+    first = np.concatenate([[0], np.cumsum(nframes)])
+    for u in range(0, U, 40):
+        sl = orc.scale_and_penalize(lats[u], 1.0, 0.2, 0.0)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        t = arrays["state_time"][arrays["state_off"][u]:arrays["state_off"][u + 1]]
+        want, mis = orc.frame_post(sl, t, nframes[u], alpha, beta, total)
+        _check_frames(off, labels, logps, int(first[u]), want)
+    assert off[-1] == len(labels)
+
+
 def test_frame_post_pool_follows_the_batches(ctx_fresh):
     """The lean kernel's record pool is sized by what the context's earlier batches asked for: a batch of long arcs
     (thirty ranks an arc: far beyond the four records per arc a new context starts with) goes to the general
