@@ -311,7 +311,7 @@ def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
 
 
 C4 = {"lattices": 100000, "states": 5000, "fanout": 3, "seed": 20260003}  # BASELINE configs[3], north_star's scaling target
-STRONG_REFERENCE = os.path.join("profiles", "r03_strong_c4_1gpu.json")   # this leg at N = 1, taken on a box of the same pool
+STRONG_REFERENCE = os.path.join("profiles", "r04_strong_c4_1gpu.json")   # this leg at N = 1, taken on a box of the same pool
 
 
 def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, barrier, lattices, reps=3):
@@ -365,7 +365,7 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
     f, fkeep = klat_amd.Batch._filter(None, None)
     off = np.zeros(b.U + 1, np.int64)
     n = C.c_int64(0)
-    times, err = [], None
+    times, compute, err = [], [], None
     tu = tr = 0
     for it in range(reps + 1):  # (the first pass allocates: not counted)
         barrier()
@@ -373,6 +373,8 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
         try:
             b.forward_backward(*SCALES)
             klat_amd._check(L.klat_segment_index(b.h, C.byref(f), klat_amd._p(off), None, C.c_int64(0), C.byref(n)))
+            if it:
+                compute.append(time.perf_counter() - t0)  # (the sizing call has read the records' counts back: the device is done)
         except Exception as e:  # (the whole list with its index on ONE GPU is the tightest fit)
             err = "%s: %s" % (type(e).__name__, str(e)[:200])
         if world > 1:  # a rank that failed must not leave the others inside the gather: they all learn of it first
@@ -387,7 +389,8 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
         barrier()
         if it:
             times.append(time.perf_counter() - t0)
-    tot = torch.tensor([float(A), float(n.value), step_s, median(times) if times else 0.0, 1.0 if err else 0.0], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(A), float(n.value), step_s, median(times) if times else 0.0, 1.0 if err else 0.0, median(compute) if compute else 0.0],
+                       dtype=torch.float64, device="cuda")
     if world > 1:
         sums = tot.clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
@@ -395,7 +398,7 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
         total_arcs, total_records, failed = float(sums[0]), float(sums[1]), float(tot[4]) > 0
     else:
         total_arcs, total_records, failed = float(A), float(n.value), err is not None
-    step_max, pipe_max = float(tot[2]), float(tot[3])
+    step_max, pipe_max, compute_max = float(tot[2]), float(tot[3]), float(tot[5])
     out = None
     if rank == 0:
         ref = None
@@ -411,6 +414,10 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
                "pipeline": "klat_forward_backward + klat_segment_index" + (" + klat_gather_index to rank 0 (RCCL, device buffers)" if comm is not None else ""),
                "pipeline_seconds": pipe_max if not failed else None,
                "node_arcs_per_s": total_arcs / pipe_max if (pipe_max > 0 and not failed) else None,
+               # the same without the gather: every rank keeps its records (the tools' `ark:out.JOB` tables) -- the 34 GB of
+               # this list's records into ONE GPU's links are a transfer the one-GPU line does not have
+               "pipeline_compute_seconds": compute_max if not failed else None,
+               "node_arcs_per_s_compute": total_arcs / compute_max if (compute_max > 0 and not failed) else None,
                "index_records": total_records, "error": err}
         if comm is not None and not failed:
             st = comm.stats()
@@ -424,6 +431,8 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
             out["speedup_vs_1gpu"] = out["node_arcs_per_s"] / ref["node_arcs_per_s"]
             if ref.get("node_arcs_per_s_step"):
                 out["speedup_vs_1gpu_step"] = out["node_arcs_per_s_step"] / ref["node_arcs_per_s_step"]
+            if out.get("node_arcs_per_s_compute"):  # (at N = 1 the pipeline has no gather: its rate is the compute rate)
+                out["speedup_vs_1gpu_compute"] = out["node_arcs_per_s_compute"] / ref["node_arcs_per_s"]
         else:
             out["speedup_vs_1gpu"] = None  # (no 1-GPU record of this list size: compare the per-N lines of the scaling run)
     b.close()
