@@ -36,8 +36,10 @@ def _run(ctx, arrays, steps=1):
         b.forward_backward(1.0, 0.1, 0.5)
     out = b.alpha_beta() + b.totals() + (b.arc_logpost(),)
     off, rec = b.segment_index()
+    nframes = [int(arrays["state_time"][arrays["state_off"][u + 1] - 1]) for u in range(len(arrays["state_off"]) - 1)]
+    foff, flab, flogp = b.frame_post(nframes)  # (both accumulators launch their size classes on the context's side streams)
     b.close()
-    return out + (off, rec)
+    return out + (off, rec, foff, flab, flogp)
 
 
 def _same(a, b):
