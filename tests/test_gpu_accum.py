@@ -409,6 +409,28 @@ def test_index_of_long_lattices(ctx, shape):
         _check_sorted_records(got, [(w[0], w[1], w[4]) for w in want], 2, tol=1e-9)
 
 
+def test_index_of_a_lattice_of_more_than_sixteen_pieces(ctx):
+    """300 000 arcs: 23 pieces, more runs than the gather's banded merge keeps in LDS -- its plain merge (a search of
+    every other run per record) against the oracle, beside a lattice of five pieces and a short one."""
+    ns = np.array([30000, 200, 10000], np.int32)
+    fo = np.array([10, 3, 6], np.int32)
+    arrays = klat_amd.synth(20260032, ns, fo)
+    arrays["olabel"] = (1 + arrays["olabel"] % 300).astype(np.int32)
+    arrays["ilabel"] = arrays["olabel"].copy()
+    scales = (1.0, 0.3, 0.0)
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(*scales)
+    soff, srec = b.segment_index()
+    b.close()
+    for u, lat in enumerate(_split(arrays)):
+        s0, s1 = int(arrays["state_off"][u]), int(arrays["state_off"][u + 1])
+        sl = orc.scale_and_penalize(lat, *scales)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        want = orc.segment_index(sl, arrays["state_time"][s0:s1], alpha, beta, total)
+        got = [(int(r["label"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in srec[soff[u]:soff[u + 1]]]
+        _check_sorted_records(got, want, 3, tol=1e-9)
+
+
 @pytest.mark.parametrize("shape", ["C2", "C4"])
 def test_segment_index_full_size_properties(ctx, shape):
     """The segment index at BASELINE's sizes -- configs[1] whole (10 000 lattices x 2 000 states: the 512 x 12 class)
