@@ -332,7 +332,7 @@ __device__ __forceinline__ OutRecord decode_record(const Rec& r) {
 // (Chunks of the INPUT instead, every record searching the whole of every other run from samples in LDS, scattered 24-byte
 // records over the lattice's whole output from thirty workgroups on eight L2s: lines reached memory in pieces, and the
 // configs[4]-shaped mix's 36 M records took 2.2 ms; plain binary searches from one workgroup per lattice 20 ms.)
-static constexpr int kGatherChunk = 4096, kGatherRuns = 16, kGatherBand = 6144;  // (a band's values in LDS: 48 KB)
+static constexpr int kGatherChunk = 4096, kGatherRuns = 32, kGatherBand = 6144;  // (a band's values in LDS: 48 KB)
 struct GatherChunk {
   int32_t u, first;  // band first / kGatherChunk of lattice u (a lattice in one run: its records [first, first + kGatherChunk))
 };
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void index_gather_kernel(AccumArgs a, const in
     return;
   }
   const IndexItem* its = a.piece_items + a.piece_first[u];
-  if (pieces > kGatherRuns) {  // (workgroup-uniform; a lattice of more than 200 000 arcs) a chunk of the input, plain binary searches
+  if (pieces > kGatherRuns) {  // (workgroup-uniform; a lattice of more than 400 000 arcs) a chunk of the input, plain binary searches
     for (int f = ch.first + tid; f < last; f += 256) {
       int p = 0, j = f;
       while (j >= a.item_records[its[p].slot]) j -= a.item_records[its[p].slot], ++p;

@@ -409,11 +409,12 @@ def test_index_of_long_lattices(ctx, shape):
         _check_sorted_records(got, [(w[0], w[1], w[4]) for w in want], 2, tol=1e-9)
 
 
-def test_index_of_a_lattice_of_more_than_sixteen_pieces(ctx):
-    """300 000 arcs: 23 pieces, more runs than the gather's banded merge keeps in LDS -- its plain merge (a search of
-    every other run per record) against the oracle, beside a lattice of five pieces and a short one."""
-    ns = np.array([30000, 200, 10000], np.int32)
-    fo = np.array([10, 3, 6], np.int32)
+def test_index_of_lattices_of_many_pieces(ctx):
+    """300 000 arcs: 23 pieces through the gather's banded merge; 450 000 arcs: 34 pieces, more runs than that merge keeps
+    in LDS -- its plain merge (a search of every other run per record); against the oracle, beside a lattice of five pieces
+    and a short one."""
+    ns = np.array([30000, 200, 45000, 10000], np.int32)
+    fo = np.array([10, 3, 10, 6], np.int32)
     arrays = klat_amd.synth(20260032, ns, fo)
     arrays["olabel"] = (1 + arrays["olabel"] % 300).astype(np.int32)
     arrays["ilabel"] = arrays["olabel"].copy()
