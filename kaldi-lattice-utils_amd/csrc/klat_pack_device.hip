@@ -365,7 +365,10 @@ __global__ __launch_bounds__(kTC, 6) void pack_count_kernel(PackDevArgs a, int l
 
 // The same pass with the lattice's tables in its scratch rows in HBM (L2 atomics): for the lattices
 // above `lds_hi` bytes of tables.
-__global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, int lds_hi) {
+// (Its counters -- in-degrees, then the counting sort's cursors -- in LDS all the same where 4 (S + 2) bytes fit, up to 38 000
+// states: the two passes of L2 atomics were half of this kernel's time.)
+__global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, int lds_hi, int lds_counters) {
+  extern __shared__ int32_t lcnt[];  // [S + 2] where it fits
   __shared__ int sh[kTG / 64];
   __shared__ int sh_bad, sh_mr, sh_mtf, sh_mtb, sh_linked, sh_span;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
@@ -377,7 +380,9 @@ __global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, i
   const int64_t sb = s0 + 2 * (int64_t)u;
   int32_t* cnt = a.cnt + sb;
   int32_t* row = a.row + sb;
-  int32_t* cur = a.r0b + sb;  // (scratch for the counting sort's cursors here)
+  const bool in_lds = (int64_t)sizeof(int32_t) * (S + 2) <= (int64_t)lds_counters;  // (workgroup-uniform)
+  int32_t* cur = in_lds ? lcnt : a.r0b + sb;  // (the counting sort's cursors: LDS, or scratch in L2)
+  int32_t* deg = in_lds ? lcnt : cnt;         // the in-degrees while they are counted
   int32_t* flist = a.flist + s0;
   int32_t* in_arc = a.in_arc + a0;
   int32_t* out_arc = a.out_arc + a0;
@@ -385,19 +390,33 @@ __global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, i
   const int32_t* dst = a.dst + a0;
   if (tid == 0) sh_bad = 0, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0, sh_span = 1;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
-  for (int s = tid; s < S + 2; s += kTG) cnt[s] = 0;
+  for (int s = tid; s < S + 2; s += kTG) deg[s] = 0;
   __syncthreads();
   int mr = 1;
-  for (int i = tid; i < A; i += kTG) {
-    const int s = src[i], t = dst[i];
-    const int prev = i > 0 ? src[i - 1] : 0;
-    if (s < 0 || s >= S || s < prev) {
-      atomicMax(&sh_bad, 2);
-    } else if (t <= s || t >= S) {
-      atomicMax(&sh_bad, 1);
-    } else {
-      atomicAdd(&cnt[t], 1);
-      mr = max(mr, t - s);
+  constexpr int kAhead = 8;  // arcs a thread has in flight (one after the other, a thread's hundred trips to L2 were the pass)
+  for (int ib = tid; ib < A; ib += kTG * kAhead) {
+    int vs[kAhead], vt[kAhead], vp[kAhead];
+#pragma unroll
+    for (int x = 0; x < kAhead; ++x) {
+      const int i = min(ib + x * kTG, A - 1);
+      vs[x] = src[i], vt[x] = dst[i], vp[x] = i > 0 ? src[i - 1] : 0;
+    }
+#pragma unroll
+    for (int x = 0; x < kAhead; ++x) {
+      const int i = ib + x * kTG;
+      if (i >= A) continue;
+      const int s = vs[x], t = vt[x];
+      if (s < 0 || s >= S || s < vp[x]) {
+        atomicMax(&sh_bad, 2);
+      } else if (t <= s || t >= S) {
+        atomicMax(&sh_bad, 1);
+      } else {
+        atomicAdd(&deg[t], 1);
+        mr = max(mr, t - s);
+        // the row table from the arcs themselves (grouped by ascending source): arc i is the first out-arc of every
+        // state behind its predecessor's source up to its own -- no search per state
+        for (int q = (i > 0 ? vp[x] + 1 : 0); q <= s; ++q) row[q] = i;
+      }
     }
   }
   atomicMax(&sh_span, mr);
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, i
   int carry_c = 0, mtf = 1, mtb = 1;
   for (int base = 0; base <= S; base += kTG) {
     const int p = base + tid;
-    const int c = (p < S) ? cnt[p] : 0;
+    const int c = (p < S) ? deg[p] : 0;
     const int nterm = (p < S) ? c + (p == 0 ? 1 : 0) : nfinal;
     if (p <= S) {
       mtf = max(mtf, nterm);
@@ -432,40 +451,97 @@ __global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, i
     }
     int tot_c;
     const int ex_c = block_scan<kTG>(c, &tot_c, sh);
-    if (p <= S) cnt[p] = carry_c + ex_c;
+    if (p <= S) {
+      cnt[p] = carry_c + ex_c;
+      if (in_lds) lcnt[p] = carry_c + ex_c;  // (the cursors start at the buckets' first entries)
+    }
     carry_c += tot_c;
   }
   if (tid == 0) cnt[S + 1] = A + nfinal;
   __syncthreads();
-  for (int s = tid; s < S; s += kTG) cur[s] = cnt[s];
-  for (int s = tid; s <= S; s += kTG) row[s] = lower_bound_src(src, A, s);
+  if (!in_lds)
+    for (int s = tid; s < S; s += kTG) cur[s] = cnt[s];
+  for (int s = (A > 0 ? src[A - 1] + 1 : 0) + tid; s <= S; s += kTG) row[s] = A;  // (the states behind the last arc's source)
   __syncthreads();
-  for (int i = tid; i < A; i += kTG) in_arc[atomicAdd(&cur[dst[i]], 1)] = i;
+  for (int ib = tid; ib < A; ib += kTG * kAhead) {
+    int vt[kAhead], at[kAhead];
+#pragma unroll
+    for (int x = 0; x < kAhead; ++x) vt[x] = dst[min(ib + x * kTG, A - 1)];
+#pragma unroll
+    for (int x = 0; x < kAhead; ++x) at[x] = ib + x * kTG < A ? atomicAdd(&cur[vt[x]], 1) : 0;
+#pragma unroll
+    for (int x = 0; x < kAhead; ++x)
+      if (ib + x * kTG < A) in_arc[at[x]] = ib + x * kTG;
+  }
   __syncthreads();
+  // sixteen keys in registers, ascending (the 60-comparator network of klat_frame.hip): a state's in-arcs / out-arcs are
+  // loaded together, ordered and written back -- insertion sorts in place were chains of dependent trips to L2, twenty
+  // states a thread, and a wave waits for the lane with the longest
+  auto sort16 = [](uint32_t (&k)[16]) {
+    auto ce = [](uint32_t& x, uint32_t& y) {
+      const uint32_t lo = min(x, y), hi = max(x, y);
+      x = lo, y = hi;
+    };
+    ce(k[0], k[13]); ce(k[1], k[12]); ce(k[2], k[15]); ce(k[3], k[14]); ce(k[4], k[8]); ce(k[5], k[6]); ce(k[7], k[11]); ce(k[9], k[10]);
+    ce(k[0], k[5]); ce(k[1], k[7]); ce(k[2], k[9]); ce(k[3], k[4]); ce(k[6], k[13]); ce(k[8], k[14]); ce(k[10], k[15]); ce(k[11], k[12]);
+    ce(k[0], k[1]); ce(k[2], k[3]); ce(k[4], k[5]); ce(k[6], k[8]); ce(k[7], k[9]); ce(k[10], k[11]); ce(k[12], k[13]); ce(k[14], k[15]);
+    ce(k[0], k[2]); ce(k[1], k[3]); ce(k[4], k[10]); ce(k[5], k[11]); ce(k[6], k[7]); ce(k[8], k[9]); ce(k[12], k[14]); ce(k[13], k[15]);
+    ce(k[1], k[2]); ce(k[3], k[12]); ce(k[4], k[6]); ce(k[5], k[7]); ce(k[8], k[10]); ce(k[9], k[11]); ce(k[13], k[14]);
+    ce(k[1], k[4]); ce(k[2], k[6]); ce(k[5], k[8]); ce(k[7], k[10]); ce(k[9], k[13]); ce(k[11], k[14]);
+    ce(k[2], k[4]); ce(k[3], k[6]); ce(k[9], k[12]); ce(k[11], k[13]);
+    ce(k[3], k[5]); ce(k[6], k[8]); ce(k[7], k[9]); ce(k[10], k[12]);
+    ce(k[3], k[4]); ce(k[5], k[6]); ce(k[7], k[8]); ce(k[9], k[10]); ce(k[11], k[12]);
+    ce(k[6], k[7]); ce(k[8], k[9]);
+  };
   for (int s = tid; s < S; s += kTG) {
     const int b = cnt[s], e = cnt[s + 1];
-    for (int i = b + 1; i < e; ++i) {
-      const int v = in_arc[i];
-      int j = i - 1;
-      while (j >= b && in_arc[j] > v) {
-        in_arc[j + 1] = in_arc[j];
-        --j;
+    const int r0 = row[s], r1 = row[s + 1];
+    if (e - b <= 16) {
+      uint32_t k[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) k[j] = b + j < e ? (uint32_t)in_arc[b + j] : 0xFFFFFFFFu;
+      sort16(k);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (b + j < e) in_arc[b + j] = (int32_t)k[j];
+    } else {
+      for (int i = b + 1; i < e; ++i) {
+        const int v = in_arc[i];
+        int j = i - 1;
+        while (j >= b && in_arc[j] > v) {
+          in_arc[j + 1] = in_arc[j];
+          --j;
+        }
+        in_arc[j + 1] = v;
       }
-      in_arc[j + 1] = v;
     }
-    const int nb = row[s + 1] - row[s] + (dev_is_final(a, s0 + s) ? 1 : 0);
+    const int nb = r1 - r0 + (dev_is_final(a, s0 + s) ? 1 : 0);
     mtb = max(mtb, nb);
     for (int k = 0; k < kNumLaneChoices; ++k) bsum[k] += (max(nb, 1) + (1 << k) - 1) >> k;
     int nearest = S;
-    for (int i = row[s]; i < row[s + 1]; ++i) {  // out-arcs: farthest destination first, equal destinations in arc order
-      const int dv = dst[i];
-      nearest = min(nearest, dv);
-      int j = i - 1;
-      while (j >= row[s] && dst[out_arc[j]] < dv) {
-        out_arc[j + 1] = out_arc[j];
-        --j;
+    if (r1 - r0 <= 16 && S < (1 << 27)) {  // out-arcs: farthest destination first, equal destinations in arc order
+      uint32_t k[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int dv = r0 + j < r1 ? dst[r0 + j] : S;
+        if (r0 + j < r1) nearest = min(nearest, dv);
+        k[j] = r0 + j < r1 ? ((uint32_t)(S - dv) << 4) | (uint32_t)j : 0xFFFFFFFFu;
       }
-      out_arc[j + 1] = i;
+      sort16(k);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (r0 + j < r1) out_arc[r0 + j] = r0 + (int32_t)(k[j] & 15u);
+    } else {
+      for (int i = r0; i < r1; ++i) {
+        const int dv = dst[i];
+        nearest = min(nearest, dv);
+        int j = i - 1;
+        while (j >= r0 && dst[out_arc[j]] < dv) {
+          out_arc[j + 1] = out_arc[j];
+          --j;
+        }
+        out_arc[j + 1] = i;
+      }
     }
     if (nearest == s + 1) atomicAdd(&sh_linked, 1);
   }
@@ -845,7 +921,14 @@ hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, const int c
     if (class_need[c] > 0)
       hipLaunchKernelGGL(pack_count_kernel, dim3(num_lattices), dim3(kTC), (size_t)class_need[c], stream, a,
                          c == 0 ? -1 : kPackCountClassLds[c - 1], kPackCountClassLds[c]);
-  if (any_global) hipLaunchKernelGGL(pack_count_global_kernel, dim3(num_lattices), dim3(kTG), 0, stream, a, kPackCountMaxLds);
+  if (any_global) {
+    static bool global_attr_done = false;
+    if (!global_attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_count_global_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPackCountMaxLds);
+      global_attr_done = true;
+    }
+    hipLaunchKernelGGL(pack_count_global_kernel, dim3(num_lattices), dim3(kTG), (size_t)kPackCountMaxLds, stream, a, kPackCountMaxLds, kPackCountMaxLds);
+  }
   return hipGetLastError();
 }
 
