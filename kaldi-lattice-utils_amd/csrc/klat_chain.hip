@@ -17,6 +17,7 @@ namespace klat {
 
 namespace {
 
+constexpr int kPrepAhead = 8;  // arcs of a state chain_prep_kernel has in flight
 constexpr int kTP = 1024;  // chain_prep_kernel: a lattice of 20 000 states is 20 turns of its workgroup (256 threads: 80, and the batch waited for them)
 // Waves per workgroup of the walks.  The waves share nothing, and single-wave workgroups pack a CU's LDS best
 // (the dispatcher spreads them evenly over the four SIMDs: KLAT_CHAIN_DEBUG shows where every wave ran).
@@ -128,11 +129,26 @@ __global__ __launch_bounds__(kTP) void chain_prep_kernel(ChainPrepArgs a) {
       const int i0 = cnt[s], i1 = cnt[s + 1];
       const int nterm = i1 - i0 + (s == 0 ? 1 : 0);
       if (s == 0) *r++ = chain_record(0.0, kChainSpecial | (nterm == 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
-      for (int i = i0; i < i1; ++i) {
-        const int64_t x = a0 + in_arc[i];
-        const double cost = arc_cost(a.graph[x], a.acoustic[x], a.ilabel[x] != 0, a.sp);
-        note(cost);
-        *r++ = chain_record(cost, (uint32_t)(s - a.src[x]) | (i == i1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
+      // (eight arcs' numbers, then their data, in flight together: arc by arc a state was two dependent trips to memory per
+      // arc, and the longest lattice's threads have twenty states each)
+      for (int ib = i0; ib < i1; ib += kPrepAhead) {
+        int ax[kPrepAhead], sv[kPrepAhead], il[kPrepAhead];
+        float gr[kPrepAhead], ac[kPrepAhead];
+#pragma unroll
+        for (int j = 0; j < kPrepAhead; ++j) ax[j] = in_arc[min(ib + j, i1 - 1)];
+#pragma unroll
+        for (int j = 0; j < kPrepAhead; ++j) {
+          const int64_t x = a0 + ax[j];
+          gr[j] = a.graph[x], ac[j] = a.acoustic[x], il[j] = a.ilabel[x], sv[j] = a.src[x];
+        }
+#pragma unroll
+        for (int j = 0; j < kPrepAhead; ++j) {
+          const int i = ib + j;
+          if (i >= i1) break;
+          const double cost = arc_cost(gr[j], ac[j], il[j] != 0, a.sp);
+          note(cost);
+          *r++ = chain_record(cost, (uint32_t)(s - sv[j]) | (i == i1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
+        }
       }
       if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, a.tropical != 0);
       if (fin) *r++ = chain_record(fcost, 1u | kChainFinal, c9v, a.status, a.tropical != 0);
@@ -146,10 +162,23 @@ __global__ __launch_bounds__(kTP) void chain_prep_kernel(ChainPrepArgs a) {
         if (!(rec & kChainSpecial)) rec |= kChainSpecial;  // (a dead final weight already reads the constant zero)
         *r++ = rec;
       }
-      for (int i = o0; i < o1; ++i) {
-        const int64_t x = a0 + out_arc[i];
-        const double cost = arc_cost(a.graph[x], a.acoustic[x], a.ilabel[x] != 0, a.sp);
-        *r++ = chain_record(cost, (uint32_t)(a.dst[x] - s) | (i == o1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
+      for (int ib = o0; ib < o1; ib += kPrepAhead) {
+        int ax[kPrepAhead], dv[kPrepAhead], il[kPrepAhead];
+        float gr[kPrepAhead], ac[kPrepAhead];
+#pragma unroll
+        for (int j = 0; j < kPrepAhead; ++j) ax[j] = out_arc[min(ib + j, o1 - 1)];
+#pragma unroll
+        for (int j = 0; j < kPrepAhead; ++j) {
+          const int64_t x = a0 + ax[j];
+          gr[j] = a.graph[x], ac[j] = a.acoustic[x], il[j] = a.ilabel[x], dv[j] = a.dst[x];
+        }
+#pragma unroll
+        for (int j = 0; j < kPrepAhead; ++j) {
+          const int i = ib + j;
+          if (i >= o1) break;
+          const double cost = arc_cost(gr[j], ac[j], il[j] != 0, a.sp);
+          *r++ = chain_record(cost, (uint32_t)(dv[j] - s) | (i == o1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
+        }
       }
       if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, a.tropical != 0);
     }
