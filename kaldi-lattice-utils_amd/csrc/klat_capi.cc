@@ -1094,8 +1094,11 @@ static int ensure_chain_records(klat_batch* b, const klat_scales& s, const Scale
   if (!same) {
     int rc;
     DevBuf<int32_t> sf, sb2;
+    DevBuf<uint64_t> arc_records;
     DevBuf<uint64_t>& recs = tropical ? b->ch_recs_t : b->ch_recs;
-    if ((rc = recs.alloc(b->chain_records)) || (rc = sf.alloc((size_t)(b->S + 2 * b->U))) || (rc = sb2.alloc((size_t)(b->S + 2 * b->U)))) return rc;
+    if ((rc = recs.alloc(b->chain_records)) || (rc = sf.alloc((size_t)(b->S + 2 * b->U))) || (rc = sb2.alloc((size_t)(b->S + 2 * b->U))) ||
+        (rc = arc_records.alloc((size_t)b->A)))
+      return rc;
     KLAT_HIP(hipMemsetAsync(b->ch_status.p, 0, sizeof(int32_t), c->stream));       // [0]: a cost that fits no record
     KLAT_HIP(hipMemsetAsync(b->ch_status.p + 2, 0, 2 * sizeof(int32_t), c->stream));  // [2..3]: the largest |cost| (a double's bits)
     ChainPrepArgs cp;
@@ -1117,6 +1120,7 @@ static int ensure_chain_records(klat_batch* b, const klat_scales& s, const Scale
     cp.out_arc = b->ch_out_arc.p;
     cp.scratch_f = sf.p;
     cp.scratch_b = sb2.p;
+    cp.arc_records = arc_records.p;
     cp.sp = sp;
     cp.tropical = tropical ? 1 : 0;
     cp.status = b->ch_status.p;

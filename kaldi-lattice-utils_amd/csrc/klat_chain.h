@@ -73,6 +73,7 @@ struct ChainPrepArgs {
   // the stream packer's count pass: lattice u owns entries [state_off[u] + 2u, +S+2)
   const int32_t* cnt; const int32_t* row; const int32_t* in_arc; const int32_t* out_arc;
   int32_t* scratch_f; int32_t* scratch_b;  // same shape (the packer's r0f / r0b, not yet in use)
+  uint64_t* arc_records;                  // [A] a temporary: every arc's record in the arcs' own order (chain_prep_kernel)
   ScaleParams sp;
   int32_t tropical;  // the records hold the costs themselves (klat_viterbi), not exp(-cost)
   int32_t* status;  // [1] set when a cost does not fit a record

@@ -17,7 +17,7 @@ namespace klat {
 
 namespace {
 
-constexpr int kPrepAhead = 8;  // arcs of a state chain_prep_kernel has in flight
+constexpr int kPrepAhead = 4;  // arcs a thread of chain_prep_kernel has in flight
 constexpr int kTP = 1024;  // chain_prep_kernel: a lattice of 20 000 states is 20 turns of its workgroup (256 threads: 80, and the batch waited for them)
 // Waves per workgroup of the walks.  The waves share nothing, and single-wave workgroups pack a CU's LDS best
 // (the dispatcher spreads them evenly over the four SIMDs: KLAT_CHAIN_DEBUG shows where every wave ran).
@@ -120,67 +120,90 @@ __global__ __launch_bounds__(kTP) void chain_prep_kernel(ChainPrepArgs a) {
     const double ac = fabs(cost);
     if (ac < 1.0e30) mxc = fmax(mxc, ac);
   };
+  // A thread per ARC, three times.  First in the arcs' own order -- five arrays read as they lie --: the arc's record
+  // (its weight; the distance between its states, the same in both streams) into a row of the batch's temporaries.  Then the
+  // backward stream in the order of out_arc (a state's arcs among themselves: the rows read are the neighbours') and the
+  // forward stream in that of in_arc: ONE random 8-byte read per arc, and its destination, where gathering the arc itself
+  // there was five (12 GB of sectors for the mix's 38 M arcs).  An arc's record lies at its state's first record plus its
+  // place among the state's arcs.  (A thread per state walked its arcs one by one -- a wave as long as its state of most
+  // arcs, every record behind two dependent trips to memory.)
+  const bool trop = a.tropical != 0;
+  const int A = (int)(a.arc_off[u + 1] - a0);
+  uint64_t* wrow = a.arc_records + a0;
+  // (kPrepAhead arcs a thread at a time, every stage's loads asked for together: one arc after the other a thread's turn
+  // was two or three trips to memory in a row, and all sixteen waves of the workgroup are in the same loop)
+  for (int jb = tid; jb < A; jb += kTP * kPrepAhead) {
+    float gr[kPrepAhead], ac[kPrepAhead];
+    int il[kPrepAhead], sv[kPrepAhead], dv[kPrepAhead];
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) {
+      const int64_t x = a0 + min(jb + q * kTP, A - 1);
+      gr[q] = a.graph[x], ac[q] = a.acoustic[x], il[q] = a.ilabel[x], sv[q] = a.src[x], dv[q] = a.dst[x];
+    }
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) {
+      const int j = jb + q * kTP;
+      if (j >= A) continue;
+      const double cost = arc_cost(gr[q], ac[q], il[q] != 0, a.sp);
+      note(cost);
+      wrow[j] = chain_record(cost, (uint32_t)(dv[q] - sv[q]), c9v, a.status, trop);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int ib = tid; ib < A; ib += kTP * kPrepAhead) {
+    int j[kPrepAhead], sv[kPrepAhead], r0[kPrepAhead], r1[kPrepAhead], base[kPrepAhead];
+    uint64_t w[kPrepAhead];
+    bool fin[kPrepAhead];
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) j[q] = out_arc[min(ib + q * kTP, A - 1)];
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) sv[q] = a.src[a0 + j[q]], w[q] = wrow[j[q]];
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) r0[q] = row[sv[q]], r1[q] = row[sv[q] + 1], base[q] = pb[sv[q] + 1], fin[q] = is_final(sv[q]);
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) {
+      const int i = ib + q * kTP;
+      if (i < A) a.recs[cl.rec_b + (Tb - base[q]) + (fin[q] ? 1 : 0) + (i - r0[q])] = w[q] | (i == r1[q] - 1 ? kChainLast : 0);
+    }
+  }
+  for (int ib = tid; ib < A; ib += kTP * kPrepAhead) {
+    int j[kPrepAhead], sv[kPrepAhead], c0[kPrepAhead], c1[kPrepAhead], base[kPrepAhead];
+    uint64_t w[kPrepAhead];
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) j[q] = in_arc[min(ib + q * kTP, A - 1)];
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) sv[q] = a.dst[a0 + j[q]], w[q] = wrow[j[q]];
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) c0[q] = cnt[sv[q]], c1[q] = cnt[sv[q] + 1], base[q] = pf[sv[q]];
+#pragma unroll
+    for (int q = 0; q < kPrepAhead; ++q) {
+      const int i = ib + q * kTP;
+      if (i < A) a.recs[cl.rec_f + base[q] + (i - c0[q]) + (sv[q] == 0 ? 1 : 0)] = w[q] | (i == c1[q] - 1 ? kChainLast : 0);
+    }
+  }
+  // ... and a thread per state for what is not an arc: the start state's constant one, a state without terms, the final weights
   for (int s = tid; s < S; s += kTP) {
     const bool fin = is_final(s);
     const double fcost = fin ? arc_cost(a.final_graph[s0 + s], a.final_acoustic[s0 + s], false, a.sp) : 0.0;
     note(fcost);
     {
       uint64_t* r = a.recs + cl.rec_f + pf[s];
-      const int i0 = cnt[s], i1 = cnt[s + 1];
-      const int nterm = i1 - i0 + (s == 0 ? 1 : 0);
-      if (s == 0) *r++ = chain_record(0.0, kChainSpecial | (nterm == 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
-      // (eight arcs' numbers, then their data, in flight together: arc by arc a state was two dependent trips to memory per
-      // arc, and the longest lattice's threads have twenty states each)
-      for (int ib = i0; ib < i1; ib += kPrepAhead) {
-        int ax[kPrepAhead], sv[kPrepAhead], il[kPrepAhead];
-        float gr[kPrepAhead], ac[kPrepAhead];
-#pragma unroll
-        for (int j = 0; j < kPrepAhead; ++j) ax[j] = in_arc[min(ib + j, i1 - 1)];
-#pragma unroll
-        for (int j = 0; j < kPrepAhead; ++j) {
-          const int64_t x = a0 + ax[j];
-          gr[j] = a.graph[x], ac[j] = a.acoustic[x], il[j] = a.ilabel[x], sv[j] = a.src[x];
-        }
-#pragma unroll
-        for (int j = 0; j < kPrepAhead; ++j) {
-          const int i = ib + j;
-          if (i >= i1) break;
-          const double cost = arc_cost(gr[j], ac[j], il[j] != 0, a.sp);
-          note(cost);
-          *r++ = chain_record(cost, (uint32_t)(s - sv[j]) | (i == i1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
-        }
-      }
-      if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, a.tropical != 0);
-      if (fin) *r++ = chain_record(fcost, 1u | kChainFinal, c9v, a.status, a.tropical != 0);
+      const int n_in = cnt[s + 1] - cnt[s];
+      const int nterm = n_in + (s == 0 ? 1 : 0);
+      if (s == 0) r[0] = chain_record(0.0, kChainSpecial | (nterm == 1 ? kChainLast : 0), c9v, a.status, trop);
+      if (nterm == 0) r[0] = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, trop);
+      if (fin) r[max(nterm, 1)] = chain_record(fcost, 1u | kChainFinal, c9v, a.status, trop);
     }
     {
       uint64_t* r = a.recs + cl.rec_b + (Tb - pb[s + 1]);
-      const int o0 = row[s], o1 = row[s + 1];
-      const int nterm = o1 - o0 + (fin ? 1 : 0);
+      const int nterm = row[s + 1] - row[s] + (fin ? 1 : 0);
       if (fin) {
-        uint64_t rec = chain_record(fcost, nterm == 1 ? kChainLast : 0, c9v, a.status, a.tropical != 0);
+        uint64_t rec = chain_record(fcost, nterm == 1 ? kChainLast : 0, c9v, a.status, trop);
         if (!(rec & kChainSpecial)) rec |= kChainSpecial;  // (a dead final weight already reads the constant zero)
-        *r++ = rec;
+        r[0] = rec;
       }
-      for (int ib = o0; ib < o1; ib += kPrepAhead) {
-        int ax[kPrepAhead], dv[kPrepAhead], il[kPrepAhead];
-        float gr[kPrepAhead], ac[kPrepAhead];
-#pragma unroll
-        for (int j = 0; j < kPrepAhead; ++j) ax[j] = out_arc[min(ib + j, o1 - 1)];
-#pragma unroll
-        for (int j = 0; j < kPrepAhead; ++j) {
-          const int64_t x = a0 + ax[j];
-          gr[j] = a.graph[x], ac[j] = a.acoustic[x], il[j] = a.ilabel[x], dv[j] = a.dst[x];
-        }
-#pragma unroll
-        for (int j = 0; j < kPrepAhead; ++j) {
-          const int i = ib + j;
-          if (i >= o1) break;
-          const double cost = arc_cost(gr[j], ac[j], il[j] != 0, a.sp);
-          *r++ = chain_record(cost, (uint32_t)(dv[j] - s) | (i == o1 - 1 ? kChainLast : 0), c9v, a.status, a.tropical != 0);
-        }
-      }
-      if (nterm == 0) *r++ = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, a.tropical != 0);
+      if (nterm == 0) r[0] = chain_record(0.0, kChainSpecial | kChainWhich | kChainLast, c9v, a.status, trop);
     }
   }
   for (int d = 32; d > 0; d >>= 1) mxc = fmax(mxc, __shfl_xor(mxc, d, 64));
