@@ -1,4 +1,5 @@
-"""Stress test of the FAR path (sources older than the ring) under a full chip: 6 000 lattices with
+"""(A checker script, not a pytest module: it lives with the tests because it calls the oracle.)
+Stress test of the FAR path (sources older than the ring) under a full chip: 6 000 lattices with
 every third arc stretched over 17-60 states, four layouts; flow properties over all arcs and oracle
 parity on a sample."""
 import os, sys

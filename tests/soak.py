@@ -1,6 +1,7 @@
-"""Randomised parity soak: random batch shapes, layouts, scales, final-state patterns, infinite
+"""(A checker script, not a pytest module: it lives with the tests because it calls the oracle.)
+Randomised parity soak: random batch shapes, layouts, scales, final-state patterns, infinite
 costs and long-span arcs through forward-backward, the index accumulators, the Viterbi twin and
-the utterance scores, all against the oracle.  usage: tools/soak.py [seconds] [seed]"""
+the utterance scores, all against the oracle.  usage: tests/soak.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
