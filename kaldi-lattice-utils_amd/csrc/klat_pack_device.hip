@@ -255,17 +255,22 @@ __global__ __launch_bounds__(kTC, 6) void pack_count_kernel(PackDevArgs a, int l
   for (int s = tid; s < S; s += kTC) {
     const int b = s > 0 ? cnt[s - 1] : 0, e = cnt[s], n = e - b;
     if (n <= 1) continue;
-    if (n <= 4) {  // in registers: a sorting network on up to four arc numbers
-      int v[4];
+    if (n <= 8) {  // in registers: a sorting network on up to eight arc numbers (up to four: one wave in two had a lane with more, and waited for its insertion sort)
+      int v[8];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) v[x] = x < n ? (int)in_arc[b + x] : 0x10000 + x;
+      for (int x = 0; x < 8; ++x) v[x] = x < n ? (int)in_arc[b + x] : 0x10000 + x;
       auto cswap = [&](int x, int y) {
         const int lo = min(v[x], v[y]), hi = max(v[x], v[y]);
         v[x] = lo, v[y] = hi;
       };
-      cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+      cswap(0, 1), cswap(2, 3), cswap(4, 5), cswap(6, 7);
+      cswap(0, 2), cswap(1, 3), cswap(4, 6), cswap(5, 7);
+      cswap(1, 2), cswap(5, 6);
+      cswap(0, 4), cswap(1, 5), cswap(2, 6), cswap(3, 7);
+      cswap(2, 4), cswap(3, 5);
+      cswap(1, 2), cswap(3, 4), cswap(5, 6);
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+      for (int x = 0; x < 8; ++x)
         if (x < n) in_arc[b + x] = (IA)v[x];
       continue;
     }
@@ -290,27 +295,30 @@ __global__ __launch_bounds__(kTC, 6) void pack_count_kernel(PackDevArgs a, int l
   for (int s = tid; s < S; s += kTC) {
     const int b = row[s], e = row[s + 1], deg = e - b;
     if (deg <= 0) continue;
-    if (deg <= 4) {
-      int d[4], id[4];
+    if (deg <= 8) {
+      // one key an arc: (S - destination) << 3 | its place among the state's arcs -- ascending is destination descending,
+      // arc ascending; the slots behind the last arc sort to the end
+      uint32_t k[8];
+      int nearest = S;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        id[x] = b + x;
-        d[x] = x < deg ? dst[b + x] : -1 - x;  // (the slots behind the last arc sort to the end, in order)
+      for (int x = 0; x < 8; ++x) {
+        const int dv = x < deg ? dst[b + x] : S;
+        if (x < deg) nearest = min(nearest, dv);
+        k[x] = x < deg ? ((uint32_t)(S - dv) << 3) | (uint32_t)x : 0xFFFFFFFFu;
       }
-      // sorting network on (destination descending, arc ascending)
       auto cswap = [&](int x, int y) {
-        if (d[x] < d[y] || (d[x] == d[y] && id[x] > id[y])) {
-          const int td = d[x], ti = id[x];
-          d[x] = d[y], id[x] = id[y];
-          d[y] = td, id[y] = ti;
-        }
+        const uint32_t lo = min(k[x], k[y]), hi = max(k[x], k[y]);
+        k[x] = lo, k[y] = hi;
       };
-      cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
-      int nearest = d[0];
+      cswap(0, 1), cswap(2, 3), cswap(4, 5), cswap(6, 7);
+      cswap(0, 2), cswap(1, 3), cswap(4, 6), cswap(5, 7);
+      cswap(1, 2), cswap(5, 6);
+      cswap(0, 4), cswap(1, 5), cswap(2, 6), cswap(3, 7);
+      cswap(2, 4), cswap(3, 5);
+      cswap(1, 2), cswap(3, 4), cswap(5, 6);
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        if (x < deg) a.out_arc[a0 + b + x] = id[x], nearest = d[x];
-      }
+      for (int x = 0; x < 8; ++x)
+        if (x < deg) a.out_arc[a0 + b + x] = b + (int32_t)(k[x] & 7u);
       linked += nearest == s + 1 ? 1 : 0;
     } else {
       int32_t* out_arc = a.out_arc + a0;
