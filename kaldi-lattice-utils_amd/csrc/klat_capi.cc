@@ -46,6 +46,9 @@ int hip_fail(hipError_t e, const char* what) {
 
 using namespace klat;
 
+// SweepArgs::role_mask of the classes' sweeps (tools/sweep_roles.py scans the masks on the C2 batch)
+static const uint32_t kSweepRoleMask = 0x07;
+
 // Runs the pieces of one sweep side by side: the first on the context's stream, the others on side
 // streams that fork from it and join it again, so that the few long workgroups of a skewed batch run
 // beside the many short ones.  The pieces are the layout classes (the class with the longest chain
@@ -1268,6 +1271,8 @@ int klat_forward_backward_ex(klat_batch* b, const klat_scales* sc, uint32_t flag
       ca2.ring_slots = lc.W;
       ca2.far_prefetch = lc.far;
       ca2.deep_prefetch = b->deep_prefetch;
+      ca2.role_mask = kSweepRoleMask;
+      if (const char* rm = std::getenv("KLAT_SWEEP_ROLE_MASK")) ca2.role_mask = (uint32_t)std::strtoul(rm, nullptr, 0);
       return ca2;
     };
     const bool with_chain = chain_ok;
