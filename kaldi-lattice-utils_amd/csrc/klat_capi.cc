@@ -47,7 +47,7 @@ int hip_fail(hipError_t e, const char* what) {
 using namespace klat;
 
 // SweepArgs::role_mask of the classes' sweeps (tools/sweep_roles.py scans the masks on the C2 batch)
-static const uint32_t kSweepRoleMask = 0x07;
+static const uint32_t kSweepRoleMask = 0x100;  // (in a forward job wave 0 walks the chain, in a backward job wave 1)
 
 // Runs the pieces of one sweep side by side: the first on the context's stream, the others on side
 // streams that fork from it and join it again, so that the few long workgroups of a skewed batch run

@@ -73,9 +73,10 @@ struct SweepArgs {
   // null, or a device word: the launch does nothing while it is zero (the classes of the lattices swept in
   // segments run only when klat_chain.hip raised its flag)
   const int32_t* run_if = nullptr;
-  // bit (blockIdx >> 8) & 7 set: the workgroup's two waves swap roles (wave 1 stages, wave 0 walks the chain).  The
-  // dispatcher puts a workgroup's waves on SIMDs s and s + 2 of its CU and 256 consecutive workgroups on 256 CUs: the mask
-  // decides which SIMDs of a CU carry the chain waves of its first, second ... workgroup (klat_capi.cc: kSweepRoleMask)
+  // Which of a workgroup's two waves stages and which walks the chain.  The dispatcher puts them on SIMDs s and s + 2 of
+  // the workgroup's CU and 256 consecutive workgroups on 256 CUs, so this decides which SIMDs of a CU carry its chain waves.
+  // 0: wave 0 stages.  0x100: the waves of a FORWARD job swap roles (klat_capi.cc: kSweepRoleMask); 0x200: those of a
+  // backward job; else bit (blockIdx >> 8) & 7 -- the workgroup's turn on its CU -- set: swapped (tools/sweep_roles.py)
   uint32_t role_mask = 0;
 };
 

@@ -173,8 +173,9 @@ __global__ __launch_bounds__(128) void sweep_kernel(SweepArgs args) {
   const int lane = threadIdx.x & 63;
   const int slot = lane / G;
   const int sub = lane % G;
-  const bool producer = (threadIdx.x < 64) != (((args.role_mask >> ((blockIdx.x >> 8) & 7)) & 1u) != 0);  // wave 0, or wave 1 where the mask says so
   const SweepJob job = args.jobs[blockIdx.x];
+  const bool swapped = (args.role_mask & 0x100u) ? job.dir == 0 : (args.role_mask & 0x200u) ? job.dir != 0 : ((args.role_mask >> ((blockIdx.x >> 8) & 7)) & 1u) != 0;
+  const bool producer = (threadIdx.x < 64) != swapped;  // wave 0, or wave 1 where the mask says so
   const int nchunks = job.nchunks;
   // long chains first: both waves of a job on the batch's critical path (priority tag 3, skewed
   // batches only) outrank the waves they share a SIMD with
