@@ -190,14 +190,21 @@ __device__ void fr_bitonic_sort(FKey* data, int n, FKey* tile, Less less) {
 
 // block-wide exclusive scan of one int per thread (NT threads)
 // (TAIL = false: no barrier behind the last read of sh -- the caller does not write sh again before its next barrier)
+// inclusive prefix sum over the wave by DPP: four shifts within the rows of sixteen lanes, then the rows' last lanes handed
+// on (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- six adds, no trip through the LDS crossbar
+__device__ __forceinline__ int fr_wave_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return v;
+}
 template <int NT = kFrThreads, bool TAIL = true>
 __device__ int fr_block_scan(int v, int* total, int* sh /* [NT/64] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = v;
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
+  const int inc = fr_wave_scan(v);
   if (lane == 63) sh[wave] = inc;
   __syncthreads();
   int pre = 0, tot = 0;
@@ -214,11 +221,7 @@ __device__ int fr_block_scan(int v, int* total, int* sh /* [NT/64] */) {
 template <int NT = kFrThreads, bool TAIL = true>
 __device__ int2 fr_block_scan2(int v, int w, int* total_v, int* total_w, int* sh /* [2 * NT/64] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int iv = v, iw = w;
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(iv, off, 64), x = __shfl_up(iw, off, 64);
-    if (lane >= off) iv += t, iw += x;
-  }
+  const int iv = fr_wave_scan(v), iw = fr_wave_scan(w);
   if (lane == 63) sh[wave] = iv, sh[NT / 64 + wave] = iw;
   __syncthreads();
   int pv = 0, tv = 0, pw = 0, tw = 0;
