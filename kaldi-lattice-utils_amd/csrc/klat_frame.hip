@@ -1482,14 +1482,21 @@ __global__ __launch_bounds__(kFrLeanThreads / SC / (DENSE == 2 ? 2 : 1), (BIG ||
     // ---- 1. entries per rank from a difference array over the spans, and the buckets' offsets ----
     for (int k = tid; k <= tc; k += NT) lboff[k] = 0;
     if (tid == 0) tile_max = 0, wide_n = 0;
-    auto first_at_least = [&](int rank) {  // first arc whose first rank is >= rank (spans in LDS)
+    // first arc whose first rank is >= rank (spans in LDS): the wave's lanes probe 64 places of the range at once -- three
+    // trips to LDS for 6 000 arcs where a binary search by every thread for itself took thirteen (every wave finds the same)
+    auto first_at_least = [&](int rank) {
+      const int l64 = tid & 63;
       int l = 0, h = nA;
-      while (l < h) {
-        const int mid = (l + h) >> 1;
-        if ((int)(lspan[mid] & 0xFFFFu) < rank) l = mid + 1;
-        else h = mid;
+      while (h - l > 64) {  // (wave-uniform)
+        const int step = (h - l + 63) >> 6;
+        const int at = min(l + (l64 + 1) * step - 1, h - 1);
+        const int below = __popcll(__ballot((int)(lspan[at] & 0xFFFFu) < rank));  // the probes are ascending: the first `below` lanes
+        const int nl = below ? min(l + below * step, h) : l;                     // behind the last probe below rank
+        const int nh = below < 64 ? min(l + (below + 1) * step, h) : h;          // up to and with the first probe not below
+        l = nl, h = nh;
       }
-      return l;
+      const int below = __popcll(__ballot(l + l64 < h && (int)(lspan[min(l + l64, h - 1)] & 0xFFFFu) < rank));
+      return l + below;
     };
     // arcs that can cover a rank of the tile: first rank below the tile's end, and (no arc is longer than
     // `longest`) above its start less that -- by binary search over the spans in LDS, or to the block of ranks
