@@ -715,11 +715,13 @@ def main():
                 # the context it runs on, and the skewed shapes below are sensitive to how a process's streams map onto the
                 # hardware queues)
                 pctx = klat_amd.Ctx(0)
-                for _ in range(4):
-                    t0 = time.perf_counter()
-                    klat_amd.forward_backward_host(pctx, pin, SCALES, pieces=0, fuse=FUSE, out=pout, host_threads=host_threads)
-                    times.append(time.perf_counter() - t0)
-                pctx.close()
+                try:
+                    for _ in range(4):
+                        t0 = time.perf_counter()
+                        klat_amd.forward_backward_host(pctx, pin, SCALES, pieces=0, fuse=FUSE, out=pout, host_threads=host_threads)
+                        times.append(time.perf_counter() - t0)
+                finally:
+                    pctx.close()
                 sec_p = median(times[1:])
                 out["boundary"]["pipelined"] = {"what": "klat_forward_backward_host: the compact descriptor in, alpha / beta / totals / arc posteriors out, "
                                                         "page-locked buffers, the batch in pieces over three streams", "seconds_per_batch": sec_p,

@@ -212,6 +212,8 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
               longs.push_back((int32_t)u);
               first[(size_t)u] = (int32_t)slots;
               slots += (arcs + kPieceStride - 1) / kPieceStride;
+            } else {
+              st.any_general = true;  // (no piece slots: the general kernel must run for it even if nothing else is long)
             }
             continue;
           }
@@ -233,13 +235,15 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       // (slicing, pieces, general kernel) on the context's stream, the classes on side streams, largest first.
       std::vector<SweepPiece> work;
       AccumArgs long_args = a;
-      if (st.num_long > 0) {
+      if (st.num_long > 0 || st.any_general) {
         // long lattices: cut where the source states' time changes, the pieces through the two largest classes' kernel
         // (a piece has at most kPieceStride + kPieceWindow = 15 360 arcs), what could not be cut through the general kernel
         long_args.min_arcs = kHashClassArcs[kHashClasses - 1], long_args.max_arcs = 0x7FFFFFFF;
         work.push_back(SweepPiece{0, [&](hipStream_t s) {
-                                    hipError_t e = launch_index_slice(a, position, st.long_list.p, (int)st.num_long, s);
-                                    if (e == hipSuccess) e = launch_index_hash2(a, pk, position, kHashClasses - 2, st.piece_items.p, (int)st.num_piece_slots, s);
+                                    hipError_t e = hipSuccess;
+                                    if (st.num_long > 0) e = launch_index_slice(a, position, st.long_list.p, (int)st.num_long, s);
+                                    if (e == hipSuccess && st.num_long > 0)
+                                      e = launch_index_hash2(a, pk, position, kHashClasses - 2, st.piece_items.p, (int)st.num_piece_slots, s);
                                     if (e == hipSuccess) e = launch_index(long_args, (int)b->U, position, s);
                                     return e;
                                   }});

@@ -340,7 +340,10 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
     v.label_min = pk.label_min, v.time_bits = pk.time_bits;
     v.dupbit_off = (uint32_t)H * 4u;
   }
-  QEntry* queue = reinterpret_cast<QEntry*>(reinterpret_cast<Rec*>(a.rec_scratch) + row);  // (24 B a slot: room for n entries)
+  // (24 B a slot: room for n entries.  A piece's row may start 8 bytes past a 16-byte boundary -- its cut is wherever the
+  // times allow; the queue's 16-byte accesses are then two-dword aligned, which global memory serves, at the price of a
+  // split line now and then on this rare path.  The copy-out below, which every record takes, does align itself.)
+  QEntry* queue = reinterpret_cast<QEntry*>(reinterpret_cast<Rec*>(a.rec_scratch) + row);
   // the list of repeated keys' arcs: behind the queue in the record row (16 of a slot's 24 bytes are the queue's),
   // out of the way of the payloads the fold writes while it reads the list
   uint32_t* duplist = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(reinterpret_cast<Rec*>(a.rec_scratch) + row) +
@@ -800,8 +803,12 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
   __syncthreads();  // every thread is done with `order` (and with the counters behind it)
   {
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    const int stage_recs = lds_bytes / (int)sizeof(Rec) & ~1;  // (even: every pass starts on a 16-byte boundary)
-    uint64_t* stage = reinterpret_cast<uint64_t*>(smem);  // [stage_recs][3]
+    // A whole lattice's row starts on a 16-byte boundary; a piece's row starts at an arbitrary cut, so row * 24 bytes may
+    // be 8 past one.  The records are staged one 8-byte word further on then (h), which puts the 16-byte pairs of LDS on the
+    // 16-byte pairs of the row: a lone head word, whole uint4 stores, a lone tail word.
+    const int h = (int)(row & 1);
+    const int stage_recs = (lds_bytes - 8) / (int)sizeof(Rec) & ~1;  // (even: every pass starts on the same parity)
+    uint64_t* stage = reinterpret_cast<uint64_t*>(smem);  // [h + stage_recs * 3]
     uint64_t* out64 = reinterpret_cast<uint64_t*>(recs);
     for (int base = 0; base < m; base += stage_recs) {  // (m is workgroup-uniform)
 #pragma unroll
@@ -813,16 +820,17 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
         Payload q;
         if (POSITION && (dupmask & (1u << j))) q = payload[i];  // (t0, t1) of the first arc attaining the maximum
         else q = payload_of<POSITION>(key[j], i, pk.label_min, pk.time_bits);
-        stage[p * 3 + 0] = img[j];
-        stage[p * 3 + 1] = q.k1;
-        stage[p * 3 + 2] = q.k2;
+        stage[h + p * 3 + 0] = img[j];
+        stage[h + p * 3 + 1] = q.k1;
+        stage[h + p * 3 + 2] = q.k2;
       }
       lds_barrier();
-      const int cnt = min(stage_recs, m - base) * 3;  // 8-byte words; the row starts on a 16-byte boundary and base * 3 is even
+      const int cnt = min(stage_recs, m - base) * 3;  // 8-byte words of this pass; base * 3 is even
       const uint4* stage4 = reinterpret_cast<const uint4*>(stage);
-      uint4* out4 = reinterpret_cast<uint4*>(out64 + (size_t)base * 3);
-      for (int i = tid; i < cnt / 2; i += T) out4[i] = stage4[i];
-      if ((cnt & 1) && tid == 0) out64[(size_t)base * 3 + cnt - 1] = stage[cnt - 1];
+      uint4* out4 = reinterpret_cast<uint4*>(out64 + (size_t)base * 3 - h);
+      for (int i = h + tid; i < (cnt + h) / 2; i += T) out4[i] = stage4[i];
+      if (h && tid == 0) out64[(size_t)base * 3] = stage[1];
+      if (((cnt + h) & 1) && tid == 0) out64[(size_t)base * 3 + cnt - 1] = stage[h + cnt - 1];
       lds_barrier();
     }
   }

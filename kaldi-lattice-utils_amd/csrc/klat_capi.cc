@@ -1643,23 +1643,26 @@ int klat_forward_backward_host(klat_ctx* c, const klat_batch_desc_compact* d, co
   const int64_t A = d->arc_off[U] - d->arc_off[0];
   if (pieces <= 0) pieces = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, A / (8 << 20)));  // pieces of eight million arcs or more
   pieces = (int32_t)std::min<int64_t>(pieces, U);
+  int rc = compact_check(d);  // (before anything is created for the call)
+  if (rc != KLAT_OK) return rc;
   KLAT_HIP(hipSetDevice(c->device));
   // Three helper contexts made together on first use, the caller's own stream left out: the runtime deals streams onto
   // its hardware queues in the order they are created, and three made in a row sit on three queues -- with the caller's
   // stream as one of the three the call took 32 - 35 ms instead of 28 in three of four process set-ups (with and without
   // PyTorch in the process, four or eight hardware queues: tools/host_pipe_probe.py), two streams instead of three 31.6.
+  // The helpers belong to the context, so two host threads that share ONE context take turns here (contexts are per host
+  // thread, include/klat.h; this keeps a caller that shares one anyway from running two calls over the same streams).
+  std::lock_guard<std::mutex> pipe_lock(c->pipe_mu);
   klat_ctx* ctxs[3] = {c, nullptr, nullptr};
   const int lanes = pieces >= 3 ? 3 : pieces;
   for (int i = 0; lanes > 1 && i < lanes; ++i) {
     if (!c->pipe[i]) {
-      int rc = ctx_create(c->device, &c->pipe[i], false);
+      rc = ctx_create(c->device, &c->pipe[i], false);
       if (rc != KLAT_OK) return rc;
     }
     ctxs[i] = c->pipe[i];
   }
   const uint32_t flags = arc_logpost ? 0u : KLAT_FB_NO_ARC_POSTERIORS;
-  int rc = compact_check(d);
-  if (rc != KLAT_OK) return rc;
   klat_batch* live[3] = {nullptr, nullptr, nullptr};
   struct Piece {
     int64_t u0 = 0, u1 = 0, s0 = 0, a0 = 0;

@@ -206,6 +206,7 @@ struct klat_ctx {
   // klat_forward_backward_host pipelines the pieces of a batch over three helper contexts (streams and pools of their
   // own), created when the call first runs and gone with this context
   klat_ctx* pipe[3] = {nullptr, nullptr, nullptr};
+  std::mutex pipe_mu;  // one klat_forward_backward_host at a time per context: the helpers' streams and pools are the call's
 };
 
 // device scratch + cached result of the accumulate stage (klat_accum_api.cc)
@@ -231,6 +232,7 @@ struct klat_accum_state {
   // lattices of more than kHashClassArcs[last] arcs: cut into pieces on the device (index_slice_kernel), a piece a work
   // item of the largest classes; what could not be cut takes the general kernel
   int64_t num_long = 0, num_piece_slots = 0;
+  bool any_general = false;  // some lattice is longer than the slicing takes (1 024 pieces): the general kernel runs for it
   bool pieces_live = false;  // the last sizing call went through the hash kernel (piece_count is current)
   klat::DevBuf<int32_t> long_list, piece_first, piece_count, item_records;
   klat::DevBuf<klat::IndexItem> piece_items;

@@ -422,8 +422,10 @@ __global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, i
         atomicAdd(&deg[t], 1);
         mr = max(mr, t - s);
         // the row table from the arcs themselves (grouped by ascending source): arc i is the first out-arc of every
-        // state behind its predecessor's source up to its own -- no search per state
-        for (int q = (i > 0 ? vp[x] + 1 : 0); q <= s; ++q) row[q] = i;
+        // state behind its predecessor's source up to its own -- no search per state.  (The predecessor may be the
+        // malformed arc this pass exists to reject: its source below zero must not move the fill's start before the
+        // lattice's own rows; one above S leaves nothing to fill.)
+        for (int q = (i > 0 ? max(vp[x], -1) + 1 : 0); q <= s; ++q) row[q] = i;
       }
     }
   }

@@ -39,7 +39,8 @@ __device__ __forceinline__ void slice_prepare(int n, TimeOf t, int32_t* before, 
     }
   }
   __syncthreads();
-  // the maxima before every block, the minima from every block on: one wave each, 64 blocks a step
+  // the maxima before every block, the minima from every block on: one wave each, 64 blocks a step (a workgroup of a
+  // single wave takes both in turn)
   if (wave == 0) {
     int32_t run = (int32_t)0x80000000;
     for (int b0 = 0; b0 < nb; b0 += 64) {
@@ -55,7 +56,8 @@ __device__ __forceinline__ void slice_prepare(int n, TimeOf t, int32_t* before, 
       if (b < nb) before[b] = excl;
       run = max(run, __shfl(up, 63, 64));
     }
-  } else if (wave == 1 || waves == 1) {
+  }
+  if (wave == (waves > 1 ? 1 : 0)) {
     int32_t run = 0x7FFFFFFF;
     if (lane == 0) from[nb] = run;
     for (int b1 = nb; b1 > 0; b1 -= 64) {  // blocks [b1 - 64, b1), lane l takes block b1 - 1 - l

@@ -1,7 +1,7 @@
 // klat-archive-scan -- lists the entries of a lattice archive as the --devices tools see them: the
 // archive is mapped and scanned for the entry boundaries without building a lattice
 // (archive-index.h), then every entry is parsed from its byte range.  Prints per entry
-//   key  begin  end  t|b  states  arcs
+//   key  begin  end  t|b  states  arcs  s|u      (s: start state 0 and every arc to a higher state; u: TopSort has work to do)
 // Not one of the reference's tools: test plumbing for the scanner every rank of a multi-GPU run
 // relies on to agree on the entries it does not parse.
 #include <cstdio>
@@ -28,11 +28,17 @@ int main(int argc, char* argv[]) {
       ArchiveEntry e;
       archive.ScanNext(&e);
       long long states = -1, arcs = -1;
+      char sorted = '-';
       if (parse) {
         CompactLattice clat;
         archive.Read(e, &clat);
         states = clat.NumStates();
         arcs = clat.NumArcs();
+        {
+          FlatLattice fl;
+          ToFlat(clat, &fl);
+          sorted = IsTopSortedFromZero(fl) ? 's' : 'u';
+        }
         // a binary entry read straight into arrays must be the object form flattened
         FlatLattice direct, via_object;
         if (archive.ReadFlat(e, &direct)) {
@@ -50,7 +56,7 @@ int main(int argc, char* argv[]) {
           KLAT_ERR("entry " << e.key << ": not a binary CompactLattice");
         }
       }
-      std::printf("%s %zu %zu %c %lld %lld\n", e.key.c_str(), e.begin, e.end, e.binary ? 'b' : 't', states, arcs);
+      std::printf("%s %zu %zu %c %lld %lld %c\n", e.key.c_str(), e.begin, e.end, e.binary ? 'b' : 't', states, arcs, sorted);
       ++n;
     }
     KLAT_LOG("Scanned " << n << " entries of " << archive.size() << " bytes.");

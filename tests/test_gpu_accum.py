@@ -432,21 +432,35 @@ def test_index_of_lattices_of_many_pieces(ctx):
         _check_sorted_records(got, want, 3, tol=1e-9)
 
 
+@pytest.mark.parametrize("how", ["generic", "tools"])
 @pytest.mark.parametrize("shape", ["C2", "C4"])
-def test_segment_index_full_size_properties(ctx, shape):
+def test_segment_index_full_size_properties(ctx, shape, how):
     """The segment index at BASELINE's sizes -- configs[1] whole (10 000 lattices x 2 000 states: the 512 x 12 class)
     and 2 000 lattices of configs[3]'s shape (5 000 states, 14 997 arcs: the 1 024 x 15 class) -- through what does
     not depend on the size: one record per distinct (lattice, label, t0, t1) of the word arcs, no more and no fewer;
     every lattice's records in descending order of logp, equal values by ascending key
     (kwsbin2/lattice-word-index-segment.cc:98-126); and folding keeps the mass: the records' exp(logp) add up to the word
-    arcs' posteriors, lattice by lattice (LogAdd of a key's arcs, :165-171)."""
+    arcs' posteriors, lattice by lattice (LogAdd of a key's arcs, :165-171).  `tools` is the instantiation the tools
+    run (host/bin/sharded-index.h): scales fused into the streams, sweep without the arc-posterior pass -- the index forms
+    the through-likelihoods from alpha / beta itself; the first lattices are checked against the oracle record by record."""
     U, S = (10000, 2000) if shape == "C2" else (2000, 5000)
     arrays = klat_amd.synth(20260001 if shape == "C2" else 20260003, np.full(U, S, np.int32), np.full(U, 3, np.int32))
-    b = klat_amd.Batch(ctx, arrays)
-    b.forward_backward(1.0, 0.1, 0.0)
-    post = b.arc_logpost()
+    scales = (1.0, 0.1, 0.0)
+    b = klat_amd.Batch(ctx, arrays, fuse_scales=scales if how == "tools" else None)
+    b.forward_backward(*scales, arc_posteriors=how != "tools")
     off, rec = b.segment_index()
+    post = b.arc_logpost()  # (tools: the posterior pass runs now, after the index, for the mass check below)
     b.close()
+    for u in range(4 if shape == "C2" else 2):
+        s0, s1 = int(arrays["state_off"][u]), int(arrays["state_off"][u + 1])
+        a0, a1 = int(arrays["arc_off"][u]), int(arrays["arc_off"][u + 1])
+        one = {k: (arrays[k][a0:a1] if len(arrays[k]) == len(arrays["src"]) else arrays[k][s0:s1]) for k in arrays if k not in ("state_off", "arc_off")}
+        one["state_off"], one["arc_off"] = np.array([0, s1 - s0], np.int64), np.array([0, a1 - a0], np.int64)
+        sl = orc.scale_and_penalize(_split(one)[0], *scales)
+        alpha, beta, total, _, _ = orc.alphas_betas(sl)
+        want = orc.segment_index(sl, arrays["state_time"][s0:s1], alpha, beta, total)
+        got = [(int(r["label"]), int(r["t0"]), int(r["t1"]), float(r["logp"])) for r in rec[off[u]:off[u + 1]]]
+        _check_sorted_records(got, want, 3, tol=1e-8)
     lat_of_arc = np.repeat(np.arange(U, dtype=np.int64), np.diff(arrays["arc_off"]))
     word = arrays["olabel"] != 0
     gsrc = arrays["src"].astype(np.int64) + arrays["state_off"][lat_of_arc]

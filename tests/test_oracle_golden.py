@@ -235,3 +235,54 @@ def test_kbest_oracle_against_enumeration_of_all_paths():
                 for i in p:
                     cc = np.float32(cc + cost[i])
                 assert cc == c
+
+
+@pytest.mark.parametrize("name", ["egs_expand_lattice.char.txt", "egs_expand_lattice2.char.txt",
+                                  "egs_char_lattice.lattice-format.ark.txt", "egs_ctc_input.lattice-format.txt",
+                                  "egs_word_lattice.ark.txt", "multi_final_lattice.ark.txt"])
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 0.0), (0.7, 0.3, 0.5)])
+def test_frame_post_equals_path_enumeration(golden_dir, name, scales):
+    """lattice-to-word-frame-post has no known-answer vector in the reference (the one accumulator whose oracle is
+    unpinned), so the oracle's frame posteriors are held against something that is NOT a restatement of the tool's loop
+    (latbin/lattice-to-word-frame-post.cc:93-135): the reference's own test idiom, every path of the lattice enumerated
+    (fstext/expand-subpaths-test-utils.h:10-52).  P(word w at frame k) = the mass of the paths whose arc across frame
+    k carries w; frames in order, entries by (logp desc, label asc) on the float values (:126-131)."""
+    for lat in latfmt.read_text_archive(os.path.join(golden_dir, name)):
+        lat = orc.scale_and_penalize(latfmt.prepare(lat), *scales)
+        try:
+            times, T, _ = orc.state_times(lat)
+        except RuntimeError:
+            # a character lattice whose transition-id strings give its states no consistent times (the reference's
+            # CompactLatticeStateTimes asserts on it): aligned here by making every arc as long as the difference of its
+            # ends' longest distances from the start state, so that the lattice's structure still serves the test
+            src_of = np.repeat(np.arange(lat.S), np.diff(lat.arc_begin))
+            depth = np.zeros(lat.S, np.int32)
+            for i in range(lat.A):  # (top-sorted: sources ascend)
+                depth[lat.dst[i]] = max(depth[lat.dst[i]], depth[src_of[i]] + 1)
+            lat.dur[:] = depth[lat.dst] - depth[src_of]
+            lat.final_dur[:] = 0
+            fin = ~(np.isinf(lat.final_graph) & np.isinf(lat.final_acoustic))
+            lat.final_dur[fin] = depth[fin].max() - depth[fin]
+            times, T, _ = orc.state_times(lat)
+        alpha, beta, total, _, _ = orc.alphas_betas(lat)
+        post, mis = orc.frame_post(lat, times, T, alpha, beta, total)
+        paths = latfmt.brute_force_paths(lat)
+        assert len(paths) > 0 and len(post) == T
+        tot = latfmt.logsumexp(ll for _, ll in paths)
+        assert abs(tot - total) < 1e-9
+        src_of = np.repeat(np.arange(lat.S), np.diff(lat.arc_begin))
+        mass = [dict() for _ in range(T)]
+        for arcs, ll in paths:
+            for i in arcs:
+                if lat.ilabel[i] == 0:
+                    continue
+                for k in range(int(times[src_of[i]]), min(int(times[lat.dst[i]]), T)):
+                    mass[k].setdefault(int(lat.ilabel[i]), []).append(ll)
+        for k in range(T):
+            want = {w: latfmt.logsumexp(v) - tot for w, v in mass[k].items()}
+            got = post[k]
+            assert sorted(l for l, _ in got) == sorted(want)
+            for l, p in got:
+                assert abs(float(p) - want[l]) <= 2e-6 * max(1.0, abs(want[l])), (name, k, l, float(p), want[l])
+            vals = [(-np.float32(p), l) for l, p in got]
+            assert vals == sorted(vals)  # (logp desc, label asc) on the stored floats
