@@ -497,6 +497,7 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
   StageQueue<std::unique_ptr<WriteJob>> write_q(2);
   std::thread reader_thread, writer_thread;
   std::atomic<bool> stop{false};
+  bool reader_ended = false;  // the reader's end marker has been taken off read_q (nothing more will come)
   std::exception_ptr writer_error;
   try {
     std::unique_ptr<Writer> writer;
@@ -644,6 +645,7 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
     int64_t num_lattices = 0;
     for (;;) {
       std::unique_ptr<SuperBatch> sb = read_q.Pop();
+      if (sb->end) reader_ended = true;
       if (sb->error) std::rethrow_exception(sb->error);
       if (sb->end) break;
       if (writer_error) std::rethrow_exception(writer_error);
@@ -742,8 +744,10 @@ int RunIndexTool(const CommonOptions& co, const IndexOptions& io, const ShardOpt
     // the stages must not outlive this frame: unblock and join them
     stop.store(true);
     if (reader_thread.joinable()) {
+      // (a reader that failed -- a cyclic lattice, a truncated entry -- has handed over its end marker with the error and
+      // is gone: there is nothing left to drain, and a drain would wait for a marker that never comes)
       std::thread drain([&]() {
-        for (;;)
+        while (!reader_ended)
           if (read_q.Pop()->end) break;
       });
       reader_thread.join();

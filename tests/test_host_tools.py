@@ -20,8 +20,8 @@ import klat_amd  # noqa: E402
 TOOLS = ["lattice-to-word-frame-post", "lattice-word-index-segment", "lattice-word-index-position"]
 
 
-def run(tool, *args, stdin=None):
-    p = subprocess.run([os.path.join(BIN, tool)] + list(args), input=stdin, capture_output=True, timeout=300)
+def run(tool, *args, stdin=None, timeout=300):
+    p = subprocess.run([os.path.join(BIN, tool)] + list(args), input=stdin, capture_output=True, timeout=timeout)
     return p.returncode, p.stdout, p.stderr.decode(errors="replace")
 
 
@@ -733,6 +733,6 @@ def test_tools_top_sort_what_needs_it(tmp_path, tool, nint):
     bin_cyc = str(tmp_path / "cyclic.ark")
     rc, _, err = run("klat-lattice-copy", "ark:" + cyc, "ark:" + bin_cyc)
     assert rc == 0, err
-    for src in (cyc, bin_cyc):
-        rc, out, err = run(tool, *args, "ark:" + src, "ark,t:-")
+    for src in (cyc, bin_cyc):  # (a failing reader stage must end the run, not leave the other stages waiting for it)
+        rc, out, err = run(tool, *args, "ark:" + src, "ark,t:-", timeout=60)
         assert rc == 255 and "Topological sorting of state-level lattice failed" in err, (rc, err[-300:])

@@ -1,6 +1,7 @@
 """klat_batch_create on a batch whose arrays are already on the device: the device passes of the
 stream packer (klat_batch_get_pack_timings) and the wall time of the call, then one forward-backward
--- the one-shot path every tool runs.  usage: pack_time.py [lattices] [states] [fanout] [reps]"""
+-- the one-shot path every tool runs.  usage: pack_time.py [lattices] [states] [fanout] [reps] [fuse: 1|0]
+(KLAT_PACK_PROFILE=1 adds the count pass's phase cycles and the host stages of klat_batch_create on stderr)"""
 import ctypes as C
 import os
 import sys
@@ -16,6 +17,7 @@ U = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 FO = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 REPS = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+FUSE = (1.0, 0.1, 0.0) if (len(sys.argv) <= 5 or sys.argv[5] != "0") else None
 a = klat_amd.synth(20260001, np.full(U, NS, np.int32), np.full(U, FO, np.int32))
 hip = C.CDLL("libamdhip64.so")
 dev, ptrs = dict(a), []
@@ -30,9 +32,9 @@ ctx = klat_amd.Ctx(0)
 A = int(a["arc_off"][-1])
 for rep in range(REPS):
     t0 = time.perf_counter()
-    b = klat_amd.Batch(ctx, dev)
+    b = klat_amd.Batch(ctx, dev, fuse_scales=FUSE)
     t1 = time.perf_counter()
-    b.forward_backward(1.0, 0.1, 0.0)
+    b.forward_backward(1.0, 0.1, 0.0, arc_posteriors=False)
     ctx.sync()
     t2 = time.perf_counter()
     pt, ft = b.pack_timings(), b.timings()
