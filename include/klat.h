@@ -333,6 +333,8 @@ int klat_nbest(klat_batch* batch, const float* arc_cost /* [A] */, int32_t k, in
 /* The streams of a batch as klat_batch_create built them on the device (for tests: they must equal
  * klat_pack_host's, bit for bit).  Arrays of fwd_slots + bwd_slots entries each. */
 int klat_batch_get_streams(klat_batch* batch, int32_t* sw, float* sg, float* sa);
+/* The same for a batch with fused costs (klat_pack_options.fuse_scales): the third array holds the 16-bit residuals. */
+int klat_batch_get_fused_streams(klat_batch* batch, int32_t* sw, float* sg, int16_t* sl);
 
 /* Host-only view of the packed lockstep streams (no device needed): the host packer that defines
  * the stream format klat_batch_create's device packer reproduces.  jobs: 24-byte records {int64 chunk_off; int32 nchunks, dir, lane_tab, tag} (tag: bits 0-1 wave priority, 8-15 G, 16-27 W of the job's layout class);

@@ -435,9 +435,10 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   b->h_state_off.assign(d->state_off, d->state_off + b->U + 1);
   b->h_arc_off.assign(d->arc_off, d->arc_off + b->U + 1);
 
-#define UP(buf, ptr, n)                                              \
+#define UP(buf, ptr, n) UPP(buf, ptr, n, 0)
+#define UPP(buf, ptr, n, pad)                                        \
   do {                                                               \
-    rc = b->buf.upload(ptr, (size_t)(n), c->stream);                 \
+    rc = b->buf.upload(ptr, (size_t)(n), c->stream, pad);            \
     if (rc != KLAT_OK) {                                             \
       klat_batch_destroy(b);                                         \
       return rc;                                                     \
@@ -466,12 +467,12 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   } while (0)
   UP(state_off, d->state_off, b->U + 1);
   UP(arc_off, d->arc_off, b->U + 1);
-  UP(src, d->src, b->A);
-  UP(dst, d->dst, b->A);
-  UP(ilabel, d->ilabel, b->A);
+  UPP(src, d->src, b->A, 4);
+  UPP(dst, d->dst, b->A, 4);
+  UPP(ilabel, d->ilabel, b->A, 4);
   if (d->olabel) UP(olabel, d->olabel, b->A);
-  UP(graph, d->graph, b->A);
-  UP(acoustic, d->acoustic, b->A);
+  UPP(graph, d->graph, b->A, 4);
+  UPP(acoustic, d->acoustic, b->A, 4);
   if (d->state_time) UP(state_time, d->state_time, b->S);
   UP(final_graph, d->final_graph, b->S);
   UP(final_acoustic, d->final_acoustic, b->S);
@@ -480,18 +481,31 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     UP(sg, P.sg.data(), P.sg.size());
     UP(sa, P.sa.data(), P.sa.size());
   } else {
-    // pass 1 on the device: validation, arcs by destination, rounds per lattice for every lane count
+    // pass 1 on the device: validation, the tables the fill pass reads, rounds per lattice for every lane count.
+    // Lattices with short arcs take the lean passes (klat_pack_lean.hip; KLAT_PACK_LEAN=0: none does), the others
+    // the general ones; which lattice is which is known for sure only when the lean count pass has read its arcs.
     DevBuf<int32_t> cnt, row, r0f, r0b, flist, in_arc, out_arc, status;
     DevBuf<LatticeRounds> d_rounds;
-    DevBuf<int8_t> d_lat_g;
+    DevBuf<int8_t> d_lat_g, d_pred;
     DevBuf<PackEntry> d_entries;
+    DevBuf<LeanEntry> d_lentries;
+    DevBuf<uint32_t> meta;
+    DevBuf<int32_t> tpf, tpb;
+    DevBuf<uint8_t> d_lean_ok, d_only, d_only2, d_only3, d_reround;
     const int32_t status0[4] = {0, -1, 1, 0};
-    if ((rc = cnt.alloc((size_t)(S_tot + 2 * U))) || (rc = row.alloc((size_t)(S_tot + 2 * U))) || (rc = r0f.alloc((size_t)(S_tot + 2 * U))) ||
-        (rc = r0b.alloc((size_t)(S_tot + 2 * U))) || (rc = flist.alloc((size_t)S_tot)) || (rc = in_arc.alloc((size_t)A_tot)) || (rc = out_arc.alloc((size_t)A_tot)) ||
-        (rc = d_rounds.alloc((size_t)U)) || (rc = status.upload(status0, 4, c->stream))) {
+    if ((rc = row.alloc((size_t)(S_tot + 2 * U))) || (rc = r0f.alloc((size_t)(S_tot + 2 * U))) || (rc = r0b.alloc((size_t)(S_tot + 2 * U))) ||
+        (rc = flist.alloc((size_t)S_tot)) || (rc = d_rounds.alloc((size_t)U)) || (rc = status.upload(status0, 4, c->stream))) {
       klat_batch_destroy(b);
       return rc;
     }
+    bool general_tables = false;  // cnt, in_arc, out_arc: only when some lattice takes the general passes
+    auto need_general_tables = [&]() -> int {
+      if (general_tables) return KLAT_OK;
+      int r = KLAT_OK;
+      if ((r = cnt.alloc((size_t)(S_tot + 2 * U))) || (r = in_arc.alloc((size_t)A_tot)) || (r = out_arc.alloc((size_t)A_tot))) return r;
+      general_tables = true;
+      return KLAT_OK;
+    };
     PackDevArgs pa;
     std::memset(&pa, 0, sizeof(pa));
     pa.state_off = b->state_off.p;
@@ -503,36 +517,71 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pa.acoustic = b->acoustic.p;
     pa.final_graph = b->final_graph.p;
     pa.final_acoustic = b->final_acoustic.p;
-    pa.cnt = cnt.p;
     pa.row = row.p;
     pa.r0f = r0f.p;
     pa.r0b = r0b.p;
     pa.flist = flist.p;
-    pa.out_arc = out_arc.p;
-    pa.in_arc = in_arc.p;
     pa.lat_rounds = d_rounds.p;
     pa.status = status.p;
+    pa.num_arcs = A_tot;
     std::vector<LatticeRounds> h_rounds((size_t)U);
     int32_t h_status[4] = {0, -1, 1, 0};
-    // the count pass keeps a lattice's tables in LDS: the launch of the narrowest class that holds them
-    int class_need[kPackCountClasses] = {0, 0, 0};
-    bool any_global = false;
-    for (int64_t u = 0; u < U; ++u) {
-      const int need = pack_count_lds_bytes(d->state_off[u + 1] - d->state_off[u], d->arc_off[u + 1] - d->arc_off[u]);
-      int k = 0;
-      while (k < kPackCountClasses && need > kPackCountClassLds[k]) ++k;
-      if (k == kPackCountClasses)
-        any_global = true;
-      else
-        class_need[k] = std::max(class_need[k], need);
+    const char* lean_env = std::getenv("KLAT_PACK_LEAN");
+    const bool lean_enabled = !(lean_env && std::atoi(lean_env) == 0);
+    const char* level_env = std::getenv("KLAT_LEVEL");
+    const int level_mode = level_env == nullptr ? -1 : std::atoi(level_env);
+    const bool plan_levels = o.lanes_per_lattice == 0 && level_mode != 0 && U > 0;
+    // which count pass a lattice takes, as far as its sizes tell: the LDS class of its tables
+    std::vector<uint8_t> known_general((size_t)U, lean_enabled ? 0 : 1), lean_ok((size_t)U, 0);
+    std::vector<int8_t> pred;
+    int lean_need[kPackLeanClasses] = {0, 0, 0};
+    size_t num_known_general = lean_enabled ? 0 : (size_t)U, num_lean = 0;
+    if (lean_enabled) {
+      predict_lanes(U, d->state_off, d->arc_off, o, &pred);
+      for (int64_t u = 0; u < U; ++u) {
+        const int need = pack_lean_lds_bytes(d->state_off[u + 1] - d->state_off[u], d->arc_off[u + 1] - d->arc_off[u]);
+        int k = 0;
+        while (k < kPackLeanClasses && need > kPackLeanClassLds[k]) ++k;
+        if (k == kPackLeanClasses)
+          known_general[(size_t)u] = 1, ++num_known_general;
+        else
+          lean_need[k] = std::max(lean_need[k], need), ++num_lean;
+      }
     }
+    // the general count pass over the lattices flagged in `only` (null: all): the launch of the narrowest LDS class per lattice
+    auto general_count = [&](const std::vector<uint8_t>* only, DevBuf<uint8_t>* d_flags) -> hipError_t {
+      int class_need[kPackCountClasses] = {0, 0, 0};
+      bool any_global = false;
+      for (int64_t u = 0; u < U; ++u) {
+        if (only && !(*only)[(size_t)u]) continue;
+        const int need = pack_count_lds_bytes(d->state_off[u + 1] - d->state_off[u], d->arc_off[u + 1] - d->arc_off[u]);
+        int k = 0;
+        while (k < kPackCountClasses && need > kPackCountClassLds[k]) ++k;
+        if (k == kPackCountClasses)
+          any_global = true;
+        else
+          class_need[k] = std::max(class_need[k], need);
+      }
+      if (need_general_tables() != KLAT_OK) return hipErrorOutOfMemory;
+      pa.cnt = cnt.p;
+      pa.in_arc = in_arc.p;
+      pa.out_arc = out_arc.p;
+      pa.only = nullptr;
+      if (only) {
+        if (d_flags->upload(only->data(), only->size(), c->stream) != KLAT_OK) return hipErrorOutOfMemory;
+        pa.only = d_flags->p;
+      }
+      const hipError_t e = launch_pack_count(pa, (int)U, class_need, any_global, c->stream);
+      pa.only = nullptr;
+      return e;
+    };
     DevBuf<unsigned long long> d_prof;
     if (std::getenv("KLAT_PACK_PROFILE") != nullptr) {
-      if ((rc = d_prof.alloc(8))) {
+      if ((rc = d_prof.alloc(24))) {
         klat_batch_destroy(b);
         return rc;
       }
-      KLAT_HIP_B(hipMemsetAsync(d_prof.p, 0, 8 * sizeof(unsigned long long), c->stream));
+      KLAT_HIP_B(hipMemsetAsync(d_prof.p, 0, 24 * sizeof(unsigned long long), c->stream));
       pa.prof = d_prof.p;
     }
     // fused costs: the batch's largest finite cost decides the unit of the 16-bit residuals
@@ -552,31 +601,42 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     hipEvent_t* pev = b->pack_ev;
     for (int i = 0; i < klat_batch::kPackEvents; ++i) KLAT_HIP_B(hipEventCreate(&pev[i]));
     KLAT_HIP_B(hipEventRecord(pev[0], c->stream));
-    if (b->fused) {
-      // (beside the count pass on a side stream it gained nothing: the count pass took the 0.2 ms longer)
-      KLAT_HIP_B(launch_pack_maxcost(pa, A_tot, S_tot, c->stream));
-      KLAT_HIP_B(hipMemcpyAsync(&h_maxcost, d_maxcost.p, sizeof(h_maxcost), hipMemcpyDeviceToHost, c->stream));
-    }
-    hipError_t he = launch_pack_count(pa, (int)U, class_need, any_global, c->stream);
-    if (he == hipSuccess) he = hipEventRecord(pev[1], c->stream);
-    if (he == hipSuccess && U > 0)
-      he = hipMemcpyAsync(h_rounds.data(), d_rounds.p, sizeof(LatticeRounds) * h_rounds.size(), hipMemcpyDeviceToHost, c->stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
-    // The level planner (below) runs behind the count pass at once, its answer comes back in the same wait: one trip to
-    // the device less per batch (0.26 ms of C2's 4.8).
-    std::vector<uint8_t> on_level((size_t)U, 0);
-    DevBuf<int32_t> order, lvoff, depth;  // level planning's tables, until the level streams are written
-    DevBuf<int32_t> lv_counters, lv_records;
-    std::vector<int32_t> h_depth, h_records;
-    const char* level_env = std::getenv("KLAT_LEVEL");
-    const int level_mode = level_env == nullptr ? -1 : std::atoi(level_env);
-    const bool plan_levels = o.lanes_per_lattice == 0 && level_mode != 0 && U > 0;
-    if (he == hipSuccess && plan_levels) {
-      if ((rc = lv_counters.alloc((size_t)(S_tot + 2 * U))) || (rc = order.alloc((size_t)S_tot)) || (rc = lvoff.alloc((size_t)(S_tot + 2 * U))) ||
-          (rc = depth.alloc((size_t)U)) || (rc = lv_records.alloc((size_t)U))) {
+    hipError_t he = hipSuccess;
+    if (num_lean > 0) {
+      if ((rc = meta.alloc((size_t)A_tot + 4)) || (rc = tpf.alloc((size_t)((S_tot >> 3) + 2 * U + 2))) || (rc = tpb.alloc((size_t)((S_tot >> 3) + 2 * U + 2))) ||
+          (rc = d_lean_ok.alloc((size_t)U)) || (rc = d_pred.upload(pred.data(), pred.size(), c->stream))) {
         klat_batch_destroy(b);
         return rc;
       }
+      KLAT_HIP_B(hipMemsetAsync(d_lean_ok.p, 0, (size_t)U, c->stream));
+      pa.meta = meta.p;
+      pa.tpf = tpf.p;
+      pa.tpb = tpb.p;
+      pa.lean_ok = d_lean_ok.p;
+      pa.lat_g_pred = d_pred.p;
+      pa.level_probe = plan_levels ? 1 : 0;
+      // (the lean count pass reads every arc's costs on its way; with lattices it does not see, the pass of its own)
+      pa.fold_maxcost = b->fused && num_known_general == 0 ? 1 : 0;
+    }
+    if (b->fused && !pa.fold_maxcost) KLAT_HIP_B(launch_pack_maxcost(pa, A_tot, S_tot, c->stream));
+    if (num_lean > 0) he = launch_pack_count_lean(pa, (int)U, lean_need, c->stream);
+    if (he == hipSuccess && num_known_general > 0) he = general_count(num_lean > 0 ? &known_general : nullptr, &d_only);
+    if (he == hipSuccess) he = hipEventRecord(pev[1], c->stream);
+    if (he == hipSuccess && b->fused) he = hipMemcpyAsync(&h_maxcost, d_maxcost.p, sizeof(h_maxcost), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess && U > 0)
+      he = hipMemcpyAsync(h_rounds.data(), d_rounds.p, sizeof(LatticeRounds) * h_rounds.size(), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess && num_lean > 0) he = hipMemcpyAsync(lean_ok.data(), d_lean_ok.p, (size_t)U, hipMemcpyDeviceToHost, c->stream);
+    // The level planner (below) runs behind the general count pass at once when every lattice takes that pass: its answer
+    // comes back in the same wait.  With lean lattices it waits for their verdict (it reads the general tables).
+    std::vector<uint8_t> on_level((size_t)U, 0);
+    DevBuf<int32_t> order, lvoff, depth;  // level planning's tables, until the level streams are written
+    DevBuf<int32_t> lv_counters, lv_records;
+    std::vector<int32_t> h_depth((size_t)U, -1), h_records((size_t)U, 0);
+    auto level_plan = [&](const uint8_t* only) -> hipError_t {
+      if (lv_counters.alloc((size_t)(S_tot + 2 * U)) || order.alloc((size_t)S_tot) || lvoff.alloc((size_t)(S_tot + 2 * U)) || depth.alloc((size_t)U) ||
+          lv_records.alloc((size_t)U))
+        return hipErrorOutOfMemory;
       LevelPlanArgs lp;
       lp.state_off = b->state_off.p;
       lp.arc_off = b->arc_off.p;
@@ -590,14 +650,16 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       lp.depth = depth.p;
       lp.records = lv_records.p;
       lp.status = status.p;
-      h_depth.resize((size_t)U), h_records.resize((size_t)U);
-      he = hipEventRecord(pev[2], c->stream);
-      if (he == hipSuccess) he = launch_level_plan(lp, (int)U, c->stream);
-      if (he == hipSuccess) he = hipEventRecord(pev[3], c->stream);
+      lp.only = only;
+      hipError_t e = hipEventRecord(pev[2], c->stream);
+      if (e == hipSuccess) e = launch_level_plan(lp, (int)U, c->stream);
+      if (e == hipSuccess) e = hipEventRecord(pev[3], c->stream);
       b->pack_level_timed = true;
-      if (he == hipSuccess) he = hipMemcpyAsync(h_depth.data(), depth.p, sizeof(int32_t) * (size_t)U, hipMemcpyDeviceToHost, c->stream);
-      if (he == hipSuccess) he = hipMemcpyAsync(h_records.data(), lv_records.p, sizeof(int32_t) * (size_t)U, hipMemcpyDeviceToHost, c->stream);
-    }
+      if (e == hipSuccess) e = hipMemcpyAsync(h_depth.data(), depth.p, sizeof(int32_t) * (size_t)U, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(h_records.data(), lv_records.p, sizeof(int32_t) * (size_t)U, hipMemcpyDeviceToHost, c->stream);
+      return e;
+    };
+    if (he == hipSuccess && plan_levels && num_lean == 0) he = level_plan(nullptr);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) {
       klat_batch_destroy(b);
@@ -611,11 +673,46 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       std::fprintf(stderr, "klat pack_count phases, cycles per lattice: clear %.0f  arcs %.0f  states %.0f  scatter %.0f  buckets %.0f  in_arc out %.0f  out-arcs %.0f  tail %.0f\n",
                    h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7] / n);
     }
-    if (h_status[0] != 0)
-      FAIL(h_status[0] == 2 ? KLAT_ERR_BAD_TOPOLOGY : KLAT_ERR_INVALID_ARG,
-           "lattice " + std::to_string(h_status[1]) +
-               (h_status[0] == 2 ? ": arc with dst <= src or out of range (lattice is not topologically sorted)"
-                                 : ": malformed CSR (state ids out of range or arcs not grouped by source)"));
+    auto fail_status = [&]() {
+      return set_error(h_status[0] == 2 ? KLAT_ERR_BAD_TOPOLOGY : KLAT_ERR_INVALID_ARG,
+                       "lattice " + std::to_string(h_status[1]) +
+                           (h_status[0] == 2 ? ": arc with dst <= src or out of range (lattice is not topologically sorted)"
+                                             : ": malformed CSR (state ids out of range or arcs not grouped by source)"));
+    };
+    if (h_status[0] != 0) {
+      klat_batch_destroy(b);
+      return fail_status();
+    }
+    // the lattices the lean count pass has left alone (a long arc, a candidate of the level path ...): the general pass now,
+    // and the level planner over everything that has the general tables
+    if (num_lean > 0) {
+      std::vector<uint8_t> unfit((size_t)U, 0), have_general(known_general);
+      size_t num_unfit = 0;
+      for (int64_t u = 0; u < U; ++u)
+        if (!known_general[(size_t)u] && !lean_ok[(size_t)u]) unfit[(size_t)u] = 1, have_general[(size_t)u] = 1, ++num_unfit;
+      if (num_unfit > 0 || (plan_levels && num_known_general > 0)) {
+        if (num_unfit > 0) he = general_count(&unfit, &d_only2);
+        if (he == hipSuccess && num_unfit > 0)
+          he = hipMemcpyAsync(h_rounds.data(), d_rounds.p, sizeof(LatticeRounds) * h_rounds.size(), hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess && plan_levels) {
+          if ((rc = d_only3.upload(have_general.data(), have_general.size(), c->stream))) {
+            klat_batch_destroy(b);
+            return rc;
+          }
+          he = level_plan(d_only3.p);
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) {
+          klat_batch_destroy(b);
+          return hip_fail(he, "stream packing (count pass of the lattices with long arcs)");
+        }
+        if (h_status[0] != 0) {
+          klat_batch_destroy(b);
+          return fail_status();
+        }
+      }
+    }
     // Lattices whose topological depth is far below their states take the level-synchronous path
     // (klat_level.hip) instead of a stream: Kahn's levels on the device, the choice on the host.
     // Only with the automatic layout (a caller that fixes the lanes asks for streams).
@@ -709,13 +806,52 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     rc = build_jobs(U, d->state_off, h_rounds.data(), lat_g, o, &P, &job_lats, &chunk_total, &err, b->num_chain > 0 ? on_chain.data() : nullptr);
     if (rc != KLAT_OK) FAIL(rc, err);
     lap("plan+jobs");
-    // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, slot)
-    std::vector<PackEntry> entries;
+    // Which fill pass writes a job: the lean one when all its lattices have the lean tables (and none is swept in segments:
+    // klat_viterbi builds those lattices' cost records from the general tables), else the general one -- whose tables the
+    // job's other lattices then need too, for the job's direction (bit 0 of `redo`: forward, bit 1: backward).
+    std::vector<uint8_t> job_general(P.jobs.size(), 0), redo((size_t)U, 0), reround((size_t)U, 0);
+    size_t num_general_jobs = 0, num_redo = 0, num_reround = 0;
     for (size_t j = 0; j < P.jobs.size(); ++j) {
-      const int ntiles = P.jobs[j].nchunks * kChunkRounds / kPackTileRounds;
-      for (int t = 0; t < ntiles; t += kPackTilesPerGroup)
-        entries.push_back(PackEntry{(int32_t)j, t, std::min(kPackTilesPerGroup, ntiles - t), 0});
+      bool g = false;
+      for (int64_t u : job_lats[j]) g = g || !lean_ok[(size_t)u] || on_chain[(size_t)u];
+      if (!g) continue;
+      job_general[j] = 1, ++num_general_jobs;
+      for (int64_t u : job_lats[j]) redo[(size_t)u] |= (uint8_t)(1 << P.jobs[j].dir);
     }
+    {
+      std::vector<uint8_t> recount((size_t)U, 0);  // lattices with lean tables that need the general ones after all
+      size_t num_recount = 0;
+      for (int64_t u = 0; u < U; ++u) {
+        if (redo[(size_t)u]) ++num_redo;
+        if (redo[(size_t)u] && lean_ok[(size_t)u]) recount[(size_t)u] = 1, ++num_recount;
+        if (lean_ok[(size_t)u] && redo[(size_t)u] != 3 && lat_g[(size_t)u] >= 0 && lat_g[(size_t)u] != pred[(size_t)u]) reround[(size_t)u] = 1, ++num_reround;
+      }
+      if (num_recount > 0) {
+        he = general_count(&recount, &d_only2);
+        if (he != hipSuccess) {
+          klat_batch_destroy(b);
+          return hip_fail(he, "stream packing (count pass of the lattices that share a job with long arcs)");
+        }
+      }
+    }
+    // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, run of tiles)
+    std::vector<PackEntry> entries;
+    std::vector<LeanEntry> lentries;  // by lanes per lattice: one launch each
+    int lean_count[kNumLaneChoices] = {0, 0, 0, 0, 0, 0, 0};
+    for (int lg = -1; lg < kNumLaneChoices; ++lg)
+      for (size_t j = 0; j < P.jobs.size(); ++j) {
+        int jlg = 0;
+        while ((1 << jlg) < job_lanes(P.jobs[j].tag)) ++jlg;
+        if (job_general[j] ? lg != -1 : lg != jlg) continue;
+        const int ntiles = P.jobs[j].nchunks * kChunkRounds / kPackTileRounds;
+        for (int t = 0; t < ntiles; t += kPackTilesPerGroup) {
+          const int nt = std::min(kPackTilesPerGroup, ntiles - t);
+          if (job_general[j])
+            entries.push_back(PackEntry{(int32_t)j, t, nt, 0});
+          else
+            lentries.push_back(LeanEntry{P.jobs[j].chunk_off, P.jobs[j].lane_tab, P.jobs[j].tag, P.jobs[j].dir, t, nt, (int32_t)j}), ++lean_count[lg];
+        }
+      }
     const size_t nslots = (size_t)chunk_total * kChunkRounds;  // chunk_total counts 16-byte units
     AL(sw, nslots);
     AL(sg, nslots);
@@ -735,23 +871,35 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     }
     UP(jobs, P.jobs.data(), P.jobs.size());
     UP(lanes, P.lanes.data(), P.lanes.size());
-    if ((rc = d_entries.upload(entries.data(), entries.size(), c->stream)) || (rc = d_lat_g.upload(lat_g.data(), lat_g.size(), c->stream))) {
+    if ((rc = d_entries.upload(entries.data(), entries.size(), c->stream)) || (rc = d_lentries.upload(lentries.data(), lentries.size(), c->stream)) ||
+        (rc = d_lat_g.upload(lat_g.data(), lat_g.size(), c->stream)) || (num_redo > 0 && num_lean > 0 && (rc = d_only.upload(redo.data(), redo.size(), c->stream))) ||
+        (num_reround > 0 && (rc = d_reround.upload(reround.data(), reround.size(), c->stream)))) {
       klat_batch_destroy(b);
       return rc;
     }
     pa.lat_g = d_lat_g.p;
     pa.entries = d_entries.p;
+    pa.lentries = d_lentries.p;
     pa.jobs = b->jobs.p;
     pa.lanes = b->lanes.p;
     pa.sw = b->sw.p;
     pa.sg = b->sg.p;
     pa.sa = b->sa.p;
     he = hipEventRecord(pev[4], c->stream);
-    if (he == hipSuccess) he = launch_pack_rounds(pa, (int)U, c->stream);
+    if (he == hipSuccess && num_redo > 0) {
+      pa.only = num_lean > 0 ? d_only.p : nullptr;  // (bit 0: the forward rounds, bit 1: the backward rounds)
+      he = launch_pack_rounds(pa, (int)U, c->stream);
+      pa.only = nullptr;
+    }
+    if (he == hipSuccess && num_reround > 0) {
+      pa.reround = d_reround.p;
+      he = launch_pack_rounds_lean(pa, (int)U, c->stream);
+    }
     if (he == hipSuccess) he = hipEventRecord(pev[5], c->stream);
     int max_lpw = 1;
     for (const LayoutClass& lc : P.classes) max_lpw = std::max(max_lpw, 64 / lc.G);
     if (he == hipSuccess) he = launch_pack_fill(pa, (int)entries.size(), max_lpw, c->stream);
+    if (he == hipSuccess) he = launch_pack_fill_lean(pa, lean_count, c->stream);
     if (he == hipSuccess) he = hipEventRecord(pev[6], c->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);  // scratch and entries go out of scope below
@@ -760,6 +908,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       return hip_fail(he, "stream packing (fill pass)");
     }
     lap("entries+rounds+fill+wait");
+    (void)num_general_jobs;
     P.far_terms = h_status[3];
 
     if (b->num_level > 0) {  // the level streams: the arcs as the level sweep consumes them
@@ -846,6 +995,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   AL(alpha, b->S + b->U);
   AL(beta, b->S + b->U);
 #undef UP
+#undef UPP
 #undef AL
 #undef FAIL
 #undef KLAT_HIP_B
@@ -1517,6 +1667,20 @@ int klat_batch_get_streams(klat_batch* b, int32_t* sw, float* sg, float* sa) {
   if (sw) KLAT_HIP(hipMemcpyAsync(sw, b->sw.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
   if (sg) KLAT_HIP(hipMemcpyAsync(sg, b->sg.p, n * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
   if (sa) KLAT_HIP(hipMemcpyAsync(sa, b->sa.p, n * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
+  KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
+  return KLAT_OK;
+}
+
+int klat_batch_get_fused_streams(klat_batch* b, int32_t* sw, float* sg, int16_t* sl) {
+  if (!b) return set_error(KLAT_ERR_INVALID_ARG, "batch is null");
+  if (!b->fused) return set_error(KLAT_ERR_STATE, "the batch was not built with fused costs");
+  KLAT_HIP(hipSetDevice(b->ctx->device));
+  PoolScope pool_scope(&b->ctx->pool);
+  const size_t n = (size_t)(b->info.fwd_slots + b->info.bwd_slots);
+  if (n == 0) return KLAT_OK;
+  if (sw) KLAT_HIP(hipMemcpyAsync(sw, b->sw.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
+  if (sg) KLAT_HIP(hipMemcpyAsync(sg, b->sg.p, n * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
+  if (sl) KLAT_HIP(hipMemcpyAsync(sl, b->sl.p, n * sizeof(int16_t), hipMemcpyDeviceToHost, b->ctx->stream));
   KLAT_HIP(hipStreamSynchronize(b->ctx->stream));
   return KLAT_OK;
 }

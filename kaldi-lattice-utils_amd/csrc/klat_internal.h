@@ -160,9 +160,12 @@ struct DevBuf {
     o.p = nullptr;
     o.n = o.cap = 0;
   }
-  int upload(const T* host, size_t count, hipStream_t s) {
-    int rc = alloc(count);
+  // pad: elements allocated (not copied) behind the array: the stream packer reads the arc arrays four elements a load,
+  // and the last load of the batch may reach past the last arc
+  int upload(const T* host, size_t count, hipStream_t s, size_t pad = 0) {
+    int rc = alloc(count + pad);
     if (rc != KLAT_OK) return rc;
+    n = count;
     if (count == 0) return KLAT_OK;
     // hipMemcpyDefault: the source may be host or device memory (klat_batch_desc's arc and state
     // arrays may already live on the GPU)

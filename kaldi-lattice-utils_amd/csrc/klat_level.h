@@ -37,6 +37,7 @@ struct LevelPlanArgs {
   int32_t* depth;       // [U] number of levels, or -1: not for this path
   int32_t* records;     // [U] records per direction (sum over the levels of ceil(states / 64))
   const int32_t* status;  // [2] the count pass's verdict: non-zero, a lattice of the batch is malformed and nothing is planned
+  const uint8_t* only;    // [U] or null: plan only these lattices (the others have no tables of the general count pass)
 };
 
 // Writes the level streams of the lattices on the level path (after level_plan_kernel).

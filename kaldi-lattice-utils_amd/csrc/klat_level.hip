@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void level_plan_kernel(LevelPlanArgs a) {
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
   const int S = (int)(a.state_off[u + 1] - s0);
   // (launched behind the count pass without waiting for its verdict: a batch with a malformed lattice is walked by nobody)
-  if (S < kLevelMinStates || S > kLevelMaxStates || (a.status && a.status[0] != 0)) {
+  if (S < kLevelMinStates || S > kLevelMaxStates || (a.status && a.status[0] != 0) || (a.only && !a.only[u])) {
     if (lane == 0) a.depth[u] = -1;
     return;
   }

@@ -121,8 +121,8 @@ PlanCost plan_cost(int64_t U, const LatticeRounds* lr, const std::vector<int8_t>
 
 }  // namespace
 
-void plan_layout(int64_t U, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* lr,
-                 const klat_pack_options& opt, std::vector<int8_t>* lat_g, const uint8_t* skip) {
+void predict_lanes(int64_t U, const int64_t* state_off, const int64_t* arc_off, const klat_pack_options& opt, std::vector<int8_t>* lat_g,
+                   const uint8_t* skip) {
   std::vector<int8_t>& g = *lat_g;
   g.assign((size_t)U, -1);
   if (opt.lanes_per_lattice != 0) {
@@ -152,6 +152,13 @@ void plan_layout(int64_t U, const int64_t* state_off, const int64_t* arc_off, co
     jobs = nj;
     if (!changed) break;
   }
+}
+
+void plan_layout(int64_t U, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* lr,
+                 const klat_pack_options& opt, std::vector<int8_t>* lat_g, const uint8_t* skip) {
+  std::vector<int8_t>& g = *lat_g;
+  predict_lanes(U, state_off, arc_off, opt, lat_g, skip);
+  if (opt.lanes_per_lattice != 0) return;
   // round budgets below the longest chain
   const std::vector<int8_t> base(g);
   std::vector<int8_t> best(g), cur(g);

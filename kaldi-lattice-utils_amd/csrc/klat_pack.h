@@ -75,6 +75,11 @@ int pack_batch(const klat_batch_desc& d, const klat_pack_options& opt, PackedBat
 void plan_layout(int64_t num_lattices, const int64_t* state_off, const int64_t* arc_off, const LatticeRounds* rounds,
                  const klat_pack_options& opt, std::vector<int8_t>* lat_g,
                  const uint8_t* skip = nullptr /* [num_lattices] lattices that take no stream (level path) */);
+// What plan_layout starts from, known from the offsets alone (the lean count pass computes every lattice's rounds for it
+// before the plan exists): the lattice's fanout rounded up to a power of two, halved while the batch would need more
+// than 8192 workgroups; a caller's fixed lanes.
+void predict_lanes(int64_t num_lattices, const int64_t* state_off, const int64_t* arc_off, const klat_pack_options& opt,
+                   std::vector<int8_t>* lat_g, const uint8_t* skip = nullptr);
 int build_jobs(int64_t num_lattices, const int64_t* state_off, const LatticeRounds* rounds, const std::vector<int8_t>& lat_g,
                const klat_pack_options& opt, PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats,
                int64_t* chunk_total, std::string* err,

@@ -29,6 +29,24 @@ __host__ __device__ static inline int pack_count_lds_bytes(int64_t S, int64_t A)
   return (int)(8 * (S + 2) + 2 * ((A + 1) & ~(int64_t)1));
 }
 
+// The lean passes (klat_pack_lean.hip), for lattices whose arcs are at most kPackLeanMaxSpan states long.  LDS of the
+// lean count pass: in-degrees and first out-arcs (8 (S + 2) bytes), two bits a state, the arcs by destination as 16-bit
+// numbers, a byte an arc; three classes again, a lattice above the last one takes the general passes.
+static constexpr int kPackLeanClasses = 3;
+static constexpr int kPackLeanClassLds[kPackLeanClasses] = {38 * 1024, 76 * 1024, kPackCountMaxLds};  // 4, 2, 1 workgroups per CU
+__host__ __device__ static inline int pack_lean_lds_bytes(int64_t S, int64_t A) {
+  if (A >= 65536 || S >= (1 << 20)) return 0x7FFFFFFF;
+  return (int)(8 * (S + 2) + 8 * ((S + 31) / 32 + 1) + 2 * ((A + 1) & ~(int64_t)1) + ((A + 3) & ~(int64_t)3));
+}
+// A forward tile of the lean fill pass reads the arcs of `longest arc` more states than it holds positions.
+static constexpr int kPackLeanMaxSpan = 64;
+
+// one workgroup of pack_fill_lean_kernel: tiles [tile_begin, tile_begin + tile_count) of a job, with what it needs of the job
+struct LeanEntry {
+  int64_t chunk_off;
+  int32_t lane_tab, tag, dir, tile_begin, tile_count, job;
+};
+
 struct PackDevArgs {
   // the CSR batch
   const int64_t* state_off; const int64_t* arc_off;
@@ -57,6 +75,19 @@ struct PackDevArgs {
   double lo_inv_unit;
   unsigned long long* maxcost;  // [1] bits of the largest finite |cost| of the batch (pack_maxcost_kernel)
   unsigned long long* prof;  // [8] or null: phase cycles of the count pass (KLAT_PACK_PROFILE=1)
+  // general passes over a part of the batch: only the lattices with only[u] != 0 (null: every lattice)
+  const uint8_t* only;
+  // lean passes (klat_pack_lean.hip); r0f / r0b then hold a position's first round in bits 0-23, its terms in bits 24-30
+  const int8_t* lat_g_pred;  // [U] log2(lanes) the plan is expected to choose: the lean count pass leaves r0f / r0b for it
+  int64_t num_arcs;          // of the batch
+  uint32_t* meta;            // [A] arc length | place among its destination's in-arcs << 8 | among its source's out-arcs << 16 | word << 24
+  int32_t* tpf;              // tile tables: the position that holds round 32 m of lattice u at [(state_off[u] >> 3) + 2 u + m]
+  int32_t* tpb;
+  uint8_t* lean_ok;          // [U] out: the lean count pass has packed the lattice's tables (0: it is left to the general passes)
+  const uint8_t* reround;    // [U] pack_rounds_lean_kernel: the lattices whose lanes are not the expected ones
+  int32_t fold_maxcost;      // the lean count pass also finds the batch's largest cost (a.maxcost): no pack_maxcost_kernel
+  int32_t level_probe;       // lattices the level path may take (klat_level.hip reads the general tables) are left alone
+  const LeanEntry* lentries;
 };
 
 // class_need[c]: the largest pack_count_lds_bytes among the lattices of LDS class c (0: none);
@@ -65,6 +96,11 @@ hipError_t launch_pack_count(const PackDevArgs& a, int num_lattices, const int c
                              hipStream_t stream);
 // the largest finite cost of the batch under a.fsp (arcs and final weights)
 hipError_t launch_pack_maxcost(const PackDevArgs& a, int64_t num_arcs, int64_t num_states, hipStream_t stream);
+// The lean passes: count (validation, tables, rounds of every lane count, the batch's largest cost when a.fused, r0f / r0b
+// for a.lat_g_pred; class_need over kPackLeanClassLds), the prefix sums again for a.reround, fill over a.lentries.
+hipError_t launch_pack_count_lean(const PackDevArgs& a, int num_lattices, const int class_need[kPackLeanClasses], hipStream_t stream);
+hipError_t launch_pack_rounds_lean(const PackDevArgs& a, int num_lattices, hipStream_t stream);
+hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[kNumLaneChoices] /* entries per log2(lanes), a.lentries sorted by it */, hipStream_t stream);
 hipError_t launch_pack_rounds(const PackDevArgs& a, int num_lattices, hipStream_t stream);
 // max_lpw: the most lattices any job holds (64 / its lanes per lattice)
 hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, int max_lpw, hipStream_t stream);

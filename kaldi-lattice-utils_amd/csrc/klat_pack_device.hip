@@ -27,6 +27,7 @@
 #include "klat_device.h"
 #include "klat_math.h"
 #include "klat_pack_device.h"
+#include "klat_pack_common.h"
 
 namespace klat {
 
@@ -38,31 +39,6 @@ constexpr int kTG = 1024;     // pack_count_global_kernel: its passes are chains
 constexpr int kTC = 512;      // pack_count_kernel
 
 
-__device__ __forceinline__ bool dev_is_final(const PackDevArgs& a, int64_t gs) {
-  return !(a.final_graph[gs] == INFINITY && a.final_acoustic[gs] == INFINITY);
-}
-
-// exclusive prefix sum of one int per thread; returns the thread's prefix, *total = block sum
-template <int T>
-__device__ int block_scan(int v, int* total, int* sh /* [T/64] */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = v;
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += t;
-  }
-  __syncthreads();  // sh may still be read from a previous call
-  if (lane == 63) sh[wave] = incl;
-  __syncthreads();
-  int off = 0, tot = 0;
-  for (int w = 0; w < T / 64; ++w) {
-    if (w < wave) off += sh[w];
-    tot += sh[w];
-  }
-  *total = tot;
-  return off + incl - v;
-}
-
 __device__ __forceinline__ int lower_bound_src(const int32_t* src, int n, int s) {
   int lo = 0, hi = n;
   while (lo < hi) {
@@ -73,10 +49,6 @@ __device__ __forceinline__ int lower_bound_src(const int32_t* src, int n, int s)
       hi = mid;
   }
   return lo;
-}
-
-__device__ __forceinline__ void report_bad(const PackDevArgs& a, int code, int u) {
-  if (atomicCAS(&a.status[0], 0, code) == 0) a.status[1] = u;
 }
 
 // exclusive prefix sums of three ints per thread with one pair of barriers
@@ -131,7 +103,7 @@ __global__ __launch_bounds__(kTC, 6) void pack_count_kernel(PackDevArgs a, int l
   const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
   const int need = pack_count_lds_bytes(S, A);
   // every lattice belongs to exactly one launch: the narrowest LDS class it fits
-  if (need <= lds_lo || need > lds_hi) return;
+  if (need <= lds_lo || need > lds_hi || (a.only && !a.only[u])) return;
   if (tid < (int)(sizeof(LatticeRounds) / sizeof(int32_t))) reinterpret_cast<int32_t*>(&a.lat_rounds[u])[tid] = 0;
   if (S <= 0) {
     if (tid == 0 && (S < 0 || A != 0)) report_bad(a, 1 /* KLAT_ERR_INVALID_ARG */, u);
@@ -383,7 +355,7 @@ __global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, i
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
   const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
-  if (pack_count_lds_bytes(S, A) <= lds_hi) return;
+  if (pack_count_lds_bytes(S, A) <= lds_hi || (a.only && !a.only[u])) return;
   if (tid < (int)(sizeof(LatticeRounds) / sizeof(int32_t))) reinterpret_cast<int32_t*>(&a.lat_rounds[u])[tid] = 0;
   const int64_t sb = s0 + 2 * (int64_t)u;
   int32_t* cnt = a.cnt + sb;
@@ -608,7 +580,8 @@ __global__ __launch_bounds__(kT) void pack_rounds_kernel(PackDevArgs a) {
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t s0 = a.state_off[u];
   const int S = (int)(a.state_off[u + 1] - s0);
-  if (S <= 0 || a.lat_g[u] < 0) return;
+  const int dirs = a.only ? a.only[u] : 3;  // bit 0: the forward rounds, bit 1: the backward rounds (a lattice's other direction may belong to the lean passes)
+  if (S <= 0 || a.lat_g[u] < 0 || !dirs) return;
   const int k = a.lat_g[u];
   const int64_t sb = s0 + 2 * (int64_t)u;
   const int32_t* cnt = a.cnt + sb;
@@ -630,12 +603,13 @@ __global__ __launch_bounds__(kT) void pack_rounds_kernel(PackDevArgs a) {
     int tot_r, tot_b;
     const int ex_r = block_scan<kT>(nr, &tot_r, sh);
     const int ex_b = block_scan<kT>(nrb, &tot_b, sh);
-    if (p <= S) r0f[p] = carry_r + ex_r;
-    if (p < S) r0b[p] = (carry_b + ex_b) | (fin << 31);  // bit 31: the position's state is final (the fill pass reads nothing else for it)
+    if (p <= S && (dirs & 1)) r0f[p] = carry_r + ex_r;
+    if (p < S && (dirs & 2)) r0b[p] = (carry_b + ex_b) | (fin << 31);  // bit 31: the position's state is final (the fill pass reads nothing else for it)
     carry_r += tot_r;
     carry_b += tot_b;
   }
-  if (tid == 0) r0f[S + 1] = carry_r, r0b[S] = carry_b;
+  if (tid == 0 && (dirs & 1)) r0f[S + 1] = carry_r;
+  if (tid == 0 && (dirs & 2)) r0b[S] = carry_b;
 }
 
 // ---- fill ----
@@ -646,39 +620,6 @@ constexpr int kTF = 256;
 constexpr int kFillUnroll = KLAT_FILL_UNROLL;
 constexpr int kTileRounds = kPackTileRounds;     // 32: 8 chunks, what a job's length is a multiple of
 constexpr int kWin = kTileRounds + 2;            // window of positions a tile can hold, per lattice (+ one past the end)
-constexpr int kM = 0x7FFFFFFF;
-
-struct TermCtx {
-  int lg, W, LPW, k;  // lg = log2(lanes per lattice): no integer division in this kernel (runtime divisors cost ~40 instructions each)
-};
-// term word of term j of position p (first round r, nr rounds) of the lattice in slot k
-__device__ __forceinline__ uint32_t term_word(const TermCtx& c, int p, int r, int nr, int j, int rel, bool word, bool nil, bool* far) {
-  const uint32_t cell_mask = (uint32_t)(c.W - 1);
-  const uint32_t own_cell = (uint32_t)((p & cell_mask) * c.LPW + c.k);
-  const int rr = r + (j >> c.lg);
-  uint32_t w;
-  *far = false;
-  if (nil) {
-    w = kNil | own_cell;
-  } else if (rel == 0) {
-    w = kOne | own_cell;
-  } else if (rel >= c.W) {
-    w = kFar | (uint32_t)rel;
-    *far = true;
-  } else {
-    w = (uint32_t)(((p - rel) & cell_mask) * c.LPW + c.k);
-    if (rel == 1 && (j >> c.lg) == 0) w |= kBypass;
-  }
-  if (word) w |= kWord;
-  if (!*far) w |= (uint32_t)(c.W * c.LPW + c.k) << kWrShift;  // the lattice's dummy cell unless COMMIT
-  if (rr == r) w |= kFirst;
-  if (rr == r + nr - 1) {
-    w |= kLast;
-    if ((j & ((1 << c.lg) - 1)) == 0 && !*far) w = (w & ~(kCellMask << kWrShift)) | kCommit | (own_cell << kWrShift);
-  }
-  return w;
-}
-
 // One workgroup per (job, run of tiles).  Per tile:
 //   windows   first round (r0f / r0b; backward: bit 31 = final state) and first term (cnt / row) of
 //             the positions that can have a round in the tile: one global round trip;

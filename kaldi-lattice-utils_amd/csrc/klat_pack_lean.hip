@@ -1,0 +1,823 @@
+// klat_pack_lean.hip -- the stream packer's passes for lattices whose arcs are short (every arc at most
+// kPackLeanMaxSpan states long, at most 127 terms a position): the same streams as klat_pack_device.hip writes, bit
+// for bit, from fewer bytes.  What makes the general passes expensive is the order of the FORWARD stream: its terms
+// are grouped by destination while the caller's arcs are grouped by source, so the general count pass leaves the
+// arcs sorted by destination in HBM and the general fill pass gathers every arc through that table, once per
+// direction, next to a second table for the backward order.  With short arcs none of it is needed: the in-arcs of
+// the positions of one tile lie within `span` states before them in the caller's own order, so a tile reads ONE
+// contiguous run of arcs, and all that has to be known about an arc beyond its own fields is its place among the
+// in-arcs of its destination and among the out-arcs of its source -- a byte each.
+//
+//   pack_count_lean_kernel  one workgroup per lattice, its tables in LDS.  One pass over the arcs (16-byte loads):
+//                           validation, in-degrees (LDS atomics), the first out-arc of every state from the arcs'
+//                           own order, the longest arc, the batch's largest cost (what pack_maxcost_kernel computed
+//                           in a pass of its own).  Prefix sums over the states: the first round of every position
+//                           for the lanes the plan is EXPECTED to give the lattice (a.lat_g_pred: known from the
+//                           offsets alone; what pack_rounds_kernel computed in a pass of its own after the plan), with
+//                           the position's number of terms in the upper byte, the rounds for every lane count (the
+//                           planner's input), and which position holds the first round of every tile (the fill
+//                           pass's binary search).  A counting sort in LDS only -- it yields every arc's place among
+//                           its destination's in-arcs; its place among its source's out-arcs (farthest first) comes
+//                           from the neighbouring arcs.  Out: 4 bytes an arc (`meta`: length, the two places, the
+//                           word bit) and 12 bytes a state.
+//   pack_rounds_lean_kernel the same prefix sums again for the lattices whose lanes the plan chose otherwise.
+//   pack_fill_lean_kernel   one workgroup per (job, run of tiles), a tile assembled in LDS and stored as whole lines
+//                           like pack_fill_kernel's.  Per tile one round trip for the arcs (destination or source,
+//                           meta, the two costs: 16 bytes an arc, 16-byte loads of consecutive arcs) behind one for
+//                           the positions' first rounds, and the second is asked for a tile ahead.
+//
+// A lattice the count pass finds unfit (a long arc, a position with more than 127 terms, a candidate of the level
+// path) is left to the general passes: a.lean_ok[u] stays 0.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "klat_device.h"
+#include "klat_level.h"
+#include "klat_math.h"
+#include "klat_pack_common.h"
+#include "klat_pack_device.h"
+
+namespace klat {
+
+namespace {
+
+constexpr int kTL = 256;  // threads of every kernel here
+constexpr uint32_t kRoundMask = 0xFFFFFFu;  // a position's first round in pf / pb; bits 24-30 its terms, bit 31 (pb) final state
+
+// exclusive prefix sums of N ints per thread with one pair of barriers
+template <int T, int N>
+__device__ void block_scan_n(const int (&v)[N], int (&ex)[N], int (&tot)[N], int* sh /* [N * T/64] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) incl[c] = v[c];
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      const int t = __shfl_up(incl[c], d, 64);
+      if (lane >= d) incl[c] += t;
+    }
+  }
+  __syncthreads();  // sh may still be read from a previous call
+  if (lane == 63) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) sh[c * (T / 64) + wave] = incl[c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    int off = 0, t = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) {
+      const int x = sh[c * (T / 64) + w];
+      if (w < wave) off += x;
+      t += x;
+    }
+    tot[c] = t;
+    ex[c] = off + incl[c] - v[c];
+  }
+}
+
+// four consecutive elements of an array, quad q of it: one 16-byte load (the arrays start on 256-byte boundaries and are
+// allocated four elements longer than the batch has arcs: the batch's last quad may reach past the last arc)
+template <class V, class T>
+__device__ __forceinline__ V load_quad(const T* base, int64_t q, int64_t) {
+  return reinterpret_cast<const V*>(base)[q];
+}
+
+__device__ __forceinline__ int elem(const int4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ float elem(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ uint32_t elem(const uint4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// first entry of lattice u's rows in the tile tables (tpf / tpb): a lattice of S states owns S / 8 + 2 entries at
+// least, one per 32 rounds -- the count pass leaves a lattice with more than 4 S rounds to the general passes
+__device__ __forceinline__ int64_t tile_row(int64_t state_base, int64_t u) { return (state_base >> 3) + 2 * u; }
+__device__ __forceinline__ int tile_cap(int S) { return (S >> 3) + 2; }
+
+constexpr int kStatesPerThread = 4;
+
+// The prefix sums of one lattice over its positions, for k = log2(lanes): forward (pf, tpf) from the in-degrees,
+// backward (pb, tpb) from the out-degrees and the final flags.  nterm_f(p) / nterm_b(q) give the terms of forward
+// position p < S and backward position q < S (and bit 31 of nterm_b: the position's state is final); nfinal the terms
+// of forward position S.  Returns false when a lattice does not fit the tables (more than 4 S rounds).
+// Also what the planner wants to know: rounds for every lane count and the most terms of a position, when `sums`.
+template <class FT, class FB, class PerF>
+__device__ bool lean_prefix(const PackDevArgs& a, int u, int64_t s0, int S, int k, FT nterm_f, FB nterm_b, int nfinal, PerF per_forward,
+                            int* sh, int (*fsum)[kNumLaneChoices], int (*bsum)[kNumLaneChoices], int* mtf_out, int* mtb_out) {
+  const int tid = threadIdx.x;
+  const int64_t sb = s0 + 2 * (int64_t)u, tb = tile_row(s0, u);
+  const int cap = tile_cap(S);
+  int32_t* pf = a.r0f + sb;
+  int32_t* pb = a.r0b + sb;
+  int32_t* tpf = a.tpf + tb;
+  int32_t* tpb = a.tpb + tb;
+  int mtf = 1, mtb = 1;
+  bool fits = true;
+  auto tiles = [&](int32_t* tp, int p, int r, int nr) {  // the tiles whose first round lies in position p
+    for (int m = (r + kPackTileRounds - 1) / kPackTileRounds; m * kPackTileRounds < r + nr; ++m) {
+      if (m < cap)
+        tp[m] = p;
+      else
+        fits = false;
+    }
+  };
+  // forward: positions 0 .. S - 1 (position S, the final weights, behind the loop)
+  int carry[2] = {0, 0};
+  for (int base = 0; base < S; base += kTL * kStatesPerThread) {
+    const int p0 = base + tid * kStatesPerThread;
+    int nt[kStatesPerThread], nr[kStatesPerThread], v[2] = {0, 0}, ex[2], tot[2];
+#pragma unroll
+    for (int e = 0; e < kStatesPerThread; ++e) {
+      const int p = p0 + e;
+      nt[e] = p < S ? nterm_f(p) : 0;
+      nr[e] = p < S ? (max(nt[e], 1) + (1 << k) - 1) >> k : 0;
+      v[0] += nr[e];
+      v[1] += p < S ? nt[e] - (p == 0 ? 1 : 0) : 0;  // the in-degree
+    }
+    block_scan_n<kTL, 2>(v, ex, tot, sh);
+    int r = carry[0] + ex[0], c = carry[1] + ex[1];
+#pragma unroll
+    for (int e = 0; e < kStatesPerThread; ++e) {
+      const int p = p0 + e;
+      if (p >= S) break;
+      pf[p] = r | (min(nt[e], 127) << 24);
+      tiles(tpf, p, r, nr[e]);
+      per_forward(p, c);
+      mtf = max(mtf, nt[e]);
+      if (fsum)
+        for (int kk = 0; kk < kNumLaneChoices; ++kk) (*fsum)[kk] += (max(nt[e], 1) + (1 << kk) - 1) >> kk;
+      r += nr[e];
+      c += nt[e] - (p == 0 ? 1 : 0);
+    }
+    carry[0] += tot[0], carry[1] += tot[1];
+  }
+  if (tid == 0) {
+    const int nr = (max(nfinal, 1) + (1 << k) - 1) >> k;
+    pf[S] = carry[0] | (min(nfinal, 127) << 24);
+    pf[S + 1] = carry[0] + nr;
+    tiles(tpf, S, carry[0], nr);
+    mtf = max(mtf, nfinal);
+    if (fsum)
+      for (int kk = 0; kk < kNumLaneChoices; ++kk) (*fsum)[kk] += (max(nfinal, 1) + (1 << kk) - 1) >> kk;
+    if (carry[0] + nr > 4 * S) fits = false;
+  }
+  // backward: position q = the state S - 1 - q
+  int carry_b = 0;
+  for (int base = 0; base < S; base += kTL * kStatesPerThread) {
+    const int q0 = base + tid * kStatesPerThread;
+    int nt[kStatesPerThread], nr[kStatesPerThread], v[1] = {0}, ex[1], tot[1];
+#pragma unroll
+    for (int e = 0; e < kStatesPerThread; ++e) {
+      const int q = q0 + e;
+      nt[e] = q < S ? nterm_b(q) : 0;
+      nr[e] = q < S ? (max(nt[e] & 0xFFFFFF, 1) + (1 << k) - 1) >> k : 0;
+      v[0] += nr[e];
+    }
+    block_scan_n<kTL, 1>(v, ex, tot, sh);
+    int r = carry_b + ex[0];
+#pragma unroll
+    for (int e = 0; e < kStatesPerThread; ++e) {
+      const int q = q0 + e;
+      if (q >= S) break;
+      const int n = nt[e] & 0xFFFFFF;
+      pb[q] = r | (min(n, 127) << 24) | (nt[e] & (int)0x80000000);
+      tiles(tpb, q, r, nr[e]);
+      mtb = max(mtb, n);
+      if (bsum)
+        for (int kk = 0; kk < kNumLaneChoices; ++kk) (*bsum)[kk] += (max(n, 1) + (1 << kk) - 1) >> kk;
+      r += nr[e];
+    }
+    carry_b += tot[0];
+  }
+  if (tid == 0) {
+    pb[S] = carry_b;
+    if (carry_b > 4 * S) fits = false;
+  }
+  if (mtf > 127 || mtb > 127) fits = false;
+  if (mtf_out) *mtf_out = mtf, *mtb_out = mtb;
+  return fits;
+}
+
+__global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int lds_lo, int lds_hi) {
+  extern __shared__ int32_t lds[];
+  __shared__ int sh[2 * (kTL / 64)];
+  __shared__ int sh_bad, sh_unfit, sh_span, sh_mr, sh_mtf, sh_mtb, sh_linked, sh_nfinal;
+  __shared__ int sh_rounds[2 * kNumLaneChoices];
+  __shared__ unsigned long long sh_mc;
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
+  const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
+  const int need = pack_lean_lds_bytes(S, A);
+  if (need <= lds_lo || need > lds_hi) return;  // every lattice belongs to one launch: the narrowest LDS class it fits
+  if (tid < (int)(sizeof(LatticeRounds) / sizeof(int32_t))) reinterpret_cast<int32_t*>(&a.lat_rounds[u])[tid] = 0;
+  if (S <= 0) {
+    if (tid == 0) {
+      if (S < 0 || A != 0)
+        report_bad(a, 1 /* KLAT_ERR_INVALID_ARG */, u);
+      else
+        a.lean_ok[u] = 1;  // nothing to pack
+    }
+    return;
+  }
+  unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = a.prof ? __builtin_readcyclecounter() : 0;
+  auto stamp = [&](int phase) {
+    if (a.prof) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      pc[phase] += now - pt;
+      pt = now;
+    }
+  };
+  const int nl = (S + 31) / 32 + 1;
+  int32_t* indeg = lds;                                          // [S + 2] in-degrees, then the counting sort's cursors
+  int32_t* row = lds + (S + 2);                                  // [S + 2] first out-arc
+  uint32_t* link = reinterpret_cast<uint32_t*>(lds + 2 * (S + 2));  // [nl] a bit a state: it has an arc to its successor
+  uint32_t* finb = link + nl;                                    // [nl] a bit a state: it is final
+  uint16_t* bucket = reinterpret_cast<uint16_t*>(finb + nl);     // [A] arcs by destination
+  uint8_t* relb = reinterpret_cast<uint8_t*>(bucket + ((A + 1) & ~1));  // [A] length of every arc
+  const int64_t sb = s0 + 2 * (int64_t)u;
+  if (tid == 0) sh_bad = 0, sh_unfit = 0, sh_span = 1, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0, sh_nfinal = 0, sh_mc = 0ull;
+  if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
+  for (int s = tid; s < S + 2; s += kTL) indeg[s] = 0;
+  for (int s = tid; s < 2 * nl; s += kTL) link[s] = 0;
+  __syncthreads();
+  stamp(0);
+  // ---- the arcs, four a lane and load
+  const int64_t q0 = a0 >> 2, q1 = (a0 + A + 3) >> 2;
+  constexpr int kUn = 3;  // quads a thread has in flight
+  double mc = 0.0;
+  int span = 1;
+  for (int64_t qb = q0 + tid; qb < q1; qb += kTL * kUn) {
+    int4 vs[kUn], vd[kUn], vi[kUn];
+    float4 vg[kUn], va[kUn];
+    int vp[kUn];
+#pragma unroll
+    for (int x = 0; x < kUn; ++x) {
+      const int64_t q = min(qb + x * kTL, q1 - 1);
+      vs[x] = load_quad<int4>(a.src, q, a.num_arcs);
+      vd[x] = load_quad<int4>(a.dst, q, a.num_arcs);
+      vp[x] = 4 * q > a0 ? a.src[4 * q - 1] : 0;
+      if (a.fold_maxcost) {
+        vg[x] = load_quad<float4>(a.graph, q, a.num_arcs);
+        va[x] = load_quad<float4>(a.acoustic, q, a.num_arcs);
+        if (a.fsp.penalized) vi[x] = load_quad<int4>(a.ilabel, q, a.num_arcs);
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < kUn; ++x) {
+      const int64_t q = qb + x * kTL;
+      if (q >= q1) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = (int)(4 * q + e - a0);
+        if (i < 0 || i >= A) continue;  // (a neighbouring lattice's arc)
+        const int s = elem(vs[x], e), t = elem(vd[x], e);
+        const int prev = e == 0 ? vp[x] : elem(vs[x], e - 1);
+        if (s < 0 || s >= S || (i > 0 && s < prev)) {
+          atomicMax(&sh_bad, 2);  // malformed CSR
+        } else if (t <= s || t >= S) {
+          atomicMax(&sh_bad, 1);  // not topologically sorted
+        } else {
+          atomicAdd(&indeg[t], 1);
+          const int rel = t - s;
+          span = max(span, rel);
+          relb[i] = (uint8_t)min(rel, 255);
+          if (rel == 1) atomicOr(&link[s >> 5], 1u << (s & 31));
+          // arc i is the first out-arc of every state behind its predecessor's source up to its own (the predecessor may be
+          // the malformed arc this pass exists to reject: its source below zero must not move the fill before the table)
+          for (int qq = (i > 0 ? max(prev, -1) + 1 : 0); qq <= s; ++qq) row[qq] = i;
+          if (a.fold_maxcost) {
+            const double c = fabs(arc_cost(elem(vg[x], e), elem(va[x], e), a.fsp.penalized ? elem(vi[x], e) != 0 : false, a.fsp));
+            if (c < 1.0e30) mc = fmax(mc, c);
+          }
+        }
+      }
+    }
+  }
+  // the final weights: a bit a state, the largest cost
+  for (int s = tid; s < S; s += kTL) {
+    const float fg = a.final_graph[s0 + s], fa = a.final_acoustic[s0 + s];
+    if (!(fg == INFINITY && fa == INFINITY)) atomicOr(&finb[s >> 5], 1u << (s & 31));
+    if (a.fold_maxcost) {
+      const double c = fabs(arc_cost(fg, fa, false, a.fsp));
+      if (c < 1.0e30) mc = fmax(mc, c);
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) span = max(span, __shfl_xor(span, d, 64));
+  if ((tid & 63) == 0) atomicMax(&sh_span, span);
+  if (a.fold_maxcost) {  // (whatever becomes of the lattice below: the batch's largest cost covers every lattice)
+    for (int d = 32; d > 0; d >>= 1) mc = fmax(mc, __shfl_xor(mc, d, 64));
+    if ((tid & 63) == 0 && mc > 0.0) atomicMax(&sh_mc, (unsigned long long)__double_as_longlong(mc));
+  }
+  stamp(1);
+  __syncthreads();
+  stamp(2);
+  if (a.fold_maxcost && tid == 0 && sh_mc != 0ull) atomicMax(a.maxcost, sh_mc);  // (positive doubles order like their bit patterns)
+  if (sh_bad) {
+    if (tid == 0) report_bad(a, sh_bad == 2 ? 1 /* INVALID_ARG */ : 2 /* BAD_TOPOLOGY */, u);
+    return;
+  }
+  {  // the states behind the last arc's source; the states linked to their successor
+    const int last = A > 0 ? a.src[a0 + A - 1] : -1;
+    for (int s = last + 1 + tid; s <= S + 1; s += kTL) row[s] = A;
+    int linked = 0;
+    for (int w = tid; w < nl; w += kTL) linked += __popc(link[w]);
+    int nfin = 0;
+    for (int w = tid; w < nl; w += kTL) nfin += __popc(finb[w]);
+    for (int d = 32; d > 0; d >>= 1) linked += __shfl_xor(linked, d, 64), nfin += __shfl_xor(nfin, d, 64);
+    if ((tid & 63) == 0) atomicAdd(&sh_linked, linked), atomicAdd(&sh_nfinal, nfin);
+  }
+  __syncthreads();
+  const int linked = sh_linked, nfinal = sh_nfinal;
+  // unfit for these passes: a long arc; a lattice the level path may want (it reads the general pass's tables)
+  if (sh_span > kPackLeanMaxSpan) return;
+  if (a.level_probe && S >= kLevelMinStates && S <= kLevelMaxStates && !(linked > (S - linked + 1) * (S / kLevelMinWidth))) return;
+  stamp(3);
+  // ---- prefix sums over the positions
+  const int k = a.lat_g_pred[u];
+  int fsum[kNumLaneChoices] = {0}, bsum[kNumLaneChoices] = {0};
+  int mtf, mtb, mr = sh_span;
+  auto is_final = [&](int s) { return (finb[s >> 5] >> (s & 31)) & 1u; };
+  const bool fits = lean_prefix(
+      a, u, s0, S, max(k, 0), [&](int p) { return indeg[p] + (p == 0 ? 1 : 0); },
+      [&](int q) {
+        const int s = S - 1 - q;
+        const int fin = (int)is_final(s);
+        return (row[s + 1] - row[s] + fin) | (fin << 31);
+      },
+      nfinal,
+      [&](int p, int c) {
+        indeg[p] = c;  // (the counting sort's cursor: the bucket's first entry)
+        a.row[sb + p] = row[p];
+        if (is_final(p)) mr = max(mr, S - p);
+      },
+      sh, &fsum, &bsum, &mtf, &mtb);
+  // the final states in state order (forward position S holds one term for each)
+  {
+    int carry = 0;
+    for (int base = 0; base < nl; base += kTL) {
+      const int w = base + tid;
+      const uint32_t bits = w < nl ? finb[w] : 0u;
+      int v[1] = {(int)__popc(bits)}, ex[1], tot[1];
+      block_scan_n<kTL, 1>(v, ex, tot, sh);
+      int at = carry + ex[0];
+      for (uint32_t m = bits; m; m &= m - 1) a.flist[s0 + at++] = w * 32 + __ffs(m) - 1;
+      carry += tot[0];
+    }
+  }
+  if (!fits) atomicMax(&sh_unfit, 1);
+  for (int d = 32; d > 0; d >>= 1) {
+    mr = max(mr, __shfl_xor(mr, d, 64));
+    mtf = max(mtf, __shfl_xor(mtf, d, 64));
+    mtb = max(mtb, __shfl_xor(mtb, d, 64));
+#pragma unroll
+    for (int kk = 0; kk < kNumLaneChoices; ++kk) fsum[kk] += __shfl_xor(fsum[kk], d, 64), bsum[kk] += __shfl_xor(bsum[kk], d, 64);
+  }
+  if ((tid & 63) == 0) {
+    atomicMax(&sh_mr, mr);
+    atomicMax(&sh_mtf, mtf);
+    atomicMax(&sh_mtb, mtb);
+    for (int kk = 0; kk < kNumLaneChoices; ++kk) atomicAdd(&sh_rounds[kk], fsum[kk]), atomicAdd(&sh_rounds[kNumLaneChoices + kk], bsum[kk]);
+  }
+  __syncthreads();
+  if (sh_unfit) return;
+  stamp(4);
+  // ---- counting sort of the arcs by destination, in LDS: where an arc stands among the in-arcs of its destination
+  for (int64_t qb = q0 + tid; qb < q1; qb += kTL * kUn) {
+    int4 vd[kUn];
+#pragma unroll
+    for (int x = 0; x < kUn; ++x) vd[x] = load_quad<int4>(a.dst, min(qb + x * kTL, q1 - 1), a.num_arcs);
+#pragma unroll
+    for (int x = 0; x < kUn; ++x) {
+      const int64_t q = qb + x * kTL;
+      if (q >= q1) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = (int)(4 * q + e - a0);
+        if (i < 0 || i >= A) continue;
+        bucket[atomicAdd(&indeg[elem(vd[x], e)], 1)] = (uint16_t)i;
+      }
+    }
+  }
+  __syncthreads();
+  stamp(5);
+  // ---- meta: length | place among the destination's in-arcs (by arc number) << 8 | place among the source's out-arcs
+  // (farthest destination first, equal destinations by arc number) << 16 | word << 24
+  for (int64_t qb = q0 + tid; qb < q1; qb += kTL * kUn) {
+    int4 vs[kUn], vd[kUn], vi[kUn];
+#pragma unroll
+    for (int x = 0; x < kUn; ++x) {
+      const int64_t q = min(qb + x * kTL, q1 - 1);
+      vs[x] = load_quad<int4>(a.src, q, a.num_arcs);
+      vd[x] = load_quad<int4>(a.dst, q, a.num_arcs);
+      vi[x] = load_quad<int4>(a.ilabel, q, a.num_arcs);
+    }
+#pragma unroll
+    for (int x = 0; x < kUn; ++x) {
+      const int64_t q = qb + x * kTL;
+      if (q >= q1) continue;
+      uint32_t m[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = (int)(4 * q + e - a0);
+        m[e] = 0;
+        if (i < 0 || i >= A) continue;
+        const int s = elem(vs[x], e), t = elem(vd[x], e), rel = t - s;
+        int jr = 0, orank = 0;
+        for (int y = t > 0 ? indeg[t - 1] : 0, ye = indeg[t]; y < ye; ++y) jr += (int)bucket[y] < i ? 1 : 0;
+        for (int y = row[s], ye = row[s + 1]; y < ye; ++y) {
+          const int ry = relb[y];
+          orank += (ry > rel || (ry == rel && y < i)) ? 1 : 0;
+        }
+        m[e] = (uint32_t)rel | ((uint32_t)jr << 8) | ((uint32_t)orank << 16) | (elem(vi[x], e) != 0 ? 1u << 24 : 0u);
+      }
+      if (4 * q >= a0 && 4 * q + 4 <= a0 + A) {
+        reinterpret_cast<uint4*>(a.meta)[q] = make_uint4(m[0], m[1], m[2], m[3]);
+      } else {  // (a quad shared with a neighbouring lattice)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * q + e >= a0 && 4 * q + e < a0 + A) a.meta[4 * q + e] = m[e];
+      }
+    }
+  }
+  stamp(6);
+  if (a.prof && tid == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.prof[i], pc[i]);
+  if (tid < kNumLaneChoices) {
+    a.lat_rounds[u].fwd[tid] = sh_rounds[tid];
+    a.lat_rounds[u].bwd[tid] = sh_rounds[kNumLaneChoices + tid];
+  }
+  if (tid == 0) {
+    a.row[sb + S] = A;
+    a.row[sb + S + 1] = linked;  // (the spare entry of the row table: the level planner's chain test)
+    atomicMax(&a.status[2], sh_mr);
+    a.lat_rounds[u].max_rel = sh_mr;
+    a.lat_rounds[u].max_terms = min(sh_mtf, 64) | (min(sh_mtb, 64) << 16);
+    a.lat_rounds[u].max_span = sh_span;
+    a.lean_ok[u] = 1;
+  }
+}
+
+// The prefix sums again, from the terms the count pass left in the upper bytes, for the lattices whose lanes the plan
+// did not choose as expected (a.reround[u] != 0).
+__global__ __launch_bounds__(kTL) void pack_rounds_lean_kernel(PackDevArgs a) {
+  __shared__ int sh[2 * (kTL / 64)];
+  const int u = blockIdx.x;
+  if (!a.reround[u]) return;
+  const int64_t s0 = a.state_off[u];
+  const int S = (int)(a.state_off[u + 1] - s0);
+  if (S <= 0 || a.lat_g[u] < 0) return;
+  const int64_t sb = s0 + 2 * (int64_t)u;
+  const int32_t* pf = a.r0f + sb;
+  const int32_t* pb = a.r0b + sb;
+  const int nfinal = (pf[S] >> 24) & 0x7F;
+  // (every thread reads its own positions' old entries before it writes them: lean_prefix loads nterm first)
+  (void)lean_prefix(
+      a, u, s0, S, a.lat_g[u], [&](int p) { return (pf[p] >> 24) & 0x7F; },
+      [&](int q) { return ((pb[q] >> 24) & 0x7F) | (pb[q] & (int)0x80000000); }, nfinal, [](int, int) {}, sh, nullptr, nullptr, nullptr, nullptr);
+}
+
+// ---- fill ----
+constexpr int kTR = kPackTileRounds;  // 32 rounds a tile
+constexpr int kWinL = kTR + 2;        // positions a tile can hold, per lattice, and one behind them
+constexpr int kMaxTiles = kPackTilesPerGroup;
+
+// Everything that depends on the lanes per lattice is a compile-time constant (one instantiation per lane count: the
+// first version, with the lane count in registers, wanted 217 VGPRs and spent its time in scratch memory).
+template <int LG, bool FUSED>
+__global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, int entry0) {
+  constexpr int G = 1 << LG, LPW = 64 >> LG, GMASK = G - 1;
+  constexpr int LG_TPS = LG + 2, TPS = 1 << LG_TPS;  // threads a lattice has to itself: kTL / LPW
+  constexpr int kWinPerThread = (LPW * kWinL + kTL - 1) / kTL;
+  __shared__ __attribute__((aligned(16))) uint32_t tw[kTR * 64];
+  __shared__ __attribute__((aligned(16))) float tg[kTR * 64];
+  __shared__ __attribute__((aligned(16))) float ta[FUSED ? 4 : kTR * 64];
+  __shared__ __attribute__((aligned(16))) int16_t tl[FUSED ? kTR * 64 : 8];  // the residuals
+  __shared__ int32_t win[LPW * kWinL];
+  __shared__ int32_t sh_tp[LPW * (kMaxTiles + 1)];
+  __shared__ int64_t sh_s0[LPW];
+  __shared__ int sh_q0[LPW], sh_S[LPW], sh_lat[LPW], sh_span[LPW], sh_alo[LPW], sh_ahi[LPW];
+  const LeanEntry e = a.lentries[entry0 + blockIdx.x];
+  const int W = job_ring(e.tag), AL = job_stored_lanes(e.tag);
+  const int tid = threadIdx.x;
+  const bool fwd = e.dir == 0;
+  const int row_units = AL * LPW;
+  const uint32_t cell_mask = (uint32_t)(W - 1);
+  const int32_t* rtab = fwd ? a.r0f : a.r0b;
+  int nfar = 0;
+  // the job's lattices; for each the position that holds the first round of every tile of the run
+  if (tid < LPW) {
+    const LaneInfo li = a.lanes[e.lane_tab + tid];
+    int S = 0, span = 0, q0 = 0;
+    int64_t s0 = 0;
+    if (li.lattice >= 0) {
+      S = li.num_states;
+      s0 = li.state_base;
+      span = a.lat_rounds[li.lattice].max_span;
+      q0 = (int)a.arc_off[li.lattice];  // (a batch has fewer than 2^31 arcs)
+    }
+    sh_lat[tid] = li.lattice, sh_S[tid] = S, sh_span[tid] = span, sh_s0[tid] = s0, sh_q0[tid] = q0;
+  }
+  __syncthreads();
+  for (int i = tid; i < LPW * (e.tile_count + 1); i += kTL) {
+    const int k = i / (e.tile_count + 1), t = i - k * (e.tile_count + 1);
+    const int u = sh_lat[k];
+    int p = 0;
+    if (u >= 0) {
+      const int S = sh_S[k], P = fwd ? S + 1 : S;
+      const int64_t sb = sh_s0[k] + 2 * (int64_t)u;
+      const int total = rtab[sb + P];
+      const int m = e.tile_begin + t;
+      p = m * kTR < total ? (fwd ? a.tpf : a.tpb)[tile_row(sh_s0[k], u) + m] : P;
+    }
+    sh_tp[k * (kMaxTiles + 1) + t] = p;
+  }
+  __syncthreads();
+  // window of tile t: thread i holds entry o = i % kWinL of lattice k = i / kWinL (the first round of position plo + o);
+  // thread 2 k the number of lattice k's first arc of the tile, thread 2 k + 1 the end of its arcs
+  int wr[kWinPerThread], wa = 0;
+  auto ask_window = [&](int t) {
+#pragma unroll
+    for (int x = 0; x < kWinPerThread; ++x) {
+      const int i = tid + x * kTL;
+      wr[x] = kM;
+      if (i >= LPW * kWinL) continue;
+      const int k = i / kWinL, o = i - k * kWinL;
+      const int u = sh_lat[k];
+      if (u < 0) continue;
+      const int P = fwd ? sh_S[k] + 1 : sh_S[k];
+      const int plo = sh_tp[k * (kMaxTiles + 1) + t];
+      if (plo + o <= P) wr[x] = (rtab + (sh_s0[k] + 2 * (int64_t)u))[plo + o];
+    }
+    wa = 0;
+    if (tid < 2 * LPW) {
+      const int k = tid >> 1, o = tid & 1;
+      const int u = sh_lat[k];
+      const int S = sh_S[k], P = fwd ? S + 1 : S;
+      const int plo = sh_tp[k * (kMaxTiles + 1) + t];
+      if (u >= 0 && plo < P) {
+        const int phi = min(sh_tp[k * (kMaxTiles + 1) + t + 1], P - 1);
+        // forward: the in-arcs of positions plo .. phi leave the states plo - span .. phi - 1; backward: positions
+        // plo .. phi are the states S - 1 - phi .. S - 1 - plo
+        const int st = fwd ? (o == 0 ? max(plo - sh_span[k], 0) : min(phi, S)) : (o == 0 ? S - 1 - phi : S - plo);
+        wa = (a.row + (sh_s0[k] + 2 * (int64_t)u))[st];
+      }
+    }
+  };
+  ask_window(0);
+  for (int t = 0; t < e.tile_count; ++t) {
+    const int R0 = (e.tile_begin + t) * kTR;
+    // ---- the window into LDS; padding everywhere (zero-weight terms that park their unused result in the lattice's
+    // dummy cell behind the ring)
+#pragma unroll
+    for (int x = 0; x < kWinPerThread; ++x) {
+      const int i = tid + x * kTL;
+      if (i >= LPW * kWinL) continue;
+      win[i] = wr[x];
+    }
+    if (tid < 2 * LPW) ((tid & 1) ? sh_ahi : sh_alo)[tid >> 1] = wa;
+    for (int i = tid; i < 8 * row_units; i += kTL) {  // one 16-byte unit (4 rounds of a lane) per store
+      const int slot = i & (LPW - 1);  // unit = lane * LPW + slot, a row is a whole number of lanes
+      const uint32_t w = kNil | ((uint32_t)(W * LPW + slot) << kWrShift);
+      reinterpret_cast<uint4*>(tw)[i] = make_uint4(w, w, w, w);
+      reinterpret_cast<float4*>(tg)[i] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+      if (FUSED)
+        reinterpret_cast<int2*>(tl)[i] = make_int2(0, 0);
+      else
+        reinterpret_cast<float4*>(ta)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    // slot of (round rr of the tile, lane sub, lattice k)
+    auto slot_of = [&](int k, int dr, int sub) { return (int)((__umul24(dr >> 2, row_units) + sub * LPW + k) << 2) + (dr & 3); };
+    auto put_cost = [&](int i, uint32_t w, float g, float ac) {
+      if (FUSED) {
+        // the cost as the reference forms it (ScaleLattice, AddWordInsPen, ConvertToCost), kept as a float and
+        // a 16-bit residual in units of the batch's lo_unit
+        const double c = arc_cost(g, ac, (w & kWord) != 0, a.fsp);
+        const float hi = (float)c;
+        int n = 0;
+        if (c < 1.0e30 && c > -1.0e30) n = max(-32767, min(32767, (int)rint((c - (double)hi) * a.lo_inv_unit)));
+        tg[i] = hi;
+        tl[i] = (int16_t)n;
+      } else {
+        tg[i] = g;
+        ta[i] = ac;
+      }
+    };
+    // the flags and the write cell of term j of a position (first round r, nr rounds; own_cell its ring cell, dummy the lattice's dummy cell)
+    auto finish_word = [&](uint32_t w, int j, int jq, int nr, uint32_t own_cell, uint32_t dummy, bool far) {
+      if (!far) w |= dummy << kWrShift;
+      if (jq == 0) w |= kFirst;
+      if (jq == nr - 1) {
+        w |= kLast;
+        if ((j & GMASK) == 0 && !far) w = (w & ~(kCellMask << kWrShift)) | kCommit | (own_cell << kWrShift);
+      }
+      return w;
+    };
+    // ---- the arcs: the lattice in slot k has the threads [k * TPS, (k + 1) * TPS) to itself, four consecutive arcs a lane
+    {
+      const int k = tid >> LG_TPS, gl = tid & (TPS - 1);
+      const int plo = sh_tp[k * (kMaxTiles + 1) + t], S = sh_S[k], P = fwd ? S + 1 : S;
+      const int n = min(sh_tp[k * (kMaxTiles + 1) + t + 1], P - 1) - plo + 1;  // positions that may have a round here
+      const int a0 = sh_q0[k], alo = sh_alo[k], ahi = sh_ahi[k];
+      const int32_t* wk = win + k * kWinL;
+      const uint32_t dummy = (uint32_t)(W * LPW + k);
+      const int qlo = (a0 + alo) >> 2, qhi = (a0 + ahi + 3) >> 2;
+      const int32_t* ends = fwd ? a.dst : a.src;
+      constexpr int kQ = 2;  // quads a thread has in flight
+      bool asked = false;
+      for (int qb = qlo + gl; qb < qhi; qb += kQ * TPS) {
+        int4 ve[kQ];
+        uint4 vm[kQ];
+        float4 vg[kQ], va[kQ];
+#pragma unroll
+        for (int x = 0; x < kQ; ++x) {
+          const int q = min(qb + x * TPS, qhi - 1);
+          ve[x] = reinterpret_cast<const int4*>(ends)[q];
+          vm[x] = reinterpret_cast<const uint4*>(a.meta)[q];
+          vg[x] = reinterpret_cast<const float4*>(a.graph)[q];
+          va[x] = reinterpret_cast<const float4*>(a.acoustic)[q];
+        }
+        if (!asked && t + 1 < e.tile_count) ask_window(t + 1);  // (behind the arcs' loads: it lands while they are worked on)
+        asked = true;
+#pragma unroll
+        for (int x = 0; x < kQ; ++x) {
+          const int q = qb + x * TPS;
+          if (q >= qhi) continue;
+#pragma unroll
+          for (int el = 0; el < 4; ++el) {
+            const int i = 4 * q + el - a0;
+            if (i < alo || i >= ahi) continue;
+            const uint32_t m = elem(vm[x], el);
+            const int rel = (int)(m & 0xFFu);
+            const int p = fwd ? elem(ve[x], el) : S - 1 - elem(ve[x], el);
+            const int o = p - plo;
+            if ((unsigned)o >= (unsigned)n) continue;
+            const int w0 = wk[o];
+            const int r = w0 & (int)kRoundMask, nr = (wk[o + 1] & (int)kRoundMask) - r;
+            // the term's number within its position: behind the constant-one term of a final state (backward)
+            const int j = fwd ? (int)((m >> 8) & 0xFFu) : (int)((m >> 16) & 0xFFu) + (int)((uint32_t)w0 >> 31);
+            const int jq = j >> LG, dr = r + jq - R0;
+            if ((unsigned)dr >= (unsigned)kTR) continue;
+            const uint32_t own_cell = (((uint32_t)p & cell_mask) << (6 - LG)) + (uint32_t)k;
+            const bool far = rel >= W;
+            uint32_t w;
+            if (far) {
+              w = kFar | (uint32_t)rel;
+              ++nfar;
+            } else {
+              w = (((uint32_t)(p - rel) & cell_mask) << (6 - LG)) + (uint32_t)k;
+              if (rel == 1 && jq == 0) w |= kBypass;
+            }
+            w |= (m & (1u << 24)) << 6;  // kWord
+            w = finish_word(w, j, jq, nr, own_cell, dummy, far);
+            const int at = slot_of(k, dr, j & GMASK);
+            tw[at] = w;
+            put_cost(at, w, elem(vg[x], el), elem(va[x], el));
+          }
+        }
+      }
+      if (!asked && t + 1 < e.tile_count) ask_window(t + 1);
+    }
+    // ---- one thread per position: what is not an arc
+#pragma unroll 1
+    for (int i = tid; i < LPW * (kTR + 1); i += kTL) {
+      const int k = i / (kTR + 1), o = i - k * (kTR + 1);
+      if (sh_lat[k] < 0) continue;
+      const int S = sh_S[k], P = fwd ? S + 1 : S;
+      const int p = sh_tp[k * (kMaxTiles + 1) + t] + o;
+      if (p >= P || p > sh_tp[k * (kMaxTiles + 1) + t + 1]) continue;
+      const int w0 = win[k * kWinL + o];
+      const int r = w0 & (int)kRoundMask, nr = (win[k * kWinL + o + 1] & (int)kRoundMask) - r;
+      if (r >= R0 + kTR || r + nr <= R0) continue;
+      const int jlo = max(0, (R0 - r) << LG), jhi = min(nr << LG, (R0 + kTR - r) << LG);
+      const int nterm = (w0 >> 24) & 0x7F;
+      const bool lead = fwd ? p == 0 : ((uint32_t)w0 >> 31) != 0;  // alpha[start] = 0; a final state's weight
+      const uint32_t own_cell = (((uint32_t)p & cell_mask) << (6 - LG)) + (uint32_t)k, dummy = (uint32_t)(W * LPW + k);
+      if (jlo == 0 && (lead || nterm == 0)) {
+        float g = 0.0f, ac = 0.0f;
+        if (lead && !fwd) g = a.final_graph[sh_s0[k] + S - 1 - p], ac = a.final_acoustic[sh_s0[k] + S - 1 - p];
+        const uint32_t w = finish_word((lead ? kOne : kNil) | own_cell, 0, 0, nr, own_cell, dummy, false);
+        const int at = slot_of(k, r - R0, 0);
+        tw[at] = w;
+        if (lead) put_cost(at, w, g, ac);  // (a NIL term keeps the padding's infinite cost)
+      }
+      // lanes of the position's rounds that carry no term (cost: the padding's)
+#pragma unroll 1
+      for (int jj = max(max(nterm, 1), jlo); jj < jhi; ++jj) {
+        if ((jj & GMASK) >= AL) continue;
+        const int jq = jj >> LG;
+        uint32_t w = kNil | (dummy << kWrShift);
+        if (jq == 0) w |= kFirst;
+        if (jq == nr - 1) w |= kLast;
+        tw[slot_of(k, r + jq - R0, jj & GMASK)] = w;
+      }
+    }
+    // ---- forward position S: one term per final state (up to 127 of them), a thread each
+    if (fwd) {
+#pragma unroll 1
+      for (int i = tid; i < LPW * 128; i += kTL) {
+        const int k = i >> 7, jj = i & 127;
+        const int S = sh_S[k], plo = sh_tp[k * (kMaxTiles + 1) + t];
+        if (sh_lat[k] < 0 || plo > S || sh_tp[k * (kMaxTiles + 1) + t + 1] < S) continue;  // (position S has no round here)
+        const int w0 = win[k * kWinL + S - plo];
+        const int r = w0 & (int)kRoundMask, nr = (win[k * kWinL + S - plo + 1] & (int)kRoundMask) - r;
+        const int jq = jj >> LG, dr = r + jq - R0;
+        if (jj >= ((w0 >> 24) & 0x7F) || (unsigned)dr >= (unsigned)kTR) continue;
+        const int s = a.flist[sh_s0[k] + jj];
+        const int rel = S - s;
+        const bool far = rel >= W;
+        const uint32_t own_cell = (((uint32_t)S & cell_mask) << (6 - LG)) + (uint32_t)k, dummy = (uint32_t)(W * LPW + k);
+        uint32_t w = far ? kFar | (uint32_t)rel : (((uint32_t)(S - rel) & cell_mask) << (6 - LG)) + (uint32_t)k;
+        if (!far && rel == 1 && jq == 0) w |= kBypass;
+        nfar += far ? 1 : 0;
+        w = finish_word(w, jj, jq, nr, own_cell, dummy, far);
+        const int at = slot_of(k, dr, jj & GMASK);
+        tw[at] = w;
+        put_cost(at, w, a.final_graph[sh_s0[k] + s], a.final_acoustic[sh_s0[k] + s]);
+      }
+    }
+    __syncthreads();
+    // ---- the tile leaves as whole lines
+    {
+      const int64_t base = (e.chunk_off + (int64_t)(R0 >> 2) * row_units) << 2;  // first slot of the tile
+      uint4* gw = reinterpret_cast<uint4*>(a.sw + base);
+      float4* gg = reinterpret_cast<float4*>(a.sg + base);
+      const uint4* lw = reinterpret_cast<const uint4*>(tw);
+      const float4* lg4 = reinterpret_cast<const float4*>(tg);
+      if (FUSED) {  // the residuals: four 16-bit words per unit
+        int2* gl = reinterpret_cast<int2*>(a.sl + base);
+        const int2* ll = reinterpret_cast<const int2*>(tl);
+        for (int i = tid; i < 8 * row_units; i += kTL) {
+          gw[i] = lw[i];
+          gg[i] = lg4[i];
+          gl[i] = ll[i];
+        }
+      } else {
+        float4* ga = reinterpret_cast<float4*>(a.sa + base);
+        const float4* la = reinterpret_cast<const float4*>(ta);
+        for (int i = tid; i < 8 * row_units; i += kTL) {
+          gw[i] = lw[i];
+          gg[i] = lg4[i];
+          ga[i] = la[i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int d = 32; d > 0; d >>= 1) nfar += __shfl_xor(nfar, d, 64);
+  if ((tid & 63) == 0 && nfar) atomicAdd(&a.status[3], nfar);
+}
+
+}  // namespace
+
+hipError_t launch_pack_count_lean(const PackDevArgs& a, int num_lattices, const int class_need[kPackLeanClasses], hipStream_t stream) {
+  if (num_lattices <= 0) return hipSuccess;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_count_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPackCountMaxLds);
+    attr_done = true;
+  }
+  for (int c = 0; c < kPackLeanClasses; ++c)
+    if (class_need[c] > 0)
+      hipLaunchKernelGGL(pack_count_lean_kernel, dim3(num_lattices), dim3(kTL), (size_t)class_need[c], stream, a, c == 0 ? -1 : kPackLeanClassLds[c - 1],
+                         kPackLeanClassLds[c]);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_rounds_lean(const PackDevArgs& a, int num_lattices, hipStream_t stream) {
+  if (num_lattices <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_rounds_lean_kernel, dim3(num_lattices), dim3(kTL), 0, stream, a);
+  return hipGetLastError();
+}
+
+namespace {
+template <int LG>
+void launch_fill_lean_lg(const PackDevArgs& a, int entry0, int count, hipStream_t stream) {
+  if (a.fused)
+    hipLaunchKernelGGL((pack_fill_lean_kernel<LG, true>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+  else
+    hipLaunchKernelGGL((pack_fill_lean_kernel<LG, false>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+}
+}  // namespace
+
+// entries sorted by lanes per lattice: count[lg] of them for 2^lg lanes, one launch each
+hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[kNumLaneChoices], hipStream_t stream) {
+  int at = 0;
+  for (int lg = 0; lg < kNumLaneChoices; ++lg) {
+    if (count[lg] <= 0) continue;
+    switch (lg) {
+      case 0: launch_fill_lean_lg<0>(a, at, count[lg], stream); break;
+      case 1: launch_fill_lean_lg<1>(a, at, count[lg], stream); break;
+      case 2: launch_fill_lean_lg<2>(a, at, count[lg], stream); break;
+      case 3: launch_fill_lean_lg<3>(a, at, count[lg], stream); break;
+      case 4: launch_fill_lean_lg<4>(a, at, count[lg], stream); break;
+      case 5: launch_fill_lean_lg<5>(a, at, count[lg], stream); break;
+      default: launch_fill_lean_lg<6>(a, at, count[lg], stream); break;
+    }
+    at += count[lg];
+  }
+  return hipGetLastError();
+}
+
+}  // namespace klat

@@ -437,6 +437,14 @@ class Batch:
         _check(lib().klat_batch_get_streams(self.h, _p(sw), _p(sg), _p(sa)))
         return sw, sg, sa
 
+    def fused_streams(self):
+        """(sw, sg, sl) of a batch built with fuse_scales: term words, (float)cost, 16-bit residuals."""
+        i = self.info()
+        n = i["fwd_slots"] + i["bwd_slots"]
+        sw, sg, sl = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.int16)
+        _check(lib().klat_batch_get_fused_streams(self.h, _p(sw), _p(sg), _p(sl)))
+        return sw, sg, sl
+
     def viterbi(self, graph_scale=1.0, acoustic_scale=1.0, insertion_penalty=0.0):
         s = Scales(graph_scale, acoustic_scale, insertion_penalty)
         _check(lib().klat_viterbi(self.h, C.byref(s)))
