@@ -837,12 +837,12 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, run of tiles)
     std::vector<PackEntry> entries;
     std::vector<LeanEntry> lentries;  // by lanes per lattice: one launch each
-    int lean_count[kNumLaneChoices] = {0, 0, 0, 0, 0, 0, 0};
-    for (int lg = -1; lg < kNumLaneChoices; ++lg)
+    int lean_count[2 * kNumLaneChoices] = {0};
+    for (int lg = -1; lg < 2 * kNumLaneChoices; ++lg)  // (the general jobs, then the lean ones by lanes and direction)
       for (size_t j = 0; j < P.jobs.size(); ++j) {
         int jlg = 0;
         while ((1 << jlg) < job_lanes(P.jobs[j].tag)) ++jlg;
-        if (job_general[j] ? lg != -1 : lg != jlg) continue;
+        if (job_general[j] ? lg != -1 : lg != 2 * jlg + (P.jobs[j].dir ? 1 : 0)) continue;
         const int ntiles = P.jobs[j].nchunks * kChunkRounds / kPackTileRounds;
         for (int t = 0; t < ntiles; t += kPackTilesPerGroup) {
           const int nt = std::min(kPackTilesPerGroup, ntiles - t);
@@ -909,6 +909,18 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     }
     lap("entries+rounds+fill+wait");
     (void)num_general_jobs;
+    if (pa.prof && !lentries.empty()) {  // (a build with -DKLAT_FILL_PROFILE fills these)
+      unsigned long long h[24];
+      KLAT_HIP_B(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));
+      size_t nf = 0;
+      for (const LeanEntry& le : lentries) nf += le.dir == 0 ? 1 : 0;
+      for (int dir = 0; dir < 2 && h[8] + h[16] != 0; ++dir) {
+        const double n = (double)std::max<size_t>(dir ? lentries.size() - nf : nf, 1);
+        const unsigned long long* q = h + 8 + 8 * dir;
+        std::fprintf(stderr, "klat pack_fill_lean %s, cycles per workgroup (%.0f): setup %.0f  window+init %.0f  barrier %.0f  arcs %.0f  positions %.0f  finals+barrier %.0f  store %.0f  barrier %.0f\n",
+                     dir ? "backward" : "forward", n, q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n, q[6] / n, q[7] / n);
+      }
+    }
     P.far_terms = h_status[3];
 
     if (b->num_level > 0) {  // the level streams: the arcs as the level sweep consumes them

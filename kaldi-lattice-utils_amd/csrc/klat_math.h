@@ -45,6 +45,14 @@ __device__ __forceinline__ double arc_cost(float g, float a, bool word, const Sc
   return (double)g2 + (double)a2;
 }
 
+// |cost| rounded to a float, for the batch's largest cost (pack_maxcost_kernel, pack_count_lean_kernel: only its binary
+// exponent is used, and both passes must agree on it)
+__device__ __forceinline__ float arc_cost_abs_f(float g, float a, bool word, const ScaleParams& sp) {
+  float g2, a2;
+  arc_cost_parts(g, a, word, sp, g2, a2);
+  return fabsf(g2 + a2);
+}
+
 // The same cost for a stream term in seven instructions, valid whenever graph_scale >= 0 (see
 // StreamCost::general): with a non-negative scale, scale * inf is inf or NaN and the arc stays
 // dead either way, so ScaleLattice's special case for Zero needs no test; multiplying by 1 is the

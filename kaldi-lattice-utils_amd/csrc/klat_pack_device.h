@@ -100,7 +100,7 @@ hipError_t launch_pack_maxcost(const PackDevArgs& a, int64_t num_arcs, int64_t n
 // for a.lat_g_pred; class_need over kPackLeanClassLds), the prefix sums again for a.reround, fill over a.lentries.
 hipError_t launch_pack_count_lean(const PackDevArgs& a, int num_lattices, const int class_need[kPackLeanClasses], hipStream_t stream);
 hipError_t launch_pack_rounds_lean(const PackDevArgs& a, int num_lattices, hipStream_t stream);
-hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[kNumLaneChoices] /* entries per log2(lanes), a.lentries sorted by it */, hipStream_t stream);
+hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[2 * kNumLaneChoices] /* entries per (log2(lanes), direction), a.lentries sorted that way */, hipStream_t stream);
 hipError_t launch_pack_rounds(const PackDevArgs& a, int num_lattices, hipStream_t stream);
 // max_lpw: the most lattices any job holds (64 / its lanes per lattice)
 hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, int max_lpw, hipStream_t stream);

@@ -549,30 +549,30 @@ __global__ __launch_bounds__(kTG) void pack_count_global_kernel(PackDevArgs a, i
 // Fused costs: the largest finite cost of the batch (the residuals' unit follows from it).  Positive doubles
 // order like their bit patterns.
 __global__ __launch_bounds__(kT) void pack_maxcost_kernel(PackDevArgs a, int64_t num_arcs, int64_t num_states) {
-  double m = 0.0;
+  float m = 0.0f;
   // four arcs a lane and load (the arrays start on 256-byte boundaries), the last few one by one
   const int64_t quads = num_arcs / 4;
   for (int64_t q = (int64_t)blockIdx.x * kT + threadIdx.x; q < quads; q += (int64_t)gridDim.x * kT) {
     const float4 g = reinterpret_cast<const float4*>(a.graph)[q], ac = reinterpret_cast<const float4*>(a.acoustic)[q];
     int4 w = {0, 0, 0, 0};
     if (a.fsp.penalized) w = reinterpret_cast<const int4*>(a.ilabel)[q];
-    const double c0 = fabs(arc_cost(g.x, ac.x, w.x != 0, a.fsp)), c1 = fabs(arc_cost(g.y, ac.y, w.y != 0, a.fsp));
-    const double c2 = fabs(arc_cost(g.z, ac.z, w.z != 0, a.fsp)), c3 = fabs(arc_cost(g.w, ac.w, w.w != 0, a.fsp));
-    if (c0 < 1.0e30) m = fmax(m, c0);
-    if (c1 < 1.0e30) m = fmax(m, c1);
-    if (c2 < 1.0e30) m = fmax(m, c2);
-    if (c3 < 1.0e30) m = fmax(m, c3);
+    const float c0 = arc_cost_abs_f(g.x, ac.x, w.x != 0, a.fsp), c1 = arc_cost_abs_f(g.y, ac.y, w.y != 0, a.fsp);
+    const float c2 = arc_cost_abs_f(g.z, ac.z, w.z != 0, a.fsp), c3 = arc_cost_abs_f(g.w, ac.w, w.w != 0, a.fsp);
+    if (c0 < 1.0e30f) m = fmaxf(m, c0);
+    if (c1 < 1.0e30f) m = fmaxf(m, c1);
+    if (c2 < 1.0e30f) m = fmaxf(m, c2);
+    if (c3 < 1.0e30f) m = fmaxf(m, c3);
   }
   for (int64_t i = quads * 4 + (int64_t)blockIdx.x * kT + threadIdx.x; i < num_arcs; i += (int64_t)gridDim.x * kT) {
-    const double c = fabs(arc_cost(a.graph[i], a.acoustic[i], a.fsp.penalized ? a.ilabel[i] != 0 : false, a.fsp));
-    if (c < 1.0e30) m = fmax(m, c);
+    const float c = arc_cost_abs_f(a.graph[i], a.acoustic[i], a.fsp.penalized ? a.ilabel[i] != 0 : false, a.fsp);
+    if (c < 1.0e30f) m = fmaxf(m, c);
   }
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < num_states; i += (int64_t)gridDim.x * kT) {
-    const double c = fabs(arc_cost(a.final_graph[i], a.final_acoustic[i], false, a.fsp));
-    if (c < 1.0e30) m = fmax(m, c);
+    const float c = arc_cost_abs_f(a.final_graph[i], a.final_acoustic[i], false, a.fsp);
+    if (c < 1.0e30f) m = fmaxf(m, c);
   }
-  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(a.maxcost, (unsigned long long)__double_as_longlong(m));
+  for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(a.maxcost, (unsigned long long)__double_as_longlong((double)m));
 }
 
 __global__ __launch_bounds__(kT) void pack_rounds_kernel(PackDevArgs a) {

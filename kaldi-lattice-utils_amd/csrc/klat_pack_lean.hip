@@ -30,6 +30,7 @@
 // path) is left to the general passes: a.lean_ok[u] stays 0.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "klat_device.h"
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   // ---- the arcs, four a lane and load
   const int64_t q0 = a0 >> 2, q1 = (a0 + A + 3) >> 2;
   constexpr int kUn = 3;  // quads a thread has in flight
-  double mc = 0.0;
+  float mc = 0.0f;
   int span = 1;
   for (int64_t qb = q0 + tid; qb < q1; qb += kTL * kUn) {
     int4 vs[kUn], vd[kUn], vi[kUn];
@@ -287,27 +288,38 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
           // the malformed arc this pass exists to reject: its source below zero must not move the fill before the table)
           for (int qq = (i > 0 ? max(prev, -1) + 1 : 0); qq <= s; ++qq) row[qq] = i;
           if (a.fold_maxcost) {
-            const double c = fabs(arc_cost(elem(vg[x], e), elem(va[x], e), a.fsp.penalized ? elem(vi[x], e) != 0 : false, a.fsp));
-            if (c < 1.0e30) mc = fmax(mc, c);
+            const float c = arc_cost_abs_f(elem(vg[x], e), elem(va[x], e), a.fsp.penalized ? elem(vi[x], e) != 0 : false, a.fsp);
+            if (c < 1.0e30f) mc = fmaxf(mc, c);
           }
         }
       }
     }
   }
-  // the final weights: a bit a state, the largest cost
-  for (int s = tid; s < S; s += kTL) {
-    const float fg = a.final_graph[s0 + s], fa = a.final_acoustic[s0 + s];
-    if (!(fg == INFINITY && fa == INFINITY)) atomicOr(&finb[s >> 5], 1u << (s & 31));
-    if (a.fold_maxcost) {
-      const double c = fabs(arc_cost(fg, fa, false, a.fsp));
-      if (c < 1.0e30) mc = fmax(mc, c);
+  // the final weights: a bit a state, the largest cost (eight states a thread in flight: one after the other, a thread's
+  // trips to memory were a fifth of this pass)
+  for (int sbase = 0; sbase < S; sbase += 8 * kTL) {
+    float fg[8], fa[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int s = min(sbase + x * kTL + tid, S - 1);
+      fg[x] = a.final_graph[s0 + s], fa[x] = a.final_acoustic[s0 + s];
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int s = sbase + x * kTL + tid;
+      if (s >= S) continue;
+      if (!(fg[x] == INFINITY && fa[x] == INFINITY)) atomicOr(&finb[s >> 5], 1u << (s & 31));
+      if (a.fold_maxcost) {
+        const float c = arc_cost_abs_f(fg[x], fa[x], false, a.fsp);
+        if (c < 1.0e30f) mc = fmaxf(mc, c);
+      }
     }
   }
   for (int d = 32; d > 0; d >>= 1) span = max(span, __shfl_xor(span, d, 64));
   if ((tid & 63) == 0) atomicMax(&sh_span, span);
   if (a.fold_maxcost) {  // (whatever becomes of the lattice below: the batch's largest cost covers every lattice)
-    for (int d = 32; d > 0; d >>= 1) mc = fmax(mc, __shfl_xor(mc, d, 64));
-    if ((tid & 63) == 0 && mc > 0.0) atomicMax(&sh_mc, (unsigned long long)__double_as_longlong(mc));
+    for (int d = 32; d > 0; d >>= 1) mc = fmaxf(mc, __shfl_xor(mc, d, 64));
+    if ((tid & 63) == 0 && mc > 0.0f) atomicMax(&sh_mc, (unsigned long long)__double_as_longlong((double)mc));
   }
   stamp(1);
   __syncthreads();
@@ -424,10 +436,24 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
         if (i < 0 || i >= A) continue;
         const int s = elem(vs[x], e), t = elem(vd[x], e), rel = t - s;
         int jr = 0, orank = 0;
-        for (int y = t > 0 ? indeg[t - 1] : 0, ye = indeg[t]; y < ye; ++y) jr += (int)bucket[y] < i ? 1 : 0;
-        for (int y = row[s], ye = row[s + 1]; y < ye; ++y) {
-          const int ry = relb[y];
-          orank += (ry > rel || (ry == rel && y < i)) ? 1 : 0;
+        {  // (the first four entries of either list at once: one after the other, the LDS round trips were this pass)
+          const int yb = t > 0 ? indeg[t - 1] : 0, ye = indeg[t];
+          int b4[4];
+#pragma unroll
+          for (int z = 0; z < 4; ++z) b4[z] = bucket[min(yb + z, ye - 1)];
+#pragma unroll
+          for (int z = 0; z < 4; ++z) jr += (yb + z < ye && b4[z] < i) ? 1 : 0;
+          for (int y = yb + 4; y < ye; ++y) jr += (int)bucket[y] < i ? 1 : 0;
+          const int rb = row[s], re = row[s + 1];
+          int r4[4];
+#pragma unroll
+          for (int z = 0; z < 4; ++z) r4[z] = relb[min(rb + z, re - 1)];
+#pragma unroll
+          for (int z = 0; z < 4; ++z) orank += (rb + z < re && (r4[z] > rel || (r4[z] == rel && rb + z < i))) ? 1 : 0;
+          for (int y = rb + 4; y < re; ++y) {
+            const int ry = relb[y];
+            orank += (ry > rel || (ry == rel && y < i)) ? 1 : 0;
+          }
         }
         m[e] = (uint32_t)rel | ((uint32_t)jr << 8) | ((uint32_t)orank << 16) | (elem(vi[x], e) != 0 ? 1u << 24 : 0u);
       }
@@ -484,8 +510,11 @@ constexpr int kMaxTiles = kPackTilesPerGroup;
 
 // Everything that depends on the lanes per lattice is a compile-time constant (one instantiation per lane count: the
 // first version, with the lane count in registers, wanted 217 VGPRs and spent its time in scratch memory).
-template <int LG, bool FUSED>
-__global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, int entry0) {
+template <int LG, bool FUSED, bool FWD>
+#ifndef KLAT_FILL_LEAN_WAVES
+#define KLAT_FILL_LEAN_WAVES 4
+#endif
+__global__ __launch_bounds__(kTL, KLAT_FILL_LEAN_WAVES) void pack_fill_lean_kernel(PackDevArgs a, int entry0) {
   constexpr int G = 1 << LG, LPW = 64 >> LG, GMASK = G - 1;
   constexpr int LG_TPS = LG + 2, TPS = 1 << LG_TPS;  // threads a lattice has to itself: kTL / LPW
   constexpr int kWinPerThread = (LPW * kWinL + kTL - 1) / kTL;
@@ -496,15 +525,27 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
   __shared__ int32_t win[LPW * kWinL];
   __shared__ int32_t sh_tp[LPW * (kMaxTiles + 1)];
   __shared__ int64_t sh_s0[LPW];
-  __shared__ int sh_q0[LPW], sh_S[LPW], sh_lat[LPW], sh_span[LPW], sh_alo[LPW], sh_ahi[LPW];
+  __shared__ int sh_q0[LPW], sh_S[LPW], sh_lat[LPW], sh_span[LPW];
+  __shared__ int sh_finals;  // some lattice's forward position S (its final weights) has a round in the tile
   const LeanEntry e = a.lentries[entry0 + blockIdx.x];
   const int W = job_ring(e.tag), AL = job_stored_lanes(e.tag);
   const int tid = threadIdx.x;
-  const bool fwd = e.dir == 0;
+  constexpr bool fwd = FWD;
   const int row_units = AL * LPW;
   const uint32_t cell_mask = (uint32_t)(W - 1);
   const int32_t* rtab = fwd ? a.r0f : a.r0b;
   int nfar = 0;
+#ifdef KLAT_FILL_PROFILE  // shader cycles of thread 0 per phase, summed over the workgroups (a.prof[8 ..], KLAT_PACK_PROFILE=1)
+  unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+#define STAMP(phase)                                                \
+  do {                                                              \
+    const unsigned long long now = __builtin_readcyclecounter();   \
+    pc[phase] += now - pt;                                          \
+    pt = now;                                                       \
+  } while (0)
+#else
+#define STAMP(phase)
+#endif
   // the job's lattices; for each the position that holds the first round of every tile of the run
   if (tid < LPW) {
     const LaneInfo li = a.lanes[e.lane_tab + tid];
@@ -534,8 +575,12 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
   }
   __syncthreads();
   // window of tile t: thread i holds entry o = i % kWinL of lattice k = i / kWinL (the first round of position plo + o);
-  // thread 2 k the number of lattice k's first arc of the tile, thread 2 k + 1 the end of its arcs
-  int wr[kWinPerThread], wa = 0;
+  // every thread also the tile's arcs of the lattice it works for (its first arc, the end of its arcs)
+  const int myk = tid >> LG_TPS, gl = tid & (TPS - 1);
+  const int myS = sh_S[myk], myP = fwd ? myS + 1 : myS, my_a0 = sh_q0[myk];
+  const int32_t* my_row = a.row + (sh_s0[myk] + 2 * (int64_t)max(sh_lat[myk], 0));
+  const bool my_lat = sh_lat[myk] >= 0;
+  int wr[kWinPerThread], nalo = 0, nahi = 0;
   auto ask_window = [&](int t) {
 #pragma unroll
     for (int x = 0; x < kWinPerThread; ++x) {
@@ -549,22 +594,36 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
       const int plo = sh_tp[k * (kMaxTiles + 1) + t];
       if (plo + o <= P) wr[x] = (rtab + (sh_s0[k] + 2 * (int64_t)u))[plo + o];
     }
-    wa = 0;
-    if (tid < 2 * LPW) {
-      const int k = tid >> 1, o = tid & 1;
-      const int u = sh_lat[k];
-      const int S = sh_S[k], P = fwd ? S + 1 : S;
-      const int plo = sh_tp[k * (kMaxTiles + 1) + t];
-      if (u >= 0 && plo < P) {
-        const int phi = min(sh_tp[k * (kMaxTiles + 1) + t + 1], P - 1);
-        // forward: the in-arcs of positions plo .. phi leave the states plo - span .. phi - 1; backward: positions
-        // plo .. phi are the states S - 1 - phi .. S - 1 - plo
-        const int st = fwd ? (o == 0 ? max(plo - sh_span[k], 0) : min(phi, S)) : (o == 0 ? S - 1 - phi : S - plo);
-        wa = (a.row + (sh_s0[k] + 2 * (int64_t)u))[st];
-      }
+    nalo = nahi = 0;
+    const int plo = sh_tp[myk * (kMaxTiles + 1) + t];
+    if (my_lat && plo < myP) {
+      const int phi = min(sh_tp[myk * (kMaxTiles + 1) + t + 1], myP - 1);
+      // forward: the in-arcs of positions plo .. phi leave the states plo - span .. phi - 1; backward: positions
+      // plo .. phi are the states S - 1 - phi .. S - 1 - plo
+      nalo = my_row[fwd ? max(plo - sh_span[myk], 0) : myS - 1 - phi];
+      nahi = my_row[fwd ? min(phi, myS) : myS - plo];
     }
   };
+  // the arcs of a tile, four consecutive ones a lane and load: kQ quads a thread in flight
+  constexpr int kQ = 2;
+  const int32_t* ends = fwd ? a.dst : a.src;
+  int4 ve[kQ];
+  uint4 vm[kQ];
+  float4 vg[kQ], va[kQ];
+  auto ask_arcs = [&](int qb, int qlo, int qhi) {
+#pragma unroll
+    for (int x = 0; x < kQ; ++x) {
+      const int q = max(min(qb + x * TPS, qhi - 1), qlo);
+      ve[x] = reinterpret_cast<const int4*>(ends)[q];
+      vm[x] = reinterpret_cast<const uint4*>(a.meta)[q];
+      vg[x] = reinterpret_cast<const float4*>(a.graph)[q];
+      va[x] = reinterpret_cast<const float4*>(a.acoustic)[q];
+    }
+  };
+  // a barrier for what the workgroup keeps in LDS (__syncthreads would also wait for the loads in flight: the next tile's)
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   ask_window(0);
+  STAMP(0);
   for (int t = 0; t < e.tile_count; ++t) {
     const int R0 = (e.tile_begin + t) * kTR;
     // ---- the window into LDS; padding everywhere (zero-weight terms that park their unused result in the lattice's
@@ -575,7 +634,9 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
       if (i >= LPW * kWinL) continue;
       win[i] = wr[x];
     }
-    if (tid < 2 * LPW) ((tid & 1) ? sh_ahi : sh_alo)[tid >> 1] = wa;
+    const int alo = nalo, ahi = nahi;
+    if (tid == 0) sh_finals = 0;  // (the threads below are in the same wave: they set it after this)
+    if (fwd && tid < LPW && sh_lat[tid] >= 0 && sh_tp[tid * (kMaxTiles + 1) + t] <= sh_S[tid] && sh_tp[tid * (kMaxTiles + 1) + t + 1] >= sh_S[tid]) sh_finals = 1;
     for (int i = tid; i < 8 * row_units; i += kTL) {  // one 16-byte unit (4 rounds of a lane) per store
       const int slot = i & (LPW - 1);  // unit = lane * LPW + slot, a row is a whole number of lanes
       const uint32_t w = kNil | ((uint32_t)(W * LPW + slot) << kWrShift);
@@ -586,9 +647,15 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
       else
         reinterpret_cast<float4*>(ta)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    __syncthreads();
+    STAMP(1);
+    lds_barrier();
+    STAMP(2);
     // slot of (round rr of the tile, lane sub, lattice k)
-    auto slot_of = [&](int k, int dr, int sub) { return (int)((__umul24(dr >> 2, row_units) + sub * LPW + k) << 2) + (dr & 3); };
+    auto slot_of = [&](int k, int dr, int sub) {
+      int unit;  // (the chunk's row + the lane's units + the lattice: one 24-bit multiply-add, which hipcc would not pick)
+      asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(unit) : "v"(dr >> 2), "s"(row_units), "v"(sub * LPW + k));
+      return (unit << 2) + (dr & 3);
+    };
     auto put_cost = [&](int i, uint32_t w, float g, float ac) {
       if (FUSED) {
         // the cost as the reference forms it (ScaleLattice, AddWordInsPen, ConvertToCost), kept as a float and
@@ -614,71 +681,55 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
       }
       return w;
     };
-    // ---- the arcs: the lattice in slot k has the threads [k * TPS, (k + 1) * TPS) to itself, four consecutive arcs a lane
+    // ---- the arcs: the lattice in slot k has the threads [k * TPS, (k + 1) * TPS) to itself
     {
-      const int k = tid >> LG_TPS, gl = tid & (TPS - 1);
-      const int plo = sh_tp[k * (kMaxTiles + 1) + t], S = sh_S[k], P = fwd ? S + 1 : S;
+      const int k = myk, S = myS, P = myP, a0 = my_a0;
+      const int plo = sh_tp[k * (kMaxTiles + 1) + t];
       const int n = min(sh_tp[k * (kMaxTiles + 1) + t + 1], P - 1) - plo + 1;  // positions that may have a round here
-      const int a0 = sh_q0[k], alo = sh_alo[k], ahi = sh_ahi[k];
       const int32_t* wk = win + k * kWinL;
       const uint32_t dummy = (uint32_t)(W * LPW + k);
       const int qlo = (a0 + alo) >> 2, qhi = (a0 + ahi + 3) >> 2;
-      const int32_t* ends = fwd ? a.dst : a.src;
-      constexpr int kQ = 2;  // quads a thread has in flight
-      bool asked = false;
+      ask_arcs(qlo + gl, qlo, qhi);
+      if (t + 1 < e.tile_count) ask_window(t + 1);  // (behind the arcs' loads: it lands while they are worked on)
       for (int qb = qlo + gl; qb < qhi; qb += kQ * TPS) {
-        int4 ve[kQ];
-        uint4 vm[kQ];
-        float4 vg[kQ], va[kQ];
-#pragma unroll
-        for (int x = 0; x < kQ; ++x) {
-          const int q = min(qb + x * TPS, qhi - 1);
-          ve[x] = reinterpret_cast<const int4*>(ends)[q];
-          vm[x] = reinterpret_cast<const uint4*>(a.meta)[q];
-          vg[x] = reinterpret_cast<const float4*>(a.graph)[q];
-          va[x] = reinterpret_cast<const float4*>(a.acoustic)[q];
-        }
-        if (!asked && t + 1 < e.tile_count) ask_window(t + 1);  // (behind the arcs' loads: it lands while they are worked on)
-        asked = true;
+        if (qb != qlo + gl) ask_arcs(qb, qlo, qhi);
 #pragma unroll
         for (int x = 0; x < kQ; ++x) {
           const int q = qb + x * TPS;
-          if (q >= qhi) continue;
+          const int ib = q < qhi ? 4 * q - a0 - alo : ahi;  // (a quad behind the lattice's last: no element passes the test below)
 #pragma unroll
           for (int el = 0; el < 4; ++el) {
-            const int i = 4 * q + el - a0;
-            if (i < alo || i >= ahi) continue;
+            // everything without a branch up to the three stores: the tests cost less as one mask than as four jumps
             const uint32_t m = elem(vm[x], el);
             const int rel = (int)(m & 0xFFu);
             const int p = fwd ? elem(ve[x], el) : S - 1 - elem(ve[x], el);
-            const int o = p - plo;
-            if ((unsigned)o >= (unsigned)n) continue;
-            const int w0 = wk[o];
-            const int r = w0 & (int)kRoundMask, nr = (wk[o + 1] & (int)kRoundMask) - r;
+            const unsigned o = (unsigned)(p - plo);
+            bool ok = (unsigned)(ib + el) < (unsigned)(ahi - alo) && o < (unsigned)n;
+            const unsigned oc = min(o, (unsigned)kTR);  // (a window holds kTR + 2 entries)
+            const int w0 = wk[oc], w1 = wk[oc + 1];
+            const int r = w0 & (int)kRoundMask, nr = (w1 & (int)kRoundMask) - r;
             // the term's number within its position: behind the constant-one term of a final state (backward)
             const int j = fwd ? (int)((m >> 8) & 0xFFu) : (int)((m >> 16) & 0xFFu) + (int)((uint32_t)w0 >> 31);
             const int jq = j >> LG, dr = r + jq - R0;
-            if ((unsigned)dr >= (unsigned)kTR) continue;
-            const uint32_t own_cell = (((uint32_t)p & cell_mask) << (6 - LG)) + (uint32_t)k;
-            const bool far = rel >= W;
-            uint32_t w;
-            if (far) {
-              w = kFar | (uint32_t)rel;
-              ++nfar;
-            } else {
-              w = (((uint32_t)(p - rel) & cell_mask) << (6 - LG)) + (uint32_t)k;
-              if (rel == 1 && jq == 0) w |= kBypass;
+            ok = ok && (unsigned)dr < (unsigned)kTR;
+            const uint32_t own12 = ((((uint32_t)p & cell_mask) << (6 - LG)) + (uint32_t)k) << kWrShift;
+            const bool far = rel >= W, last = jq == nr - 1;
+            uint32_t w = (((uint32_t)(p - rel) & cell_mask) << (6 - LG)) + (uint32_t)k;
+            w |= (rel == 1 && jq == 0) ? kBypass : 0u;
+            w |= (last && (j & GMASK) == 0) ? (kCommit | own12) : (dummy << kWrShift);
+            w = far ? (kFar | (uint32_t)rel) : w;
+            w |= ((m & (1u << 24)) << 6) | (jq == 0 ? kFirst : 0u) | (last ? kLast : 0u);
+            if (ok) {
+              nfar += far ? 1 : 0;
+              const int at = slot_of(k, dr, j & GMASK);
+              tw[at] = w;
+              put_cost(at, w, elem(vg[x], el), elem(va[x], el));
             }
-            w |= (m & (1u << 24)) << 6;  // kWord
-            w = finish_word(w, j, jq, nr, own_cell, dummy, far);
-            const int at = slot_of(k, dr, j & GMASK);
-            tw[at] = w;
-            put_cost(at, w, elem(vg[x], el), elem(va[x], el));
           }
         }
       }
-      if (!asked && t + 1 < e.tile_count) ask_window(t + 1);
     }
+    STAMP(3);
     // ---- one thread per position: what is not an arc
 #pragma unroll 1
     for (int i = tid; i < LPW * (kTR + 1); i += kTL) {
@@ -713,8 +764,9 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
         tw[slot_of(k, r + jq - R0, jj & GMASK)] = w;
       }
     }
+    STAMP(4);
     // ---- forward position S: one term per final state (up to 127 of them), a thread each
-    if (fwd) {
+    if (fwd && sh_finals) {
 #pragma unroll 1
       for (int i = tid; i < LPW * 128; i += kTL) {
         const int k = i >> 7, jj = i & 127;
@@ -737,7 +789,8 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
         put_cost(at, w, a.final_graph[sh_s0[k] + s], a.final_acoustic[sh_s0[k] + s]);
       }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(5);
     // ---- the tile leaves as whole lines
     {
       const int64_t base = (e.chunk_off + (int64_t)(R0 >> 2) * row_units) << 2;  // first slot of the tile
@@ -763,8 +816,15 @@ __global__ __launch_bounds__(kTL, 4) void pack_fill_lean_kernel(PackDevArgs a, i
         }
       }
     }
-    __syncthreads();
+    STAMP(6);
+    lds_barrier();
+    STAMP(7);
   }
+#ifdef KLAT_FILL_PROFILE
+  if (a.prof && tid == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.prof[(fwd ? 8 : 16) + i], pc[i]);
+#endif
+#undef STAMP
   for (int d = 32; d > 0; d >>= 1) nfar += __shfl_xor(nfar, d, 64);
   if ((tid & 63) == 0 && nfar) atomicAdd(&a.status[3], nfar);
 }
@@ -793,29 +853,37 @@ hipError_t launch_pack_rounds_lean(const PackDevArgs& a, int num_lattices, hipSt
 
 namespace {
 template <int LG>
-void launch_fill_lean_lg(const PackDevArgs& a, int entry0, int count, hipStream_t stream) {
-  if (a.fused)
-    hipLaunchKernelGGL((pack_fill_lean_kernel<LG, true>), dim3(count), dim3(kTL), 0, stream, a, entry0);
-  else
-    hipLaunchKernelGGL((pack_fill_lean_kernel<LG, false>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+void launch_fill_lean_lg(const PackDevArgs& a, bool fwd, int entry0, int count, hipStream_t stream) {
+  if (count <= 0) return;
+  if (a.fused) {
+    if (fwd)
+      hipLaunchKernelGGL((pack_fill_lean_kernel<LG, true, true>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+    else
+      hipLaunchKernelGGL((pack_fill_lean_kernel<LG, true, false>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+  } else {
+    if (fwd)
+      hipLaunchKernelGGL((pack_fill_lean_kernel<LG, false, true>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+    else
+      hipLaunchKernelGGL((pack_fill_lean_kernel<LG, false, false>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+  }
 }
 }  // namespace
 
-// entries sorted by lanes per lattice: count[lg] of them for 2^lg lanes, one launch each
-hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[kNumLaneChoices], hipStream_t stream) {
+// entries sorted by lanes per lattice, then by direction: count[2 lg + dir] of them for 2^lg lanes, one launch each
+hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[2 * kNumLaneChoices], hipStream_t stream) {
   int at = 0;
-  for (int lg = 0; lg < kNumLaneChoices; ++lg) {
-    if (count[lg] <= 0) continue;
-    switch (lg) {
-      case 0: launch_fill_lean_lg<0>(a, at, count[lg], stream); break;
-      case 1: launch_fill_lean_lg<1>(a, at, count[lg], stream); break;
-      case 2: launch_fill_lean_lg<2>(a, at, count[lg], stream); break;
-      case 3: launch_fill_lean_lg<3>(a, at, count[lg], stream); break;
-      case 4: launch_fill_lean_lg<4>(a, at, count[lg], stream); break;
-      case 5: launch_fill_lean_lg<5>(a, at, count[lg], stream); break;
-      default: launch_fill_lean_lg<6>(a, at, count[lg], stream); break;
+  for (int c = 0; c < 2 * kNumLaneChoices; ++c) {
+    const bool fwd = (c & 1) == 0;
+    switch (c >> 1) {
+      case 0: launch_fill_lean_lg<0>(a, fwd, at, count[c], stream); break;
+      case 1: launch_fill_lean_lg<1>(a, fwd, at, count[c], stream); break;
+      case 2: launch_fill_lean_lg<2>(a, fwd, at, count[c], stream); break;
+      case 3: launch_fill_lean_lg<3>(a, fwd, at, count[c], stream); break;
+      case 4: launch_fill_lean_lg<4>(a, fwd, at, count[c], stream); break;
+      case 5: launch_fill_lean_lg<5>(a, fwd, at, count[c], stream); break;
+      default: launch_fill_lean_lg<6>(a, fwd, at, count[c], stream); break;
     }
-    at += count[lg];
+    at += std::max(count[c], 0);
   }
   return hipGetLastError();
 }
