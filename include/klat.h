@@ -106,6 +106,11 @@ typedef struct {
    * to 2^-40 of the batch's largest.  klat_forward_backward / klat_viterbi with other scales then return
    * KLAT_ERR_STATE.  The tools know their scales before they read a lattice and set this. */
   const klat_scales* fuse_scales;
+  /* non-zero: arc and state arrays of klat_batch_desc that are device pointers (16-byte aligned, readable up to the
+   * next multiple of 16 bytes -- any device allocator's blocks are) are used in place instead of copied: the caller keeps
+   * them alive and unchanged until klat_batch_destroy.  (A copy of C2's arrays is 2.9 GB of device traffic, 0.6 ms.)
+   * Host arrays are uploaded as always. */
+  int32_t borrow_device_arrays;
 } klat_pack_options;
 
 typedef struct {

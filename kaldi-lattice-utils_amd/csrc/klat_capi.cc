@@ -127,6 +127,13 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
     if (on_level[u] || S <= 0) continue;
     sum_states += (double)S;
     longest = std::max(longest, (double)S);
+  }
+  // cycles: a stream round of a lone workgroup ~320, a state of a full chip ~60 SIMD-cycles over 1024 SIMDs
+  // (first of all: a full batch ends here, before a candidate is looked at)
+  if (mode < 0 && longest * 320.0 < 1.3 * sum_states * 60.0 / 1024.0) return;
+  for (int64_t u = 0; u < U; ++u) {
+    const int64_t S = state_off[u + 1] - state_off[u];
+    if (on_level[u] || S <= 0) continue;
     if (S >= 2 * (int64_t)chain_segment_states(S, arc_off[u + 1] - arc_off[u], seg) && lr[u].max_span <= kChainMaxSpan) cand.push_back(u);
   }
   if (cand.empty()) return;
@@ -136,8 +143,6 @@ static void choose_chain_lattices(int64_t U, const int64_t* state_off, const int
   });
   size_t take = cand.size();
   if (mode < 0) {
-    // cycles: a stream round of a lone workgroup ~320, a state of a full chip ~60 SIMD-cycles over 1024 SIMDs
-    if (longest * 320.0 < 1.3 * sum_states * 60.0 / 1024.0) return;
     // All the candidates or none.  (Round 3 first took the lattices above the cheapest size threshold and left the
     // others to three classes of streams beside the segment path: 0.90 ms on the C5/8 shard when the four HIP
     // streams got a hardware queue each, 1.05 - 1.4 ms when the runtime's queue lottery made one of the classes
@@ -330,6 +335,7 @@ static void ctx_release(klat_ctx* c) {
   }
   if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->pinned) (void)hipHostFree(c->pinned);
   c->pool.clear();
   delete c;
 }
@@ -379,7 +385,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     host_stages += buf;
     t_last = now;
   };
-  klat_pack_options o = {0, 0, 0, nullptr};
+  klat_pack_options o = {0, 0, 0, nullptr, 0};
   if (opt) o = *opt;
   // The streams are built on the device from the CSR arrays (klat_pack_device.hip); the host
   // packer (same streams, bit for bit) remains behind klat_pack_host and KLAT_HOST_PACK=1.
@@ -467,15 +473,30 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
   } while (0)
   UP(state_off, d->state_off, b->U + 1);
   UP(arc_off, d->arc_off, b->U + 1);
-  UPP(src, d->src, b->A, 4);
-  UPP(dst, d->dst, b->A, 4);
-  UPP(ilabel, d->ilabel, b->A, 4);
-  if (d->olabel) UP(olabel, d->olabel, b->A);
-  UPP(graph, d->graph, b->A, 4);
-  UPP(acoustic, d->acoustic, b->A, 4);
-  if (d->state_time) UP(state_time, d->state_time, b->S);
-  UP(final_graph, d->final_graph, b->S);
-  UP(final_acoustic, d->final_acoustic, b->S);
+  // the arc and state arrays: copied (host arrays: uploaded), or used where they are (klat_pack_options.borrow_device_arrays)
+  auto on_device = [&](const void* ptr) {
+    hipPointerAttribute_t attr;
+    const bool dev = ptr && ((uintptr_t)ptr & 15) == 0 && hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();  // (hipPointerGetAttributes on plain host memory reports an error: not ours)
+    return dev;
+  };
+#define UPB(buf, ptr, n, pad)                                        \
+  do {                                                               \
+    if (o.borrow_device_arrays && !host_pack && on_device(ptr))      \
+      b->buf.borrow(ptr, (size_t)(n));                               \
+    else                                                             \
+      UPP(buf, ptr, n, pad);                                         \
+  } while (0)
+  UPB(src, d->src, b->A, 4);
+  UPB(dst, d->dst, b->A, 4);
+  UPB(ilabel, d->ilabel, b->A, 4);
+  if (d->olabel) UPB(olabel, d->olabel, b->A, 0);
+  UPB(graph, d->graph, b->A, 4);
+  UPB(acoustic, d->acoustic, b->A, 4);
+  if (d->state_time) UPB(state_time, d->state_time, b->S, 0);
+  UPB(final_graph, d->final_graph, b->S, 0);
+  UPB(final_acoustic, d->final_acoustic, b->S, 0);
+#undef UPB
   if (host_pack) {
     UP(sw, P.sw.data(), P.sw.size());
     UP(sg, P.sg.data(), P.sg.size());
@@ -524,7 +545,41 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pa.lat_rounds = d_rounds.p;
     pa.status = status.p;
     pa.num_arcs = A_tot;
-    std::vector<LatticeRounds> h_rounds((size_t)U);
+    // where the count pass's verdicts come back: page-locked memory of the context when no other call holds it
+    std::unique_lock<std::mutex> pinned_lock(c->pinned_mu, std::try_to_lock);
+    std::vector<LatticeRounds> h_rounds_pageable;
+    std::vector<uint8_t> lean_ok_pageable;
+    LatticeRounds* h_rounds_p = nullptr;
+    uint8_t* lean_ok_p = nullptr;
+    {
+      const size_t want = sizeof(LatticeRounds) * (size_t)U + (size_t)U + 64;
+      if (pinned_lock.owns_lock() && c->pinned_bytes < want) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr, c->pinned_bytes = 0;
+        void* ptr = nullptr;
+        if (hipHostMalloc(&ptr, want + want / 2, hipHostMallocDefault) == hipSuccess)
+          c->pinned = ptr, c->pinned_bytes = want + want / 2;
+        else
+          (void)hipGetLastError();
+      }
+      if (pinned_lock.owns_lock() && c->pinned_bytes >= want) {
+        h_rounds_p = static_cast<LatticeRounds*>(c->pinned);
+        lean_ok_p = reinterpret_cast<uint8_t*>(h_rounds_p + U);
+        std::memset(lean_ok_p, 0, (size_t)U);
+      } else {
+        h_rounds_pageable.resize((size_t)U);
+        lean_ok_pageable.assign((size_t)U, 0);
+        h_rounds_p = h_rounds_pageable.data();
+        lean_ok_p = lean_ok_pageable.data();
+      }
+    }
+    struct {
+      LatticeRounds* p;
+      size_t n;
+      LatticeRounds* data() const { return p; }
+      size_t size() const { return n; }
+    } h_rounds = {h_rounds_p, (size_t)U};
+    uint8_t* const lean_ok = lean_ok_p;
     int32_t h_status[4] = {0, -1, 1, 0};
     const char* lean_env = std::getenv("KLAT_PACK_LEAN");
     const bool lean_enabled = !(lean_env && std::atoi(lean_env) == 0);
@@ -532,7 +587,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     const int level_mode = level_env == nullptr ? -1 : std::atoi(level_env);
     const bool plan_levels = o.lanes_per_lattice == 0 && level_mode != 0 && U > 0;
     // which count pass a lattice takes, as far as its sizes tell: the LDS class of its tables
-    std::vector<uint8_t> known_general((size_t)U, lean_enabled ? 0 : 1), lean_ok((size_t)U, 0);
+    std::vector<uint8_t> known_general((size_t)U, lean_enabled ? 0 : 1);
     std::vector<int8_t> pred;
     int lean_need[kPackLeanClasses] = {0, 0, 0};
     size_t num_known_general = lean_enabled ? 0 : (size_t)U, num_lean = 0;
@@ -626,7 +681,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     if (he == hipSuccess && U > 0)
       he = hipMemcpyAsync(h_rounds.data(), d_rounds.p, sizeof(LatticeRounds) * h_rounds.size(), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
-    if (he == hipSuccess && num_lean > 0) he = hipMemcpyAsync(lean_ok.data(), d_lean_ok.p, (size_t)U, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess && num_lean > 0) he = hipMemcpyAsync(lean_ok, d_lean_ok.p, (size_t)U, hipMemcpyDeviceToHost, c->stream);
     // The level planner (below) runs behind the general count pass at once when every lattice takes that pass: its answer
     // comes back in the same wait.  With lean lattices it waits for their verdict (it reads the general tables).
     std::vector<uint8_t> on_level((size_t)U, 0);
@@ -713,6 +768,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         }
       }
     }
+    lap("verdicts");
     // Lattices whose topological depth is far below their states take the level-synchronous path
     // (klat_level.hip) instead of a stream: Kahn's levels on the device, the choice on the host.
     // Only with the automatic layout (a caller that fixes the lanes asks for streams).
@@ -753,6 +809,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         b->lv_records.take(records);
       }
     }
+    lap("levels");
     // Long lattices of a batch that waits for them are swept in segments (klat_chain.hip): the choice, their
     // segments.  (Their arc records are built when a sweep first needs them, for the scales it is called with:
     // ensure_chain_records.)  Only with the automatic layout.
@@ -792,6 +849,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         KLAT_HIP_B(hipStreamSynchronize(c->stream));  // (cl is read by the upload)
       }
     }
+    lap("chain choice");
     // the plan: lanes per lattice, layout classes, jobs
     std::vector<int8_t> lat_g;
     plan_layout(U, d->state_off, d->arc_off, h_rounds.data(), o, &lat_g, skip.data());
@@ -834,6 +892,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         }
       }
     }
+    lap("job kinds");
     // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, run of tiles)
     std::vector<PackEntry> entries;
     std::vector<LeanEntry> lentries;  // by lanes per lattice: one launch each
@@ -852,6 +911,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
             lentries.push_back(LeanEntry{P.jobs[j].chunk_off, P.jobs[j].lane_tab, P.jobs[j].tag, P.jobs[j].dir, t, nt, (int32_t)j}), ++lean_count[lg];
         }
       }
+    lap("entries");
     const size_t nslots = (size_t)chunk_total * kChunkRounds;  // chunk_total counts 16-byte units
     AL(sw, nslots);
     AL(sg, nslots);
@@ -885,6 +945,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     pa.sw = b->sw.p;
     pa.sg = b->sg.p;
     pa.sa = b->sa.p;
+    lap("allocs+uploads");
     he = hipEventRecord(pev[4], c->stream);
     if (he == hipSuccess && num_redo > 0) {
       pa.only = num_lean > 0 ? d_only.p : nullptr;  // (bit 0: the forward rounds, bit 1: the backward rounds)
@@ -902,6 +963,13 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     if (he == hipSuccess) he = launch_pack_fill_lean(pa, lean_count, c->stream);
     if (he == hipSuccess) he = hipEventRecord(pev[6], c->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, c->stream);
+    // (while the fill pass runs: the posterior kernel's work items)
+    {
+      size_t n_items = 0;
+      for (int64_t u = 0; u < U; ++u) n_items += (size_t)std::max<int64_t>(1, (d->arc_off[u + 1] - d->arc_off[u] + kPostItemArcs - 1) / kPostItemArcs);
+      P.items.reserve(n_items);
+      for (int64_t u = 0; u < U; ++u) append_post_items(&P.items, d->arc_off[u], d->arc_off[u + 1], u);
+    }
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);  // scratch and entries go out of scope below
     if (he != hipSuccess) {
       klat_batch_destroy(b);
@@ -954,8 +1022,6 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         return hip_fail(he, "level streams");
       }
     }
-    for (int64_t u = 0; u < U; ++u)
-      append_post_items(&P.items, d->arc_off[u], d->arc_off[u + 1], u);
     if (b->num_chain > 0) {  // the count pass's tables stay: klat_viterbi builds the segment path's COST records from them, when it first runs
       b->ch_cnt.take(cnt);
       b->ch_row.take(row);
@@ -1049,9 +1115,9 @@ static int compact_upload(klat_ctx* c, const klat_batch_desc_compact* d, Compact
   static const int32_t zero = 0;  // (outlives the asynchronous copy)
   int rc;
   if ((rc = up->deg.upload(d->out_degree, (size_t)S, c->stream)) || (rc = up->span.upload(d->span, (size_t)A, c->stream)) ||
-      (rc = up->label.upload(d->label, (size_t)A, c->stream)) || (rc = up->graph.upload(d->graph, (size_t)A, c->stream)) ||
-      (rc = up->acoustic.upload(d->acoustic, (size_t)A, c->stream)) || (rc = up->fg.upload(d->final_graph, (size_t)S, c->stream)) ||
-      (rc = up->fa.upload(d->final_acoustic, (size_t)S, c->stream)) || (rc = up->src.alloc((size_t)A)) || (rc = up->dst.alloc((size_t)A)) ||
+      (rc = up->label.upload(d->label, (size_t)A, c->stream, 4)) || (rc = up->graph.upload(d->graph, (size_t)A, c->stream, 4)) ||
+      (rc = up->acoustic.upload(d->acoustic, (size_t)A, c->stream, 4)) || (rc = up->fg.upload(d->final_graph, (size_t)S, c->stream)) ||
+      (rc = up->fa.upload(d->final_acoustic, (size_t)S, c->stream)) || (rc = up->src.alloc((size_t)A + 4)) || (rc = up->dst.alloc((size_t)A + 4)) ||
       (rc = up->status.upload(&zero, 1, c->stream)) || (d->state_time && (rc = up->time.upload(d->state_time, (size_t)S, c->stream))))
     return rc;
   if ((rc = up->so.upload(d->state_off, (size_t)U + 1, c->stream)) || (rc = up->ao.upload(d->arc_off, (size_t)U + 1, c->stream))) return rc;
@@ -1091,7 +1157,25 @@ static int compact_finish(klat_ctx* c, const klat_batch_desc_compact* d, Compact
   full.final_graph = up->fg.p;
   full.final_acoustic = up->fa.p;
   full.state_time = d->state_time ? up->time.p : nullptr;
-  return klat_batch_create(c, &full, opt, out);
+  // the batch uses these arrays where they are, and owns them from here on (a copy of each was 28 bytes an arc of device traffic)
+  klat_pack_options o = {0, 0, 0, nullptr, 0};
+  if (opt) o = *opt;
+  o.borrow_device_arrays = 1;
+  const int rc = klat_batch_create(c, &full, &o, out);
+  if (rc != KLAT_OK) return rc;
+  klat_batch* b = *out;
+  auto own = [](auto& mine, auto& theirs) {
+    if (mine.borrowed && mine.p == theirs.p) mine.take(theirs);
+  };
+  own(b->src, up->src);
+  own(b->dst, up->dst);
+  own(b->ilabel, up->label);  // (olabel keeps pointing into it)
+  own(b->graph, up->graph);
+  own(b->acoustic, up->acoustic);
+  own(b->final_graph, up->fg);
+  own(b->final_acoustic, up->fa);
+  if (d->state_time) own(b->state_time, up->time);
+  return KLAT_OK;
 }
 
 int klat_batch_create_compact(klat_ctx* c, const klat_batch_desc_compact* d, const klat_pack_options* opt, klat_batch** out) {
@@ -1929,7 +2013,7 @@ struct klat_packed {
 int klat_pack_host(const klat_batch_desc* d, const klat_pack_options* opt, klat_packed** out) {
   if (!d || !out) return set_error(KLAT_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
-  klat_pack_options o = {0, 0, 0, nullptr};
+  klat_pack_options o = {0, 0, 0, nullptr, 0};
   if (opt) o = *opt;
   o.fuse_scales = nullptr;  // (the host packer defines the generic stream format)
   klat_packed* p = new (std::nothrow) klat_packed();

@@ -115,14 +115,20 @@ struct DevBuf {
   size_t n = 0;    // elements in use
   size_t cap = 0;  // elements allocated
   DevPool* pool = nullptr;  // where the block came from and goes back to
+  bool borrowed = false;    // p is the caller's memory (klat_pack_options.borrow_device_arrays): never freed here
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p && !(pool && pool->give(p, cap * sizeof(T)))) (void)hipFree(p);
+    if (p && !borrowed && !(pool && pool->give(p, cap * sizeof(T)))) (void)hipFree(p);
     p = nullptr;
     n = cap = 0;
+    borrowed = false;
+  }
+  void borrow(const T* device_ptr, size_t count) {  // the caller keeps the array alive and unchanged while this object uses it
+    release();
+    p = const_cast<T*>(device_ptr), n = cap = count, pool = nullptr, borrowed = true;
   }
   // contents unspecified; an allocation that is large enough is kept (hipFree + hipMalloc of the
   // gigabyte-sized scratch of the accumulate stage costs tens of milliseconds)
@@ -156,9 +162,10 @@ struct DevBuf {
   }
   void take(DevBuf& o) {  // steals o's block
     release();
-    p = o.p, n = o.n, cap = o.cap, pool = o.pool;
+    p = o.p, n = o.n, cap = o.cap, pool = o.pool, borrowed = o.borrowed;
     o.p = nullptr;
     o.n = o.cap = 0;
+    o.borrowed = false;
   }
   // pad: elements allocated (not copied) behind the array: the stream packer reads the arc arrays four elements a load,
   // and the last load of the batch may reach past the last arc
@@ -210,6 +217,12 @@ struct klat_ctx {
   // own), created when the call first runs and gone with this context
   klat_ctx* pipe[3] = {nullptr, nullptr, nullptr};
   std::mutex pipe_mu;  // one klat_forward_backward_host at a time per context: the helpers' streams and pools are the call's
+  // page-locked host scratch of klat_batch_create (the count pass's verdicts come back through it: into pageable memory the
+  // copy goes through the runtime's staging buffers, ~0.1 ms for 10 000 lattices); one call at a time uses it, a second
+  // one running beside it on the same context takes pageable memory
+  std::mutex pinned_mu;
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
 };
 
 // device scratch + cached result of the accumulate stage (klat_accum_api.cc)

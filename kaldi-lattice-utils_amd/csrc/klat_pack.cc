@@ -200,27 +200,53 @@ double plan_cycles(int64_t U, const int64_t* state_off, const int64_t* arc_off, 
   return plan_cost(U, lr, g).cycles;
 }
 
+// keys in ascending order of their upper 32 bits, equal ones as they stood (the lower bits here count upwards: the whole
+// key ascending); three stable passes over the digits that differ (std::sort: 0.2 ms for 10 000 keys, this: a tenth)
+static void radix_sort_high32(std::vector<uint64_t>* keys, std::vector<uint64_t>* tmp) {
+  const size_t n = keys->size();
+  if (n < 64) {
+    std::sort(keys->begin(), keys->end());
+    return;
+  }
+  tmp->resize(n);
+  uint64_t lo = ~0ull, hi = 0;
+  for (uint64_t k : *keys) lo = std::min(lo, k >> 32), hi = std::max(hi, k >> 32);
+  std::vector<uint64_t>*from = keys, *to = tmp;
+  for (int shift = 0; shift < 33 && ((hi - lo) >> shift) != 0; shift += 11) {
+    size_t count[2049] = {0};
+    for (uint64_t k : *from) ++count[(((k >> 32) - lo) >> shift & 2047) + 1];
+    for (int i = 0; i < 2048; ++i) count[i + 1] += count[i];
+    for (uint64_t k : *from) (*to)[count[((k >> 32) - lo) >> shift & 2047]++] = k;
+    std::swap(from, to);
+  }
+  if (from != keys) keys->swap(*tmp);
+}
+
 int64_t slice_jobs(const int64_t* state_off, const LatticeRounds* lr, const std::vector<int64_t>& members,
                    const std::vector<int64_t>& rf, const std::vector<int64_t>& rb, int G, int W, int64_t chunk_base,
                    PackedBatch* out, std::vector<std::vector<int64_t>>* job_lats) {
   const int LPW = 64 / G;
   const int D = kDeepPrefetchChunks;
   // ---- slicing: lattices of similar length share a wave ----
+  // (sorted by rounds, longest first, equal rounds in the members' order: one 64-bit key a lattice -- a stable sort
+  // through a comparison that looks the rounds up took 0.3 ms of klat_batch_create on 10 000 lattices)
   struct ProtoJob {
     int dir;
     int64_t rounds;
     std::vector<int64_t> lat;
   };
   std::vector<ProtoJob> proto;
+  std::vector<uint64_t> keys(members.size()), keys_tmp;
   for (int dir = 0; dir < 2; ++dir) {
     const std::vector<int64_t>& r = dir ? rb : rf;
-    std::vector<int64_t> order(members);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r[a] > r[b]; });
-    for (size_t i = 0; i < order.size(); i += LPW) {
+    for (size_t i = 0; i < members.size(); ++i) keys[i] = ((uint64_t)(0x7FFFFFFF - r[members[i]]) << 32) | (uint64_t)i;
+    radix_sort_high32(&keys, &keys_tmp);
+    for (size_t i = 0; i < keys.size(); i += LPW) {
       ProtoJob pj;
       pj.dir = dir;
-      pj.rounds = r[order[i]];
-      for (size_t j = i; j < std::min(order.size(), i + (size_t)LPW); ++j) pj.lat.push_back(order[j]);
+      pj.rounds = r[members[(size_t)(keys[i] & 0xFFFFFFFFu)]];
+      pj.lat.reserve(LPW);
+      for (size_t j = i; j < std::min(keys.size(), i + (size_t)LPW); ++j) pj.lat.push_back(members[(size_t)(keys[j] & 0xFFFFFFFFu)]);
       proto.push_back(std::move(pj));
     }
   }

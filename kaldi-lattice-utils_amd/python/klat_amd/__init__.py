@@ -68,7 +68,7 @@ class Scales(C.Structure):
 
 class PackOptions(C.Structure):
     _fields_ = [("lanes_per_lattice", C.c_int32), ("ring_slots", C.c_int32),
-                ("host_threads", C.c_int32), ("fuse_scales", C.c_void_p)]
+                ("host_threads", C.c_int32), ("fuse_scales", C.c_void_p), ("borrow_device_arrays", C.c_int32)]
 
 
 class BatchInfo(C.Structure):
@@ -291,9 +291,10 @@ class Ctx:
 
 
 class Batch:
-    def __init__(self, ctx, arrays, lanes_per_lattice=0, ring_slots=0, host_threads=0, fuse_scales=None):
+    def __init__(self, ctx, arrays, lanes_per_lattice=0, ring_slots=0, host_threads=0, fuse_scales=None, borrow=False):
         """fuse_scales: (graph_scale, acoustic_scale, insertion_penalty) every sweep of the batch will use
-        (klat_pack_options.fuse_scales: 10-byte stream slots), or None."""
+        (klat_pack_options.fuse_scales: 10-byte stream slots), or None.  borrow: device arrays among `arrays` are used
+        in place (klat_pack_options.borrow_device_arrays): the caller keeps them alive while the batch lives."""
         self.ctx = ctx
         self.h = C.c_void_p()
         _live.add(self)
@@ -302,7 +303,7 @@ class Batch:
         self.S = int(self._keep["state_off"][-1]) if self.U else 0
         self.A = int(self._keep["arc_off"][-1]) if self.U else 0
         fs = Scales(*fuse_scales) if fuse_scales is not None else None
-        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads, C.addressof(fs) if fs is not None else None)
+        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads, C.addressof(fs) if fs is not None else None, 1 if borrow else 0)
         self.h = C.c_void_p()
         _check(lib().klat_batch_create(ctx.h, C.byref(self.desc), C.byref(opt), C.byref(self.h)))
 
@@ -327,7 +328,7 @@ class Batch:
         self.U = d.num_lattices
         self.S = int(keep["state_off"][-1]) if self.U else 0
         self.A = int(keep["arc_off"][-1]) if self.U else 0
-        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads, None)
+        opt = PackOptions(lanes_per_lattice, ring_slots, host_threads, None, 0)
         _check(lib().klat_batch_create_compact(ctx.h, C.byref(d), C.byref(opt), C.byref(self.h)))
         return self
 

@@ -1,6 +1,6 @@
 """klat_batch_create on a batch whose arrays are already on the device: the device passes of the
 stream packer (klat_batch_get_pack_timings) and the wall time of the call, then one forward-backward
--- the one-shot path every tool runs.  usage: pack_time.py [lattices] [states] [fanout] [reps] [fuse: 1|0]
+-- the one-shot path every tool runs.  usage: pack_time.py [lattices] [states] [fanout] [reps] [fuse: 1|0] [borrow: 0|1]
 (KLAT_PACK_PROFILE=1 adds the count pass's phase cycles and the host stages of klat_batch_create on stderr)"""
 import ctypes as C
 import os
@@ -18,6 +18,7 @@ NS = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 FO = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 REPS = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 FUSE = (1.0, 0.1, 0.0) if (len(sys.argv) <= 5 or sys.argv[5] != "0") else None
+BORROW = len(sys.argv) > 6 and sys.argv[6] == "1"
 a = klat_amd.synth(20260001, np.full(U, NS, np.int32), np.full(U, FO, np.int32))
 hip = C.CDLL("libamdhip64.so")
 dev, ptrs = dict(a), []
@@ -32,7 +33,7 @@ ctx = klat_amd.Ctx(0)
 A = int(a["arc_off"][-1])
 for rep in range(REPS):
     t0 = time.perf_counter()
-    b = klat_amd.Batch(ctx, dev, fuse_scales=FUSE)
+    b = klat_amd.Batch(ctx, dev, fuse_scales=FUSE, borrow=BORROW)
     t1 = time.perf_counter()
     b.forward_backward(1.0, 0.1, 0.0, arc_posteriors=False)
     ctx.sync()
