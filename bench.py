@@ -48,7 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "kaldi-lattice-utils_amd", "python"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-TRAFFIC_PROFILE = os.path.join("profiles", "r04_hbm_traffic.json")  # PMC passes of this round's kernels
+TRAFFIC_PROFILE = os.path.join("profiles", "r05_hbm_traffic.json")  # PMC passes of this round's kernels
 SCALES = (1.0, 0.1, 0.0)
 FUSE = SCALES  # klat_pack_options.fuse_scales of every batch of the run (--no-fuse: None): 10-byte stream slots
 
@@ -110,6 +110,19 @@ def cpu_baseline(ns, fo, seed, scales, target_seconds=12.0):
                          int(probe["arc_off"][-1]) * 24 / 1e6)}
 
 
+def source_hash():
+    """sha1 over the kernel sources (csrc/), so that a profile taken from other sources shows: the traffic file records
+    the hash (and the commit) it was taken at (tools/prof_summarize.py), the bench line names both."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "kaldi-lattice-utils_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def measured_traffic(kernel_substr):
     """HBM bytes per sweep launch from this round's PMC passes (FETCH_SIZE / WRITE_SIZE collected in
     separate rocprofv3 runs of this same command, corrected as MI355X_MICROARCH.md prescribes;
@@ -119,9 +132,14 @@ def measured_traffic(kernel_substr):
         t = json.load(open(f))
     except Exception:
         return None
+    meta = t.get("__profile__", {})
+    now = source_hash()
     for k, v in t.items():
         if kernel_substr in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v:
-            return {"bytes": v["hbm_bytes_per_launch"], "source": TRAFFIC_PROFILE, "kernel": k}
+            return {"bytes": v["hbm_bytes_per_launch"], "kernel": k,
+                    "source": "%s (taken at commit %s, kernel sources %s; this run's kernel sources %s%s)" % (
+                        TRAFFIC_PROFILE, meta.get("commit", "?"), meta.get("source_hash", "?"), now,
+                        "" if meta.get("source_hash") == now else ": the profile is of other sources")}
     return None
 
 
@@ -281,7 +299,7 @@ def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
     rows = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        b = klat_amd.Batch(ctx, dev, fuse_scales=FUSE)
+        b = klat_amd.Batch(ctx, dev, fuse_scales=FUSE, borrow=True)  # (klat_pack_options.borrow_device_arrays: no copy of the arrays)
         t1 = time.perf_counter()
         b.forward_backward(*SCALES, arc_posteriors=False)  # what the tools call: sweep + totals, no per-arc pass
         ctx.sync()
@@ -300,9 +318,13 @@ def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
     fb, seg = med(r[1] for r in rows), med(r[2] for r in rows)
     wall = [med(r[3] for r in rows), med(r[4] for r in rows), med(r[5] for r in rows)]
     del keep
-    return {"what": "fresh C2 batch, CSR arrays resident on the device: stream packing + one forward-backward without the per-arc "
-                    "posterior pass (KLAT_FB_NO_ARC_POSTERIORS, the tools' call) + segment index; device time by HIP events, "
-                    "wall time of the calls",
+    S = int(arrays["state_off"][-1])
+    fb_bytes = 32.0 * A + 32.0 * S  # SURVEY.md 8d "fb-only": what ONE forward-backward of the batch must move
+    return {"what": "fresh C2 batch, CSR arrays resident on the device and used in place (borrow_device_arrays): stream packing + one "
+                    "forward-backward without the per-arc posterior pass (KLAT_FB_NO_ARC_POSTERIORS, the tools' call) + segment "
+                    "index; device time by HIP events, wall time of the calls",
+            "frac": fb_bytes / ((pack["device_ms"] + fb) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_what": "fb-only algorithmic bytes (32 B/arc + 32 B/state) / (pack + sweep device time) / 8 TB/s",
             "pack_device_ms": pack, "forward_backward_device_ms": fb, "segment_index_device_ms": seg,
             "device_ms": pack["device_ms"] + fb, "arcs_per_s": A / ((pack["device_ms"] + fb) * 1e-3),
             "device_ms_with_index": pack["device_ms"] + fb + seg, "arcs_per_s_with_index": A / ((pack["device_ms"] + fb + seg) * 1e-3),
@@ -314,7 +336,7 @@ C4 = {"lattices": 100000, "states": 5000, "fanout": 3, "seed": 20260003}  # BASE
 STRONG_REFERENCE = os.path.join("profiles", "r04_strong_c4_1gpu.json")   # this leg at N = 1, taken on a box of the same pool
 
 
-def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, barrier, lattices, reps=3):
+def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, barrier, lattices, reps=3, steps=5, warmup=3):
     """north_star's own scaling claim: the SAME list of lattices (BASELINE configs[3]: 100 000 x 5 000 states x
     fanout 3) at every N, strong scaling -- the reference's parallel model is TaskSequencer over one fixed archive
     (kwsbin2/lattice-word-index-segment.cc:260-275).  Every rank takes its klat_partition_by_arcs range (it
@@ -354,14 +376,14 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
     b = klat_amd.Batch(ctx, dev, host_threads=host_threads, fuse_scales=FUSE)
     create_s = time.perf_counter() - t0
     A = b.A
-    for _ in range(3):
+    for _ in range(warmup):
         b.forward_backward(*SCALES)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(steps):
         b.forward_backward(*SCALES)
     barrier()
-    step_s = (time.perf_counter() - t0) / 5
+    step_s = (time.perf_counter() - t0) / steps
     f, fkeep = klat_amd.Batch._filter(None, None)
     off = np.zeros(b.U + 1, np.int64)
     n = C.c_int64(0)
@@ -409,6 +431,7 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
         out = {"workload": "BASELINE configs[3] WHOLE: %d lattices x %d states x fanout %d (seed %d), the same list at every N; "
                            "rank r sweeps its klat_partition_by_arcs range" % (lattices, C4["states"], C4["fanout"], C4["seed"]),
                "scaling": "strong", "ranks": world, "total_arcs": total_arcs, "rank0_lattices": hi - lo, "rank0_arcs": A,
+               "steps": steps, "warmup": warmup,
                "rank0_generate_seconds": gen_s, "rank0_batch_create_seconds": create_s,
                "step_seconds": step_max, "node_arcs_per_s_step": total_arcs / step_max if step_max > 0 else None,
                "pipeline": "klat_forward_backward + klat_segment_index" + (" + klat_gather_index to rank 0 (RCCL, device buffers)" if comm is not None else ""),
@@ -440,6 +463,29 @@ def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, b
     torch.cuda.empty_cache()
     ctx.trim()
     return out
+
+
+def promote_strong(out, world):
+    """At N > 1 the line answers north_star's question directly: the top-level fields the driver parses (value,
+    ms_per_step, scaling, config.workload) are the STRONG-scaling step on BASELINE configs[3] whole -- the same list at
+    every N, forward-backward + arc posteriors, max over ranks between barriers; the weak-scaled configs[1] line (what
+    N = 1 reports) moves to `weak_c2`, the gather-inclusive pipeline stays under `strong_c4`."""
+    st = out.get("strong_c4")
+    if world <= 1 or not st or st.get("error") or not st.get("node_arcs_per_s_step"):
+        out["promoted"] = None
+        return
+    keep = ("value", "ms_per_step", "scaling", "config", "steps", "warmup")
+    out["weak_c2"] = {k: out.get(k) for k in keep}
+    out["value"] = st["node_arcs_per_s_step"]
+    out["ms_per_step"] = 1e3 * st["step_seconds"]
+    out["scaling"] = "strong"
+    out["steps"], out["warmup"] = st.get("steps", out.get("steps")), st.get("warmup", out.get("warmup"))
+    out["config"] = {"workload": st["workload"], "total_arcs": st["total_arcs"], "ranks": st["ranks"],
+                     "sharding": "klat_partition_by_arcs ranges of ONE list, no data-path collective",
+                     "fused_scales": FUSE is not None}
+    out["speedup_vs_1gpu_step"] = st.get("speedup_vs_1gpu_step")
+    out["transport_ranks"] = (out.get("index_gather") or {}).get("transport_ranks")
+    out["promoted"] = "strong_c4.node_arcs_per_s_step (north_star: >= 6x at 8 GPUs on configs[3]); roofline / kernel_ms / one_shot / weak_c2 describe the configs[1] batch"
 
 
 def dry_run(args, rank, world):
@@ -500,9 +546,17 @@ def dry_run(args, rank, world):
         assert int(tot[0]) == L and int(tot[1]) == int(whole["arc_off"][-1]), (tot, L)
         strong = {"scaling": "strong", "ranks": world, "lattices": L, "total_arcs": int(tot[1]), "ranges_tile_the_list": True}
     if rank == 0:
-        print(json.dumps({"metric": "lattice-arcs/sec (whole node) on forward-backward + arc posteriors", "value": None,
-                          "unit": "lattice-arcs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "dry_run": True, "index_gather": gathered, "strong_c4": strong}))
+        line = {"metric": "lattice-arcs/sec (whole node) on forward-backward + arc posteriors", "value": None,
+                "unit": "lattice-arcs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                "config": {"workload": "dry run"}, "dry_run": True, "index_gather": gathered, "strong_c4": strong}
+        if strong is not None and world > 1:  # the same promotion as a real run's (promote_strong), with stand-in figures
+            strong.update({"workload": "stand-in for BASELINE configs[3] WHOLE: %d lattices, the same list at every N" % L,
+                           "node_arcs_per_s_step": 1.0, "step_seconds": 1.0, "steps": args.steps, "warmup": args.warmup})
+            if gathered:
+                line["index_gather"] = dict(gathered, transport_ranks=gathered["ranks"])
+            promote_strong(line, world)
+            line["value"] = None  # (nothing was measured)
+        print(json.dumps(line))
 
 
 def main():
@@ -780,7 +834,7 @@ def main():
                 assert tu == world * batch.U, (tu, world, batch.U)
                 rec, roff = comm._fetch(klat_amd.SEGMENT_DTYPE, 0, tu, tr)  # order check on the host, outside the timing
                 assert roff[-1] == tr and np.array_equal(roff[:batch.U + 1], off), "rank 0's own records must come first, unchanged"
-                out["index_gather"] = {"ranks": nranks, "transport": "RCCL send/recv from device buffers, all-gather of sizes",
+                out["index_gather"] = {"ranks": nranks, "transport_ranks": nranks, "transport": "RCCL send/recv from device buffers, all-gather of sizes",
                                        "utterances": int(tu), "records": int(tr), "payload_bytes_into_rank0": st["payload_bytes"],
                                        "seconds": sec, "GB_per_s_into_rank0": st["payload_bytes"] / sec / 1e9 if sec > 0 else None,
                                        "order": "rank order = input order (checked)"}
@@ -794,7 +848,9 @@ def main():
     ctx.trim()
     if not args.no_strong:
         try:
-            strong = strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, barrier, args.strong_lattices)
+            # (at N > 1 this leg's step is the line's headline: the K steps and W warm-ups the driver asked for)
+            strong = strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, barrier, args.strong_lattices,
+                                   steps=args.steps if world > 1 else 5, warmup=args.warmup if world > 1 else 3)
             if rank == 0:
                 out["strong_c4"] = strong
         except Exception as e:
@@ -833,6 +889,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline:  # (at every N: the same host cores, the same sample)
             out["cpu_baseline"] = cpu_baseline(ns, fo, args.seed, SCALES)
+        promote_strong(out, world)
         print(json.dumps(out))
     batch.close()
     ctx.close()

@@ -156,7 +156,12 @@ def test_bench_gpus_flag_starts_the_ranks(tmp_path):
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True
-    assert out["index_gather"] == {"ranks": 2, "records": out["index_gather"]["records"], "order_restored": True}
+    assert {k: out["index_gather"][k] for k in ("ranks", "order_restored")} == {"ranks": 2, "order_restored": True}
+    # at N > 1 the fields the driver parses are the strong-scaling step on configs[3] (north_star's question), the weak
+    # configs[1] line moves aside
+    assert out["scaling"] == "strong" and "configs[3]" in out["config"]["workload"] and out["config"]["ranks"] == 2
+    assert out["promoted"].startswith("strong_c4.node_arcs_per_s_step") and out["weak_c2"]["scaling"] == "weak"
+    assert out["transport_ranks"] == 2
     # the strong-scaling leg (north_star's claim: the SAME configs[3] list at every N): the two ranks' ranges tile one list
     assert out["strong_c4"]["scaling"] == "strong" and out["strong_c4"]["ranks"] == 2 and out["strong_c4"]["ranges_tile_the_list"]
     assert out["strong_c4"]["lattices"] == 96 and out["strong_c4"]["total_arcs"] > 0

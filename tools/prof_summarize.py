@@ -44,6 +44,25 @@ for k, t in traffic.items():
     wr = 1024.0 * t.get("WRITE_SIZE_KiB_mean", 0.0)
     out[k] = dict(t, hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr,
                   hbm_bytes_per_launch=rd + wr)
+# what the profile was taken from: the commit and a hash over the kernel sources (bench.py names both in
+# roofline.traffic_source and says so when its own sources differ)
+import hashlib
+import subprocess
+h = hashlib.sha1()
+csrc = os.path.join(root, "kaldi-lattice-utils_amd", "csrc")
+for name in sorted(os.listdir(csrc)):
+    if name.endswith((".hip", ".h", ".cc")):
+        h.update(name.encode())
+        h.update(open(os.path.join(csrc, name), "rb").read())
+try:
+    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+    if subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "kaldi-lattice-utils_amd/csrc"], text=True).strip():
+        commit += "+uncommitted"
+except Exception:
+    commit = "?"
+out["__profile__"] = {"commit": commit, "source_hash": h.hexdigest()[:12]}
 json.dump(out, open(os.path.join(dst, "%s_hbm_traffic.json" % tag), "w"), indent=1, sort_keys=True)
 for k, t in out.items():
+    if k == "__profile__":
+        continue
     print("%-60s read %.3f GB  write %.3f GB" % (k[:60], t["hbm_read_bytes_per_launch"] / 1e9, t["hbm_write_bytes_per_launch"] / 1e9))
