@@ -30,13 +30,14 @@ __host__ __device__ static inline int pack_count_lds_bytes(int64_t S, int64_t A)
 }
 
 // The lean passes (klat_pack_lean.hip), for lattices whose arcs are at most kPackLeanMaxSpan states long.  LDS of the
-// lean count pass: in-degrees and first out-arcs (8 (S + 2) bytes), two bits a state, the arcs by destination as 16-bit
-// numbers, a byte an arc; three classes again, a lattice above the last one takes the general passes.
+// lean count pass: in-degrees (4 (S + 2) bytes), first out-arcs and arcs by destination as 16-bit numbers, two bits a
+// state, a byte an arc; three classes again (256 / 512 / 1 024 threads: sixteen waves a CU in each), a lattice above the
+// last one takes the general passes.
 static constexpr int kPackLeanClasses = 3;
-static constexpr int kPackLeanClassLds[kPackLeanClasses] = {38 * 1024, 76 * 1024, kPackCountMaxLds};  // 4, 2, 1 workgroups per CU
+static constexpr int kPackLeanClassLds[kPackLeanClasses] = {31 * 1024 + 512, 79 * 1024, kPackCountMaxLds};  // 5, 2, 1 workgroups per CU
 __host__ __device__ static inline int pack_lean_lds_bytes(int64_t S, int64_t A) {
   if (A >= 65536 || S >= (1 << 20)) return 0x7FFFFFFF;
-  return (int)(8 * (S + 2) + 8 * ((S + 31) / 32 + 1) + 2 * ((A + 1) & ~(int64_t)1) + ((A + 3) & ~(int64_t)3));
+  return (int)(4 * (S + 2) + 8 * ((S + 31) / 32 + 1) + 2 * ((A + 1) & ~(int64_t)1) + 2 * ((S + 3) & ~(int64_t)1) + ((A + 3) & ~(int64_t)3));
 }
 // A forward tile of the lean fill pass reads the arcs of `longest arc` more states than it holds positions.
 static constexpr int kPackLeanMaxSpan = 64;

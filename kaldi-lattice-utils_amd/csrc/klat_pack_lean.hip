@@ -103,7 +103,7 @@ constexpr int kStatesPerThread = 4;
 // position p < S and backward position q < S (and bit 31 of nterm_b: the position's state is final); nfinal the terms
 // of forward position S.  Returns false when a lattice does not fit the tables (more than 4 S rounds).
 // Also what the planner wants to know: rounds for every lane count and the most terms of a position, when `sums`.
-template <class FT, class FB, class PerF>
+template <int T, class FT, class FB, class PerF>
 __device__ bool lean_prefix(const PackDevArgs& a, int u, int64_t s0, int S, int k, FT nterm_f, FB nterm_b, int nfinal, PerF per_forward,
                             int* sh, int (*fsum)[kNumLaneChoices], int (*bsum)[kNumLaneChoices], int* mtf_out, int* mtb_out) {
   const int tid = threadIdx.x;
@@ -125,7 +125,7 @@ __device__ bool lean_prefix(const PackDevArgs& a, int u, int64_t s0, int S, int 
   };
   // forward: positions 0 .. S - 1 (position S, the final weights, behind the loop)
   int carry[2] = {0, 0};
-  for (int base = 0; base < S; base += kTL * kStatesPerThread) {
+  for (int base = 0; base < S; base += T * kStatesPerThread) {
     const int p0 = base + tid * kStatesPerThread;
     int nt[kStatesPerThread], nr[kStatesPerThread], v[2] = {0, 0}, ex[2], tot[2];
 #pragma unroll
@@ -136,7 +136,7 @@ __device__ bool lean_prefix(const PackDevArgs& a, int u, int64_t s0, int S, int 
       v[0] += nr[e];
       v[1] += p < S ? nt[e] - (p == 0 ? 1 : 0) : 0;  // the in-degree
     }
-    block_scan_n<kTL, 2>(v, ex, tot, sh);
+    block_scan_n<T, 2>(v, ex, tot, sh);
     int r = carry[0] + ex[0], c = carry[1] + ex[1];
 #pragma unroll
     for (int e = 0; e < kStatesPerThread; ++e) {
@@ -165,7 +165,7 @@ __device__ bool lean_prefix(const PackDevArgs& a, int u, int64_t s0, int S, int 
   }
   // backward: position q = the state S - 1 - q
   int carry_b = 0;
-  for (int base = 0; base < S; base += kTL * kStatesPerThread) {
+  for (int base = 0; base < S; base += T * kStatesPerThread) {
     const int q0 = base + tid * kStatesPerThread;
     int nt[kStatesPerThread], nr[kStatesPerThread], v[1] = {0}, ex[1], tot[1];
 #pragma unroll
@@ -175,7 +175,7 @@ __device__ bool lean_prefix(const PackDevArgs& a, int u, int64_t s0, int S, int 
       nr[e] = q < S ? (max(nt[e] & 0xFFFFFF, 1) + (1 << k) - 1) >> k : 0;
       v[0] += nr[e];
     }
-    block_scan_n<kTL, 1>(v, ex, tot, sh);
+    block_scan_n<T, 1>(v, ex, tot, sh);
     int r = carry_b + ex[0];
 #pragma unroll
     for (int e = 0; e < kStatesPerThread; ++e) {
@@ -200,9 +200,12 @@ __device__ bool lean_prefix(const PackDevArgs& a, int u, int64_t s0, int S, int 
   return fits;
 }
 
-__global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int lds_lo, int lds_hi) {
+// T threads: 256 for the narrowest LDS class (four workgroups a CU), 512 and 1 024 for the wider ones (two, one): sixteen
+// waves a CU whatever the lattices' size
+template <int T>
+__global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int lds_lo, int lds_hi) {
   extern __shared__ int32_t lds[];
-  __shared__ int sh[2 * (kTL / 64)];
+  __shared__ int sh[2 * (T / 64)];
   __shared__ int sh_bad, sh_unfit, sh_span, sh_mr, sh_mtf, sh_mtb, sh_linked, sh_nfinal;
   __shared__ int sh_rounds[2 * kNumLaneChoices];
   __shared__ unsigned long long sh_mc;
@@ -231,16 +234,16 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   };
   const int nl = (S + 31) / 32 + 1;
   int32_t* indeg = lds;                                          // [S + 2] in-degrees, then the counting sort's cursors
-  int32_t* row = lds + (S + 2);                                  // [S + 2] first out-arc
-  uint32_t* link = reinterpret_cast<uint32_t*>(lds + 2 * (S + 2));  // [nl] a bit a state: it has an arc to its successor
+  uint32_t* link = reinterpret_cast<uint32_t*>(lds + (S + 2));   // [nl] a bit a state: it has an arc to its successor
   uint32_t* finb = link + nl;                                    // [nl] a bit a state: it is final
   uint16_t* bucket = reinterpret_cast<uint16_t*>(finb + nl);     // [A] arcs by destination
-  uint8_t* relb = reinterpret_cast<uint8_t*>(bucket + ((A + 1) & ~1));  // [A] length of every arc
+  uint16_t* row = bucket + ((A + 1) & ~1);                       // [S + 2] first out-arc (a lean lattice has fewer than 65 536 arcs)
+  uint8_t* relb = reinterpret_cast<uint8_t*>(row + ((S + 3) & ~1));  // [A] length of every arc
   const int64_t sb = s0 + 2 * (int64_t)u;
   if (tid == 0) sh_bad = 0, sh_unfit = 0, sh_span = 1, sh_mr = 1, sh_mtf = 1, sh_mtb = 1, sh_linked = 0, sh_nfinal = 0, sh_mc = 0ull;
   if (tid < 2 * kNumLaneChoices) sh_rounds[tid] = 0;
-  for (int s = tid; s < S + 2; s += kTL) indeg[s] = 0;
-  for (int s = tid; s < 2 * nl; s += kTL) link[s] = 0;
+  for (int s = tid; s < S + 2; s += T) indeg[s] = 0;
+  for (int s = tid; s < 2 * nl; s += T) link[s] = 0;
   __syncthreads();
   stamp(0);
   // ---- the arcs, four a lane and load
@@ -248,13 +251,13 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   constexpr int kUn = 3;  // quads a thread has in flight
   float mc = 0.0f;
   int span = 1;
-  for (int64_t qb = q0 + tid; qb < q1; qb += kTL * kUn) {
+  for (int64_t qb = q0 + tid; qb < q1; qb += T * kUn) {
     int4 vs[kUn], vd[kUn], vi[kUn];
     float4 vg[kUn], va[kUn];
     int vp[kUn];
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = min(qb + x * kTL, q1 - 1);
+      const int64_t q = min(qb + x * T, q1 - 1);
       vs[x] = load_quad<int4>(a.src, q, a.num_arcs);
       vd[x] = load_quad<int4>(a.dst, q, a.num_arcs);
       vp[x] = 4 * q > a0 ? a.src[4 * q - 1] : 0;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
     }
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = qb + x * kTL;
+      const int64_t q = qb + x * T;
       if (q >= q1) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
           if (rel == 1) atomicOr(&link[s >> 5], 1u << (s & 31));
           // arc i is the first out-arc of every state behind its predecessor's source up to its own (the predecessor may be
           // the malformed arc this pass exists to reject: its source below zero must not move the fill before the table)
-          for (int qq = (i > 0 ? max(prev, -1) + 1 : 0); qq <= s; ++qq) row[qq] = i;
+          for (int qq = (i > 0 ? max(prev, -1) + 1 : 0); qq <= s; ++qq) row[qq] = (uint16_t)i;
           if (a.fold_maxcost) {
             const float c = arc_cost_abs_f(elem(vg[x], e), elem(va[x], e), a.fsp.penalized ? elem(vi[x], e) != 0 : false, a.fsp);
             if (c < 1.0e30f) mc = fmaxf(mc, c);
@@ -297,16 +300,16 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   }
   // the final weights: a bit a state, the largest cost (eight states a thread in flight: one after the other, a thread's
   // trips to memory were a fifth of this pass)
-  for (int sbase = 0; sbase < S; sbase += 8 * kTL) {
+  for (int sbase = 0; sbase < S; sbase += 8 * T) {
     float fg[8], fa[8];
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
-      const int s = min(sbase + x * kTL + tid, S - 1);
+      const int s = min(sbase + x * T + tid, S - 1);
       fg[x] = a.final_graph[s0 + s], fa[x] = a.final_acoustic[s0 + s];
     }
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
-      const int s = sbase + x * kTL + tid;
+      const int s = sbase + x * T + tid;
       if (s >= S) continue;
       if (!(fg[x] == INFINITY && fa[x] == INFINITY)) atomicOr(&finb[s >> 5], 1u << (s & 31));
       if (a.fold_maxcost) {
@@ -331,11 +334,11 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   }
   {  // the states behind the last arc's source; the states linked to their successor
     const int last = A > 0 ? a.src[a0 + A - 1] : -1;
-    for (int s = last + 1 + tid; s <= S + 1; s += kTL) row[s] = A;
+    for (int s = last + 1 + tid; s <= S + 1; s += T) row[s] = (uint16_t)A;
     int linked = 0;
-    for (int w = tid; w < nl; w += kTL) linked += __popc(link[w]);
+    for (int w = tid; w < nl; w += T) linked += __popc(link[w]);
     int nfin = 0;
-    for (int w = tid; w < nl; w += kTL) nfin += __popc(finb[w]);
+    for (int w = tid; w < nl; w += T) nfin += __popc(finb[w]);
     for (int d = 32; d > 0; d >>= 1) linked += __shfl_xor(linked, d, 64), nfin += __shfl_xor(nfin, d, 64);
     if ((tid & 63) == 0) atomicAdd(&sh_linked, linked), atomicAdd(&sh_nfinal, nfin);
   }
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   int fsum[kNumLaneChoices] = {0}, bsum[kNumLaneChoices] = {0};
   int mtf, mtb, mr = sh_span;
   auto is_final = [&](int s) { return (finb[s >> 5] >> (s & 31)) & 1u; };
-  const bool fits = lean_prefix(
+  const bool fits = lean_prefix<T>(
       a, u, s0, S, max(k, 0), [&](int p) { return indeg[p] + (p == 0 ? 1 : 0); },
       [&](int q) {
         const int s = S - 1 - q;
@@ -367,11 +370,11 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   // the final states in state order (forward position S holds one term for each)
   {
     int carry = 0;
-    for (int base = 0; base < nl; base += kTL) {
+    for (int base = 0; base < nl; base += T) {
       const int w = base + tid;
       const uint32_t bits = w < nl ? finb[w] : 0u;
       int v[1] = {(int)__popc(bits)}, ex[1], tot[1];
-      block_scan_n<kTL, 1>(v, ex, tot, sh);
+      block_scan_n<T, 1>(v, ex, tot, sh);
       int at = carry + ex[0];
       for (uint32_t m = bits; m; m &= m - 1) a.flist[s0 + at++] = w * 32 + __ffs(m) - 1;
       carry += tot[0];
@@ -395,13 +398,13 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   if (sh_unfit) return;
   stamp(4);
   // ---- counting sort of the arcs by destination, in LDS: where an arc stands among the in-arcs of its destination
-  for (int64_t qb = q0 + tid; qb < q1; qb += kTL * kUn) {
+  for (int64_t qb = q0 + tid; qb < q1; qb += T * kUn) {
     int4 vd[kUn];
 #pragma unroll
-    for (int x = 0; x < kUn; ++x) vd[x] = load_quad<int4>(a.dst, min(qb + x * kTL, q1 - 1), a.num_arcs);
+    for (int x = 0; x < kUn; ++x) vd[x] = load_quad<int4>(a.dst, min(qb + x * T, q1 - 1), a.num_arcs);
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = qb + x * kTL;
+      const int64_t q = qb + x * T;
       if (q >= q1) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -415,18 +418,18 @@ __global__ __launch_bounds__(kTL) void pack_count_lean_kernel(PackDevArgs a, int
   stamp(5);
   // ---- meta: length | place among the destination's in-arcs (by arc number) << 8 | place among the source's out-arcs
   // (farthest destination first, equal destinations by arc number) << 16 | word << 24
-  for (int64_t qb = q0 + tid; qb < q1; qb += kTL * kUn) {
+  for (int64_t qb = q0 + tid; qb < q1; qb += T * kUn) {
     int4 vs[kUn], vd[kUn], vi[kUn];
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = min(qb + x * kTL, q1 - 1);
+      const int64_t q = min(qb + x * T, q1 - 1);
       vs[x] = load_quad<int4>(a.src, q, a.num_arcs);
       vd[x] = load_quad<int4>(a.dst, q, a.num_arcs);
       vi[x] = load_quad<int4>(a.ilabel, q, a.num_arcs);
     }
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = qb + x * kTL;
+      const int64_t q = qb + x * T;
       if (q >= q1) continue;
       uint32_t m[4];
 #pragma unroll
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(kTL) void pack_rounds_lean_kernel(PackDevArgs a) {
   const int32_t* pb = a.r0b + sb;
   const int nfinal = (pf[S] >> 24) & 0x7F;
   // (every thread reads its own positions' old entries before it writes them: lean_prefix loads nterm first)
-  (void)lean_prefix(
+  (void)lean_prefix<kTL>(
       a, u, s0, S, a.lat_g[u], [&](int p) { return (pf[p] >> 24) & 0x7F; },
       [&](int q) { return ((pb[q] >> 24) & 0x7F) | (pb[q] & (int)0x80000000); }, nfinal, [](int, int) {}, sh, nullptr, nullptr, nullptr, nullptr);
 }
@@ -835,13 +838,21 @@ hipError_t launch_pack_count_lean(const PackDevArgs& a, int num_lattices, const 
   if (num_lattices <= 0) return hipSuccess;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_count_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPackCountMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_count_lean_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, kPackCountMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_count_lean_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kPackCountMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_count_lean_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, kPackCountMaxLds);
     attr_done = true;
   }
-  for (int c = 0; c < kPackLeanClasses; ++c)
-    if (class_need[c] > 0)
-      hipLaunchKernelGGL(pack_count_lean_kernel, dim3(num_lattices), dim3(kTL), (size_t)class_need[c], stream, a, c == 0 ? -1 : kPackLeanClassLds[c - 1],
-                         kPackLeanClassLds[c]);
+  for (int c = 0; c < kPackLeanClasses; ++c) {
+    if (class_need[c] <= 0) continue;
+    const int lo = c == 0 ? -1 : kPackLeanClassLds[c - 1], hi = kPackLeanClassLds[c];
+    if (c == 0)
+      hipLaunchKernelGGL(pack_count_lean_kernel<256>, dim3(num_lattices), dim3(256), (size_t)class_need[c], stream, a, lo, hi);
+    else if (c == 1)
+      hipLaunchKernelGGL(pack_count_lean_kernel<512>, dim3(num_lattices), dim3(512), (size_t)class_need[c], stream, a, lo, hi);
+    else
+      hipLaunchKernelGGL(pack_count_lean_kernel<1024>, dim3(num_lattices), dim3(1024), (size_t)class_need[c], stream, a, lo, hi);
+  }
   return hipGetLastError();
 }
 
