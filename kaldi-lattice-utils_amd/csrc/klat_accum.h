@@ -109,8 +109,16 @@ hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool posi
 // source states' time within kPieceWindow arcs before every multiple of kPieceStride.  `long_list`: the lattices (device),
 // whose piece slots (a.piece_first, ceil(arcs / kPieceStride) each) the kernel fills; a lattice whose times descend
 // somewhere, or that has no change of time inside a window, keeps piece_count 0 and takes the general kernel.
-static const int kPieceStride = 13312, kPieceWindow = 2048;
-hipError_t launch_index_slice(const AccumArgs& a, bool position, const int32_t* long_list, int count, hipStream_t stream);
+// Two shapes: pieces of up to 13 312 + 2 048 arcs for the 1 024 x 15 class (lattices above 16 384 arcs only), or of up to
+// 6 144 + 2 048 arcs for the 512 x 16 class, which every lattice above 8 192 arcs then takes (two workgroups a CU
+// where the 1 024-thread classes run one: index_piece_shape decides, klat_accum_api.cc).
+struct PieceShape {
+  int32_t stride, window;  // a cut within `window` arcs before every multiple of `stride`
+  int32_t cls;             // the hash kernel's size class of the pieces
+  int32_t long_arcs;       // lattices of more arcs are cut
+};
+static const PieceShape kPiecesBig = {13312, 2048, 4, 16384}, kPiecesSmall = {4096, 2048, 2, 6144};
+hipError_t launch_index_slice(const AccumArgs& a, bool position, const PieceShape& shape, const int32_t* long_list, int count, hipStream_t stream);
 int64_t index_gather_chunks(const int64_t* record_off_host, int num_lattices);
 hipError_t launch_index_gather(const AccumArgs& a, int num_lattices, bool position, const int64_t* record_off, const int64_t* record_off_host,
                                void* chunk_buf, OutRecord* out, hipStream_t stream);

@@ -50,9 +50,16 @@ int ensure_index_scratch(klat_batch* b) {
 
 // The cached per-lattice records gathered into one dense device array (utterance-major): what the
 // fetch call copies to the host and what the multi-GPU gather sends from (klat_dist.h).
-int gather_dense(klat_batch* b, const AccumArgs& a, bool position) {
+int gather_dense(klat_batch* b, const AccumArgs& a_in, bool position) {
   klat_accum_state& st = b->accum;
   if (st.dense_mode == st.cached_mode) return KLAT_OK;
+  // (whoever calls: the pieces of the last sizing call are this state's, not the caller's -- klat_index_device_records,
+  // what the multi-GPU gather sends from, came without them and handed long lattices' runs over unmerged)
+  AccumArgs a = a_in;
+  if (st.pieces_live)
+    a.piece_first = st.piece_first.p, a.piece_count = st.piece_count.p, a.item_records = st.item_records.p, a.piece_items = st.piece_items.p;
+  else
+    a.piece_first = nullptr, a.piece_count = nullptr, a.item_records = nullptr, a.piece_items = nullptr;
   klat_ctx* c = b->ctx;
   const int64_t total = st.record_off[b->U];
   int rc;
@@ -183,10 +190,20 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       if (!st.classes_ready) {
         std::vector<int32_t> cls((size_t)b->U);
         int64_t cnt[kHashClasses + 1] = {0};
+        // Lattices of 6 145 .. 16 384 arcs run whole in the 1 024-thread classes (one workgroup a CU).  Cutting them in
+        // pieces for the 512 x 12 class instead (two workgroups a CU, KLAT_INDEX_PIECES=small) was measured in round 5
+        // on the configs[3] shard (12 500 x 14 997 arcs): index 4.21 -> 4.39 ms (the pieces fill their workgroups to
+        // 61 %, a slicing launch and an atomic per piece on top), and the gather that merges the pieces' runs
+        // 1.9 -> 5.0 ms -- so they stay whole; only lattices above 16 384 arcs are cut (13 312 + 2 048 arcs a piece).
+        {
+          const char* env = std::getenv("KLAT_INDEX_PIECES");
+          st.pieces = env && std::string(env) == "small" ? kPiecesSmall : kPiecesBig;
+        }
         for (int64_t u = 0; u < b->U; ++u) {
           const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
           int k = 0;
           while (k < kHashClasses && arcs > kHashClassArcs[k]) ++k;
+          if (arcs > st.pieces.long_arcs) k = kHashClasses;  // (long: cut in pieces)
           cls[(size_t)u] = k;
           ++cnt[k];
         }
@@ -208,10 +225,10 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
         for (int64_t u = 0; u < b->U; ++u) {
           const int64_t arcs = b->h_arc_off[u + 1] - b->h_arc_off[u];
           if (cls[(size_t)u] == kHashClasses) {  // a long lattice: piece slots for the slicing to fill
-            if (arcs <= (int64_t)1024 * kPieceStride) {  // (the slicing kernel keeps a thread's pieces in four registers: 1 024 pieces a lattice; beyond: the general kernel)
+            if (arcs <= (int64_t)1024 * st.pieces.stride) {  // (the slicing kernel: a thread per piece, 1 024 pieces a lattice; beyond: the general kernel)
               longs.push_back((int32_t)u);
               first[(size_t)u] = (int32_t)slots;
-              slots += (arcs + kPieceStride - 1) / kPieceStride;
+              slots += (arcs + st.pieces.stride - 1) / st.pieces.stride;
             } else {
               st.any_general = true;  // (no piece slots: the general kernel must run for it even if nothing else is long)
             }
@@ -236,14 +253,14 @@ int run_index(klat_batch* b, bool position, const int32_t* state_len, const klat
       std::vector<SweepPiece> work;
       AccumArgs long_args = a;
       if (st.num_long > 0 || st.any_general) {
-        // long lattices: cut where the source states' time changes, the pieces through the two largest classes' kernel
-        // (a piece has at most kPieceStride + kPieceWindow = 15 360 arcs), what could not be cut through the general kernel
-        long_args.min_arcs = kHashClassArcs[kHashClasses - 1], long_args.max_arcs = 0x7FFFFFFF;
+        // long lattices: cut where the source states' time changes, the pieces (at most stride + window arcs) through
+        // their class's kernel, what could not be cut through the general kernel
+        long_args.min_arcs = st.pieces.long_arcs, long_args.max_arcs = 0x7FFFFFFF;
         work.push_back(SweepPiece{0, [&](hipStream_t s) {
                                     hipError_t e = hipSuccess;
-                                    if (st.num_long > 0) e = launch_index_slice(a, position, st.long_list.p, (int)st.num_long, s);
+                                    if (st.num_long > 0) e = launch_index_slice(a, position, st.pieces, st.long_list.p, (int)st.num_long, s);
                                     if (e == hipSuccess && st.num_long > 0)
-                                      e = launch_index_hash2(a, pk, position, kHashClasses - 2, st.piece_items.p, (int)st.num_piece_slots, s);
+                                      e = launch_index_hash2(a, pk, position, st.pieces.cls, st.piece_items.p, (int)st.num_piece_slots, s);
                                     if (e == hipSuccess) e = launch_index(long_args, (int)b->U, position, s);
                                     return e;
                                   }});

@@ -882,9 +882,9 @@ hipError_t launch(const AccumArgs& a, const RadixPack& pk, int cls, int count, h
 
 // Pieces of a long lattice (klat_accum.h): one workgroup per lattice.  Keys repeat only among arcs whose source states
 // share their time, so a cut is good where every arc before it has an earlier source time than every arc behind it
-// (klat_slice.h); a wave looks for boundary k = the last such place at or before k * kPieceStride.
+// (klat_slice.h); a wave looks for boundary k = the last such place at or before k * shape.stride.
 template <bool POSITION>
-__global__ __launch_bounds__(1024) void index_slice_kernel(AccumArgs a, const int32_t* long_list) {
+__global__ __launch_bounds__(1024) void index_slice_kernel(AccumArgs a, PieceShape shape, const int32_t* long_list) {
   __shared__ int bad;
   __shared__ int32_t before[kSliceBlocks + 1], from[kSliceBlocks + 1];
   const int u = long_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -892,15 +892,15 @@ __global__ __launch_bounds__(1024) void index_slice_kernel(AccumArgs a, const in
   const int n = (int)(a.arc_off[u + 1] - a0);
   const int32_t* src = a.src + a0;
   const int32_t* tm = (POSITION ? a.state_len : a.state_time) + s0;
-  const int first = a.piece_first[u], pieces = (n + kPieceStride - 1) / kPieceStride;
+  const int first = a.piece_first[u], pieces = (n + shape.stride - 1) / shape.stride;
   IndexItem* items = a.piece_items + first;
   auto time_of = [&](int i) { return tm[src[i]]; };
   if (tid == 0) bad = n > 64 * kSliceBlocks ? 1 : 0;
   __syncthreads();
   if (!bad) slice_prepare(n, time_of, before, from);  // (workgroup-uniform)
   for (int k = 1 + wave; !bad && k < pieces; k += 16) {  // (wave-uniform)
-    const int target = k * kPieceStride;  // < n
-    const int cut = slice_find(n, time_of, before, from, target - kPieceWindow + 1, target, true);
+    const int target = k * shape.stride;  // < n
+    const int cut = slice_find(n, time_of, before, from, target - shape.window + 1, target, true);
     if (cut < 0) bad = 1;
     if (lane == 0) items[k].begin = cut;
   }
@@ -920,12 +920,12 @@ __global__ __launch_bounds__(1024) void index_slice_kernel(AccumArgs a, const in
   if (tid == 0) a.piece_count[u] = ok ? pieces : 0, a.num_records[u] = 0;
 }
 
-hipError_t launch_index_slice(const AccumArgs& a, bool position, const int32_t* long_list, int count, hipStream_t stream) {
+hipError_t launch_index_slice(const AccumArgs& a, bool position, const PieceShape& shape, const int32_t* long_list, int count, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   if (position)
-    hipLaunchKernelGGL(index_slice_kernel<true>, dim3(count), dim3(1024), 0, stream, a, long_list);
+    hipLaunchKernelGGL(index_slice_kernel<true>, dim3(count), dim3(1024), 0, stream, a, shape, long_list);
   else
-    hipLaunchKernelGGL(index_slice_kernel<false>, dim3(count), dim3(1024), 0, stream, a, long_list);
+    hipLaunchKernelGGL(index_slice_kernel<false>, dim3(count), dim3(1024), 0, stream, a, shape, long_list);
   return hipGetLastError();
 }
 

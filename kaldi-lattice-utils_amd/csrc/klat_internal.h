@@ -243,6 +243,7 @@ struct klat_accum_state {
   klat::DevBuf<int32_t> num_records, include, exclude, state_len;
   // the hash kernel's size classes (klat_accum.h): class c's lattices are class_list[class_begin[c] .. class_begin[c + 1])
   bool classes_ready = false;
+  klat::PieceShape pieces = klat::kPiecesBig;  // how this batch's long lattices are cut (chosen with the classes)
   klat::DevBuf<klat::IndexItem> class_items;
   int64_t class_begin[klat::kHashClasses + 1] = {0};
   // lattices of more than kHashClassArcs[last] arcs: cut into pieces on the device (index_slice_kernel), a piece a work

@@ -68,6 +68,30 @@ def test_device_records_match_host_fetch_for_position_index():
     comm.close(), b.close(), ctx.close()
 
 
+def test_device_records_merge_the_pieces_of_a_long_lattice():
+    """A lattice above 16 384 arcs is indexed in pieces whose sorted runs the gather merges.  The records the
+    multi-GPU gather sends from (klat_index_device_records, here BEFORE any host fetch) must be the merged ones:
+    round 5 found them handed over run after run."""
+    ctx = klat_amd.Ctx(0)
+    ns = np.array([50, 7000, 120], np.int32)  # 3 x 6 999 = 20 997 arcs in the middle one
+    arrays = klat_amd.synth(777, ns, np.full(3, 3, np.int32))
+    want = klat_amd.Batch(ctx, arrays)
+    want.forward_backward(1.0, 0.1, 0.0)
+    off, rec = want.segment_index()  # sizing call + host fetch
+    lo, hi = int(off[1]), int(off[2])
+    assert np.all(np.diff(rec["logp"][lo:hi]) <= 0), "the long lattice's records are sorted by descending posterior"
+    b = klat_amd.Batch(ctx, arrays)
+    b.forward_backward(1.0, 0.1, 0.0)
+    import ctypes as C
+    f, keep = klat_amd.Batch._filter(None, None)
+    o2, n = np.zeros(len(ns) + 1, np.int64), C.c_int64(0)
+    klat_amd._check(klat_amd.lib().klat_segment_index(b.h, C.byref(f), klat_amd._p(o2), None, C.c_int64(0), C.byref(n)))  # sizing only
+    comm = kdist.Comm.rccl(ctx, 0, 1, kdist.rccl_unique_id())
+    got, goff = comm.gather_index(b, klat_amd.SEGMENT_DTYPE, root=0)
+    assert goff.tolist() == off.tolist() and got.tobytes() == rec.tobytes()
+    comm.close(), b.close(), want.close(), ctx.close()
+
+
 @pytest.mark.parametrize("tool,extra", [("lattice-word-index-segment", []), ("lattice-word-index-position", []),
                                         ("lattice-word-index-segment", ["--beam=4", "--acoustic-scale=0.1"])])
 def test_tool_devices_mode_three_processes_equals_one(tmp_path, tool, extra):
