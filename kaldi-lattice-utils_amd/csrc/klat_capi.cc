@@ -582,7 +582,19 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     uint8_t* const lean_ok = lean_ok_p;
     int32_t h_status[4] = {0, -1, 1, 0};
     const char* lean_env = std::getenv("KLAT_PACK_LEAN");
-    const bool lean_enabled = !(lean_env && std::atoi(lean_env) == 0);
+    bool lean_enabled = !(lean_env && std::atoi(lean_env) == 0);
+    if (lean_enabled && o.lanes_per_lattice == 0 && !(lean_env && std::atoi(lean_env) > 0)) {
+      // A batch that may be swept in segments (klat_chain.hip: its long lattices wait for nobody -- choose_chain_lattices'
+      // first test, known from the offsets) needs the general tables for those lattices: the lean count pass would run
+      // for nothing (the configs[4] mix: 1.4 + 1.3 ms of count passes instead of 1.3).  KLAT_PACK_LEAN=1 insists.
+      const char* chain_env = std::getenv("KLAT_CHAIN");
+      double sum_states = 0, longest = 0;
+      for (int64_t u = 0; u < U; ++u) {
+        const double S = (double)(d->state_off[u + 1] - d->state_off[u]);
+        sum_states += S, longest = std::max(longest, S);
+      }
+      if (!(chain_env && std::atoi(chain_env) == 0) && !(longest * 320.0 < 1.3 * sum_states * 60.0 / 1024.0)) lean_enabled = false;
+    }
     const char* level_env = std::getenv("KLAT_LEVEL");
     const int level_mode = level_env == nullptr ? -1 : std::atoi(level_env);
     const bool plan_levels = o.lanes_per_lattice == 0 && level_mode != 0 && U > 0;

@@ -90,3 +90,118 @@ def test_batch_from_device_resident_arrays(ctx):
     for p in ptrs:
         hip.hipFree(p)
     assert np.array_equal(got, want)
+
+
+def _streams(ctx, a, lean, **kw):
+    """the batch's streams through the lean passes (KLAT_PACK_LEAN=1: also where a small batch would keep the general
+    ones for the segment path) or through the general passes alone (0)"""
+    old = os.environ.get("KLAT_PACK_LEAN")
+    os.environ["KLAT_PACK_LEAN"] = "1" if lean else "0"
+    try:
+        b = klat_amd.Batch(ctx, a, **kw)
+        info = b.info()
+        st = b.fused_streams() if kw.get("fuse_scales") else b.streams()
+        b.close()
+    finally:
+        if old is None:
+            os.environ.pop("KLAT_PACK_LEAN", None)
+        else:
+            os.environ["KLAT_PACK_LEAN"] = old
+    return info, st
+
+
+def _stretch(a, ns, rng, frac, far):
+    lat = np.repeat(np.arange(len(ns)), np.diff(a["arc_off"]))
+    src, dst = a["src"], a["dst"].copy()
+    st = (rng.rand(len(dst)) < frac) & (dst != src + 1)
+    dst[st] = np.minimum(src[st] + rng.randint(2, far, size=int(st.sum())), ns[lat][st] - 1)
+    a["dst"] = np.maximum(dst, src + 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("fuse", [None, (1.0, 0.1, 0.5)])
+@pytest.mark.parametrize("case", ["small mix", "spans to 60, many finals", "a few spans beyond the lean passes", "fixed lanes 1", "fixed lanes 8",
+                                  "fixed lanes 64", "uniform", "skewed", "C2 / 10"])
+def test_lean_passes_write_the_general_passes_streams(ctx, case, fuse):
+    """csrc/klat_pack_lean.hip (lattices whose arcs are at most 64 states long) against the general passes of
+    csrc/klat_pack_device.hip: the same streams bit for bit -- term words, costs, and with fused scales the float and
+    the 16-bit residual -- on batches that mix both kinds of lattices (a job with one long-span lattice takes the
+    general fill pass, its other lattices the general count pass after all), every lane count, many final states."""
+    rng = np.random.RandomState(7)
+    ns = np.concatenate([[1, 2, 3], rng.randint(2, 400, size=45), [1500]]).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4, 7], size=len(ns)).astype(np.int32)
+    kw = {}
+    if case == "small mix":
+        a = klat_amd.synth(11, ns, fo)
+    elif case == "spans to 60, many finals":
+        a = klat_amd.synth(12, ns, fo)
+        _stretch(a, ns, rng, 0.3, 60)
+        fin = rng.rand(len(a["final_graph"])) < 0.15
+        a["final_graph"][fin] = (rng.rand(int(fin.sum())) * 3).astype(np.float32)
+        a["final_acoustic"][fin] = (rng.rand(int(fin.sum())) * 3).astype(np.float32)
+    elif case == "a few spans beyond the lean passes":
+        a = klat_amd.synth(13, ns, fo)
+        _stretch(a, ns, rng, 0.05, 150)
+    elif case.startswith("fixed lanes"):
+        G = int(case.split()[-1])
+        a = klat_amd.synth(14 + G, ns, fo)
+        _stretch(a, ns, rng, 0.2, 40)
+        kw = {"lanes_per_lattice": G, "ring_slots": {1: 16, 8: 64, 64: 16}[G]}
+    elif case == "uniform":
+        a = klat_amd.synth(21, np.full(300, 700, np.int32), np.full(300, 3, np.int32))
+    elif case == "skewed":
+        n2 = np.exp(rng.uniform(np.log(50), np.log(6000), size=200)).astype(np.int32)
+        a = klat_amd.synth(22, n2, rng.choice([2, 3, 4, 6], size=200).astype(np.int32))
+    else:
+        a = klat_amd.synth(20260001, np.full(1000, 2000, np.int32), np.full(1000, 3, np.int32))
+    if fuse:
+        kw["fuse_scales"] = fuse
+    ig, sg = _streams(ctx, a, False, **kw)
+    il, sl = _streams(ctx, a, True, **kw)
+    for k in ("lanes_per_lattice", "ring_slots", "num_jobs", "max_rounds", "fwd_slots", "bwd_slots", "far_terms", "num_layouts"):
+        assert ig[k] == il[k], (k, ig[k], il[k])
+    for x, y in zip(sg, sl):
+        assert x.shape == y.shape and x.tobytes() == y.tobytes()
+
+
+def test_lean_count_pass_reports_malformed_lattices(ctx):
+    os.environ["KLAT_PACK_LEAN"] = "1"
+    try:
+        a = klat_amd.synth(2, np.array([6, 9, 40], np.int32), np.array([2, 3, 3], np.int32))
+        a["dst"][int(a["arc_off"][1]) + 3] = 0  # an arc of the second lattice goes backwards
+        with pytest.raises(klat_amd.KlatError) as e:
+            klat_amd.Batch(ctx, a, lanes_per_lattice=4)
+        assert e.value.code == klat_amd.ERR_BAD_TOPOLOGY and "lattice 1" in str(e.value)
+        a = klat_amd.synth(2, np.array([6, 9, 40], np.int32), np.array([2, 3, 3], np.int32))
+        a["src"][int(a["arc_off"][2]) + 5] = -7  # a source below zero in the third
+        with pytest.raises(klat_amd.KlatError) as e:
+            klat_amd.Batch(ctx, a, lanes_per_lattice=4)
+        assert e.value.code == klat_amd.ERR_INVALID_ARG and "lattice 2" in str(e.value)
+    finally:
+        os.environ.pop("KLAT_PACK_LEAN", None)
+
+
+def test_borrowed_device_arrays_give_the_same_batch(ctx):
+    """klat_pack_options.borrow_device_arrays: the caller's device arrays used in place."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    a = _arrays(5, False, True)
+    b = klat_amd.Batch(ctx, a, fuse_scales=(1.0, 0.1, 0.0))
+    b.forward_backward(1.0, 0.1, 0.0)
+    want = b.arc_logpost()
+    b.close()
+    dev, ptrs = dict(a), []
+    for name in ("src", "dst", "ilabel", "olabel", "graph", "acoustic", "final_graph", "final_acoustic", "state_time"):
+        h = np.ascontiguousarray(a[name])
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(max(h.nbytes, 4))) == 0
+        assert hip.hipMemcpy(p, C.c_void_p(h.ctypes.data), C.c_size_t(h.nbytes), C.c_int(1)) == 0
+        ptrs.append(p)
+        dev[name] = int(p.value)
+    b = klat_amd.Batch(ctx, dev, fuse_scales=(1.0, 0.1, 0.0), borrow=True)
+    b.forward_backward(1.0, 0.1, 0.0)
+    got = b.arc_logpost()
+    off, rec = b.segment_index()
+    b.close()
+    for p in ptrs:
+        hip.hipFree(p)
+    assert np.array_equal(got, want) and len(rec) > 0

@@ -11,10 +11,7 @@ import klat_amd  # noqa: E402
 
 
 def build(ctx, a, lean, **kw):
-    if lean:
-        os.environ.pop("KLAT_PACK_LEAN", None)
-    else:
-        os.environ["KLAT_PACK_LEAN"] = "0"
+    os.environ["KLAT_PACK_LEAN"] = "1" if lean else "0"  # (1: also where a small batch would keep the general passes for the segment path)
     b = klat_amd.Batch(ctx, a, **kw)
     info = b.info()
     st = b.fused_streams() if kw.get("fuse_scales") else b.streams()

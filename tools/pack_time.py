@@ -19,7 +19,11 @@ FO = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 REPS = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 FUSE = (1.0, 0.1, 0.0) if (len(sys.argv) <= 5 or sys.argv[5] != "0") else None
 BORROW = len(sys.argv) > 6 and sys.argv[6] == "1"
-a = klat_amd.synth(20260001, np.full(U, NS, np.int32), np.full(U, FO, np.int32))
+if NS == 0:  # the configs[4] mix: `lattices` sizes log-uniform in 200 .. 20 000 states, fanout in {2, 3, 4, 6}
+    rng = np.random.RandomState(20260004)
+    a = klat_amd.synth(20260004, np.exp(rng.uniform(np.log(200), np.log(20000), U)).astype(np.int32), rng.choice([2, 3, 4, 6], U).astype(np.int32))
+else:
+    a = klat_amd.synth(20260001, np.full(U, NS, np.int32), np.full(U, FO, np.int32))
 hip = C.CDLL("libamdhip64.so")
 dev, ptrs = dict(a), []
 for name in ("src", "dst", "ilabel", "olabel", "graph", "acoustic", "final_graph", "final_acoustic", "state_time"):
