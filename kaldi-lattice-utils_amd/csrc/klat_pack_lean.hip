@@ -514,6 +514,9 @@ constexpr int kMaxTiles = kPackTilesPerGroup;
 // Everything that depends on the lanes per lattice is a compile-time constant (one instantiation per lane count: the
 // first version, with the lane count in registers, wanted 217 VGPRs and spent its time in scratch memory).
 template <int LG, bool FUSED, bool FWD>
+#ifndef KLAT_FILL_LEAN_Q
+#define KLAT_FILL_LEAN_Q 2  // quads of arcs a thread has in flight
+#endif
 #ifndef KLAT_FILL_LEAN_WAVES
 #define KLAT_FILL_LEAN_WAVES 4
 #endif
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(kTL, KLAT_FILL_LEAN_WAVES) void pack_fill_lean_kern
     }
   };
   // the arcs of a tile, four consecutive ones a lane and load: kQ quads a thread in flight
-  constexpr int kQ = 2;
+  constexpr int kQ = KLAT_FILL_LEAN_Q;
   const int32_t* ends = fwd ? a.dst : a.src;
   int4 ve[kQ];
   uint4 vm[kQ];
