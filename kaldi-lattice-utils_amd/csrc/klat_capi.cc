@@ -905,6 +905,9 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       }
     }
     lap("job kinds");
+    if (host_prof)
+      std::fprintf(stderr, "klat_batch_create lattices: %zu lean candidates, %zu general by size; jobs %zu of which %zu general; lattices redone by the general passes %zu, rounds redone for other lanes %zu\n",
+                   num_lean, num_known_general, P.jobs.size(), num_general_jobs, num_redo, num_reround);
     // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, run of tiles)
     std::vector<PackEntry> entries;
     std::vector<LeanEntry> lentries;  // by lanes per lattice: one launch each

@@ -205,3 +205,41 @@ def test_borrowed_device_arrays_give_the_same_batch(ctx):
     for p in ptrs:
         hip.hipFree(p)
     assert np.array_equal(got, want) and len(rec) > 0
+
+
+def test_lean_passes_leave_a_crowded_position_to_the_general_ones(ctx):
+    """A position of more than 127 terms does not fit the byte the lean passes keep its terms in (here: 140 parallel
+    arcs between two states, so both a forward and a backward position are crowded while every arc is short): the
+    lattice takes the general passes, its neighbours stay lean, the streams are the general passes' own."""
+    rng = np.random.RandomState(3)
+    S = 100
+    src = np.concatenate([np.arange(50), np.full(140, 50), np.arange(51, S - 1)]).astype(np.int32)
+    dst = (src + 1).astype(np.int32)
+    A = len(src)
+    tm = np.arange(S, dtype=np.int32)
+    fin = np.full(S, np.inf, np.float32)
+    fin0 = fin.copy()
+    fin0[S - 1] = 0.0
+    one = {"state_off": np.array([0, S], np.int64), "arc_off": np.array([0, A], np.int64), "src": src, "dst": dst,
+           "ilabel": rng.randint(0, 20, A).astype(np.int32), "graph": (rng.rand(A) * 8).astype(np.float32),
+           "acoustic": (rng.rand(A) * 40).astype(np.float32), "final_graph": fin0, "final_acoustic": fin0.copy(), "state_time": tm}
+    one["olabel"] = one["ilabel"].copy()
+    other = klat_amd.synth(9, np.array([80, 300, 41], np.int32), np.array([3, 2, 4], np.int32))
+    a = {}
+    for k in one:
+        if k in ("state_off", "arc_off"):
+            a[k] = np.concatenate([other[k], other[k][-1] + one[k][1:]])
+        else:
+            a[k] = np.concatenate([other[k], one[k]])
+    for kw in ({"lanes_per_lattice": 4}, {"lanes_per_lattice": 4, "fuse_scales": (1.0, 0.1, 0.0)}, {"lanes_per_lattice": 1, "ring_slots": 16}):
+        ig, sg = _streams(ctx, a, False, **kw)
+        il, sl = _streams(ctx, a, True, **kw)
+        assert ig["fwd_slots"] == il["fwd_slots"] and ig["bwd_slots"] == il["bwd_slots"] and ig["far_terms"] == il["far_terms"]
+        for x, y in zip(sg, sl):
+            assert x.tobytes() == y.tobytes()
+    # and the sweep over it agrees with the oracle's totals through the usual parity path: forward == backward
+    b = klat_amd.Batch(ctx, a, lanes_per_lattice=4)
+    b.forward_backward(1.0, 0.1, 0.0)
+    total, tf, tb = b.totals()
+    b.close()
+    assert np.all(np.isfinite(total)) and float(np.max(np.abs(tf - tb))) < 1e-8
