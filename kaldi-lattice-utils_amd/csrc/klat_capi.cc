@@ -910,22 +910,54 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
                    num_lean, num_known_general, P.jobs.size(), num_general_jobs, num_redo, num_reround);
     // pass 2: the rounds of every state with its lattice's lanes; pass 3: one workgroup per (job, run of tiles)
     std::vector<PackEntry> entries;
-    std::vector<LeanEntry> lentries;  // by lanes per lattice: one launch each
-    int lean_count[2 * kNumLaneChoices] = {0};
-    for (int lg = -1; lg < 2 * kNumLaneChoices; ++lg)  // (the general jobs, then the lean ones by lanes and direction)
-      for (size_t j = 0; j < P.jobs.size(); ++j) {
-        int jlg = 0;
-        while ((1 << jlg) < job_lanes(P.jobs[j].tag)) ++jlg;
-        if (job_general[j] ? lg != -1 : lg != 2 * jlg + (P.jobs[j].dir ? 1 : 0)) continue;
-        const int ntiles = P.jobs[j].nchunks * kChunkRounds / kPackTileRounds;
-        for (int t = 0; t < ntiles; t += kPackTilesPerGroup) {
-          const int nt = std::min(kPackTilesPerGroup, ntiles - t);
-          if (job_general[j])
-            entries.push_back(PackEntry{(int32_t)j, t, nt, 0});
-          else
-            lentries.push_back(LeanEntry{P.jobs[j].chunk_off, P.jobs[j].lane_tab, P.jobs[j].tag, P.jobs[j].dir, t, nt, (int32_t)j}), ++lean_count[lg];
+    // The lean jobs' entries by lanes per lattice; within a lane count a group's forward and backward job side by side --
+    // forward run i next to the backward run over the same states -- so that the group's arcs come from HBM once and
+    // from the caches the second time (one launch); jobs without such a partner by direction (a launch each).
+    std::vector<LeanEntry> lentries;
+    int lean_count[3 * kNumLaneChoices] = {0};
+    {
+      const char* pair_env = std::getenv("KLAT_FILL_PAIR");
+      const bool pairing = !(pair_env && std::atoi(pair_env) == 0);
+      std::vector<int32_t> partner(P.jobs.size(), -1);
+      if (pairing) {
+        std::vector<int32_t> bwd_of((size_t)U, -1);
+        for (size_t j = 0; j < P.jobs.size(); ++j)
+          if (!job_general[j] && P.jobs[j].dir == 1 && !job_lats[j].empty()) bwd_of[(size_t)job_lats[j][0]] = (int32_t)j;
+        for (size_t j = 0; j < P.jobs.size(); ++j) {
+          if (job_general[j] || P.jobs[j].dir != 0 || job_lats[j].empty()) continue;
+          const int32_t k = bwd_of[(size_t)job_lats[j][0]];
+          if (k >= 0 && job_lats[(size_t)k] == job_lats[j] && job_lanes(P.jobs[(size_t)k].tag) == job_lanes(P.jobs[j].tag)) partner[j] = k, partner[(size_t)k] = (int32_t)j;
         }
       }
+      auto runs_of = [&](size_t j) { return (P.jobs[j].nchunks * kChunkRounds / kPackTileRounds + kLeanTilesPerGroup - 1) / kLeanTilesPerGroup; };
+      auto push = [&](size_t j, int run, int slot) {
+        const int ntiles = P.jobs[j].nchunks * kChunkRounds / kPackTileRounds, t = run * kLeanTilesPerGroup;
+        lentries.push_back(LeanEntry{P.jobs[j].chunk_off, P.jobs[j].lane_tab, P.jobs[j].tag, P.jobs[j].dir, t, std::min(kLeanTilesPerGroup, ntiles - t), (int32_t)j});
+        ++lean_count[slot];
+      };
+      for (int lg = 0; lg < kNumLaneChoices; ++lg)
+        for (int kind = 0; kind < 3; ++kind)
+          for (size_t j = 0; j < P.jobs.size(); ++j) {
+            if (job_general[j] || job_lanes(P.jobs[j].tag) != (1 << lg)) continue;
+            if (kind < 2) {
+              if (partner[j] >= 0 || P.jobs[j].dir != kind) continue;
+              for (int r = 0; r < runs_of(j); ++r) push(j, r, 3 * lg + kind);
+            } else {
+              if (partner[j] < 0 || P.jobs[j].dir != 0) continue;
+              const size_t k = (size_t)partner[j];
+              const int nf = runs_of(j), nb = runs_of(k);
+              for (int r = 0; r < std::max(nf, nb); ++r) {
+                if (r < nf) push(j, r, 3 * lg + 2);
+                if (r < nb) push(k, nb - 1 - r, 3 * lg + 2);
+              }
+            }
+          }
+    }
+    for (size_t j = 0; j < P.jobs.size(); ++j) {
+      if (!job_general[j]) continue;
+      const int ntiles = P.jobs[j].nchunks * kChunkRounds / kPackTileRounds;
+      for (int t = 0; t < ntiles; t += kPackTilesPerGroup) entries.push_back(PackEntry{(int32_t)j, t, std::min(kPackTilesPerGroup, ntiles - t), 0});
+    }
     lap("entries");
     const size_t nslots = (size_t)chunk_total * kChunkRounds;  // chunk_total counts 16-byte units
     AL(sw, nslots);

@@ -236,17 +236,30 @@ int64_t slice_jobs(const int64_t* state_off, const LatticeRounds* lr, const std:
     std::vector<int64_t> lat;
   };
   std::vector<ProtoJob> proto;
+  // (ONE order for both directions -- by the rounds of the two streams together -- so that a group of lattices has a
+  // forward and a backward job over the same lattices: the stream packer's fill pass then writes a group's two jobs
+  // side by side and reads the group's arcs from HBM once, the second time from the Infinity Cache.  Sorted by each
+  // direction's own rounds the jobs were a little tighter where a lattice's two streams differ much in length.)
   std::vector<uint64_t> keys(members.size()), keys_tmp;
+  for (size_t i = 0; i < members.size(); ++i) keys[i] = ((uint64_t)(0x7FFFFFFF - (rf[members[i]] + rb[members[i]]) / 2) << 32) | (uint64_t)i;
+  radix_sort_high32(&keys, &keys_tmp);
+  static const bool own_order = std::getenv("KLAT_JOB_ORDER_OWN") != nullptr;  // (A/B: every direction sorted by its own rounds, as until round 5)
   for (int dir = 0; dir < 2; ++dir) {
     const std::vector<int64_t>& r = dir ? rb : rf;
-    for (size_t i = 0; i < members.size(); ++i) keys[i] = ((uint64_t)(0x7FFFFFFF - r[members[i]]) << 32) | (uint64_t)i;
-    radix_sort_high32(&keys, &keys_tmp);
+    if (own_order) {
+      for (size_t i = 0; i < members.size(); ++i) keys[i] = ((uint64_t)(0x7FFFFFFF - r[members[i]]) << 32) | (uint64_t)i;
+      radix_sort_high32(&keys, &keys_tmp);
+    }
     for (size_t i = 0; i < keys.size(); i += LPW) {
       ProtoJob pj;
       pj.dir = dir;
-      pj.rounds = r[members[(size_t)(keys[i] & 0xFFFFFFFFu)]];
+      pj.rounds = 0;
       pj.lat.reserve(LPW);
-      for (size_t j = i; j < std::min(keys.size(), i + (size_t)LPW); ++j) pj.lat.push_back(members[(size_t)(keys[j] & 0xFFFFFFFFu)]);
+      for (size_t j = i; j < std::min(keys.size(), i + (size_t)LPW); ++j) {
+        const int64_t u = members[(size_t)(keys[j] & 0xFFFFFFFFu)];
+        pj.lat.push_back(u);
+        pj.rounds = std::max(pj.rounds, r[u]);
+      }
       proto.push_back(std::move(pj));
     }
   }

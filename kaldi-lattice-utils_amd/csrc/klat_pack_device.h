@@ -42,6 +42,11 @@ __host__ __device__ static inline int pack_lean_lds_bytes(int64_t S, int64_t A) 
 // A forward tile of the lean fill pass reads the arcs of `longest arc` more states than it holds positions.
 static constexpr int kPackLeanMaxSpan = 64;
 
+// tiles one workgroup of pack_fill_lean_kernel writes (C2 fill, ms: 4 tiles 0.856, 8: 0.817, 16: 0.798, 24: 0.866, 36: 0.912)
+#ifndef KLAT_LEAN_TILES_PER_GROUP
+#define KLAT_LEAN_TILES_PER_GROUP 16
+#endif
+static constexpr int kLeanTilesPerGroup = KLAT_LEAN_TILES_PER_GROUP;
 // one workgroup of pack_fill_lean_kernel: tiles [tile_begin, tile_begin + tile_count) of a job, with what it needs of the job
 struct LeanEntry {
   int64_t chunk_off;
@@ -101,7 +106,7 @@ hipError_t launch_pack_maxcost(const PackDevArgs& a, int64_t num_arcs, int64_t n
 // for a.lat_g_pred; class_need over kPackLeanClassLds), the prefix sums again for a.reround, fill over a.lentries.
 hipError_t launch_pack_count_lean(const PackDevArgs& a, int num_lattices, const int class_need[kPackLeanClasses], hipStream_t stream);
 hipError_t launch_pack_rounds_lean(const PackDevArgs& a, int num_lattices, hipStream_t stream);
-hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[2 * kNumLaneChoices] /* entries per (log2(lanes), direction), a.lentries sorted that way */, hipStream_t stream);
+hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[3 * kNumLaneChoices] /* entries per (log2(lanes), forward | backward | both side by side), a.lentries sorted that way */, hipStream_t stream);
 hipError_t launch_pack_rounds(const PackDevArgs& a, int num_lattices, hipStream_t stream);
 // max_lpw: the most lattices any job holds (64 / its lanes per lattice)
 hipError_t launch_pack_fill(const PackDevArgs& a, int num_entries, int max_lpw, hipStream_t stream);

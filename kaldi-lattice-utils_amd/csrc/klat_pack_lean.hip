@@ -509,31 +509,49 @@ __global__ __launch_bounds__(kTL) void pack_rounds_lean_kernel(PackDevArgs a) {
 // ---- fill ----
 constexpr int kTR = kPackTileRounds;  // 32 rounds a tile
 constexpr int kWinL = kTR + 2;        // positions a tile can hold, per lattice, and one behind them
-constexpr int kMaxTiles = kPackTilesPerGroup;
+constexpr int kMaxTiles = kLeanTilesPerGroup;
 
 // Everything that depends on the lanes per lattice is a compile-time constant (one instantiation per lane count: the
 // first version, with the lane count in registers, wanted 217 VGPRs and spent its time in scratch memory).
-template <int LG, bool FUSED, bool FWD>
 #ifndef KLAT_FILL_LEAN_Q
 #define KLAT_FILL_LEAN_Q 2  // quads of arcs a thread has in flight
 #endif
 #ifndef KLAT_FILL_LEAN_WAVES
 #define KLAT_FILL_LEAN_WAVES 4
 #endif
-__global__ __launch_bounds__(kTL, KLAT_FILL_LEAN_WAVES) void pack_fill_lean_kernel(PackDevArgs a, int entry0) {
+// what a workgroup of the fill pass keeps in LDS
+template <int LG, bool FUSED>
+struct FillLds {
+  static constexpr int LPW = 64 >> LG;
+  __attribute__((aligned(16))) uint32_t tw[kTR * 64];
+  __attribute__((aligned(16))) float tg[kTR * 64];
+  __attribute__((aligned(16))) float ta[FUSED ? 4 : kTR * 64];
+  __attribute__((aligned(16))) int16_t tl[FUSED ? kTR * 64 : 8];  // the residuals
+  int32_t win[LPW * kWinL];
+  int32_t tp[LPW * (kMaxTiles + 1)];
+  int64_t s0[LPW];
+  int q0[LPW], S[LPW], lat[LPW], span[LPW];
+  int finals;  // some lattice's forward position S (its final weights) has a round in the tile
+};
+
+// one entry: tiles [tile_begin, tile_begin + tile_count) of a job
+template <int LG, bool FUSED, bool FWD>
+__device__ __forceinline__ void fill_lean_run(const PackDevArgs& a, const LeanEntry& e, FillLds<LG, FUSED>& lds) {
   constexpr int G = 1 << LG, LPW = 64 >> LG, GMASK = G - 1;
   constexpr int LG_TPS = LG + 2, TPS = 1 << LG_TPS;  // threads a lattice has to itself: kTL / LPW
   constexpr int kWinPerThread = (LPW * kWinL + kTL - 1) / kTL;
-  __shared__ __attribute__((aligned(16))) uint32_t tw[kTR * 64];
-  __shared__ __attribute__((aligned(16))) float tg[kTR * 64];
-  __shared__ __attribute__((aligned(16))) float ta[FUSED ? 4 : kTR * 64];
-  __shared__ __attribute__((aligned(16))) int16_t tl[FUSED ? kTR * 64 : 8];  // the residuals
-  __shared__ int32_t win[LPW * kWinL];
-  __shared__ int32_t sh_tp[LPW * (kMaxTiles + 1)];
-  __shared__ int64_t sh_s0[LPW];
-  __shared__ int sh_q0[LPW], sh_S[LPW], sh_lat[LPW], sh_span[LPW];
-  __shared__ int sh_finals;  // some lattice's forward position S (its final weights) has a round in the tile
-  const LeanEntry e = a.lentries[entry0 + blockIdx.x];
+  uint32_t* const tw = lds.tw;
+  float* const tg = lds.tg;
+  float* const ta = lds.ta;
+  int16_t* const tl = lds.tl;
+  int32_t* const win = lds.win;
+  int32_t* const sh_tp = lds.tp;
+  int64_t* const sh_s0 = lds.s0;
+  int* const sh_q0 = lds.q0;
+  int* const sh_S = lds.S;
+  int* const sh_lat = lds.lat;
+  int* const sh_span = lds.span;
+  int& sh_finals = lds.finals;
   const int W = job_ring(e.tag), AL = job_stored_lanes(e.tag);
   const int tid = threadIdx.x;
   constexpr bool fwd = FWD;
@@ -827,12 +845,24 @@ __global__ __launch_bounds__(kTL, KLAT_FILL_LEAN_WAVES) void pack_fill_lean_kern
     STAMP(7);
   }
 #ifdef KLAT_FILL_PROFILE
-  if (a.prof && tid == 0)
+  if (a.prof && threadIdx.x == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&a.prof[(fwd ? 8 : 16) + i], pc[i]);
 #endif
 #undef STAMP
   for (int d = 32; d > 0; d >>= 1) nfar += __shfl_xor(nfar, d, 64);
   if ((tid & 63) == 0 && nfar) atomicAdd(&a.status[3], nfar);
+}
+
+// DIRS: 0 the entries are forward jobs', 1 backward jobs', 2 either (the entry says: a workgroup-uniform branch; the two
+// directions of one group of lattices dispatched next to each other read the same arcs within microseconds of each other)
+template <int LG, bool FUSED, int DIRS>
+__global__ __launch_bounds__(kTL, KLAT_FILL_LEAN_WAVES) void pack_fill_lean_kernel(PackDevArgs a, int entry0) {
+  __shared__ FillLds<LG, FUSED> lds;
+  const LeanEntry e = a.lentries[entry0 + blockIdx.x];
+  if (DIRS == 0 || (DIRS == 2 && e.dir == 0))
+    fill_lean_run<LG, FUSED, true>(a, e, lds);
+  else
+    fill_lean_run<LG, FUSED, false>(a, e, lds);
 }
 
 }  // namespace
@@ -867,35 +897,36 @@ hipError_t launch_pack_rounds_lean(const PackDevArgs& a, int num_lattices, hipSt
 
 namespace {
 template <int LG>
-void launch_fill_lean_lg(const PackDevArgs& a, bool fwd, int entry0, int count, hipStream_t stream) {
+void launch_fill_lean_lg(const PackDevArgs& a, int dirs, int entry0, int count, hipStream_t stream) {
   if (count <= 0) return;
+#define KLAT_FILL_LAUNCH(FUSED, DIRS) hipLaunchKernelGGL((pack_fill_lean_kernel<LG, FUSED, DIRS>), dim3(count), dim3(kTL), 0, stream, a, entry0)
   if (a.fused) {
-    if (fwd)
-      hipLaunchKernelGGL((pack_fill_lean_kernel<LG, true, true>), dim3(count), dim3(kTL), 0, stream, a, entry0);
-    else
-      hipLaunchKernelGGL((pack_fill_lean_kernel<LG, true, false>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+    if (dirs == 0) KLAT_FILL_LAUNCH(true, 0);
+    else if (dirs == 1) KLAT_FILL_LAUNCH(true, 1);
+    else KLAT_FILL_LAUNCH(true, 2);
   } else {
-    if (fwd)
-      hipLaunchKernelGGL((pack_fill_lean_kernel<LG, false, true>), dim3(count), dim3(kTL), 0, stream, a, entry0);
-    else
-      hipLaunchKernelGGL((pack_fill_lean_kernel<LG, false, false>), dim3(count), dim3(kTL), 0, stream, a, entry0);
+    if (dirs == 0) KLAT_FILL_LAUNCH(false, 0);
+    else if (dirs == 1) KLAT_FILL_LAUNCH(false, 1);
+    else KLAT_FILL_LAUNCH(false, 2);
   }
+#undef KLAT_FILL_LAUNCH
 }
 }  // namespace
 
-// entries sorted by lanes per lattice, then by direction: count[2 lg + dir] of them for 2^lg lanes, one launch each
-hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[2 * kNumLaneChoices], hipStream_t stream) {
+// a.lentries sorted by lanes per lattice; within a lane count either by direction (count[3 lg + 0 / 1]: one launch each)
+// or the two directions of a group of lattices next to each other (count[3 lg + 2]: one launch)
+hipError_t launch_pack_fill_lean(const PackDevArgs& a, const int count[3 * kNumLaneChoices], hipStream_t stream) {
   int at = 0;
-  for (int c = 0; c < 2 * kNumLaneChoices; ++c) {
-    const bool fwd = (c & 1) == 0;
-    switch (c >> 1) {
-      case 0: launch_fill_lean_lg<0>(a, fwd, at, count[c], stream); break;
-      case 1: launch_fill_lean_lg<1>(a, fwd, at, count[c], stream); break;
-      case 2: launch_fill_lean_lg<2>(a, fwd, at, count[c], stream); break;
-      case 3: launch_fill_lean_lg<3>(a, fwd, at, count[c], stream); break;
-      case 4: launch_fill_lean_lg<4>(a, fwd, at, count[c], stream); break;
-      case 5: launch_fill_lean_lg<5>(a, fwd, at, count[c], stream); break;
-      default: launch_fill_lean_lg<6>(a, fwd, at, count[c], stream); break;
+  for (int c = 0; c < 3 * kNumLaneChoices; ++c) {
+    const int dirs = c % 3;
+    switch (c / 3) {
+      case 0: launch_fill_lean_lg<0>(a, dirs, at, count[c], stream); break;
+      case 1: launch_fill_lean_lg<1>(a, dirs, at, count[c], stream); break;
+      case 2: launch_fill_lean_lg<2>(a, dirs, at, count[c], stream); break;
+      case 3: launch_fill_lean_lg<3>(a, dirs, at, count[c], stream); break;
+      case 4: launch_fill_lean_lg<4>(a, dirs, at, count[c], stream); break;
+      case 5: launch_fill_lean_lg<5>(a, dirs, at, count[c], stream); break;
+      default: launch_fill_lean_lg<6>(a, dirs, at, count[c], stream); break;
     }
     at += std::max(count[c], 0);
   }
