@@ -247,20 +247,21 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
   __syncthreads();
   stamp(0);
   // ---- the arcs, four a lane and load
-  const int64_t q0 = a0 >> 2, q1 = (a0 + A + 3) >> 2;
+  const int a0i = (int)a0;  // (a batch has fewer than 2^31 arcs: 32-bit quad numbers; with 64-bit ones every address took four instructions more)
+  const int q0 = a0i >> 2, q1 = (a0i + A + 3) >> 2;
   constexpr int kUn = 3;  // quads a thread has in flight
   float mc = 0.0f;
-  int span = 1;
-  for (int64_t qb = q0 + tid; qb < q1; qb += T * kUn) {
+  int span = 1, bad = 0;
+  for (int qb = q0 + tid; qb < q1; qb += T * kUn) {
     int4 vs[kUn], vd[kUn], vi[kUn];
     float4 vg[kUn], va[kUn];
     int vp[kUn];
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = min(qb + x * T, q1 - 1);
+      const int q = min(qb + x * T, q1 - 1);
       vs[x] = load_quad<int4>(a.src, q, a.num_arcs);
       vd[x] = load_quad<int4>(a.dst, q, a.num_arcs);
-      vp[x] = 4 * q > a0 ? a.src[4 * q - 1] : 0;
+      vp[x] = 4 * q > a0i ? a.src[4 * q - 1] : 0;
       if (a.fold_maxcost) {
         vg[x] = load_quad<float4>(a.graph, q, a.num_arcs);
         va[x] = load_quad<float4>(a.acoustic, q, a.num_arcs);
@@ -269,27 +270,34 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
     }
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = qb + x * T;
+      const int q = qb + x * T;
       if (q >= q1) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = (int)(4 * q + e - a0);
-        if (i < 0 || i >= A) continue;  // (a neighbouring lattice's arc)
+        const int i = 4 * q + e - a0i;
         const int s = elem(vs[x], e), t = elem(vd[x], e);
         const int prev = e == 0 ? vp[x] : elem(vs[x], e - 1);
-        if (s < 0 || s >= S || (i > 0 && s < prev)) {
-          atomicMax(&sh_bad, 2);  // malformed CSR
-        } else if (t <= s || t >= S) {
-          atomicMax(&sh_bad, 1);  // not topologically sorted
-        } else {
+        // (the tests as masks, the verdict in a register: nested branches with an LDS atomic in each cost every arc
+        // a dozen scalar instructions)
+        const bool mine = (unsigned)i < (unsigned)A;  // (else: a neighbouring lattice's arc)
+        const bool ok_s = (unsigned)s < (unsigned)S && (i == 0 || s >= prev);  // else: malformed CSR
+        const bool ok_t = t > s && t < S;                                      // else: not topologically sorted
+        if (mine && !(ok_s && ok_t)) bad = max(bad, ok_s ? 1 : 2);
+        if (mine && ok_s && ok_t) {
           atomicAdd(&indeg[t], 1);
           const int rel = t - s;
           span = max(span, rel);
           relb[i] = (uint8_t)min(rel, 255);
           if (rel == 1) atomicOr(&link[s >> 5], 1u << (s & 31));
-          // arc i is the first out-arc of every state behind its predecessor's source up to its own (the predecessor may be
-          // the malformed arc this pass exists to reject: its source below zero must not move the fill before the table)
-          for (int qq = (i > 0 ? max(prev, -1) + 1 : 0); qq <= s; ++qq) row[qq] = (uint16_t)i;
+          // arc i is the first out-arc of every state behind its predecessor's source up to its own: its own state, and
+          // -- rarely -- states without arcs before it (the predecessor may be the malformed arc this pass exists to
+          // reject: its source below zero must not move the fill before the table).  (Written as one loop hipcc made a
+          // vectorised 128-bit fill of it with three levels of remainder loops: forty instructions for a trip count of one.)
+          if (i == 0 || s != prev) {
+            row[s] = (uint16_t)i;
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int qq = (i > 0 ? max(prev, -1) + 1 : 0); qq < s; ++qq) row[qq] = (uint16_t)i;
+          }
           if (a.fold_maxcost) {
             const float c = arc_cost_abs_f(elem(vg[x], e), elem(va[x], e), a.fsp.penalized ? elem(vi[x], e) != 0 : false, a.fsp);
             if (c < 1.0e30f) mc = fmaxf(mc, c);
@@ -318,6 +326,7 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
       }
     }
   }
+  if (bad) atomicMax(&sh_bad, bad);
   for (int d = 32; d > 0; d >>= 1) span = max(span, __shfl_xor(span, d, 64));
   if ((tid & 63) == 0) atomicMax(&sh_span, span);
   if (a.fold_maxcost) {  // (whatever becomes of the lattice below: the batch's largest cost covers every lattice)
@@ -398,17 +407,17 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
   if (sh_unfit) return;
   stamp(4);
   // ---- counting sort of the arcs by destination, in LDS: where an arc stands among the in-arcs of its destination
-  for (int64_t qb = q0 + tid; qb < q1; qb += T * kUn) {
+  for (int qb = q0 + tid; qb < q1; qb += T * kUn) {
     int4 vd[kUn];
 #pragma unroll
     for (int x = 0; x < kUn; ++x) vd[x] = load_quad<int4>(a.dst, min(qb + x * T, q1 - 1), a.num_arcs);
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = qb + x * T;
+      const int q = qb + x * T;
       if (q >= q1) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = (int)(4 * q + e - a0);
+        const int i = 4 * q + e - a0i;
         if (i < 0 || i >= A) continue;
         bucket[atomicAdd(&indeg[elem(vd[x], e)], 1)] = (uint16_t)i;
       }
@@ -418,23 +427,23 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
   stamp(5);
   // ---- meta: length | place among the destination's in-arcs (by arc number) << 8 | place among the source's out-arcs
   // (farthest destination first, equal destinations by arc number) << 16 | word << 24
-  for (int64_t qb = q0 + tid; qb < q1; qb += T * kUn) {
+  for (int qb = q0 + tid; qb < q1; qb += T * kUn) {
     int4 vs[kUn], vd[kUn], vi[kUn];
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = min(qb + x * T, q1 - 1);
+      const int q = min(qb + x * T, q1 - 1);
       vs[x] = load_quad<int4>(a.src, q, a.num_arcs);
       vd[x] = load_quad<int4>(a.dst, q, a.num_arcs);
       vi[x] = load_quad<int4>(a.ilabel, q, a.num_arcs);
     }
 #pragma unroll
     for (int x = 0; x < kUn; ++x) {
-      const int64_t q = qb + x * T;
+      const int q = qb + x * T;
       if (q >= q1) continue;
       uint32_t m[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = (int)(4 * q + e - a0);
+        const int i = 4 * q + e - a0i;
         m[e] = 0;
         if (i < 0 || i >= A) continue;
         const int s = elem(vs[x], e), t = elem(vd[x], e), rel = t - s;
@@ -446,6 +455,7 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
           for (int z = 0; z < 4; ++z) b4[z] = bucket[min(yb + z, ye - 1)];
 #pragma unroll
           for (int z = 0; z < 4; ++z) jr += (yb + z < ye && b4[z] < i) ? 1 : 0;
+#pragma clang loop vectorize(disable) unroll(disable)
           for (int y = yb + 4; y < ye; ++y) jr += (int)bucket[y] < i ? 1 : 0;
           const int rb = row[s], re = row[s + 1];
           int r4[4];
@@ -453,6 +463,7 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
           for (int z = 0; z < 4; ++z) r4[z] = relb[min(rb + z, re - 1)];
 #pragma unroll
           for (int z = 0; z < 4; ++z) orank += (rb + z < re && (r4[z] > rel || (r4[z] == rel && rb + z < i))) ? 1 : 0;
+#pragma clang loop vectorize(disable) unroll(disable)
           for (int y = rb + 4; y < re; ++y) {
             const int ry = relb[y];
             orank += (ry > rel || (ry == rel && y < i)) ? 1 : 0;
@@ -460,12 +471,12 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
         }
         m[e] = (uint32_t)rel | ((uint32_t)jr << 8) | ((uint32_t)orank << 16) | (elem(vi[x], e) != 0 ? 1u << 24 : 0u);
       }
-      if (4 * q >= a0 && 4 * q + 4 <= a0 + A) {
+      if (4 * q >= a0i && 4 * q + 4 <= a0i + A) {
         reinterpret_cast<uint4*>(a.meta)[q] = make_uint4(m[0], m[1], m[2], m[3]);
       } else {  // (a quad shared with a neighbouring lattice)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (4 * q + e >= a0 && 4 * q + e < a0 + A) a.meta[4 * q + e] = m[e];
+          if (4 * q + e >= a0i && 4 * q + e < a0i + A) a.meta[4 * q + e] = m[e];
       }
     }
   }
