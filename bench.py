@@ -333,7 +333,7 @@ def one_shot_leg(klat_amd, torch, ctx, arrays, A, reps=5):
 
 
 C4 = {"lattices": 100000, "states": 5000, "fanout": 3, "seed": 20260003}  # BASELINE configs[3], north_star's scaling target
-STRONG_REFERENCE = os.path.join("profiles", "r04_strong_c4_1gpu.json")   # this leg at N = 1, taken on a box of the same pool
+STRONG_REFERENCE = os.path.join("profiles", "r05_strong_c4_1gpu.json")   # this leg at N = 1, taken on a box of the same pool
 
 
 def strong_c4_leg(klat_amd, torch, dist, ctx, comm, rank, world, host_threads, barrier, lattices, reps=3, steps=5, warmup=3):
