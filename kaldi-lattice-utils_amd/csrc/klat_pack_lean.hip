@@ -642,13 +642,16 @@ __device__ __forceinline__ void fill_lean_run(const PackDevArgs& a, const LeanEn
   // the arcs of a tile, four consecutive ones a lane and load: kQ quads a thread in flight
   constexpr int kQ = KLAT_FILL_LEAN_Q;
   const int32_t* ends = fwd ? a.dst : a.src;
+  const int last_quad = a.num_arcs > 0 ? (int)((a.num_arcs - 1) >> 2) : 0;
   int4 ve[kQ];
   uint4 vm[kQ];
   float4 vg[kQ], va[kQ];
   auto ask_arcs = [&](int qb, int qlo, int qhi) {
 #pragma unroll
     for (int x = 0; x < kQ; ++x) {
-      const int q = max(min(qb + x * TPS, qhi - 1), qlo);
+      // (a lane without a quad reads the lattice's first again; never past the batch's last quad: a tile without arcs at
+      // the end of the batch's last lattice starts AT the arrays' end, and borrowed arrays end there)
+      const int q = min(max(min(qb + x * TPS, qhi - 1), qlo), last_quad);
       ve[x] = reinterpret_cast<const int4*>(ends)[q];
       vm[x] = reinterpret_cast<const uint4*>(a.meta)[q];
       vg[x] = reinterpret_cast<const float4*>(a.graph)[q];
