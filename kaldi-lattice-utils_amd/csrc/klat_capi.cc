@@ -929,10 +929,12 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
           if (k >= 0 && job_lats[(size_t)k] == job_lats[j] && job_lanes(P.jobs[(size_t)k].tag) == job_lanes(P.jobs[j].tag)) partner[j] = k, partner[(size_t)k] = (int32_t)j;
         }
       }
-      auto runs_of = [&](size_t j) { return (P.jobs[j].nchunks * kChunkRounds / kPackTileRounds + kLeanTilesPerGroup - 1) / kLeanTilesPerGroup; };
+      auto tiles_of = [&](size_t j) { return (P.jobs[j].nchunks * kChunkRounds + kLeanTileRounds - 1) / kLeanTileRounds; };
+      auto runs_of = [&](size_t j) { return (tiles_of(j) + kLeanTilesPerGroup - 1) / kLeanTilesPerGroup; };
       auto push = [&](size_t j, int run, int slot) {
-        const int ntiles = P.jobs[j].nchunks * kChunkRounds / kPackTileRounds, t = run * kLeanTilesPerGroup;
-        lentries.push_back(LeanEntry{P.jobs[j].chunk_off, P.jobs[j].lane_tab, P.jobs[j].tag, P.jobs[j].dir, t, std::min(kLeanTilesPerGroup, ntiles - t), (int32_t)j});
+        const int ntiles = tiles_of(j), t = run * kLeanTilesPerGroup;
+        lentries.push_back(LeanEntry{P.jobs[j].chunk_off, P.jobs[j].lane_tab, P.jobs[j].tag, P.jobs[j].dir, t, std::min(kLeanTilesPerGroup, ntiles - t), (int32_t)j,
+                                     P.jobs[j].nchunks * kChunkRounds, 0});
         ++lean_count[slot];
       };
       for (int lg = 0; lg < kNumLaneChoices; ++lg)

@@ -47,10 +47,17 @@ static constexpr int kPackLeanMaxSpan = 64;
 #define KLAT_LEAN_TILES_PER_GROUP 16
 #endif
 static constexpr int kLeanTilesPerGroup = KLAT_LEAN_TILES_PER_GROUP;
+// rounds of a tile of the lean fill pass: kPackTileRounds (32) or twice that
+#ifndef KLAT_LEAN_TILE_ROUNDS
+#define KLAT_LEAN_TILE_ROUNDS 32
+#endif
+static constexpr int kLeanTileRounds = KLAT_LEAN_TILE_ROUNDS;
+static_assert(kLeanTileRounds % kPackTileRounds == 0, "the tile tables hold a position per kPackTileRounds rounds");
 // one workgroup of pack_fill_lean_kernel: tiles [tile_begin, tile_begin + tile_count) of a job, with what it needs of the job
 struct LeanEntry {
   int64_t chunk_off;
   int32_t lane_tab, tag, dir, tile_begin, tile_count, job;
+  int32_t rounds, pad;  // the job's rounds (a multiple of kPackTileRounds: its last tile may be a short one)
 };
 
 struct PackDevArgs {

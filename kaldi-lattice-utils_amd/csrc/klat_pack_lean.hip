@@ -518,7 +518,7 @@ __global__ __launch_bounds__(kTL) void pack_rounds_lean_kernel(PackDevArgs a) {
 }
 
 // ---- fill ----
-constexpr int kTR = kPackTileRounds;  // 32 rounds a tile
+constexpr int kTR = kLeanTileRounds;  // rounds a tile
 constexpr int kWinL = kTR + 2;        // positions a tile can hold, per lattice, and one behind them
 constexpr int kMaxTiles = kLeanTilesPerGroup;
 
@@ -603,8 +603,8 @@ __device__ __forceinline__ void fill_lean_run(const PackDevArgs& a, const LeanEn
       const int S = sh_S[k], P = fwd ? S + 1 : S;
       const int64_t sb = sh_s0[k] + 2 * (int64_t)u;
       const int total = rtab[sb + P];
-      const int m = e.tile_begin + t;
-      p = m * kTR < total ? (fwd ? a.tpf : a.tpb)[tile_row(sh_s0[k], u) + m] : P;
+      const int m = (e.tile_begin + t) * (kTR / kPackTileRounds);  // (the tables hold a position per kPackTileRounds rounds)
+      p = m * kPackTileRounds < total ? (fwd ? a.tpf : a.tpb)[tile_row(sh_s0[k], u) + m] : P;
     }
     sh_tp[k * (kMaxTiles + 1) + t] = p;
   }
@@ -664,6 +664,7 @@ __device__ __forceinline__ void fill_lean_run(const PackDevArgs& a, const LeanEn
   STAMP(0);
   for (int t = 0; t < e.tile_count; ++t) {
     const int R0 = (e.tile_begin + t) * kTR;
+    const int tile_units = (min(kTR, e.rounds - R0) >> 2) * row_units;  // 16-byte units of the tile (the job's last may be a short one)
     // ---- the window into LDS; padding everywhere (zero-weight terms that park their unused result in the lattice's
     // dummy cell behind the ring)
 #pragma unroll
@@ -675,7 +676,7 @@ __device__ __forceinline__ void fill_lean_run(const PackDevArgs& a, const LeanEn
     const int alo = nalo, ahi = nahi;
     if (tid == 0) sh_finals = 0;  // (the threads below are in the same wave: they set it after this)
     if (fwd && tid < LPW && sh_lat[tid] >= 0 && sh_tp[tid * (kMaxTiles + 1) + t] <= sh_S[tid] && sh_tp[tid * (kMaxTiles + 1) + t + 1] >= sh_S[tid]) sh_finals = 1;
-    for (int i = tid; i < 8 * row_units; i += kTL) {  // one 16-byte unit (4 rounds of a lane) per store
+    for (int i = tid; i < tile_units; i += kTL) {  // one 16-byte unit (4 rounds of a lane) per store
       const int slot = i & (LPW - 1);  // unit = lane * LPW + slot, a row is a whole number of lanes
       const uint32_t w = kNil | ((uint32_t)(W * LPW + slot) << kWrShift);
       reinterpret_cast<uint4*>(tw)[i] = make_uint4(w, w, w, w);
@@ -839,7 +840,7 @@ __device__ __forceinline__ void fill_lean_run(const PackDevArgs& a, const LeanEn
       if (FUSED) {  // the residuals: four 16-bit words per unit
         int2* gl = reinterpret_cast<int2*>(a.sl + base);
         const int2* ll = reinterpret_cast<const int2*>(tl);
-        for (int i = tid; i < 8 * row_units; i += kTL) {
+        for (int i = tid; i < tile_units; i += kTL) {
           gw[i] = lw[i];
           gg[i] = lg4[i];
           gl[i] = ll[i];
@@ -847,7 +848,7 @@ __device__ __forceinline__ void fill_lean_run(const PackDevArgs& a, const LeanEn
       } else {
         float4* ga = reinterpret_cast<float4*>(a.sa + base);
         const float4* la = reinterpret_cast<const float4*>(ta);
-        for (int i = tid; i < 8 * row_units; i += kTL) {
+        for (int i = tid; i < tile_units; i += kTL) {
           gw[i] = lw[i];
           gg[i] = lg4[i];
           ga[i] = la[i];
