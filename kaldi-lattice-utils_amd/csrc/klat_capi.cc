@@ -583,23 +583,42 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
     int32_t h_status[4] = {0, -1, 1, 0};
     const char* lean_env = std::getenv("KLAT_PACK_LEAN");
     bool lean_enabled = !(lean_env && std::atoi(lean_env) == 0);
+    // Lattices that will be swept in segments (klat_chain.hip) need the general tables: the lean count pass would run
+    // for nothing on them (the configs[4] mix: 1.4 + 1.3 ms of count passes instead of 1.3).  Which lattices those are
+    // is decided from the rounds the count pass reports -- so it is PREDICTED here from rounds estimated off the offsets
+    // (states x ceil(fanout / lanes), arcs assumed short enough), and the predicted ones take the general passes from the
+    // start.  A wrong guess costs time only: a lattice cut after all is counted again by the general pass (`redo`
+    // below), one not cut after all has taken the slower passes.  KLAT_PACK_LEAN=1: no prediction (every lattice lean).
+    std::vector<uint8_t> chain_pred((size_t)U, 0);
     if (lean_enabled && o.lanes_per_lattice == 0 && !(lean_env && std::atoi(lean_env) > 0)) {
-      // A batch that may be swept in segments (klat_chain.hip: its long lattices wait for nobody -- choose_chain_lattices'
-      // first test, known from the offsets) needs the general tables for those lattices: the lean count pass would run
-      // for nothing (the configs[4] mix: 1.4 + 1.3 ms of count passes instead of 1.3).  KLAT_PACK_LEAN=1 insists.
-      const char* chain_env = std::getenv("KLAT_CHAIN");
-      double sum_states = 0, longest = 0;
+      std::vector<LatticeRounds> est((size_t)U);
       for (int64_t u = 0; u < U; ++u) {
-        const double S = (double)(d->state_off[u + 1] - d->state_off[u]);
-        sum_states += S, longest = std::max(longest, S);
+        const int64_t S = d->state_off[u + 1] - d->state_off[u], A = d->arc_off[u + 1] - d->arc_off[u];
+        LatticeRounds& r = est[(size_t)u];
+        std::memset(&r, 0, sizeof(r));
+        const int64_t fan = S > 0 ? (A + S - 1) / S : 0;
+        for (int k = 0; k < kNumLaneChoices; ++k) r.fwd[k] = r.bwd[k] = (int32_t)std::min<int64_t>(0x7FFFFFFF, S * std::max<int64_t>(1, (fan + (1 << k) - 1) >> k));
+        r.max_rel = r.max_span = kChainMaxSpan;
+        r.max_terms = (int32_t)(std::min<int64_t>(fan, 64) | (std::min<int64_t>(fan, 64) << 16));
       }
-      if (!(chain_env && std::atoi(chain_env) == 0) && !(longest * 320.0 < 1.3 * sum_states * 60.0 / 1024.0)) lean_enabled = false;
+      std::vector<uint8_t> none((size_t)U, 0);
+      std::vector<ChainLattice> cl;
+      int seg_len = 0, cc = 0;
+      size_t nrec = 0;
+      choose_chain_lattices(U, d->state_off, d->arc_off, est.data(), o, none.data(), &chain_pred, &cl, &seg_len, &cc, &nrec);
+      // (most of the batch cut: the few lattices left are not worth launches of their own -- the configs[4] mix: 14 lean
+      // jobs beside 298 general ones cost 0.2 ms of small launches -- and the whole batch takes the general passes)
+      int64_t cut_arcs = 0;
+      for (int64_t u = 0; u < U; ++u)
+        if (chain_pred[(size_t)u]) cut_arcs += d->arc_off[u + 1] - d->arc_off[u];
+      if (2 * cut_arcs > A_tot) lean_enabled = false;
     }
     const char* level_env = std::getenv("KLAT_LEVEL");
     const int level_mode = level_env == nullptr ? -1 : std::atoi(level_env);
     const bool plan_levels = o.lanes_per_lattice == 0 && level_mode != 0 && U > 0;
     // which count pass a lattice takes, as far as its sizes tell: the LDS class of its tables
     std::vector<uint8_t> known_general((size_t)U, lean_enabled ? 0 : 1);
+    if (lean_enabled) known_general = chain_pred;
     std::vector<int8_t> pred;
     int lean_need[kPackLeanClasses] = {0, 0, 0};
     size_t num_known_general = lean_enabled ? 0 : (size_t)U, num_lean = 0;
@@ -609,7 +628,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
         const int need = pack_lean_lds_bytes(d->state_off[u + 1] - d->state_off[u], d->arc_off[u + 1] - d->arc_off[u]);
         int k = 0;
         while (k < kPackLeanClasses && need > kPackLeanClassLds[k]) ++k;
-        if (k == kPackLeanClasses)
+        if (k == kPackLeanClasses || known_general[(size_t)u])
           known_general[(size_t)u] = 1, ++num_known_general;
         else
           lean_need[k] = std::max(lean_need[k], need), ++num_lean;
@@ -686,6 +705,14 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       pa.fold_maxcost = b->fused && num_known_general == 0 ? 1 : 0;
     }
     if (b->fused && !pa.fold_maxcost) KLAT_HIP_B(launch_pack_maxcost(pa, A_tot, S_tot, c->stream));
+    // (the flags first: the lean count pass leaves the lattices alone that are known to take the general one)
+    if (num_lean > 0 && num_known_general > 0) {
+      if ((rc = d_only.upload(known_general.data(), known_general.size(), c->stream))) {
+        klat_batch_destroy(b);
+        return rc;
+      }
+      pa.lean_skip = d_only.p;
+    }
     if (num_lean > 0) he = launch_pack_count_lean(pa, (int)U, lean_need, c->stream);
     if (he == hipSuccess && num_known_general > 0) he = general_count(num_lean > 0 ? &known_general : nullptr, &d_only);
     if (he == hipSuccess) he = hipEventRecord(pev[1], c->stream);

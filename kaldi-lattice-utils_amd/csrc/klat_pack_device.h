@@ -96,6 +96,7 @@ struct PackDevArgs {
   uint32_t* meta;            // [A] arc length | place among its destination's in-arcs << 8 | among its source's out-arcs << 16 | word << 24
   int32_t* tpf;              // tile tables: the position that holds round 32 m of lattice u at [(state_off[u] >> 3) + 2 u + m]
   int32_t* tpb;
+  const uint8_t* lean_skip;  // [U] or null: lattices the lean count pass leaves alone whatever their size (they take the general passes)
   uint8_t* lean_ok;          // [U] out: the lean count pass has packed the lattice's tables (0: it is left to the general passes)
   const uint8_t* reround;    // [U] pack_rounds_lean_kernel: the lattices whose lanes are not the expected ones
   int32_t fold_maxcost;      // the lean count pass also finds the batch's largest cost (a.maxcost): no pack_maxcost_kernel

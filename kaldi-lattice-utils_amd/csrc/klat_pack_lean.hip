@@ -213,7 +213,7 @@ __global__ __launch_bounds__(T) void pack_count_lean_kernel(PackDevArgs a, int l
   const int64_t s0 = a.state_off[u], a0 = a.arc_off[u];
   const int S = (int)(a.state_off[u + 1] - s0), A = (int)(a.arc_off[u + 1] - a0);
   const int need = pack_lean_lds_bytes(S, A);
-  if (need <= lds_lo || need > lds_hi) return;  // every lattice belongs to one launch: the narrowest LDS class it fits
+  if (need <= lds_lo || need > lds_hi || (a.lean_skip && a.lean_skip[u])) return;  // every lattice belongs to one launch: the narrowest LDS class it fits
   if (tid < (int)(sizeof(LatticeRounds) / sizeof(int32_t))) reinterpret_cast<int32_t*>(&a.lat_rounds[u])[tid] = 0;
   if (S <= 0) {
     if (tid == 0) {
