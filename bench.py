@@ -117,7 +117,7 @@ def source_hash():
     h = hashlib.sha1()
     d = os.path.join(ROOT, "kaldi-lattice-utils_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cc")):
+        if name.endswith((".hip", ".h")):  # (kernels and the structures they share with the host)
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:12]

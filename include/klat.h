@@ -124,6 +124,9 @@ typedef struct {
   int32_t level_lattices;             /* lattices on the level-synchronous path (wide lattices; no stream job) */
   int32_t chain_lattices;             /* long lattices the log-semiring sweep cuts into segments (klat_chain.hip) */
   int32_t chain_segments;             /* ... and the segments they were cut into */
+  int32_t lean_jobs;                  /* sweep jobs whose streams the lean passes of the stream packer wrote (klat_pack_lean.hip:
+                                         all their lattices have short arcs); num_jobs - lean_jobs took the general passes */
+  int32_t reserved;
 } klat_batch_info;
 
 /* Per-kernel device times of the last klat_forward_backward (HIP events on the ctx stream). */

@@ -1052,7 +1052,7 @@ int klat_batch_create(klat_ctx* c, const klat_batch_desc* d, const klat_pack_opt
       return hip_fail(he, "stream packing (fill pass)");
     }
     lap("entries+rounds+fill+wait");
-    (void)num_general_jobs;
+    b->info.lean_jobs = (int32_t)(P.jobs.size() - num_general_jobs);
     if (pa.prof && !lentries.empty()) {  // (a build with -DKLAT_FILL_PROFILE fills these)
       unsigned long long h[24];
       KLAT_HIP_B(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));

@@ -76,7 +76,8 @@ class BatchInfo(C.Structure):
                 ("bwd_slots", C.c_int64), ("far_terms", C.c_int64),
                 ("lanes_per_lattice", C.c_int32), ("ring_slots", C.c_int32),
                 ("num_jobs", C.c_int32), ("max_rounds", C.c_int32), ("num_layouts", C.c_int32),
-                ("level_lattices", C.c_int32), ("chain_lattices", C.c_int32), ("chain_segments", C.c_int32)]
+                ("level_lattices", C.c_int32), ("chain_lattices", C.c_int32), ("chain_segments", C.c_int32),
+                ("lean_jobs", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

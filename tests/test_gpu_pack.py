@@ -243,3 +243,31 @@ def test_lean_passes_leave_a_crowded_position_to_the_general_ones(ctx):
     total, tf, tb = b.totals()
     b.close()
     assert np.all(np.isfinite(total)) and float(np.max(np.abs(tf - tb))) < 1e-8
+
+
+def test_batch_info_says_which_passes_packed_the_jobs(ctx):
+    """klat_batch_info.lean_jobs: forced either way it is all or nothing; by default a batch with short arcs none of
+    whose lattices is cut in segments is packed by the lean passes entirely, and a cut lattice's jobs are not."""
+    a = klat_amd.synth(20260001, np.full(600, 900, np.int32), np.full(600, 3, np.int32))
+    for env, want in (("1", "all"), ("0", "none"), (None, "by choice")):
+        old = os.environ.pop("KLAT_PACK_LEAN", None)
+        if env is not None:
+            os.environ["KLAT_PACK_LEAN"] = env
+        try:
+            b = klat_amd.Batch(ctx, a)
+            info = b.info()
+            b.close()
+        finally:
+            os.environ.pop("KLAT_PACK_LEAN", None)
+            if old is not None:
+                os.environ["KLAT_PACK_LEAN"] = old
+        assert 0 <= info["lean_jobs"] <= info["num_jobs"]
+        if want == "none":
+            assert info["lean_jobs"] == 0
+        elif want == "all" and info["chain_lattices"] == 0:
+            assert info["lean_jobs"] == info["num_jobs"]
+        elif want == "by choice":
+            if info["chain_lattices"] == 0:
+                assert info["lean_jobs"] == info["num_jobs"], info
+            else:
+                assert info["lean_jobs"] < info["num_jobs"], info

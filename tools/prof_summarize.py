@@ -51,7 +51,7 @@ import subprocess
 h = hashlib.sha1()
 csrc = os.path.join(root, "kaldi-lattice-utils_amd", "csrc")
 for name in sorted(os.listdir(csrc)):
-    if name.endswith((".hip", ".h", ".cc")):
+    if name.endswith((".hip", ".h")):  # (kernels and the structures they share with the host)
         h.update(name.encode())
         h.update(open(os.path.join(csrc, name), "rb").read())
 try:
