@@ -271,3 +271,11 @@ def test_batch_info_says_which_passes_packed_the_jobs(ctx):
                 assert info["lean_jobs"] == info["num_jobs"], info
             else:
                 assert info["lean_jobs"] < info["num_jobs"], info
+
+
+def test_packers_agree_on_random_batches():
+    """tools/pack_lean_fuzz.py, a short run: random sizes, fanouts, arc lengths on both sides of the lean passes' limit,
+    parallel arcs, final states anywhere, dead arcs, fixed and automatic lanes, plain and fused costs."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pack_lean_fuzz.py"), "80", "12345"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "all 80 equal" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
