@@ -18,8 +18,10 @@ arrays = klat_amd.synth(20260004, ns, fo, host_threads=16)
 ctx = klat_amd.Ctx(0)
 scales = (1.0, 0.1, 0.0)
 ref = None
-for label, env in (("streams", {"KLAT_CHAIN": "0"}), ("auto", {}), ("seg128", {"KLAT_CHAIN_SEG": "128"}), ("seg512", {"KLAT_CHAIN_SEG": "512"}),
-                   ("all", {"KLAT_CHAIN": "1"})):
+CASES = [("streams", {"KLAT_CHAIN": "0"}), ("auto", {}), ("seg128", {"KLAT_CHAIN_SEG": "128"}), ("seg512", {"KLAT_CHAIN_SEG": "512"}), ("all", {"KLAT_CHAIN": "1"})]
+if len(sys.argv) > 2:  # segment lengths to scan instead: chain_time.py 2500 64,96,128,160,192,256
+    CASES = [("streams", {"KLAT_CHAIN": "0"})] + [("seg%s" % v, {"KLAT_CHAIN_SEG": v}) for v in sys.argv[2].split(",")]
+for label, env in CASES:
     for k in ("KLAT_CHAIN", "KLAT_CHAIN_SEG"):
         os.environ.pop(k, None)
     os.environ.update(env)
