@@ -109,9 +109,10 @@ hipError_t launch_index_hash2(const AccumArgs& a, const RadixPack& pk, bool posi
 // source states' time within kPieceWindow arcs before every multiple of kPieceStride.  `long_list`: the lattices (device),
 // whose piece slots (a.piece_first, ceil(arcs / kPieceStride) each) the kernel fills; a lattice whose times descend
 // somewhere, or that has no change of time inside a window, keeps piece_count 0 and takes the general kernel.
-// Two shapes: pieces of up to 13 312 + 2 048 arcs for the 1 024 x 15 class (lattices above 16 384 arcs only), or of up to
-// 6 144 + 2 048 arcs for the 512 x 16 class, which every lattice above 8 192 arcs then takes (two workgroups a CU
-// where the 1 024-thread classes run one: index_piece_shape decides, klat_accum_api.cc).
+// Two shapes: pieces of up to 13 312 + 2 048 arcs for the 1 024 x 15 class (lattices above 16 384 arcs only: the default),
+// or of up to 4 096 + 2 048 arcs for the 512 x 12 class, which every lattice above 6 144 arcs then takes (two workgroups
+// a CU where the 1 024-thread classes run one; KLAT_INDEX_PIECES=small -- measured in round 5 and not chosen:
+// klat_accum_api.cc has the figures).
 struct PieceShape {
   int32_t stride, window;  // a cut within `window` arcs before every multiple of `stride`
   int32_t cls;             // the hash kernel's size class of the pieces

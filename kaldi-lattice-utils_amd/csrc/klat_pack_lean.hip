@@ -22,7 +22,8 @@
 //                           word bit) and 12 bytes a state.
 //   pack_rounds_lean_kernel the same prefix sums again for the lattices whose lanes the plan chose otherwise.
 //   pack_fill_lean_kernel   one workgroup per (job, run of tiles), a tile assembled in LDS and stored as whole lines
-//                           like pack_fill_kernel's.  Per tile one round trip for the arcs (destination or source,
+//                           like pack_fill_kernel's; a group's forward and backward job (the same lattices) side by
+//                           side in one launch, so that the group's arcs come from HBM once.  Per tile one round trip for the arcs (destination or source,
 //                           meta, the two costs: 16 bytes an arc, 16-byte loads of consecutive arcs) behind one for
 //                           the positions' first rounds, and the second is asked for a tile ahead.
 //
