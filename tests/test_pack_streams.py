@@ -138,3 +138,22 @@ def test_empty_batch_and_empty_lattice():
     a["arc_off"] = np.array([0, int(a["arc_off"][1]), int(a["arc_off"][1]), int(a["arc_off"][2])], np.int64)
     p = klat_amd.pack_host(a, 2, 8)
     assert set(p["lanes"]["lattice"][p["lanes"]["state_base"] >= 0]) == {0, 2}
+
+
+def test_forward_and_backward_jobs_share_their_lattices():
+    """One job order for both directions (slice_jobs): every group of lattices has a forward and a backward job over
+    the SAME lattices in the same slots -- what lets the device packer's fill pass write a group's two jobs side by
+    side and read the group's arcs from HBM once (csrc/klat_pack_lean.hip)."""
+    rng = np.random.RandomState(4)
+    ns = np.concatenate([rng.randint(1, 500, size=90), [3000, 2, 1]]).astype(np.int32)
+    fo = rng.choice([1, 2, 3, 4, 7], size=len(ns)).astype(np.int32)
+    a = klat_amd.synth(31, ns, fo)
+    for G in (0, 1, 4, 16):
+        h = klat_amd.pack_host(a, lanes_per_lattice=G)
+        jobs, lanes = h["jobs"], h["lanes"]
+        members = {0: {}, 1: {}}
+        for j in jobs:
+            lpw = 64 // ((int(j["tag"]) >> 8) & 0xFF)
+            lat = tuple(int(x) for x in lanes["lattice"][int(j["lane_tab"]):int(j["lane_tab"]) + lpw])
+            members[int(j["dir"])][lat[0]] = lat
+        assert members[0] == members[1] and len(members[0]) * 2 == len(jobs), G
