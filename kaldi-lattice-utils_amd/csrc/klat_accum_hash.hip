@@ -771,6 +771,9 @@ void index_hash2_kernel(AccumArgs a, RadixPack pk, int log_h, int cnt_off, int l
       p = lo;
       if (!slow) {
         int upto = 0;
+#ifndef KLAT_IDX_PLAIN_LOOPS_OFF
+#pragma clang loop vectorize(disable) unroll(disable)
+#endif
         for (int q = lo; q < hi; ++q) {
           const uint64_t f = order[q];
           p += f < floor_w ? 1 : 0;

@@ -116,7 +116,8 @@ __device__ bool lean_prefix(const PackDevArgs& a, int u, int64_t s0, int S, int 
   int32_t* tpb = a.tpb + tb;
   int mtf = 1, mtb = 1;
   bool fits = true;
-  auto tiles = [&](int32_t* tp, int p, int r, int nr) {  // the tiles whose first round lies in position p
+  auto tiles = [&](int32_t* tp, int p, int r, int nr) {  // the tiles whose first round lies in position p (none, or one)
+#pragma clang loop vectorize(disable) unroll(disable)
     for (int m = (r + kPackTileRounds - 1) / kPackTileRounds; m * kPackTileRounds < r + nr; ++m) {
       if (m < cap)
         tp[m] = p;
