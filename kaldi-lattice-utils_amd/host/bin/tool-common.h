@@ -82,7 +82,7 @@ struct CommonOptions {
   // (klat_pack_options.fuse_scales: 10-byte stream slots instead of 12).  Valid while this object lives.
   klat_pack_options PackOptions() const {
     fuse_ = {graph_scale, acoustic_scale, insertion_penalty};
-    klat_pack_options o = {lanes_per_lattice, 0, 0, &fuse_};
+    klat_pack_options o = {lanes_per_lattice, 0, 0, &fuse_, 0};
     return o;
   }
 
